@@ -1,0 +1,903 @@
+/*
+ * gzpx_oracle.c -- CPU restatement (plain C) of the gzp ParCompress<Bgzf/Mgzip> hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY (see gzpx_oracle.h).  Scalar, sequential, written the way the
+ * reference's backend works (one block at a time, hash table walked position by position) so
+ * that it checks the GPU path's *parallel* reformulation independently.
+ *
+ * Reference anchors (relative to /root/reference):
+ *   framing        src/bgzf.rs:204-237,274-303 ; src/mgzip.rs:187-218,246-275
+ *   EOF marker     src/bgzf.rs:24-38 ; appended by Bgzf::encode src/deflate.rs:622-624
+ *   stream cutting src/par/compress.rs:413-463 (write), :332-362 (flush_last), :377-388 (finish)
+ *   arithmetic     libdeflate (Cargo.lock:414-430, libdeflate-sys 1.24.0; source not vendored):
+ *                  call sites src/bgzf.rs:214-216 (deflate_compress), :224-225 (crc32).
+ *                  Restated from SURVEY.md Appendix A.0-A.6; pinned against the v1.10 binary.
+ */
+#include "gzpx_oracle.h"
+
+#include <stdlib.h>
+#include <string.h>
+
+/* ------------------------------------------------------------------ CRC-32 */
+
+static uint32_t crc_table[256];
+static int crc_table_ready;
+
+static void crc_init(void)
+{
+    for (uint32_t i = 0; i < 256; i++) {
+        uint32_t c = i;
+        for (int k = 0; k < 8; k++)
+            c = (c >> 1) ^ (0xEDB88320u & (0u - (c & 1u)));
+        crc_table[i] = c;
+    }
+    crc_table_ready = 1;
+}
+
+/* libdeflate_crc32 semantics (src/bgzf.rs:224-225 via libdeflater::Crc). */
+uint32_t gzpx_oracle_crc32(uint32_t crc, const void *buf, size_t n)
+{
+    const uint8_t *p = (const uint8_t *)buf;
+    if (!crc_table_ready)
+        crc_init();
+    crc = ~crc;
+    for (size_t i = 0; i < n; i++)
+        crc = (crc >> 8) ^ crc_table[(crc ^ p[i]) & 0xFF];
+    return ~crc;
+}
+
+/* ------------------------------------------------------------------ DEFLATE constants */
+
+#define NUM_LITLEN_SYMS 288
+#define NUM_OFFSET_SYMS 32
+#define NUM_PRECODE_SYMS 19
+#define MAX_LITLEN_CODEWORD_LEN 14
+#define MAX_OFFSET_CODEWORD_LEN 15
+#define MAX_PRE_CODEWORD_LEN 7
+#define END_OF_BLOCK 256
+#define FIRST_LEN_SYM 257
+#define MIN_MATCH_LEN 3
+#define MAX_MATCH_LEN 258
+#define WINDOW_SIZE 32768
+
+#define MIN_BLOCK_LENGTH 5000
+#define FAST_SOFT_MAX_BLOCK_LENGTH 65535
+#define FAST_SEQ_STORE_LENGTH 8192
+
+static const unsigned length_slot_base[29] = {3,  4,  5,  6,  7,  8,  9,  10, 11,  13,
+                                              15, 17, 19, 23, 27, 31, 35, 43, 51,  59,
+                                              67, 83, 99, 115, 131, 163, 195, 227, 258};
+static const uint8_t extra_length_bits[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2,
+                                              2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
+static const unsigned offset_slot_base[30] = {1,    2,    3,    4,    5,    7,     9,     13,
+                                              17,   25,   33,   49,   65,   97,    129,   193,
+                                              257,  385,  513,  769,  1025, 1537,  2049,  3073,
+                                              4097, 6145, 8193, 12289, 16385, 24577};
+static const uint8_t extra_offset_bits[30] = {0, 0, 0, 0, 1, 1, 2,  2,  3,  3,  4,  4,  5,  5,  6,
+                                              6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
+static const uint8_t extra_precode_bits[NUM_PRECODE_SYMS] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0,
+                                                             0, 0, 0, 0, 0, 0, 2, 3, 7};
+static const uint8_t precode_lens_permutation[NUM_PRECODE_SYMS] = {
+    16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+
+static unsigned length_slot(unsigned len)
+{
+    unsigned s = 28;
+    while (length_slot_base[s] > len)
+        s--;
+    return s;
+}
+
+static unsigned offset_slot(unsigned off)
+{
+    unsigned s = 29;
+    while (offset_slot_base[s] > off)
+        s--;
+    return s;
+}
+
+/* ------------------------------------------------------------------ output bitstream */
+
+struct bitwriter {
+    uint8_t *out;
+    size_t cap;
+    size_t pos;      /* bytes written */
+    uint64_t bitbuf; /* pending bits, LSB first */
+    unsigned bitcount;
+    int overflow;
+};
+
+static void bw_put_byte(struct bitwriter *w, uint8_t b)
+{
+    if (w->pos < w->cap)
+        w->out[w->pos] = b;
+    else
+        w->overflow = 1;
+    w->pos++;
+}
+
+static void bw_add(struct bitwriter *w, uint32_t bits, unsigned n)
+{
+    w->bitbuf |= (uint64_t)bits << w->bitcount;
+    w->bitcount += n;
+    while (w->bitcount >= 8) {
+        bw_put_byte(w, (uint8_t)w->bitbuf);
+        w->bitbuf >>= 8;
+        w->bitcount -= 8;
+    }
+}
+
+static void bw_align(struct bitwriter *w)
+{
+    if (w->bitcount) {
+        bw_put_byte(w, (uint8_t)w->bitbuf);
+        w->bitbuf = 0;
+        w->bitcount = 0;
+    }
+}
+
+/* ------------------------------------------------------------------ Huffman code construction (A.6) */
+
+#define NUM_SYMBOL_BITS 10
+#define SYMBOL_MASK ((1u << NUM_SYMBOL_BITS) - 1)
+
+static uint32_t reverse_codeword(uint32_t cw, unsigned len)
+{
+    uint32_t r = 0;
+    for (unsigned i = 0; i < len; i++)
+        r |= ((cw >> i) & 1u) << (len - 1 - i);
+    return r;
+}
+
+/* entries: sym | (key << NUM_SYMBOL_BITS); sorted ascending by (freq, sym). */
+static int cmp_u64(const void *a, const void *b)
+{
+    uint64_t x = *(const uint64_t *)a, y = *(const uint64_t *)b;
+    return (x > y) - (x < y);
+}
+
+void gzpx_oracle_make_huffman_code(unsigned num_syms, unsigned max_len, int compat,
+                                   const uint32_t *freqs, uint8_t *lens, uint32_t *codewords)
+{
+    uint64_t A[NUM_LITLEN_SYMS];     /* sorted leaves: (freq << 10) | sym              */
+    uint64_t NF[NUM_LITLEN_SYMS];    /* internal node frequencies                      */
+    unsigned parent[NUM_LITLEN_SYMS]; /* parent index of internal node                  */
+    unsigned depth[NUM_LITLEN_SYMS];
+    unsigned len_counts[16];
+    unsigned num_used = 0;
+
+    for (unsigned s = 0; s < num_syms; s++) {
+        lens[s] = 0;
+        codewords[s] = 0;
+        if (freqs[s])
+            A[num_used++] = ((uint64_t)freqs[s] << NUM_SYMBOL_BITS) | s;
+    }
+    qsort(A, num_used, sizeof(A[0]), cmp_u64);
+
+    if (num_used == 0 && compat == GZPX_ORACLE_COMPAT_1_10)
+        return; /* v1.10: empty code, all lengths zero (SURVEY A.7 delta 1) */
+    if (num_used < 2) {
+        unsigned sym = num_used ? (unsigned)(A[0] & SYMBOL_MASK) : 0;
+        unsigned other = sym ? sym : 1;
+        lens[0] = 1;
+        codewords[0] = 0;
+        lens[other] = 1;
+        codewords[other] = 1;
+        return;
+    }
+
+    /* two-queue tree build; ties prefer leaves */
+    {
+        const unsigned last = num_used - 1;
+        unsigned i = 0, b = 0, e = 0;
+        do {
+            uint64_t nf;
+            if (i + 1 <= last && (b == e || (A[i + 1] >> NUM_SYMBOL_BITS) <= NF[b])) {
+                nf = (A[i] >> NUM_SYMBOL_BITS) + (A[i + 1] >> NUM_SYMBOL_BITS);
+                i += 2;
+            } else if (b + 2 <= e && (i > last || NF[b + 1] < (A[i] >> NUM_SYMBOL_BITS))) {
+                nf = NF[b] + NF[b + 1];
+                parent[b] = e;
+                parent[b + 1] = e;
+                b += 2;
+            } else {
+                nf = (A[i] >> NUM_SYMBOL_BITS) + NF[b];
+                parent[b] = e;
+                i++;
+                b++;
+            }
+            NF[e] = nf;
+        } while (++e < last);
+
+        /* length counts from internal-node depths, clamping over-long codewords */
+        for (unsigned l = 0; l <= max_len; l++)
+            len_counts[l] = 0;
+        len_counts[1] = 2;
+        const unsigned root = last - 1;
+        depth[root] = 0;
+        for (int node = (int)root - 1; node >= 0; node--) {
+            unsigned d = depth[parent[node]] + 1;
+            unsigned l = d;
+            depth[node] = d;
+            if (l >= max_len) {
+                l = max_len;
+                do {
+                    l--;
+                } while (len_counts[l] == 0);
+            }
+            len_counts[l]--;
+            len_counts[l + 1] += 2;
+        }
+    }
+
+    /* longest lengths to the least frequent symbols */
+    {
+        unsigned k = 0;
+        for (unsigned l = max_len; l >= 1; l--)
+            for (unsigned c = len_counts[l]; c; c--)
+                lens[A[k++] & SYMBOL_MASK] = (uint8_t)l;
+    }
+    /* canonical codewords, bit-reversed */
+    {
+        uint32_t next[16];
+        next[0] = 0;
+        next[1] = 0;
+        for (unsigned l = 2; l <= max_len; l++)
+            next[l] = (next[l - 1] + len_counts[l - 1]) << 1;
+        for (unsigned s = 0; s < num_syms; s++)
+            if (lens[s])
+                codewords[s] = reverse_codeword(next[lens[s]]++, lens[s]);
+    }
+}
+
+/* ------------------------------------------------------------------ block flush (A.5) */
+
+struct codes {
+    uint8_t litlen_lens[NUM_LITLEN_SYMS + NUM_OFFSET_SYMS]; /* offset lens may be moved adjacent */
+    uint8_t offset_lens[NUM_OFFSET_SYMS];
+    uint32_t litlen_cw[NUM_LITLEN_SYMS];
+    uint32_t offset_cw[NUM_OFFSET_SYMS];
+};
+
+struct freqs {
+    uint32_t litlen[NUM_LITLEN_SYMS];
+    uint32_t offset[NUM_OFFSET_SYMS];
+};
+
+static struct codes static_codes;
+static int static_codes_ready;
+
+static void init_static_codes(void)
+{
+    uint32_t f[NUM_LITLEN_SYMS];
+    unsigned i;
+    /* frequencies chosen so that make_code yields the fixed code lengths (libdeflate idiom) */
+    for (i = 0; i < 144; i++)
+        f[i] = 1 << (9 - 8);
+    for (; i < 256; i++)
+        f[i] = 1 << (9 - 9);
+    for (; i < 280; i++)
+        f[i] = 1 << (9 - 7);
+    for (; i < 288; i++)
+        f[i] = 1 << (9 - 8);
+    gzpx_oracle_make_huffman_code(NUM_LITLEN_SYMS, MAX_LITLEN_CODEWORD_LEN, 0, f,
+                                  static_codes.litlen_lens, static_codes.litlen_cw);
+    for (i = 0; i < NUM_OFFSET_SYMS; i++)
+        f[i] = 1;
+    gzpx_oracle_make_huffman_code(NUM_OFFSET_SYMS, MAX_OFFSET_CODEWORD_LEN, 0, f,
+                                  static_codes.offset_lens, static_codes.offset_cw);
+    static_codes_ready = 1;
+}
+
+/* precode run-length items: sym | extra << 5 */
+static unsigned compute_precode_items(const uint8_t *lens, unsigned num_lens, uint32_t *pfreq,
+                                      unsigned *items)
+{
+    unsigned n = 0, run_start = 0;
+    memset(pfreq, 0, NUM_PRECODE_SYMS * sizeof(pfreq[0]));
+    do {
+        uint8_t len = lens[run_start];
+        unsigned run_end = run_start, extra;
+        do {
+            run_end++;
+        } while (run_end != num_lens && len == lens[run_end]);
+        if (len == 0) {
+            while (run_end - run_start >= 11) {
+                extra = run_end - run_start - 11;
+                if (extra > 0x7F)
+                    extra = 0x7F;
+                pfreq[18]++;
+                items[n++] = 18 | (extra << 5);
+                run_start += 11 + extra;
+            }
+            if (run_end - run_start >= 3) {
+                extra = run_end - run_start - 3;
+                if (extra > 0x7)
+                    extra = 0x7;
+                pfreq[17]++;
+                items[n++] = 17 | (extra << 5);
+                run_start += 3 + extra;
+            }
+        } else if (run_end - run_start >= 4) {
+            pfreq[len]++;
+            items[n++] = len;
+            run_start++;
+            do {
+                extra = run_end - run_start - 3;
+                if (extra > 0x3)
+                    extra = 0x3;
+                pfreq[16]++;
+                items[n++] = 16 | (extra << 5);
+                run_start += 3 + extra;
+            } while (run_end - run_start >= 3);
+        }
+        while (run_start != run_end) {
+            pfreq[len]++;
+            items[n++] = len;
+            run_start++;
+        }
+    } while (run_start != num_lens);
+    return n;
+}
+
+#define TOKEN_MATCH 0x80000000u
+#define TOKEN_LEN(t) ((t)&0x1FFu)
+#define TOKEN_OFF(t) (((t) >> 9) & 0xFFFFu)
+
+static void write_stored(struct bitwriter *w, const uint8_t *data, size_t len, int is_final)
+{
+    do {
+        size_t chunk = len > 65535 ? 65535 : len;
+        int last = (chunk == len);
+        bw_add(w, (is_final && last) ? 1 : 0, 1);
+        bw_add(w, 0, 2);
+        bw_align(w);
+        bw_put_byte(w, (uint8_t)(chunk & 0xFF));
+        bw_put_byte(w, (uint8_t)(chunk >> 8));
+        bw_put_byte(w, (uint8_t)(~chunk & 0xFF));
+        bw_put_byte(w, (uint8_t)((~chunk >> 8) & 0xFF));
+        for (size_t i = 0; i < chunk; i++)
+            bw_put_byte(w, data[i]);
+        data += chunk;
+        len -= chunk;
+    } while (len);
+}
+
+static void flush_block(struct bitwriter *w, int compat, const uint8_t *block_begin,
+                        size_t block_length, const uint32_t *tokens, size_t n_tokens,
+                        struct freqs *fr, int is_final)
+{
+    struct codes dyn;
+    uint32_t pfreq[NUM_PRECODE_SYMS];
+    uint8_t plens[NUM_PRECODE_SYMS];
+    uint32_t pcw[NUM_PRECODE_SYMS];
+    unsigned items[NUM_LITLEN_SYMS + NUM_OFFSET_SYMS];
+    unsigned num_items, num_litlen, num_offset, num_explicit, sym;
+    uint32_t dynamic_cost = 0, static_cost = 0, uncompressed_cost = 0;
+    const struct codes *codes;
+
+    if (!static_codes_ready)
+        init_static_codes();
+
+    fr->litlen[END_OF_BLOCK]++;
+    gzpx_oracle_make_huffman_code(NUM_LITLEN_SYMS, MAX_LITLEN_CODEWORD_LEN, compat, fr->litlen,
+                                  dyn.litlen_lens, dyn.litlen_cw);
+    gzpx_oracle_make_huffman_code(NUM_OFFSET_SYMS, MAX_OFFSET_CODEWORD_LEN, compat, fr->offset,
+                                  dyn.offset_lens, dyn.offset_cw);
+
+    for (num_litlen = NUM_LITLEN_SYMS; num_litlen > 257; num_litlen--)
+        if (dyn.litlen_lens[num_litlen - 1] != 0)
+            break;
+    for (num_offset = NUM_OFFSET_SYMS; num_offset > 1; num_offset--)
+        if (dyn.offset_lens[num_offset - 1] != 0)
+            break;
+    {
+        uint8_t all[NUM_LITLEN_SYMS + NUM_OFFSET_SYMS];
+        memcpy(all, dyn.litlen_lens, num_litlen);
+        memcpy(all + num_litlen, dyn.offset_lens, num_offset);
+        num_items = compute_precode_items(all, num_litlen + num_offset, pfreq, items);
+    }
+    gzpx_oracle_make_huffman_code(NUM_PRECODE_SYMS, MAX_PRE_CODEWORD_LEN, compat, pfreq, plens,
+                                  pcw);
+    for (num_explicit = NUM_PRECODE_SYMS; num_explicit > 4; num_explicit--)
+        if (plens[precode_lens_permutation[num_explicit - 1]] != 0)
+            break;
+
+    dynamic_cost += 5 + 5 + 4 + 3 * num_explicit;
+    for (sym = 0; sym < NUM_PRECODE_SYMS; sym++)
+        dynamic_cost += pfreq[sym] * (extra_precode_bits[sym] + plens[sym]);
+    for (sym = 0; sym < 144; sym++) {
+        dynamic_cost += fr->litlen[sym] * dyn.litlen_lens[sym];
+        static_cost += fr->litlen[sym] * 8;
+    }
+    for (; sym < 256; sym++) {
+        dynamic_cost += fr->litlen[sym] * dyn.litlen_lens[sym];
+        static_cost += fr->litlen[sym] * 9;
+    }
+    dynamic_cost += dyn.litlen_lens[END_OF_BLOCK];
+    static_cost += 7;
+    for (sym = FIRST_LEN_SYM; sym < FIRST_LEN_SYM + 29; sym++) {
+        uint32_t extra = extra_length_bits[sym - FIRST_LEN_SYM];
+        dynamic_cost += fr->litlen[sym] * (extra + dyn.litlen_lens[sym]);
+        static_cost += fr->litlen[sym] * (extra + static_codes.litlen_lens[sym]);
+    }
+    for (sym = 0; sym < 30; sym++) {
+        uint32_t extra = extra_offset_bits[sym];
+        dynamic_cost += fr->offset[sym] * (extra + dyn.offset_lens[sym]);
+        static_cost += fr->offset[sym] * (extra + 5);
+    }
+    uncompressed_cost += ((0u - (w->bitcount + 3)) & 7) + 32 +
+                         40 * (uint32_t)((block_length + 65534) / 65535 - 1) +
+                         8 * (uint32_t)block_length;
+
+    if (dynamic_cost < (static_cost < uncompressed_cost ? static_cost : uncompressed_cost)) {
+        codes = &dyn;
+        bw_add(w, is_final ? 1 : 0, 1);
+        bw_add(w, 2, 2);
+        bw_add(w, num_litlen - 257, 5);
+        bw_add(w, num_offset - 1, 5);
+        bw_add(w, num_explicit - 4, 4);
+        for (unsigned i = 0; i < num_explicit; i++)
+            bw_add(w, plens[precode_lens_permutation[i]], 3);
+        for (unsigned i = 0; i < num_items; i++) {
+            unsigned psym = items[i] & 0x1F, extra = items[i] >> 5;
+            bw_add(w, pcw[psym], plens[psym]);
+            if (psym >= 16)
+                bw_add(w, extra, extra_precode_bits[psym]);
+        }
+    } else if (static_cost < uncompressed_cost) {
+        codes = &static_codes;
+        bw_add(w, is_final ? 1 : 0, 1);
+        bw_add(w, 1, 2);
+    } else {
+        write_stored(w, block_begin, block_length, is_final);
+        return;
+    }
+
+    for (size_t i = 0; i < n_tokens; i++) {
+        uint32_t t = tokens[i];
+        if (t & TOKEN_MATCH) {
+            unsigned len = TOKEN_LEN(t), off = TOKEN_OFF(t);
+            unsigned ls = length_slot(len), os = offset_slot(off);
+            bw_add(w, codes->litlen_cw[FIRST_LEN_SYM + ls], codes->litlen_lens[FIRST_LEN_SYM + ls]);
+            bw_add(w, len - length_slot_base[ls], extra_length_bits[ls]);
+            bw_add(w, codes->offset_cw[os], codes->offset_lens[os]);
+            bw_add(w, off - offset_slot_base[os], extra_offset_bits[os]);
+        } else {
+            bw_add(w, codes->litlen_cw[t], codes->litlen_lens[t]);
+        }
+    }
+    bw_add(w, codes->litlen_cw[END_OF_BLOCK], codes->litlen_lens[END_OF_BLOCK]);
+}
+
+/* ------------------------------------------------------------------ level 1: ht_matchfinder (A.1-A.3) */
+
+#define HT_HASH_ORDER 15
+#define HT_BUCKET 2
+#define HT_REQUIRED_NBYTES 5
+
+struct ht_mf {
+    int16_t tab[1u << HT_HASH_ORDER][HT_BUCKET];
+};
+
+static uint32_t le32(const uint8_t *p)
+{
+    return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24);
+}
+
+static uint32_t lz_hash(uint32_t v, unsigned bits)
+{
+    return (uint32_t)(v * 0x1E35A7BDu) >> (32 - bits);
+}
+
+static void ht_slide(struct ht_mf *mf)
+{
+    int16_t *t = &mf->tab[0][0];
+    for (size_t i = 0; i < (size_t)HT_BUCKET << HT_HASH_ORDER; i++)
+        t[i] = (int16_t)(t[i] >= 0 ? t[i] - WINDOW_SIZE : -WINDOW_SIZE);
+}
+
+static unsigned lz_extend(const uint8_t *a, const uint8_t *b, unsigned len, unsigned max_len)
+{
+    while (len < max_len && a[len] == b[len])
+        len++;
+    return len;
+}
+
+static unsigned ht_longest_match(struct ht_mf *mf, const uint8_t **in_base_p, const uint8_t *in_next,
+                                 unsigned max_len, unsigned nice_len, uint32_t *next_hash,
+                                 unsigned *offset_ret)
+{
+    unsigned best_len = 0;
+    const uint8_t *best_ptr = in_next;
+    uint32_t cur_pos = (uint32_t)(in_next - *in_base_p);
+    const uint8_t *in_base;
+    int32_t cutoff;
+    uint32_t hash, seq;
+    int16_t cur_node, to_insert;
+    const uint8_t *matchptr;
+
+    if (cur_pos == WINDOW_SIZE) {
+        ht_slide(mf);
+        *in_base_p += WINDOW_SIZE;
+        cur_pos = 0;
+    }
+    in_base = *in_base_p;
+    cutoff = (int32_t)cur_pos - WINDOW_SIZE;
+
+    hash = *next_hash;
+    *next_hash = lz_hash(le32(in_next + 1), HT_HASH_ORDER);
+    seq = le32(in_next);
+
+    /* bucket size 2, libdeflate's hand-unrolled form: entry 0 is copied to entry 1 even when
+     * nice_len is reached on entry 0 */
+    cur_node = mf->tab[hash][0];
+    mf->tab[hash][0] = (int16_t)cur_pos;
+    if (cur_node <= cutoff)
+        goto out;
+    matchptr = in_base + cur_node;
+    to_insert = cur_node;
+    cur_node = mf->tab[hash][1];
+    mf->tab[hash][1] = to_insert;
+
+    if (le32(matchptr) == seq) {
+        best_len = lz_extend(in_next, matchptr, 4, max_len);
+        best_ptr = matchptr;
+        if (cur_node <= cutoff || best_len >= nice_len)
+            goto out;
+        matchptr = in_base + cur_node;
+        if (le32(matchptr) == seq) {
+            unsigned len = lz_extend(in_next, matchptr, 4, max_len);
+            if (len > best_len) {
+                best_len = len;
+                best_ptr = matchptr;
+            }
+        }
+    } else {
+        if (cur_node <= cutoff)
+            goto out;
+        matchptr = in_base + cur_node;
+        if (le32(matchptr) == seq) {
+            best_len = lz_extend(in_next, matchptr, 4, max_len);
+            best_ptr = matchptr;
+        }
+    }
+out:
+    *offset_ret = (unsigned)(in_next - best_ptr);
+    return best_len;
+}
+
+static void ht_skip_bytes(struct ht_mf *mf, const uint8_t **in_base_p, const uint8_t *in_next,
+                          const uint8_t *in_end, unsigned count, uint32_t *next_hash)
+{
+    int32_t cur_pos = (int32_t)(in_next - *in_base_p);
+    uint32_t hash;
+    unsigned remaining = count;
+
+    if ((size_t)count + HT_REQUIRED_NBYTES > (size_t)(in_end - in_next))
+        return;
+    if (cur_pos + (int32_t)count - 1 >= WINDOW_SIZE) {
+        ht_slide(mf);
+        *in_base_p += WINDOW_SIZE;
+        cur_pos -= WINDOW_SIZE;
+    }
+    hash = *next_hash;
+    do {
+        mf->tab[hash][1] = mf->tab[hash][0];
+        mf->tab[hash][0] = (int16_t)cur_pos;
+        hash = lz_hash(le32(++in_next), HT_HASH_ORDER);
+        cur_pos++;
+    } while (--remaining);
+    *next_hash = hash;
+}
+
+typedef void (*block_sink_fn)(void *ctx, const uint8_t *block_begin, size_t block_length,
+                              const uint32_t *tokens, size_t n_tokens, struct freqs *fr,
+                              int is_final);
+
+static void tally_literal(struct freqs *fr, uint32_t *tokens, size_t *nt, uint8_t lit)
+{
+    fr->litlen[lit]++;
+    tokens[(*nt)++] = lit;
+}
+
+static void tally_match(struct freqs *fr, uint32_t *tokens, size_t *nt, unsigned len, unsigned off)
+{
+    fr->litlen[FIRST_LEN_SYM + length_slot(len)]++;
+    fr->offset[offset_slot(off)]++;
+    tokens[(*nt)++] = TOKEN_MATCH | (off << 9) | len;
+}
+
+/* deflate_compress_fastest: greedy parse with ht_matchfinder; sub-block per 8192 sequences. */
+static int compress_fastest(const uint8_t *in, size_t n, block_sink_fn sink, void *ctx)
+{
+    const uint8_t *in_next = in, *in_end = in + n, *in_cur_base = in;
+    unsigned max_len = MAX_MATCH_LEN, nice_len = 32;
+    uint32_t next_hash = 0;
+    struct ht_mf *mf = (struct ht_mf *)malloc(sizeof(*mf));
+    /* worst case one token per byte in a sub-block of <= 65535+5000 bytes */
+    uint32_t *tokens = (uint32_t *)malloc(sizeof(uint32_t) * (FAST_SOFT_MAX_BLOCK_LENGTH + MIN_BLOCK_LENGTH + 300));
+    if (!mf || !tokens) {
+        free(mf);
+        free(tokens);
+        return -1;
+    }
+    for (size_t i = 0; i < (1u << HT_HASH_ORDER); i++)
+        mf->tab[i][0] = mf->tab[i][1] = -WINDOW_SIZE;
+
+    do {
+        const uint8_t *block_begin = in_next;
+        const uint8_t *max_block_end =
+            ((size_t)(in_end - in_next) < FAST_SOFT_MAX_BLOCK_LENGTH + MIN_BLOCK_LENGTH)
+                ? in_end
+                : in_next + FAST_SOFT_MAX_BLOCK_LENGTH;
+        struct freqs fr;
+        size_t nt = 0;
+        unsigned nseq = 0;
+        memset(&fr, 0, sizeof(fr));
+        do {
+            unsigned length, offset;
+            size_t remaining = (size_t)(in_end - in_next);
+            if (remaining < MAX_MATCH_LEN) {
+                max_len = (unsigned)remaining;
+                if (max_len < HT_REQUIRED_NBYTES) {
+                    do {
+                        tally_literal(&fr, tokens, &nt, *in_next++);
+                    } while (--max_len);
+                    break;
+                }
+                if (nice_len > max_len)
+                    nice_len = max_len;
+            }
+            length = ht_longest_match(mf, &in_cur_base, in_next, max_len, nice_len, &next_hash,
+                                      &offset);
+            if (length) {
+                tally_match(&fr, tokens, &nt, length, offset);
+                nseq++;
+                ht_skip_bytes(mf, &in_cur_base, in_next + 1, in_end, length - 1, &next_hash);
+                in_next += length;
+            } else {
+                tally_literal(&fr, tokens, &nt, *in_next++);
+            }
+        } while (in_next < max_block_end && nseq < FAST_SEQ_STORE_LENGTH);
+        sink(ctx, block_begin, (size_t)(in_next - block_begin), tokens, nt, &fr, in_next == in_end);
+    } while (in_next != in_end);
+    free(mf);
+    free(tokens);
+    return 0;
+}
+
+/* ------------------------------------------------------------------ entry points */
+
+struct emit_ctx {
+    struct bitwriter w;
+    int compat;
+};
+
+static void emit_sink(void *vctx, const uint8_t *block_begin, size_t block_length,
+                      const uint32_t *tokens, size_t n_tokens, struct freqs *fr, int is_final)
+{
+    struct emit_ctx *c = (struct emit_ctx *)vctx;
+    flush_block(&c->w, c->compat, block_begin, block_length, tokens, n_tokens, fr, is_final);
+}
+
+size_t gzpx_oracle_deflate_bound(size_t n)
+{
+    /* libdeflate_deflate_compress_bound (v1.10): 5 bytes per 10000-byte stored block + 1 + 8 */
+    size_t max_blocks = (n + 10000 - 1) / 10000;
+    if (max_blocks < 1)
+        max_blocks = 1;
+    return 5 * max_blocks + n + 1 + 8;
+}
+
+size_t gzpx_oracle_deflate_compress(int level, int compat, const uint8_t *in, size_t n,
+                                    uint8_t *out, size_t cap)
+{
+    struct emit_ctx c;
+    memset(&c, 0, sizeof(c));
+    c.w.out = out;
+    c.w.cap = cap;
+    c.compat = compat;
+    if (level < 0 || level > 1)
+        return 0; /* levels 2..12: not restated yet */
+    /* A.0: very short inputs (and level 0) are emitted as stored blocks only */
+    if (level == 0 || n <= (size_t)(55 - 4 * level)) {
+        write_stored(&c.w, in, n, 1);
+    } else {
+        if (compress_fastest(in, n, emit_sink, &c) != 0)
+            return 0;
+        bw_align(&c.w);
+    }
+    if (c.w.overflow)
+        return 0;
+    return c.w.pos;
+}
+
+struct tok_ctx {
+    uint32_t *tokens;
+    size_t max_tokens, n_tokens;
+    uint32_t *first;
+    size_t max_sub, n_sub;
+};
+
+static void tok_sink(void *vctx, const uint8_t *block_begin, size_t block_length,
+                     const uint32_t *tokens, size_t n_tokens, struct freqs *fr, int is_final)
+{
+    struct tok_ctx *c = (struct tok_ctx *)vctx;
+    (void)block_begin;
+    (void)block_length;
+    (void)fr;
+    (void)is_final;
+    if (c->n_sub < c->max_sub)
+        c->first[c->n_sub] = (uint32_t)c->n_tokens;
+    c->n_sub++;
+    for (size_t i = 0; i < n_tokens; i++) {
+        if (c->n_tokens < c->max_tokens)
+            c->tokens[c->n_tokens] = tokens[i];
+        c->n_tokens++;
+    }
+}
+
+size_t gzpx_oracle_l1_tokens(const uint8_t *in, size_t n, uint32_t *tokens, size_t max_tokens,
+                             uint32_t *sub_block_first_token, size_t max_sub_blocks,
+                             size_t *n_sub_blocks)
+{
+    struct tok_ctx c = {tokens, max_tokens, 0, sub_block_first_token, max_sub_blocks, 0};
+    if (n_sub_blocks)
+        *n_sub_blocks = 0;
+    if (n <= 51)
+        return 0;
+    if (compress_fastest(in, n, tok_sink, &c) != 0)
+        return 0;
+    if (n_sub_blocks)
+        *n_sub_blocks = c.n_sub;
+    return c.n_tokens;
+}
+
+/* ------------------------------------------------------------------ framing */
+
+/* src/bgzf.rs:24-38 */
+static const uint8_t BGZF_EOF[28] = {0x1f, 0x8b, 0x08, 0x04, 0x00, 0x00, 0x00, 0x00, 0x00, 0xff,
+                                     0x06, 0x00, 0x42, 0x43, 0x02, 0x00, 0x1b, 0x00, 0x03, 0x00,
+                                     0x00, 0x00, 0x00, 0x00, 0x00, 0x00, 0x00, 0x00};
+
+static void put_le16(uint8_t *p, uint32_t v)
+{
+    p[0] = (uint8_t)v;
+    p[1] = (uint8_t)(v >> 8);
+}
+
+static void put_le32(uint8_t *p, uint32_t v)
+{
+    p[0] = (uint8_t)v;
+    p[1] = (uint8_t)(v >> 8);
+    p[2] = (uint8_t)(v >> 16);
+    p[3] = (uint8_t)(v >> 24);
+}
+
+static size_t extra_amount(size_t n)
+{
+    size_t e = (size_t)((double)n * 0.1); /* src/bgzf.rs:45,50-52 ; src/mgzip.rs:28-30 */
+    return e < 128 ? 128 : e;
+}
+
+size_t gzpx_oracle_encode_block(int fmt, int level, int compat, const uint8_t *in, size_t n,
+                                int is_last, uint8_t *out, size_t cap, int *err)
+{
+    const size_t hdr = (fmt == GZPX_ORACLE_FMT_BGZF) ? 18 : 20;
+    size_t payload_cap, c, total;
+    uint8_t xfl;
+    int e = 0;
+    if (err)
+        *err = 0;
+    if (level < 0 || level > 12) {
+        if (err)
+            *err = 3;
+        return 0;
+    }
+    /* the reference sizes its Vec as hdr + n + extra_amount(n) + 8 and hands libdeflate
+     * the slice after the header (src/bgzf.rs:211-216): capacity n + extra + 8 */
+    payload_cap = n + extra_amount(n) + 8;
+    if (cap < hdr + payload_cap) {
+        if (err)
+            *err = 1;
+        return 0;
+    }
+    c = gzpx_oracle_deflate_compress(level, compat, in, n, out + hdr, payload_cap);
+    if (c == 0)
+        e = 1;
+    else if (fmt == GZPX_ORACLE_FMT_BGZF && c >= 65536)
+        e = 2; /* src/bgzf.rs:218-223 */
+    if (e) {
+        if (err)
+            *err = e;
+        return 0;
+    }
+    xfl = (level >= 9) ? 2 : (level <= 1) ? 4 : 0; /* src/bgzf.rs:278-284 */
+    out[0] = 0x1f;
+    out[1] = 0x8b;
+    out[2] = 8;
+    out[3] = 4;
+    put_le32(out + 4, 0);
+    out[8] = xfl;
+    out[9] = 255;
+    if (fmt == GZPX_ORACLE_FMT_BGZF) {
+        put_le16(out + 10, 6);
+        out[12] = 'B';
+        out[13] = 'C';
+        put_le16(out + 14, 2);
+        put_le16(out + 16, (uint32_t)(c + 26 - 1)); /* src/bgzf.rs:298-300 */
+    } else {
+        put_le16(out + 10, 8);
+        out[12] = 'I';
+        out[13] = 'G';
+        put_le16(out + 14, 4);
+        put_le32(out + 16, (uint32_t)(c + 28)); /* src/mgzip.rs:270-272 */
+    }
+    total = hdr + c;
+    put_le32(out + total, gzpx_oracle_crc32(0, in, n));
+    put_le32(out + total + 4, (uint32_t)n);
+    total += 8;
+    if (is_last && fmt == GZPX_ORACLE_FMT_BGZF) { /* src/deflate.rs:622-624 */
+        if (cap < total + sizeof(BGZF_EOF)) {
+            if (err)
+                *err = 1;
+            return 0;
+        }
+        memcpy(out + total, BGZF_EOF, sizeof(BGZF_EOF));
+        total += sizeof(BGZF_EOF);
+    }
+    return total;
+}
+
+size_t gzpx_oracle_compress_stream(int fmt, int level, int compat, size_t buffer_size,
+                                   const uint8_t *in, size_t n, uint8_t *out, size_t cap,
+                                   uint32_t *block_sizes, size_t max_blocks, size_t *n_blocks,
+                                   int *err)
+{
+    size_t pos = 0, opos = 0, nb = 0;
+    uint8_t *tmp;
+    size_t tmp_cap = 20 + buffer_size + extra_amount(buffer_size) + 8 + 28;
+    if (err)
+        *err = 0;
+    if (n_blocks)
+        *n_blocks = 0;
+    tmp = (uint8_t *)malloc(tmp_cap);
+    if (!tmp)
+        return 0;
+    /* write(): dispatch full blocks while strictly more than buffer_size is buffered
+     * (src/par/compress.rs:415); flush_last(true): at least one block, is_last on the final
+     * piece (src/par/compress.rs:333-341). */
+    for (;;) {
+        size_t remaining = n - pos;
+        size_t take = remaining > buffer_size ? buffer_size : remaining;
+        int is_last = (take == remaining);
+        int e = 0;
+        size_t got = gzpx_oracle_encode_block(fmt, level, compat, in + pos, take, is_last, tmp,
+                                              tmp_cap, &e);
+        if (got == 0) {
+            if (err)
+                *err = e ? e : 1;
+            free(tmp);
+            return 0;
+        }
+        if (opos + got > cap) {
+            if (err)
+                *err = 1;
+            free(tmp);
+            return 0;
+        }
+        memcpy(out + opos, tmp, got);
+        opos += got;
+        if (block_sizes && nb < max_blocks)
+            block_sizes[nb] = (uint32_t)got;
+        nb++;
+        pos += take;
+        if (is_last)
+            break;
+    }
+    free(tmp);
+    if (n_blocks)
+        *n_blocks = nb;
+    return opos;
+}
