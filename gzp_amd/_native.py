@@ -1,0 +1,273 @@
+"""ctypes binding of the C ABI in include/gzpx.h (gzp_amd/lib/libgzpx.so, built by hipcc for gfx950).
+
+There is no fallback: if the HIP library is missing or no GPU is present, loading / context
+creation raises -- the product path never routes through a CPU implementation.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libgzpx.so")
+
+OK = 0
+ERR_INVALID_ARG = 1
+ERR_BUFFER_SIZE = 2
+ERR_COMPRESSION_LEVEL = 3
+ERR_INSUFFICIENT_SPACE = 4
+ERR_BLOCK_SIZE_EXCEEDED = 5
+ERR_DEVICE = 6
+ERR_NO_DEVICE = 7
+ERR_UNSUPPORTED = 8
+
+FORMAT_BGZF = 0
+FORMAT_MGZIP = 1
+COMPAT_1_24 = 0
+COMPAT_1_10 = 1
+N_STAGES = 7
+
+EXPORTS = [
+    "gzpx_config_default", "gzpx_ctx_create", "gzpx_ctx_destroy", "gzpx_slab_bound",
+    "gzpx_compress_slab", "gzpx_compress_slab_device", "gzpx_encode_block",
+    "gzpx_alloc_compressor", "gzpx_deflate_compress", "gzpx_deflate_compress_bound",
+    "gzpx_free_compressor", "gzpx_compressor_set_compat", "gzpx_crc32",
+    "gzpx_ctx_set_profiling", "gzpx_ctx_last_stage_ms", "gzpx_stage_name", "gzpx_debug_tokens",
+    "gzpx_strerror", "gzpx_device_name", "gzpx_version",
+]
+
+
+class GzpxConfig(ctypes.Structure):
+    _fields_ = [("device", ctypes.c_int), ("format", ctypes.c_int), ("level", ctypes.c_int),
+                ("compat", ctypes.c_int), ("buffer_size", ctypes.c_size_t),
+                ("max_slab_bytes", ctypes.c_size_t)]
+
+
+class GzpxError(RuntimeError):
+    def __init__(self, code, msg, block=None):
+        super().__init__("gzpx error %d: %s%s" % (code, msg, "" if block is None else " (block %d)" % block))
+        self.code = code
+        self.block = block
+
+
+class GzpxLib:
+    """All entry points of include/gzpx.h with argtypes set."""
+
+    def __init__(self, path=LIB_PATH):
+        if not os.path.exists(path):
+            raise ImportError(
+                "gzp_amd: %s not found -- build it with `python -c 'import __graft_entry__ as g; "
+                "g.build()'` (hipcc --offload-arch=gfx950); there is no CPU fallback" % path)
+        self.path = path
+        L = self.L = ctypes.CDLL(path)
+        vp, sz, i32, u32 = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_uint32
+        psz = ctypes.POINTER(ctypes.c_size_t)
+        L.gzpx_config_default.restype = None
+        L.gzpx_config_default.argtypes = [ctypes.POINTER(GzpxConfig), i32]
+        L.gzpx_ctx_create.restype = i32
+        L.gzpx_ctx_create.argtypes = [ctypes.POINTER(GzpxConfig), ctypes.POINTER(vp)]
+        L.gzpx_ctx_destroy.restype = None
+        L.gzpx_ctx_destroy.argtypes = [vp]
+        L.gzpx_slab_bound.restype = sz
+        L.gzpx_slab_bound.argtypes = [vp, sz]
+        L.gzpx_compress_slab.restype = i32
+        L.gzpx_compress_slab.argtypes = [vp, vp, sz, i32, vp, sz, psz, vp, sz, psz]
+        L.gzpx_compress_slab_device.restype = i32
+        L.gzpx_compress_slab_device.argtypes = [vp, vp, sz, i32, vp, sz, psz, vp, sz, psz, vp]
+        L.gzpx_encode_block.restype = i32
+        L.gzpx_encode_block.argtypes = [vp, vp, sz, i32, vp, sz, psz]
+        L.gzpx_alloc_compressor.restype = vp
+        L.gzpx_alloc_compressor.argtypes = [i32]
+        L.gzpx_deflate_compress.restype = sz
+        L.gzpx_deflate_compress.argtypes = [vp, vp, sz, vp, sz]
+        L.gzpx_deflate_compress_bound.restype = sz
+        L.gzpx_deflate_compress_bound.argtypes = [vp, sz]
+        L.gzpx_free_compressor.restype = None
+        L.gzpx_free_compressor.argtypes = [vp]
+        L.gzpx_compressor_set_compat.restype = i32
+        L.gzpx_compressor_set_compat.argtypes = [vp, i32]
+        L.gzpx_crc32.restype = u32
+        L.gzpx_crc32.argtypes = [u32, vp, sz]
+        L.gzpx_ctx_set_profiling.restype = i32
+        L.gzpx_ctx_set_profiling.argtypes = [vp, i32]
+        L.gzpx_ctx_last_stage_ms.restype = i32
+        L.gzpx_ctx_last_stage_ms.argtypes = [vp, ctypes.POINTER(ctypes.c_float)]
+        L.gzpx_stage_name.restype = ctypes.c_char_p
+        L.gzpx_stage_name.argtypes = [i32]
+        L.gzpx_debug_tokens.restype = i32
+        L.gzpx_debug_tokens.argtypes = [vp, sz, vp, sz, psz, vp, psz]
+        L.gzpx_strerror.restype = ctypes.c_char_p
+        L.gzpx_strerror.argtypes = [i32]
+        L.gzpx_device_name.restype = ctypes.c_char_p
+        L.gzpx_device_name.argtypes = [vp]
+        L.gzpx_version.restype = ctypes.c_char_p
+        L.gzpx_version.argtypes = []
+
+    def strerror(self, code):
+        return self.L.gzpx_strerror(code).decode()
+
+    def check(self, code, block=None):
+        if code != OK:
+            raise GzpxError(code, self.strerror(code), block)
+
+
+_default = None
+
+
+def load():
+    """The product library (HIP build).  Raises ImportError when it has not been built."""
+    global _default
+    if _default is None:
+        _default = GzpxLib(LIB_PATH)
+    return _default
+
+
+def _u8(data):
+    if isinstance(data, np.ndarray):
+        return np.ascontiguousarray(data, dtype=np.uint8)
+    return np.frombuffer(bytes(data), dtype=np.uint8)
+
+
+class Context:
+    """gzpx_ctx: one device, one format/level/buffer_size -- the GPU-side `create_compressor`."""
+
+    def __init__(self, format=FORMAT_BGZF, level=1, buffer_size=None, compat=COMPAT_1_24, device=0,
+                 max_slab_bytes=1 << 30, lib=None):
+        self.lib = lib or load()
+        cfg = GzpxConfig()
+        self.lib.L.gzpx_config_default(ctypes.byref(cfg), format)
+        cfg.device = device
+        cfg.level = level
+        cfg.compat = compat
+        if buffer_size is not None:
+            cfg.buffer_size = buffer_size
+        cfg.max_slab_bytes = max_slab_bytes
+        self.cfg = cfg
+        self.buffer_size = cfg.buffer_size
+        self.format = format
+        h = ctypes.c_void_p()
+        self.lib.check(self.lib.L.gzpx_ctx_create(ctypes.byref(cfg), ctypes.byref(h)))
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.L.gzpx_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def device_name(self):
+        return self.lib.L.gzpx_device_name(self.h).decode()
+
+    def slab_bound(self, n):
+        return int(self.lib.L.gzpx_slab_bound(self.h, n))
+
+    def n_blocks(self, n):
+        return 1 if n == 0 else -(-n // self.buffer_size)
+
+    def compress_slab(self, data, is_last=True, return_block_sizes=False):
+        """Host buffer in, framed bytes out (gzpx_compress_slab)."""
+        a = _u8(data)
+        cap = self.slab_bound(a.size)
+        out = np.empty(cap, dtype=np.uint8)
+        nb_max = self.n_blocks(a.size)
+        sizes = np.zeros(nb_max, dtype=np.uint32)
+        out_len = ctypes.c_size_t(0)
+        nb = ctypes.c_size_t(0)
+        rc = self.lib.L.gzpx_compress_slab(self.h, a.ctypes.data, a.size, int(is_last),
+                                           out.ctypes.data, cap, ctypes.byref(out_len),
+                                           sizes.ctypes.data, nb_max, ctypes.byref(nb))
+        self.lib.check(rc, nb.value if rc == ERR_BLOCK_SIZE_EXCEEDED else None)
+        res = out[:out_len.value].tobytes()
+        if return_block_sizes:
+            return res, sizes[:nb.value].copy()
+        return res
+
+    def compress_slab_device(self, d_in_ptr, in_len, d_out_ptr, out_cap, is_last=True, stream=None,
+                             block_sizes=None):
+        """Device pointers in/out (gzpx_compress_slab_device).  Returns (out_len, n_blocks)."""
+        out_len = ctypes.c_size_t(0)
+        nb = ctypes.c_size_t(0)
+        bs_ptr, bs_n = (None, 0)
+        if block_sizes is not None:
+            bs_ptr, bs_n = block_sizes.ctypes.data, block_sizes.size
+        rc = self.lib.L.gzpx_compress_slab_device(self.h, d_in_ptr, in_len, int(is_last), d_out_ptr,
+                                                  out_cap, ctypes.byref(out_len), bs_ptr, bs_n,
+                                                  ctypes.byref(nb), stream)
+        self.lib.check(rc, nb.value if rc == ERR_BLOCK_SIZE_EXCEEDED else None)
+        return out_len.value, nb.value
+
+    def encode_block(self, data, is_last=False):
+        a = _u8(data)
+        cap = self.slab_bound(a.size)
+        out = np.empty(cap, dtype=np.uint8)
+        out_len = ctypes.c_size_t(0)
+        self.lib.check(self.lib.L.gzpx_encode_block(self.h, a.ctypes.data, a.size, int(is_last),
+                                                    out.ctypes.data, cap, ctypes.byref(out_len)))
+        return out[:out_len.value].tobytes()
+
+    def set_profiling(self, on=True):
+        self.lib.check(self.lib.L.gzpx_ctx_set_profiling(self.h, int(on)))
+
+    def last_stage_ms(self):
+        ms = (ctypes.c_float * N_STAGES)()
+        self.lib.check(self.lib.L.gzpx_ctx_last_stage_ms(self.h, ms))
+        return {self.lib.L.gzpx_stage_name(i).decode(): float(ms[i]) for i in range(N_STAGES)}
+
+    def debug_tokens(self, block):
+        toks = np.empty(65536, dtype=np.uint32)
+        first = np.zeros(4, dtype=np.uint32)
+        n = ctypes.c_size_t(0)
+        ns = ctypes.c_size_t(0)
+        self.lib.check(self.lib.L.gzpx_debug_tokens(self.h, block, toks.ctypes.data, toks.size,
+                                                    ctypes.byref(n), first.ctypes.data,
+                                                    ctypes.byref(ns)))
+        return toks[:n.value].copy(), first[:ns.value].copy()
+
+
+class Compressor:
+    """libdeflater::Compressor shape: alloc / deflate_compress / bound / free."""
+
+    def __init__(self, level=1, compat=COMPAT_1_24, lib=None):
+        self.lib = lib or load()
+        self.h = self.lib.L.gzpx_alloc_compressor(level)
+        if not self.h:
+            raise GzpxError(ERR_COMPRESSION_LEVEL, "gzpx_alloc_compressor failed")
+        self.lib.check(self.lib.L.gzpx_compressor_set_compat(self.h, compat))
+
+    def deflate_compress(self, data, cap=None):
+        a = _u8(data)
+        if cap is None:
+            cap = int(self.lib.L.gzpx_deflate_compress_bound(self.h, a.size))
+        out = np.empty(max(cap, 1), dtype=np.uint8)
+        n = self.lib.L.gzpx_deflate_compress(self.h, a.ctypes.data, a.size, out.ctypes.data, cap)
+        if n == 0:
+            raise GzpxError(ERR_INSUFFICIENT_SPACE, "gzpx_deflate_compress returned 0")
+        return out[:n].tobytes()
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.L.gzpx_free_compressor(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def crc32(data, crc=0, lib=None):
+    lib = lib or load()
+    a = _u8(data)
+    return int(lib.L.gzpx_crc32(crc, a.ctypes.data, a.size))

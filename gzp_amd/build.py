@@ -1,0 +1,37 @@
+"""Build gzp_amd/lib/libgzpx.so with hipcc for gfx950 (in-tree, so it travels with the repo)."""
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+LIB_DIR = os.path.join(_HERE, "lib")
+LIB = os.path.join(LIB_DIR, "libgzpx.so")
+INCLUDE = os.path.abspath(os.path.join(_HERE, "..", "include"))
+SOURCES = ["gzpx_kernels.hip", "gzpx_api.cpp", "gzpx_par.cpp"]
+
+
+def _hipcc():
+    for c in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
+        if c and (os.path.isabs(c) and os.path.exists(c) or not os.path.isabs(c)):
+            return c
+    return "hipcc"
+
+
+def build(force=False, verbose=False):
+    srcs = [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
+    deps = srcs + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".hpp"))]
+    deps.append(os.path.join(INCLUDE, "gzpx.h"))
+    if (not force and os.path.exists(LIB)
+            and os.path.getmtime(LIB) >= max(os.path.getmtime(d) for d in deps)):
+        return LIB
+    os.makedirs(LIB_DIR, exist_ok=True)
+    cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-pthread",
+           "-I", INCLUDE] + srcs + ["-o", LIB]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force=True, verbose=True))

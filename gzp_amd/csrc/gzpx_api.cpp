@@ -1,0 +1,534 @@
+// gzpx_api.cpp -- the C ABI of include/gzpx.h over the HIP pipeline of gzpx_kernels.hip.
+//
+// Host-side mirror of what a gzp worker thread does per block (src/par/compress.rs:279-294:
+// create_compressor once, encode per block) lifted to whole slabs: one call = every block of the
+// slab through the kernel pipeline, blocks cut and ordered exactly like ParCompress::write /
+// flush_last (src/par/compress.rs:413-463, 332-362).  No CPU fallback exists on purpose: without
+// a HIP device every entry point fails with GZPX_ERR_NO_DEVICE.
+#include <hip/hip_runtime.h>
+
+#include <mutex>
+#include <new>
+#include <string.h>
+#include <vector>
+
+#include "../../include/gzpx.h"
+#include "gzpx_device.h"
+
+using namespace gzpx;
+
+namespace {
+
+constexpr size_t kDictSize = 32768;  // DICT_SIZE, src/lib.rs:108
+constexpr uint32_t kMaxBatchBlocks = 16384;
+
+// ---- GF(2) polynomial helpers for CRC-32 combination (reflected representation) ----
+uint32_t multmodp(uint32_t a, uint32_t b) {
+    uint32_t m = 1u << 31, p = 0;
+    for (;;) {
+        if (a & m) {
+            p ^= b;
+            if ((a & (m - 1)) == 0) break;
+        }
+        m >>= 1;
+        b = (b & 1u) ? (b >> 1) ^ 0xEDB88320u : b >> 1;
+    }
+    return p;
+}
+
+// x^(2^k) mod P
+uint32_t x2k(unsigned k) {
+    uint32_t p = 1u << 30;  // x^1
+    for (unsigned i = 0; i < k; i++) p = multmodp(p, p);
+    return p;
+}
+
+// x^(8 * len) mod P
+uint32_t x8n(uint64_t len) {
+    uint32_t r = 1u << 31;  // x^0
+    unsigned k = 3;
+    while (len) {
+        if (len & 1) r = multmodp(x2k(k), r);
+        len >>= 1;
+        k++;
+    }
+    return r;
+}
+
+uint32_t crc32_combine(uint32_t crc1, uint32_t crc2, uint64_t len2) {
+    return multmodp(x8n(len2), crc1) ^ crc2;
+}
+
+struct StageEvents {
+    hipEvent_t ev[GZPX_N_STAGES + 1];
+    bool created = false;
+};
+
+}  // namespace
+
+struct gzpx_ctx {
+    gzpx_config cfg;
+    Config dcfg;
+    CrcConsts crc_consts;
+    hipStream_t stream = nullptr;
+    uint32_t batch_blocks = 0;
+    Scratch scratch = {};
+    uint8_t *d_in = nullptr;
+    size_t d_in_cap = 0;
+    uint8_t *d_out = nullptr;
+    size_t d_out_cap = 0;
+    BlockMeta *h_meta = nullptr;  // pinned, batch_blocks entries
+    uint64_t *h_total = nullptr;  // pinned
+    StageEvents events;
+    bool profiling = false;
+    float stage_ms[GZPX_N_STAGES] = {0};
+    // last call bookkeeping for the debug hooks
+    uint32_t last_nb = 0;
+    char devname[256] = {0};
+    std::mutex mu;
+};
+
+namespace {
+
+#define HIP_TRY(expr)                          \
+    do {                                       \
+        hipError_t _e = (expr);                \
+        if (_e != hipSuccess) return GZPX_ERR_DEVICE; \
+    } while (0)
+
+size_t extra_amount(size_t n) {  // src/bgzf.rs:45,50-52
+    size_t e = (size_t)((double)n * 0.1);
+    return e < 128 ? 128 : e;
+}
+
+size_t framed_bound_per_block(const gzpx_ctx *ctx) {
+    const size_t hdr = ctx->cfg.format == GZPX_FORMAT_BGZF ? 18 : 20;
+    return hdr + ctx->cfg.buffer_size + extra_amount(ctx->cfg.buffer_size) + 8;
+}
+
+uint64_t blocks_of(const gzpx_ctx *ctx, size_t in_len) {
+    const size_t bs = ctx->cfg.buffer_size;
+    return in_len == 0 ? 1 : (in_len + bs - 1) / bs;
+}
+
+int alloc_scratch(gzpx_ctx *ctx) {
+    const size_t nb = ctx->batch_blocks;
+    Scratch &s = ctx->scratch;
+    HIP_TRY(hipMalloc((void **)&s.meta, nb * sizeof(BlockMeta)));
+    HIP_TRY(hipMalloc((void **)&s.cand, nb * (size_t)kCandStride * 4));
+    HIP_TRY(hipMalloc((void **)&s.tok, nb * (size_t)kTokStride * 4));
+    HIP_TRY(hipMalloc((void **)&s.hist, nb * (size_t)kMaxSub * kHistStride * 4));
+    HIP_TRY(hipMalloc((void **)&s.codes, nb * (size_t)kMaxSub * kCodeWords * 4));
+    HIP_TRY(hipMalloc((void **)&s.hdr, nb * (size_t)kMaxSub * kHdrWords * 4));
+    HIP_TRY(hipMalloc((void **)&s.out_off, (nb + 1) * sizeof(uint64_t)));
+    HIP_TRY(hipHostMalloc((void **)&ctx->h_meta, nb * sizeof(BlockMeta), hipHostMallocDefault));
+    HIP_TRY(hipHostMalloc((void **)&ctx->h_total, 64, hipHostMallocDefault));
+    return GZPX_OK;
+}
+
+void free_scratch(gzpx_ctx *ctx) {
+    Scratch &s = ctx->scratch;
+    if (s.meta) (void)hipFree(s.meta);
+    if (s.cand) (void)hipFree(s.cand);
+    if (s.tok) (void)hipFree(s.tok);
+    if (s.hist) (void)hipFree(s.hist);
+    if (s.codes) (void)hipFree(s.codes);
+    if (s.hdr) (void)hipFree(s.hdr);
+    if (s.out_off) (void)hipFree(s.out_off);
+    if (ctx->h_meta) (void)hipHostFree(ctx->h_meta);
+    if (ctx->h_total) (void)hipHostFree(ctx->h_total);
+    if (ctx->d_in) (void)hipFree(ctx->d_in);
+    if (ctx->d_out) (void)hipFree(ctx->d_out);
+    s = Scratch{};
+}
+
+// One batch of blocks through the pipeline.  d_in/d_out are device pointers for this batch.
+int run_batch(gzpx_ctx *ctx, const uint8_t *d_in, size_t in_len, uint32_t nb, int is_last,
+              uint8_t *d_out, size_t out_cap, hipStream_t stream, size_t *produced,
+              uint32_t *block_sizes, size_t *fail_block) {
+    const Config &c = ctx->dcfg;
+    const Scratch &s = ctx->scratch;
+    const bool prof = ctx->profiling;
+    hipEvent_t *ev = ctx->events.ev;
+    int k = 0;
+    if (prof) HIP_TRY(hipEventRecord(ev[k], stream));
+    launch_init_meta(c, in_len, nb, is_last, s, stream);
+    if (prof) HIP_TRY(hipEventRecord(ev[++k], stream));
+    launch_candidates(c, d_in, in_len, nb, s, stream);
+    if (prof) HIP_TRY(hipEventRecord(ev[++k], stream));
+    launch_match_parse(c, d_in, in_len, nb, s, stream);
+    if (prof) HIP_TRY(hipEventRecord(ev[++k], stream));
+    launch_huffman(c, nb, s, stream);
+    if (prof) HIP_TRY(hipEventRecord(ev[++k], stream));
+    launch_crc32(c, d_in, in_len, nb, s, ctx->crc_consts, stream);
+    if (prof) HIP_TRY(hipEventRecord(ev[++k], stream));
+    launch_scan(nb, s, stream);
+    if (prof) HIP_TRY(hipEventRecord(ev[++k], stream));
+    launch_emit(c, d_in, in_len, nb, s, d_out, out_cap, stream);
+    if (prof) HIP_TRY(hipEventRecord(ev[++k], stream));
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(ctx->h_total, s.out_off + nb, sizeof(uint64_t), hipMemcpyDeviceToHost,
+                           stream));
+    HIP_TRY(hipMemcpyAsync(ctx->h_meta, s.meta, nb * sizeof(BlockMeta), hipMemcpyDeviceToHost,
+                           stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    if (prof) {
+        for (int i = 0; i < GZPX_N_STAGES; i++) {
+            float ms = 0;
+            HIP_TRY(hipEventElapsedTime(&ms, ev[i], ev[i + 1]));
+            ctx->stage_ms[i] += ms;
+        }
+    }
+    ctx->last_nb = nb;
+    for (uint32_t b = 0; b < nb; b++) {
+        if (ctx->h_meta[b].status == kStatusBlockSizeExceeded) {
+            *fail_block = b;
+            return GZPX_ERR_BLOCK_SIZE_EXCEEDED;
+        }
+        if (block_sizes) block_sizes[b] = ctx->h_meta[b].framed_bytes;
+    }
+    *produced = (size_t)*ctx->h_total;
+    if (*produced > out_cap) return GZPX_ERR_INSUFFICIENT_SPACE;
+    return GZPX_OK;
+}
+
+int compress_device_locked(gzpx_ctx *ctx, const uint8_t *d_in, size_t in_len, int is_last,
+                           uint8_t *d_out, size_t out_cap, size_t *out_len, uint32_t *block_sizes,
+                           size_t max_blocks, size_t *n_blocks, hipStream_t stream) {
+    const size_t bs = ctx->cfg.buffer_size;
+    if (!is_last && (in_len == 0 || in_len % bs != 0)) return GZPX_ERR_INVALID_ARG;
+    if ((in_len && !d_in) || !d_out || !out_len) return GZPX_ERR_INVALID_ARG;
+    const uint64_t total_nb = blocks_of(ctx, in_len);
+    if (block_sizes && max_blocks < total_nb) return GZPX_ERR_INVALID_ARG;
+    if (!stream) stream = ctx->stream;
+    memset(ctx->stage_ms, 0, sizeof(ctx->stage_ms));
+    size_t produced_total = 0;
+    for (uint64_t b0 = 0; b0 < total_nb; b0 += ctx->batch_blocks) {
+        const uint32_t nb = (uint32_t)((total_nb - b0 < ctx->batch_blocks) ? total_nb - b0
+                                                                          : ctx->batch_blocks);
+        const size_t in_begin = (size_t)b0 * bs;
+        size_t in_batch = in_len > in_begin ? in_len - in_begin : 0;
+        if (in_batch > (size_t)nb * bs) in_batch = (size_t)nb * bs;
+        const int last_batch = (b0 + nb == total_nb) ? is_last : 0;
+        size_t produced = 0, fail = 0;
+        int rc = run_batch(ctx, d_in + in_begin, in_batch, nb, last_batch, d_out + produced_total,
+                           out_cap - produced_total, stream, &produced,
+                           block_sizes ? block_sizes + b0 : nullptr, &fail);
+        if (rc != GZPX_OK) {
+            if (n_blocks) *n_blocks = (size_t)(b0 + fail);
+            return rc;
+        }
+        produced_total += produced;
+    }
+    *out_len = produced_total;
+    if (n_blocks) *n_blocks = (size_t)total_nb;
+    return GZPX_OK;
+}
+
+int ensure_buffers(gzpx_ctx *ctx, size_t in_len, size_t out_need) {
+    if (in_len + 16 > ctx->d_in_cap) {
+        if (ctx->d_in) (void)hipFree(ctx->d_in);
+        ctx->d_in = nullptr;
+        ctx->d_in_cap = 0;
+        const size_t cap = in_len + in_len / 8 + 4096;
+        HIP_TRY(hipMalloc((void **)&ctx->d_in, cap));
+        ctx->d_in_cap = cap;
+    }
+    if (out_need > ctx->d_out_cap) {
+        if (ctx->d_out) (void)hipFree(ctx->d_out);
+        ctx->d_out = nullptr;
+        ctx->d_out_cap = 0;
+        const size_t cap = out_need + out_need / 8 + 4096;
+        HIP_TRY(hipMalloc((void **)&ctx->d_out, cap));
+        ctx->d_out_cap = cap;
+    }
+    return GZPX_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+void gzpx_config_default(gzpx_config *cfg, int format) {
+    if (!cfg) return;
+    cfg->device = 0;
+    cfg->format = format;
+    cfg->level = 3;  // ParCompressBuilder::new: Compression::new(3), src/par/compress.rs:54-62
+    cfg->compat = GZPX_COMPAT_LIBDEFLATE_1_24;
+    // Bgzf::DEFAULT_BUFSIZE = 65280 (src/deflate.rs:583); Mgzip keeps the trait default
+    // DEFAULT_BUFSIZE = BUFSIZE = 128 KiB (src/lib.rs:330, :105)
+    cfg->buffer_size = format == GZPX_FORMAT_BGZF ? 65280 : 131072;
+    cfg->max_slab_bytes = (size_t)1 << 30;
+}
+
+int gzpx_ctx_create(const gzpx_config *cfg, gzpx_ctx **out) {
+    if (!cfg || !out) return GZPX_ERR_INVALID_ARG;
+    *out = nullptr;
+    if (cfg->format != GZPX_FORMAT_BGZF && cfg->format != GZPX_FORMAT_MGZIP) return GZPX_ERR_INVALID_ARG;
+    if (cfg->buffer_size < kDictSize) return GZPX_ERR_BUFFER_SIZE;  // src/par/compress.rs:68-74
+    if (cfg->level < 0 || cfg->level > 12) return GZPX_ERR_COMPRESSION_LEVEL;
+    if (cfg->compat != GZPX_COMPAT_LIBDEFLATE_1_24 && cfg->compat != GZPX_COMPAT_LIBDEFLATE_1_10)
+        return GZPX_ERR_INVALID_ARG;
+    if (cfg->level != 1) return GZPX_ERR_UNSUPPORTED;             // levels 0, 2..12: not built yet
+    if (cfg->buffer_size > kMaxUnit) return GZPX_ERR_UNSUPPORTED;  // > 64 KiB blocks: not built yet
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return GZPX_ERR_NO_DEVICE;
+    if (cfg->device < 0 || cfg->device >= ndev) return GZPX_ERR_INVALID_ARG;
+    if (hipSetDevice(cfg->device) != hipSuccess) return GZPX_ERR_DEVICE;
+
+    gzpx_ctx *ctx = new (std::nothrow) gzpx_ctx();
+    if (!ctx) return GZPX_ERR_DEVICE;
+    ctx->cfg = *cfg;
+    ctx->dcfg.format = (uint32_t)cfg->format;
+    ctx->dcfg.level = (uint32_t)cfg->level;
+    ctx->dcfg.compat = (uint32_t)cfg->compat;
+    ctx->dcfg.block_size = (uint32_t)cfg->buffer_size;
+    ctx->dcfg.xfl = cfg->level >= 9 ? 2u : cfg->level <= 1 ? 4u : 0u;  // src/bgzf.rs:278-284
+    for (unsigned l = 0; l < 8; l++) ctx->crc_consts.pow256[l] = x2k(11 + l);
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, cfg->device) == hipSuccess) {
+        snprintf(ctx->devname, sizeof(ctx->devname), "%s (%s, %d CUs)", prop.name, prop.gcnArchName,
+                 prop.multiProcessorCount);
+    }
+    const uint64_t want = blocks_of(ctx, cfg->max_slab_bytes ? cfg->max_slab_bytes : 1);
+    ctx->batch_blocks = (uint32_t)(want < kMaxBatchBlocks ? want : kMaxBatchBlocks);
+    if (ctx->batch_blocks == 0) ctx->batch_blocks = 1;
+    int rc = GZPX_OK;
+    if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) rc = GZPX_ERR_DEVICE;
+    if (rc == GZPX_OK) rc = alloc_scratch(ctx);
+    if (rc == GZPX_OK) {
+        for (int i = 0; i <= GZPX_N_STAGES; i++)
+            if (hipEventCreate(&ctx->events.ev[i]) != hipSuccess) rc = GZPX_ERR_DEVICE;
+        ctx->events.created = (rc == GZPX_OK);
+    }
+    if (rc != GZPX_OK) {
+        gzpx_ctx_destroy(ctx);
+        return rc;
+    }
+    *out = ctx;
+    return GZPX_OK;
+}
+
+void gzpx_ctx_destroy(gzpx_ctx *ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->cfg.device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    free_scratch(ctx);
+    if (ctx->events.created)
+        for (int i = 0; i <= GZPX_N_STAGES; i++) (void)hipEventDestroy(ctx->events.ev[i]);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+size_t gzpx_slab_bound(const gzpx_ctx *ctx, size_t in_len) {
+    if (!ctx) return 0;
+    return (size_t)blocks_of(ctx, in_len) * framed_bound_per_block(ctx) + 28 + 64;
+}
+
+int gzpx_compress_slab_device(gzpx_ctx *ctx, const void *d_in, size_t in_len, int is_last,
+                              void *d_out, size_t out_cap, size_t *out_len, uint32_t *block_sizes,
+                              size_t max_blocks, size_t *n_blocks, void *hip_stream) {
+    if (!ctx) return GZPX_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    if (hipSetDevice(ctx->cfg.device) != hipSuccess) return GZPX_ERR_DEVICE;
+    return compress_device_locked(ctx, (const uint8_t *)d_in, in_len, is_last, (uint8_t *)d_out,
+                                  out_cap, out_len, block_sizes, max_blocks, n_blocks,
+                                  (hipStream_t)hip_stream);
+}
+
+int gzpx_compress_slab(gzpx_ctx *ctx, const uint8_t *in, size_t in_len, int is_last, uint8_t *out,
+                       size_t out_cap, size_t *out_len, uint32_t *block_sizes, size_t max_blocks,
+                       size_t *n_blocks) {
+    if (!ctx || (in_len && !in) || !out || !out_len) return GZPX_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    if (hipSetDevice(ctx->cfg.device) != hipSuccess) return GZPX_ERR_DEVICE;
+    const size_t need = gzpx_slab_bound(ctx, in_len);
+    int rc = ensure_buffers(ctx, in_len, need);
+    if (rc != GZPX_OK) return rc;
+    if (in_len) HIP_TRY(hipMemcpyAsync(ctx->d_in, in, in_len, hipMemcpyHostToDevice, ctx->stream));
+    size_t produced = 0;
+    rc = compress_device_locked(ctx, ctx->d_in, in_len, is_last, ctx->d_out, ctx->d_out_cap, &produced,
+                                block_sizes, max_blocks, n_blocks, ctx->stream);
+    if (rc != GZPX_OK) return rc;
+    if (produced > out_cap) return GZPX_ERR_INSUFFICIENT_SPACE;
+    HIP_TRY(hipMemcpyAsync(out, ctx->d_out, produced, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    *out_len = produced;
+    return GZPX_OK;
+}
+
+int gzpx_encode_block(gzpx_ctx *ctx, const uint8_t *in, size_t n, int is_last, uint8_t *out,
+                      size_t out_cap, size_t *out_len) {
+    if (!ctx) return GZPX_ERR_INVALID_ARG;
+    if (n > ctx->cfg.buffer_size) return GZPX_ERR_INVALID_ARG;
+    // Bgzf::encode always runs on one block; EOF only when is_last (src/deflate.rs:613-626).
+    // A non-last block shorter than buffer_size (flush(), Q2) is still one block: run it as a
+    // "last" slab of a context-independent single block and strip nothing -- the EOF marker is
+    // the only is_last effect, so compress as last and drop the 28 trailing bytes if needed.
+    std::vector<uint8_t> tmp(gzpx_slab_bound(ctx, n));
+    size_t got = 0, nb = 0;
+    int rc = gzpx_compress_slab(ctx, in, n, 1, tmp.data(), tmp.size(), &got, nullptr, 0, &nb);
+    if (rc != GZPX_OK) return rc;
+    if (!is_last && ctx->cfg.format == GZPX_FORMAT_BGZF) got -= 28;
+    if (got > out_cap) return GZPX_ERR_INSUFFICIENT_SPACE;
+    memcpy(out, tmp.data(), got);
+    *out_len = got;
+    return GZPX_OK;
+}
+
+// ---------------------------------------------------------------- libdeflate-shaped ABI
+struct gzpx_compressor {
+    int level;
+    int compat;
+    gzpx_ctx *ctx;
+    std::vector<uint8_t> tmp;
+};
+
+gzpx_compressor *gzpx_alloc_compressor(int level) {
+    if (level < 0 || level > 12) return nullptr;
+    gzpx_compressor *c = new (std::nothrow) gzpx_compressor();
+    if (!c) return nullptr;
+    c->level = level;
+    c->compat = GZPX_COMPAT_LIBDEFLATE_1_24;
+    c->ctx = nullptr;
+    return c;
+}
+
+int gzpx_compressor_set_compat(gzpx_compressor *c, int compat) {
+    if (!c || c->ctx) return GZPX_ERR_INVALID_ARG;
+    c->compat = compat;
+    return GZPX_OK;
+}
+
+static int compressor_ctx(gzpx_compressor *c) {
+    if (c->ctx) return GZPX_OK;
+    gzpx_config cfg;
+    gzpx_config_default(&cfg, GZPX_FORMAT_MGZIP);  // Mgzip framing has no payload size limit
+    cfg.level = c->level;
+    cfg.compat = c->compat;
+    cfg.buffer_size = kMaxUnit;
+    cfg.max_slab_bytes = kMaxUnit;
+    return gzpx_ctx_create(&cfg, &c->ctx);
+}
+
+size_t gzpx_deflate_compress(gzpx_compressor *c, const void *in, size_t n, void *out, size_t cap) {
+    if (!c || (!in && n) || !out) return 0;
+    if (n > kMaxUnit) return 0;  // TODO(next): inputs above one 64 KiB unit
+    if (compressor_ctx(c) != GZPX_OK) return 0;
+    c->tmp.resize(gzpx_slab_bound(c->ctx, n));
+    size_t got = 0, nb = 0;
+    if (gzpx_compress_slab(c->ctx, (const uint8_t *)in, n, 1, c->tmp.data(), c->tmp.size(), &got,
+                           nullptr, 0, &nb) != GZPX_OK)
+        return 0;
+    const size_t payload = got - 20 - 8;
+    if (payload > cap) return 0;  // libdeflate: 0 when the output does not fit
+    memcpy(out, c->tmp.data() + 20, payload);
+    return payload;
+}
+
+size_t gzpx_deflate_compress_bound(gzpx_compressor *, size_t n) {
+    // libdeflate_deflate_compress_bound: stored blocks of >= 10000 bytes, 5 bytes each, + slack
+    size_t max_blocks = (n + 9999) / 10000;
+    if (max_blocks < 1) max_blocks = 1;
+    return 5 * max_blocks + n + 1 + 8;
+}
+
+void gzpx_free_compressor(gzpx_compressor *c) {
+    if (!c) return;
+    if (c->ctx) gzpx_ctx_destroy(c->ctx);
+    delete c;
+}
+
+uint32_t gzpx_crc32(uint32_t crc, const void *buf, size_t n) {
+    // libdeflate_crc32 semantics: crc32(crc, buf) = combine(crc, crc32(0, buf), n)
+    static std::mutex mu;
+    static gzpx_ctx *ctx = nullptr;
+    std::lock_guard<std::mutex> lock(mu);
+    if (!ctx) {
+        gzpx_config cfg;
+        gzpx_config_default(&cfg, GZPX_FORMAT_MGZIP);
+        cfg.level = 1;
+        cfg.buffer_size = kMaxUnit;
+        cfg.max_slab_bytes = (size_t)64 << 20;
+        if (gzpx_ctx_create(&cfg, &ctx) != GZPX_OK) return 0;
+    }
+    if (n == 0) return crc;
+    std::lock_guard<std::mutex> lock2(ctx->mu);
+    if (hipSetDevice(ctx->cfg.device) != hipSuccess) return 0;
+    const uint8_t *p = (const uint8_t *)buf;
+    const size_t slab_max = (size_t)ctx->batch_blocks * kMaxUnit;
+    while (n) {
+        const size_t take = n < slab_max ? n : slab_max;
+        if (ensure_buffers(ctx, take, 64) != GZPX_OK) return 0;
+        const uint32_t nb = (uint32_t)((take + kMaxUnit - 1) / kMaxUnit);
+        if (hipMemcpyAsync(ctx->d_in, p, take, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) return 0;
+        launch_init_meta(ctx->dcfg, take, nb, 0, ctx->scratch, ctx->stream);
+        launch_crc32(ctx->dcfg, ctx->d_in, take, nb, ctx->scratch, ctx->crc_consts, ctx->stream);
+        if (hipMemcpyAsync(ctx->h_meta, ctx->scratch.meta, nb * sizeof(BlockMeta), hipMemcpyDeviceToHost,
+                           ctx->stream) != hipSuccess)
+            return 0;
+        if (hipStreamSynchronize(ctx->stream) != hipSuccess) return 0;
+        for (uint32_t b = 0; b < nb; b++)
+            crc = crc32_combine(crc, ctx->h_meta[b].crc, ctx->h_meta[b].n);
+        p += take;
+        n -= take;
+    }
+    return crc;
+}
+
+// ---------------------------------------------------------------- measurement / debug hooks
+int gzpx_ctx_set_profiling(gzpx_ctx *ctx, int on) {
+    if (!ctx) return GZPX_ERR_INVALID_ARG;
+    ctx->profiling = on != 0;
+    return GZPX_OK;
+}
+
+int gzpx_ctx_last_stage_ms(const gzpx_ctx *ctx, float ms[GZPX_N_STAGES]) {
+    if (!ctx || !ms) return GZPX_ERR_INVALID_ARG;
+    for (int i = 0; i < GZPX_N_STAGES; i++) ms[i] = ctx->stage_ms[i];
+    return GZPX_OK;
+}
+
+const char *gzpx_stage_name(int stage) {
+    static const char *names[GZPX_N_STAGES] = {"k_init_meta", "k_candidates", "k_match_parse",
+                                               "k_huffman",   "k_crc32",      "k_scan",
+                                               "k_emit"};
+    return (stage >= 0 && stage < GZPX_N_STAGES) ? names[stage] : "?";
+}
+
+int gzpx_debug_tokens(gzpx_ctx *ctx, size_t block, uint32_t *tokens, size_t max_tokens,
+                      size_t *n_tokens, uint32_t *sub_first_token, size_t *n_sub) {
+    if (!ctx || !n_tokens || block >= ctx->last_nb) return GZPX_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    if (hipSetDevice(ctx->cfg.device) != hipSuccess) return GZPX_ERR_DEVICE;
+    const BlockMeta &m = ctx->h_meta[block];
+    *n_tokens = m.ntok;
+    if (n_sub) *n_sub = m.nsub;
+    if (sub_first_token)
+        for (uint32_t s = 0; s < m.nsub && s < kMaxSub; s++) sub_first_token[s] = m.sub[s].tok_begin;
+    const size_t ncopy = m.ntok < max_tokens ? m.ntok : max_tokens;
+    if (tokens && ncopy)
+        HIP_TRY(hipMemcpy(tokens, ctx->scratch.tok + block * (size_t)kTokStride, ncopy * 4,
+                          hipMemcpyDeviceToHost));
+    return GZPX_OK;
+}
+
+const char *gzpx_strerror(int code) {
+    switch (code) {
+        case GZPX_OK: return "ok";
+        case GZPX_ERR_INVALID_ARG: return "invalid argument";
+        case GZPX_ERR_BUFFER_SIZE: return "buffer size must be >= 32768 (GzpError::BufferSize)";
+        case GZPX_ERR_COMPRESSION_LEVEL: return "invalid compression level (GzpError::LibDeflaterCompressionLvl)";
+        case GZPX_ERR_INSUFFICIENT_SPACE: return "insufficient output space (GzpError::LibDeflaterCompress)";
+        case GZPX_ERR_BLOCK_SIZE_EXCEEDED: return "compressed block >= 65536 bytes (GzpError::BlockSizeExceeded)";
+        case GZPX_ERR_DEVICE: return "HIP runtime error";
+        case GZPX_ERR_NO_DEVICE: return "no HIP device (no CPU fallback exists)";
+        case GZPX_ERR_UNSUPPORTED: return "configuration valid in gzp but not built yet";
+        default: return "unknown error";
+    }
+}
+
+const char *gzpx_device_name(const gzpx_ctx *ctx) { return ctx ? ctx->devname : ""; }
+const char *gzpx_version(void) { return "gzpx 0.1 (gfx950)"; }
+
+}  // extern "C"

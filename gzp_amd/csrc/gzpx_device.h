@@ -1,0 +1,93 @@
+// gzpx_device.h -- data layout shared by the HIP kernels and the host pipeline.
+//
+// Vocabulary (follows the reference): a *block* is one BGZF/Mgzip member = one `buffer_size`
+// cut of the caller's stream (src/par/compress.rs:415-416); a *sub-block* is one DEFLATE block
+// inside its payload (libdeflate starts a new one every 8192 matches); a *token* is one
+// literal or one match of the level-1 greedy parse.
+#pragma once
+#include <stdint.h>
+
+namespace gzpx {
+
+constexpr unsigned kMaxUnit = 65536;       // max input bytes per block handled by the kernels
+constexpr unsigned kCandStride = kMaxUnit; // u32 per position
+constexpr unsigned kTokStride = kMaxUnit;  // u32 per token (worst case: all literals)
+constexpr unsigned kMaxSub = 2;            // n <= 65536 => at most 2 sub-blocks (8192 matches each)
+constexpr unsigned kSeqPerSub = 8192;      // FAST_SEQ_STORE_LENGTH
+constexpr unsigned kNumLitlen = 288;
+constexpr unsigned kNumOffset = 32;
+constexpr unsigned kHistStride = kNumLitlen + kNumOffset;  // 320 u32 per sub-block
+constexpr unsigned kHdrWords = 160;                        // dynamic header bit string, <= 4554 bits
+constexpr unsigned kCodeWords = kNumLitlen + kNumOffset;   // (codeword | len << 16) per symbol
+constexpr unsigned kPassthroughL1 = 51;                    // n <= 55 - 4*level => stored only
+
+constexpr uint32_t kTokMatch = 0x80000000u;  // token = kTokMatch | offset << 9 | length
+
+enum SubType : uint32_t { kStored = 0, kStatic = 1, kDynamic = 2 };
+
+enum BlockStatus : uint32_t {
+    kStatusOk = 0,
+    kStatusBlockSizeExceeded = 2,  // BGZF payload >= 65536 (src/bgzf.rs:218-223)
+};
+
+struct SubMeta {
+    uint32_t type;       // SubType
+    uint32_t tok_begin;  // token range in the block's token array
+    uint32_t tok_end;
+    uint32_t byte_begin;  // input range covered (for stored blocks and the uncompressed cost)
+    uint32_t byte_len;
+    uint32_t bit_begin;  // first bit of this sub-block inside the payload
+    uint32_t hdr_bits;   // bits of BFINAL+BTYPE(+dynamic header) held in hdr[]
+    uint32_t is_final;
+};
+
+struct BlockMeta {
+    uint32_t n;              // input bytes
+    uint32_t is_last;        // append BGZF_EOF
+    uint32_t ntok;
+    uint32_t nsub;
+    uint32_t payload_bytes;  // raw DEFLATE size c
+    uint32_t framed_bytes;   // header + c + footer (+ EOF)
+    uint32_t crc;
+    uint32_t status;
+    SubMeta sub[kMaxSub];
+};
+
+struct CrcConsts {
+    uint32_t pow256[8];  // x^(8*256*2^l) mod P (reflected), l = 0..7
+};
+
+struct Config {
+    uint32_t format;      // 0 BGZF, 1 Mgzip
+    uint32_t level;       // 1
+    uint32_t compat;      // 0: libdeflate >= 1.1x Huffman rule, 1: libdeflate 1.10
+    uint32_t block_size;  // buffer_size of the reference's builder
+    uint32_t xfl;         // gzip XFL byte derived from level (src/bgzf.rs:278-284)
+};
+
+// Device scratch for one batch of blocks.
+struct Scratch {
+    BlockMeta *meta;      // [nb]
+    uint32_t *cand;       // [nb][kCandStride]   d0 | d1 << 16 (match distances, 0 = none)
+    uint32_t *tok;        // [nb][kTokStride]
+    uint32_t *hist;       // [nb][kMaxSub][kHistStride]
+    uint32_t *codes;      // [nb][kMaxSub][kCodeWords]
+    uint32_t *hdr;        // [nb][kMaxSub][kHdrWords]
+    uint64_t *out_off;    // [nb + 1] byte offset of each framed block in the output
+};
+
+// Host-side launchers (gzpx_kernels.hip).  All asynchronous on `stream`.
+void launch_init_meta(const Config &cfg, uint64_t slab_len, uint32_t nb, int is_last,
+                      const Scratch &s, hipStream_t stream);
+void launch_candidates(const Config &cfg, const uint8_t *slab, uint64_t slab_len, uint32_t nb,
+                       const Scratch &s, hipStream_t stream);
+void launch_match_parse(const Config &cfg, const uint8_t *slab, uint64_t slab_len, uint32_t nb,
+                        const Scratch &s, hipStream_t stream);
+void launch_huffman(const Config &cfg, uint32_t nb, const Scratch &s, hipStream_t stream);
+void launch_crc32(const Config &cfg, const uint8_t *slab, uint64_t slab_len, uint32_t nb,
+                  const Scratch &s, const CrcConsts &cc, hipStream_t stream);
+void launch_scan(uint32_t nb, const Scratch &s, hipStream_t stream);
+void launch_emit(const Config &cfg, const uint8_t *slab, uint64_t slab_len, uint32_t nb,
+                 const Scratch &s, uint8_t *out, uint64_t out_cap, hipStream_t stream);
+
+}  // namespace gzpx

@@ -1,0 +1,130 @@
+/*
+ * gzpx.h -- C ABI of the MI355X-native per-block encoder behind gzp's ParCompress<Bgzf/Mgzip>.
+ *
+ * This is the drop-in boundary: the entry points are what gzp's FFI for this path binds today
+ * (libdeflater -> libdeflate-sys), plus one slab-level call that lets the orchestration layer
+ * hand thousands of blocks to the GPU at once.  Plain pointers and sizes only.
+ *
+ * Reference interfaces replaced (paths relative to the gzp tree, v2.0.1):
+ *
+ *   gzpx_alloc_compressor      libdeflater::Compressor::new            src/deflate.rs:596-599 (Bgzf::create_compressor)
+ *                              = libdeflate_alloc_compressor            /opt/conda/include/libdeflate.h:62-69
+ *   gzpx_deflate_compress      Compressor::deflate_compress            src/bgzf.rs:214-216, src/mgzip.rs:201-203
+ *                              = libdeflate_deflate_compress            libdeflate.h:88-91
+ *   gzpx_deflate_compress_bound  Compressor::deflate_compress_bound    libdeflate.h:93-95
+ *   gzpx_free_compressor       Drop for Compressor                     libdeflate.h:117
+ *   gzpx_crc32                 libdeflater::Crc::update / sum          src/bgzf.rs:224-225, src/check.rs:62,70
+ *                              = libdeflate_crc32                       libdeflate.h:343-344
+ *   gzpx_encode_block          FormatSpec::encode for Bgzf / Mgzip     src/lib.rs:351-358, src/deflate.rs:613-626, 463-472
+ *                              (= bgzf::compress src/bgzf.rs:204-237 + BGZF_EOF src/bgzf.rs:24-38)
+ *   gzpx_compress_slab*        the worker loop of ParCompress::run     src/par/compress.rs:279-294, applied to every
+ *                              block of a slab cut by ParCompress::write / flush_last (src/par/compress.rs:413-463, 332-362)
+ *   error codes                GzpError variants on this path          src/lib.rs:114-163
+ *
+ * Results are byte-identical to the reference's libdeflate path at the same level (see
+ * DESIGN.md for the one libdeflate-version-dependent rule selected by `compat`).
+ */
+#ifndef GZPX_H
+#define GZPX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- status codes (GzpError classes reachable on the path, src/lib.rs:114-163) ---- */
+#define GZPX_OK 0
+#define GZPX_ERR_INVALID_ARG 1         /* null pointer, non-multiple slab, ...                       */
+#define GZPX_ERR_BUFFER_SIZE 2         /* GzpError::BufferSize: buffer_size < DICT_SIZE (32768)       */
+#define GZPX_ERR_COMPRESSION_LEVEL 3   /* GzpError::LibDeflaterCompressionLvl                         */
+#define GZPX_ERR_INSUFFICIENT_SPACE 4  /* GzpError::LibDeflaterCompress(InsufficientSpace)            */
+#define GZPX_ERR_BLOCK_SIZE_EXCEEDED 5 /* GzpError::BlockSizeExceeded(c, 65536), src/bgzf.rs:218-223  */
+#define GZPX_ERR_DEVICE 6              /* HIP runtime error (the Io-like class)                       */
+#define GZPX_ERR_NO_DEVICE 7           /* no MI355X / HIP device: there is NO CPU fallback            */
+#define GZPX_ERR_UNSUPPORTED 8         /* valid in the reference, not built yet (level, block size)   */
+
+#define GZPX_FORMAT_BGZF 0
+#define GZPX_FORMAT_MGZIP 1
+
+/* libdeflate behaviour pinned by Cargo.lock is 1.24; the image's binary oracle is 1.10.  The two
+ * differ (for levels 1-4) only in how a Huffman code with no used symbol is emitted. */
+#define GZPX_COMPAT_LIBDEFLATE_1_24 0
+#define GZPX_COMPAT_LIBDEFLATE_1_10 1
+
+typedef struct gzpx_config {
+    int device;                /* HIP device ordinal                                              */
+    int format;                /* GZPX_FORMAT_*                                                   */
+    int level;                 /* flate2::Compression level (0..12 accepted by libdeflate)        */
+    int compat;                /* GZPX_COMPAT_*                                                   */
+    size_t buffer_size;        /* ParCompressBuilder::buffer_size (65280 default for BGZF)        */
+    size_t max_slab_bytes;     /* largest slab a single gzpx_compress_slab* call will be given    */
+} gzpx_config;
+
+typedef struct gzpx_ctx gzpx_ctx;
+
+/* Fills *cfg with the reference's defaults for `format` (Bgzf: buffer_size 65280, level 3 ->
+ * callers set the level they use; compat 1.24; device 0; max_slab_bytes 1 GiB). */
+void gzpx_config_default(gzpx_config *cfg, int format);
+
+/* Validates like ParCompressBuilder (src/par/compress.rs:68-74) + CompressionLvl::new and
+ * allocates device scratch.  Fails with GZPX_ERR_NO_DEVICE when no GPU is present. */
+int gzpx_ctx_create(const gzpx_config *cfg, gzpx_ctx **out);
+void gzpx_ctx_destroy(gzpx_ctx *ctx);
+
+/* Upper bound of the bytes gzpx_compress_slab* can produce for in_len input bytes. */
+size_t gzpx_slab_bound(const gzpx_ctx *ctx, size_t in_len);
+
+/*
+ * Compress one slab held in HOST memory.  The slab is cut into buffer_size blocks exactly as
+ * ParCompress::write does; when is_last == 0, in_len must be a non-zero multiple of
+ * buffer_size (the caller keeps the remainder, as write() does); when is_last != 0 the final
+ * piece may be short or empty and, for BGZF, is followed by the EOF marker.
+ * out receives the framed blocks back to back; block_sizes[i] (optional) the framed size of
+ * block i.  On GZPX_ERR_BLOCK_SIZE_EXCEEDED, *n_blocks holds the index of the failing block.
+ */
+int gzpx_compress_slab(gzpx_ctx *ctx, const uint8_t *in, size_t in_len, int is_last, uint8_t *out,
+                       size_t out_cap, size_t *out_len, uint32_t *block_sizes, size_t max_blocks,
+                       size_t *n_blocks);
+
+/* Same, with the slab and the output already resident in DEVICE memory (d_in, d_out are device
+ * pointers; hip_stream is a hipStream_t or NULL for the context's own stream).  Synchronous
+ * with respect to the host on return. */
+int gzpx_compress_slab_device(gzpx_ctx *ctx, const void *d_in, size_t in_len, int is_last,
+                              void *d_out, size_t out_cap, size_t *out_len, uint32_t *block_sizes,
+                              size_t max_blocks, size_t *n_blocks, void *hip_stream);
+
+/* FormatSpec::encode: one framed block (is_last => BGZF_EOF appended for BGZF). */
+int gzpx_encode_block(gzpx_ctx *ctx, const uint8_t *in, size_t n, int is_last, uint8_t *out,
+                      size_t out_cap, size_t *out_len);
+
+/* ---- libdeflate-shaped per-block ABI (what libdeflater binds) ---- */
+typedef struct gzpx_compressor gzpx_compressor;
+gzpx_compressor *gzpx_alloc_compressor(int level); /* NULL: bad level / no device / unsupported */
+size_t gzpx_deflate_compress(gzpx_compressor *c, const void *in, size_t n, void *out, size_t cap);
+size_t gzpx_deflate_compress_bound(gzpx_compressor *c, size_t n);
+void gzpx_free_compressor(gzpx_compressor *c);
+/* compat / device knobs for the handle above (before first use) */
+int gzpx_compressor_set_compat(gzpx_compressor *c, int compat);
+uint32_t gzpx_crc32(uint32_t crc, const void *buf, size_t n);
+
+/* ---- measurement hooks (HIP events on the launching stream; bench.py roofline leg) ---- */
+#define GZPX_N_STAGES 7
+/* stage order: init_meta, candidates, match_parse, huffman, crc32, scan, emit */
+int gzpx_ctx_set_profiling(gzpx_ctx *ctx, int on);
+int gzpx_ctx_last_stage_ms(const gzpx_ctx *ctx, float ms[GZPX_N_STAGES]);
+const char *gzpx_stage_name(int stage);
+
+/* ---- test hooks: intermediate products of the last slab call (device -> host copies) ---- */
+int gzpx_debug_tokens(gzpx_ctx *ctx, size_t block, uint32_t *tokens, size_t max_tokens,
+                      size_t *n_tokens, uint32_t *sub_first_token, size_t *n_sub);
+
+const char *gzpx_strerror(int code);
+const char *gzpx_device_name(const gzpx_ctx *ctx);
+const char *gzpx_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GZPX_H */

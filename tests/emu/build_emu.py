@@ -1,0 +1,30 @@
+"""Build tests/emu/libgzpx_emu.so: the product sources compiled with g++ against the CPU SIMT
+emulator (tests/emu/hip/hip_runtime.h).  TEST INFRASTRUCTURE ONLY -- gzp_amd never loads it."""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.abspath(os.path.join(HERE, "..", ".."))
+CSRC = os.path.join(ROOT, "gzp_amd", "csrc")
+OUT = os.path.join(HERE, "libgzpx_emu.so")
+SOURCES = [os.path.join(CSRC, "gzpx_kernels.hip"), os.path.join(CSRC, "gzpx_api.cpp"),
+           os.path.join(CSRC, "gzpx_par.cpp"), os.path.join(HERE, "emu_runtime.cpp")]
+
+
+def build(force=False):
+    srcs = [s for s in SOURCES if os.path.exists(s)]
+    deps = srcs + [os.path.join(CSRC, "gzpx_device.h"), os.path.join(ROOT, "include", "gzpx.h"),
+                   os.path.join(HERE, "hip", "hip_runtime.h")]
+    deps += [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".hpp"))]
+    if (not force and os.path.exists(OUT)
+            and os.path.getmtime(OUT) >= max(os.path.getmtime(d) for d in deps if os.path.exists(d))):
+        return OUT
+    cmd = ["g++", "-O2", "-g", "-std=c++17", "-fPIC", "-shared", "-pthread", "-Wall", "-Wno-unused-function",
+           "-I", HERE, "-I", os.path.join(ROOT, "include"), "-x", "c++"] + srcs + ["-o", OUT]
+    subprocess.check_call(cmd)
+    return OUT
+
+
+if __name__ == "__main__":
+    print(build(force="-f" in sys.argv))
