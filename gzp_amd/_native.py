@@ -59,6 +59,13 @@ class GzpxLib:
                 "gzp_amd: %s not found -- build it with `python -c 'import __graft_entry__ as g; "
                 "g.build()'` (hipcc --offload-arch=gfx950); there is no CPU fallback" % path)
         self.path = path
+        # PyTorch-ROCm bundles its own HIP runtime (same SONAME as /opt/rocm's).  Two copies in one
+        # process fight over the device, so when torch is importable let it load first; libgzpx.so
+        # then binds to the runtime that is already resident.
+        try:
+            import torch  # noqa: F401
+        except Exception:  # pragma: no cover - torch-less hosts use the system ROCm runtime
+            pass
         L = self.L = ctypes.CDLL(path)
         vp, sz, i32, u32 = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_uint32
         psz = ctypes.POINTER(ctypes.c_size_t)

@@ -14,7 +14,7 @@
 // bytes") and do not depend on the parse.  That turns the sequential compressor into a pipeline
 // of data-parallel stages, each a kernel over all blocks of a slab:
 //   k_candidates   one wave / block : LDS-resident 128 KiB bucket table, 64 positions per step
-//   k_match_parse  256 thr  / block : block input + per-position match length in LDS;
+//   k_match_parse  1024 thr / block : block input + per-position match length in LDS;
 //                                     lz_extend for every position, then the greedy parse as a
 //                                     segment-parallel pointer chase with speculative entries
 //   k_huffman      one wave / block : libdeflate's length-limited Huffman construction, header
@@ -170,6 +170,67 @@ __global__ void k_init_meta(Config cfg, uint64_t slab_len, uint32_t nb, uint32_t
 // Output: cand[p] = d0 | d1 << 16 (distances of the newer / older candidate, 0 = none).
 // ------------------------------------------------------------------------------------------
 constexpr uint32_t kBuckets = 1u << 15;
+constexpr uint32_t kCandPrefetch = 8;  // steps of input kept in flight per lane (register ring)
+
+// aligned dword pair covering in[p .. p+3]; only issued for positions that are hashed
+__device__ __forceinline__ uint2 cand_fetch(const uint8_t *in, uint32_t p, uint32_t n) {
+    uint2 v = make_uint2(0u, 0u);
+    if (p + 5 <= n) {
+        const uintptr_t a = (uintptr_t)(in + p);
+        v = *(const uint2 *)(a & ~(uintptr_t)3);  // 4-byte aligned; bytes p..p+4 are inside it
+    }
+    return v;
+}
+
+// One 64-position step.  Fast path: every lane swaps its position into its bucket at once and
+// reads the bucket back; if each lane finds its own position there, no two lanes of the step
+// shared a bucket and the pre-step bucket contents are the candidates.  Otherwise (slow path)
+// the lanes are linked in position order with a 15-round ballot match-any and the shared
+// buckets are rewritten by the last lane of each group.
+__device__ __forceinline__ void cand_step(uint32_t *tab, const uint8_t *in, uint32_t base,
+                                          uint32_t lane, uint32_t n, uint2 raw,
+                                          uint32_t *__restrict__ cand) {
+    const uint32_t p = base + lane;
+    const bool valid = p + 5 <= n;  // positions the matchfinder hashes (REQUIRED_NBYTES = 5)
+    uint32_t h = 0;
+    if (valid && p != 0)
+        h = lz_hash15(__builtin_amdgcn_alignbyte(raw.y, raw.x, (uint32_t)((uintptr_t)(in + p) & 3u)));
+    const uint32_t t = tab[h];
+    uint32_t c0 = t & 0xFFFFu, c1 = t >> 16;
+    wave_sync();  // every lane has read its bucket before any lane rewrites one
+    if (valid) tab[h] = (p & 0xFFFFu) | (c0 << 16);
+    wave_sync();
+    const uint32_t chk = tab[h];
+    const bool lost = valid && (chk & 0xFFFFu) != (p & 0xFFFFu);
+    if (__ballot(lost)) {
+        // slow path: match-any over the 15-bit bucket index
+        uint64_t same = __ballot(valid);
+        for (int bit = 0; bit < 15; bit++) {
+            const bool one = (h >> bit) & 1u;
+            const uint64_t m = __ballot(one);
+            same &= one ? m : ~m;
+        }
+        const uint64_t below = same & ((1ull << lane) - 1ull);
+        const bool is_last_of_group = ((same >> lane) >> 1) == 0;
+        if (below) {
+            const uint32_t j1 = 63u - (uint32_t)__clzll((long long)below);
+            const uint64_t below2 = below & ~(1ull << j1);
+            c1 = below2 ? ((base + 63u - (uint32_t)__clzll((long long)below2)) & 0xFFFFu) : c0;
+            c0 = (base + j1) & 0xFFFFu;
+        }
+        wave_sync();
+        if (valid && is_last_of_group) tab[h] = (p & 0xFFFFu) | (c0 << 16);
+        wave_sync();
+    }
+    uint32_t d0 = (p - c0) & 0xFFFFu, d1 = (p - c1) & 0xFFFFu;
+    if (d0 == 0 || d0 > 32767u) {
+        d0 = 0;
+        d1 = 0;
+    } else if (d1 == 0 || d1 > 32767u) {
+        d1 = 0;
+    }
+    if (p < n) cand[p] = valid ? (d0 | (d1 << 16)) : 0u;
+}
 
 __global__ __launch_bounds__(64) void k_candidates(Config cfg, const uint8_t *__restrict__ slab,
                                                    const BlockMeta *__restrict__ meta,
@@ -185,75 +246,61 @@ __global__ __launch_bounds__(64) void k_candidates(Config cfg, const uint8_t *__
     for (uint32_t i = lane; i < kBuckets; i += 64) tab[i] = 0x80008000u;
     wave_sync();
 
-    const uint64_t lane_below = (1ull << lane) - 1ull;
-    for (uint32_t base = 0; base < n; base += 64) {
-        if (base != 0 && (base & 32767u) == 0) {
-            // sweep: entries farther than 32767 behind `base` become "dead for the next 32768"
-            const uint32_t dead = (base + 0x8000u) & 0xFFFFu;
-            for (uint32_t i = lane; i < kBuckets; i += 64) {
-                const uint32_t t = tab[i];
-                uint32_t e0 = t & 0xFFFFu, e1 = t >> 16;
-                const uint32_t a0 = (base - e0) & 0xFFFFu, a1 = (base - e1) & 0xFFFFu;
-                if (a0 == 0 || a0 > 32767u) e0 = dead;
-                if (a1 == 0 || a1 > 32767u) e1 = dead;
-                tab[i] = e0 | (e1 << 16);
+    // a single wave per CU has nobody to hide HBM latency behind: keep kCandPrefetch steps of
+    // input in flight in a register ring
+    uint2 ring[kCandPrefetch];
+#pragma unroll
+    for (uint32_t k = 0; k < kCandPrefetch; k++) ring[k] = cand_fetch(in, k * 64 + lane, n);
+
+    for (uint32_t base0 = 0; base0 < n; base0 += 64 * kCandPrefetch) {
+        uint2 cur[kCandPrefetch];
+#pragma unroll
+        for (uint32_t k = 0; k < kCandPrefetch; k++) cur[k] = ring[k];
+#pragma unroll
+        for (uint32_t k = 0; k < kCandPrefetch; k++)
+            ring[k] = cand_fetch(in, base0 + (kCandPrefetch + k) * 64 + lane, n);
+#pragma unroll
+        for (uint32_t k = 0; k < kCandPrefetch; k++) {
+            const uint32_t base = base0 + k * 64;
+            if (base >= n) break;
+            if (base != 0 && (base & 32767u) == 0) {
+                // sweep: entries farther than 32767 behind `base` become "dead for the next
+                // 32768 positions" (the analogue of libdeflate's window slide)
+                const uint32_t dead = (base + 0x8000u) & 0xFFFFu;
+                for (uint32_t i = lane; i < kBuckets; i += 64) {
+                    const uint32_t t = tab[i];
+                    uint32_t e0 = t & 0xFFFFu, e1 = t >> 16;
+                    const uint32_t a0 = (base - e0) & 0xFFFFu, a1 = (base - e1) & 0xFFFFu;
+                    if (a0 == 0 || a0 > 32767u) e0 = dead;
+                    if (a1 == 0 || a1 > 32767u) e1 = dead;
+                    tab[i] = e0 | (e1 << 16);
+                }
+                wave_sync();
             }
-            wave_sync();
+            cand_step(tab, in, base, lane, n, cur[k], cand);
         }
-        const uint32_t p = base + lane;
-        const bool valid = p + 5 <= n;  // positions the matchfinder hashes (REQUIRED_NBYTES = 5)
-        uint32_t h = 0;
-        if (valid && p != 0) h = lz_hash15(load_le32_global(in + p));
-
-        // match-any over the 15-bit bucket index
-        uint64_t same = __ballot(valid);
-        for (int bit = 0; bit < 15; bit++) {
-            const bool one = (h >> bit) & 1u;
-            const uint64_t m = __ballot(one);
-            same &= one ? m : ~m;
-        }
-        const uint64_t below = same & lane_below;
-        const bool is_last_of_group = ((same >> lane) >> 1) == 0;
-
-        const uint32_t t = tab[h];
-        const uint32_t e0 = t & 0xFFFFu, e1 = t >> 16;
-        uint32_t c0, c1;
-        if (below) {
-            const uint32_t j1 = 63u - (uint32_t)__clzll((long long)below);
-            c0 = (base + j1) & 0xFFFFu;
-            const uint64_t below2 = below & ~(1ull << j1);
-            c1 = below2 ? ((base + 63u - (uint32_t)__clzll((long long)below2)) & 0xFFFFu) : e0;
-        } else {
-            c0 = e0;
-            c1 = e1;
-        }
-        uint32_t d0 = (p - c0) & 0xFFFFu, d1 = (p - c1) & 0xFFFFu;
-        if (d0 == 0 || d0 > 32767u) {
-            d0 = 0;
-            d1 = 0;
-        } else if (d1 == 0 || d1 > 32767u) {
-            d1 = 0;
-        }
-        wave_sync();  // every lane has read its bucket before any lane rewrites one
-        if (valid && is_last_of_group) tab[h] = (p & 0xFFFFu) | (c0 << 16);
-        wave_sync();
-        if (p < n) cand[p] = valid ? (d0 | (d1 << 16)) : 0u;
     }
 }
 
 // ------------------------------------------------------------------------------------------
-// k_match_parse: per block,
+// k_match_parse: per block (1024 threads, one workgroup per CU, ~156 KiB of LDS),
 //   phase 0  stage the block's bytes in LDS (coalesced dword loads),
 //   phase 1  ht_matchfinder_longest_match for EVERY position in parallel -> len8[p] (LDS),
 //   phase 2  deflate_compress_fastest's greedy parse as a segment-parallel pointer chase:
 //            272-byte segments (>= max match length, so a token leaving segment s lands in
 //            segment s+1), each thread walks its segment from a speculated entry, entries are
 //            corrected round by round until none changes (greedy chains re-synchronise within
-//            a few tokens, so this is 2-3 rounds in practice, <= #segments always),
-//   phase 3  token emission + litlen/offset histograms per sub-block (8192 matches each).
+//            a few tokens, so this is 2-3 rounds in practice, <= #segments always); the final
+//            walk marks token starts in an LDS bitmap,
+//   phase 3  position-parallel token build: token / match ranks from wave ballots + one
+//            workgroup scan, coalesced candidate loads and token stores, litlen/offset
+//            histograms per sub-block (8192 matches each) with LDS atomics.
 // ------------------------------------------------------------------------------------------
 constexpr uint32_t kSeg = 272;
 constexpr uint32_t kInWords = kMaxUnit / 4 + 4;
+constexpr uint32_t kMpThreads = 1024;
+constexpr uint32_t kMpWaves = kMpThreads / 64;
+constexpr uint32_t kMpChunks = kMaxUnit / kMpThreads;  // 64 position chunks of 1024
 
 __device__ __forceinline__ uint32_t lds_le32(const uint32_t *in_w, uint32_t byte_addr) {
     const uint32_t w = byte_addr >> 2;
@@ -279,45 +326,34 @@ __device__ __forceinline__ uint32_t lds_extend(const uint32_t *in_w, uint32_t a,
     return len < max_len ? len : max_len;
 }
 
-struct WalkResult {
-    uint32_t exit_pos;
-    uint32_t n_match;
-    uint32_t n_lit;
-};
-
-__device__ __forceinline__ WalkResult walk_segment(const uint8_t *len8, uint32_t pos,
-                                                   uint32_t seg_end) {
-    WalkResult r;
-    r.n_match = 0;
-    r.n_lit = 0;
+// walk one segment from `pos`; optionally mark every token start in tok_bits
+template <bool kMark>
+__device__ __forceinline__ uint32_t walk_segment(const uint8_t *len8, uint32_t pos, uint32_t seg_end,
+                                                 uint32_t *tok_bits) {
     while (pos < seg_end) {
         const uint32_t l = len8[pos];
-        if (l) {
-            pos += l + 3;
-            r.n_match++;
-        } else {
-            pos++;
-            r.n_lit++;
-        }
+        if (kMark) atomicOr(&tok_bits[pos >> 5], 1u << (pos & 31u));
+        pos += l ? l + 3 : 1;
     }
-    r.exit_pos = pos;
-    return r;
+    return pos;
 }
 
-__global__ __launch_bounds__(256) void k_match_parse(Config cfg, const uint8_t *__restrict__ slab,
-                                                     BlockMeta *__restrict__ meta_all,
-                                                     const uint32_t *__restrict__ cand_all,
-                                                     uint32_t *__restrict__ tok_all,
-                                                     uint32_t *__restrict__ hist_all) {
-    __shared__ uint32_t in_w[kInWords];           // block bytes (+ lead misalignment, + pad)
-    __shared__ uint8_t len8[kMaxUnit];            // 0 = literal, else match length - 3
+__global__ __launch_bounds__(kMpThreads) void k_match_parse(
+    Config cfg, const uint8_t *__restrict__ slab, BlockMeta *__restrict__ meta_all,
+    const uint32_t *__restrict__ cand_all, uint32_t *__restrict__ tok_all,
+    uint32_t *__restrict__ hist_all) {
+    __shared__ uint32_t in_w[kInWords];             // block bytes (+ lead misalignment, + pad)
+    __shared__ uint8_t len8[kMaxUnit];              // 0 = literal, else match length - 3
     __shared__ uint32_t which_bits[kMaxUnit / 32];  // 1 = the older candidate (c1) won
+    __shared__ uint32_t tok_bits[kMaxUnit / 32];    // 1 = a token starts here
     __shared__ uint32_t hist[kMaxSub * kHistStride];
     __shared__ uint32_t seg_exit[256];
-    __shared__ uint32_t wsum[4];
+    __shared__ uint32_t tok_pre[kMpChunks * kMpWaves];  // tokens before (chunk, wave)
+    __shared__ uint32_t mat_pre[kMpChunks * kMpWaves];  // matches before (chunk, wave)
+    __shared__ uint32_t wsum_t[kMpWaves], wsum_m[kMpWaves];
     __shared__ uint32_t sub1_tok, sub1_pos;
 
-    const uint32_t tid = threadIdx.x;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint32_t b = blockIdx.x;
     BlockMeta *meta = meta_all + b;
     const uint32_t n = meta->n;
@@ -331,54 +367,56 @@ __global__ __launch_bounds__(256) void k_match_parse(Config cfg, const uint8_t *
     {
         const uint32_t *src = (const uint32_t *)((uintptr_t)in - mis);
         const uint32_t ndw = (mis + n + 3) >> 2;
-        for (uint32_t i = tid; i < ndw; i += 256) in_w[i] = src[i];
-        for (uint32_t i = ndw + tid; i < ndw + 3 && i < kInWords; i += 256) in_w[i] = 0;
-        for (uint32_t i = tid; i < kMaxUnit / 32; i += 256) which_bits[i] = 0;
-        for (uint32_t i = tid; i < kMaxSub * kHistStride; i += 256) hist[i] = 0;
+        for (uint32_t i = tid; i < ndw; i += kMpThreads) in_w[i] = src[i];
+        for (uint32_t i = ndw + tid; i < ndw + 3 && i < kInWords; i += kMpThreads) in_w[i] = 0;
+        for (uint32_t i = tid; i < kMaxUnit / 32; i += kMpThreads) {
+            which_bits[i] = 0;
+            tok_bits[i] = 0;
+        }
+        for (uint32_t i = tid; i < kMaxSub * kHistStride; i += kMpThreads) hist[i] = 0;
     }
     __syncthreads();
 
-    // ---- phase 1: longest match at every position
-    for (uint32_t p = tid; p < n; p += 256) {
-        uint32_t best = 0;
-        if (p + 5 <= n) {
-            const uint32_t cd = cand[p];
-            const uint32_t d0 = cd & 0xFFFFu, d1 = cd >> 16;
-            const uint32_t rem = n - p;
-            const uint32_t max_len = rem < 258u ? rem : 258u;
-            const uint32_t nice_len = max_len < 32u ? max_len : 32u;
-            const uint32_t a = p + mis;
-            const uint32_t seq = lds_le32(in_w, a);
-            bool second = false;
+    // ---- phase 1: longest match at every position (candidate loads batched 4 deep)
+    for (uint32_t p0 = tid; p0 < n; p0 += 4 * kMpThreads) {
+        uint32_t cd[4];
+#pragma unroll
+        for (uint32_t k = 0; k < 4; k++) {
+            const uint32_t p = p0 + k * kMpThreads;
+            cd[k] = (p + 5 <= n) ? cand[p] : 0u;
+        }
+#pragma unroll
+        for (uint32_t k = 0; k < 4; k++) {
+            const uint32_t p = p0 + k * kMpThreads;
+            if (p >= n) break;
+            uint32_t best = 0;
+            const uint32_t d0 = cd[k] & 0xFFFFu, d1 = cd[k] >> 16;
             if (d0) {
+                const uint32_t rem = n - p;
+                const uint32_t max_len = rem < 258u ? rem : 258u;
+                const uint32_t nice_len = max_len < 32u ? max_len : 32u;
+                const uint32_t a = p + mis;
+                const uint32_t seq = lds_le32(in_w, a);
                 if (lds_le32(in_w, a - d0) == seq) best = lds_extend(in_w, a, a - d0, max_len);
                 if (d1 && best < nice_len && lds_le32(in_w, a - d1) == seq) {
                     const uint32_t l1 = lds_extend(in_w, a, a - d1, max_len);
                     if (l1 > best) {
                         best = l1;
-                        second = true;
+                        atomicOr(&which_bits[p >> 5], 1u << (p & 31u));
                     }
                 }
             }
-            if (second) atomicOr(&which_bits[p >> 5], 1u << (p & 31u));
+            len8[p] = (uint8_t)(best ? best - 3 : 0);
         }
-        len8[p] = (uint8_t)(best ? best - 3 : 0);
     }
     __syncthreads();
 
-    // ---- phase 2: greedy parse, speculative segment walk
+    // ---- phase 2: greedy parse, speculative segment walk (threads 0..255 own segments)
     const uint32_t seg_begin = tid * kSeg;
-    const bool active = seg_begin < n;
+    const bool active = tid < 256 && seg_begin < n;
     const uint32_t seg_end = active ? (seg_begin + kSeg < n ? seg_begin + kSeg : n) : 0;
     uint32_t entry = seg_begin;
-    WalkResult wr;
-    wr.exit_pos = 0;
-    wr.n_match = 0;
-    wr.n_lit = 0;
-    if (active) {
-        wr = walk_segment(len8, entry, seg_end);
-        seg_exit[tid] = wr.exit_pos;
-    }
+    if (active) seg_exit[tid] = walk_segment<false>(len8, entry, seg_end, tok_bits);
     for (;;) {
         __syncthreads();
         bool changed = false;
@@ -390,58 +428,100 @@ __global__ __launch_bounds__(256) void k_match_parse(Config cfg, const uint8_t *
         __syncthreads();
         if (changed) {
             entry = new_entry;
-            wr = walk_segment(len8, entry, seg_end);
-            seg_exit[tid] = wr.exit_pos;
+            seg_exit[tid] = walk_segment<false>(len8, entry, seg_end, tok_bits);
         }
         if (!__syncthreads_or(changed)) break;
     }
+    if (active) walk_segment<true>(len8, entry, seg_end, tok_bits);
+    __syncthreads();
 
-    // ---- phase 3: token emission
-    uint32_t total_tok, total_match;
-    const uint32_t tok_base = block_exclusive_scan256(wr.n_match + wr.n_lit, wsum, &total_tok);
-    const uint32_t match_base = block_exclusive_scan256(wr.n_match, wsum, &total_match);
-    if (tid == 0) {
-        sub1_tok = total_tok;  // "no second sub-block"
-        sub1_pos = n;
+    // ---- phase 3a: tokens / matches per (chunk, wave), then one workgroup-wide scan
+    const uint32_t nchunks = (n + kMpThreads - 1) / kMpThreads;
+    for (uint32_t c = 0; c < nchunks; c++) {
+        const uint32_t p = c * kMpThreads + tid;
+        const bool is_tok = p < n && ((tok_bits[p >> 5] >> (p & 31u)) & 1u);
+        const bool is_match = is_tok && len8[p] != 0;
+        const uint64_t mt = __ballot(is_tok), mm = __ballot(is_match);
+        if (lane == 0) {
+            tok_pre[c * kMpWaves + wave] = (uint32_t)__popcll(mt);
+            mat_pre[c * kMpWaves + wave] = (uint32_t)__popcll(mm);
+        }
     }
     __syncthreads();
-    if (active) {
-        uint32_t pos = entry, ti = tok_base, mc = match_base;
-        while (pos < seg_end) {
-            const uint32_t l = len8[pos];
-            uint32_t *h = hist + (mc >= kSeqPerSub ? kHistStride : 0);
-            if (l) {
+    uint32_t total_tok, total_match;
+    {
+        // entry e = chunk * 16 + wave is position order; thread e scans entry e
+        const bool have = tid < nchunks * kMpWaves;
+        const uint32_t vt = have ? tok_pre[tid] : 0, vm = have ? mat_pre[tid] : 0;
+        const uint32_t it = wave_inclusive_scan(vt, lane), im = wave_inclusive_scan(vm, lane);
+        if (lane == 63) {
+            wsum_t[wave] = it;
+            wsum_m[wave] = im;
+        }
+        __syncthreads();
+        uint32_t bt = 0, bm = 0, tt = 0, tm = 0;
+        for (uint32_t w = 0; w < kMpWaves; w++) {
+            const uint32_t st = wsum_t[w], sm = wsum_m[w];
+            if (w < wave) {
+                bt += st;
+                bm += sm;
+            }
+            tt += st;
+            tm += sm;
+        }
+        total_tok = tt;
+        total_match = tm;
+        if (have) {
+            tok_pre[tid] = bt + it - vt;
+            mat_pre[tid] = bm + im - vm;
+        }
+        if (tid == 0) {
+            sub1_tok = total_tok;  // "no second sub-block"
+            sub1_pos = n;
+        }
+    }
+    __syncthreads();
+
+    // ---- phase 3b: build tokens in position order
+    const uint64_t lane_below = (1ull << lane) - 1ull;
+    for (uint32_t c = 0; c < nchunks; c++) {
+        const uint32_t p = c * kMpThreads + tid;
+        const bool is_tok = p < n && ((tok_bits[p >> 5] >> (p & 31u)) & 1u);
+        const uint32_t l = is_tok ? len8[p] : 0;
+        const bool is_match = l != 0;
+        const uint64_t mt = __ballot(is_tok), mm = __ballot(is_match);
+        if (is_tok) {
+            const uint32_t ti = tok_pre[c * kMpWaves + wave] + (uint32_t)__popcll(mt & lane_below);
+            const uint32_t mi = mat_pre[c * kMpWaves + wave] + (uint32_t)__popcll(mm & lane_below);
+            uint32_t *h = hist + (mi >= kSeqPerSub ? kHistStride : 0);
+            if (is_match) {
                 const uint32_t len = l + 3;
-                const uint32_t cd = cand[pos];
-                const uint32_t off = ((which_bits[pos >> 5] >> (pos & 31u)) & 1u) ? (cd >> 16)
-                                                                                : (cd & 0xFFFFu);
+                const uint32_t cd = cand[p];
+                const uint32_t off = ((which_bits[p >> 5] >> (p & 31u)) & 1u) ? (cd >> 16) : (cd & 0xFFFFu);
                 uint32_t ls, le, lv, os, oe, ov;
                 length_slot(len, ls, le, lv);
                 offset_slot(off, os, oe, ov);
                 atomicAdd(&h[257 + ls], 1u);
                 atomicAdd(&h[kNumLitlen + os], 1u);
                 tok[ti] = kTokMatch | (off << 9) | len;
-                pos += len;
-                mc++;
-                if (mc == kSeqPerSub) {  // the 8192nd match closes sub-block 0
+                if (mi + 1 == kSeqPerSub) {  // the 8192nd match closes sub-block 0
                     sub1_tok = ti + 1;
-                    sub1_pos = pos;
+                    sub1_pos = p + len;
                 }
             } else {
-                const uint32_t lit = lds_byte(in_w, pos + mis);
+                const uint32_t lit = lds_byte(in_w, p + mis);
                 atomicAdd(&h[lit], 1u);
                 tok[ti] = lit;
-                pos++;
             }
-            ti++;
         }
     }
     __syncthreads();
     {
         uint32_t *hist_out = hist_all + (uint64_t)b * (kMaxSub * kHistStride);
-        for (uint32_t i = tid; i < kMaxSub * kHistStride; i += 256) hist_out[i] = hist[i];
+        for (uint32_t i = tid; i < kMaxSub * kHistStride; i += kMpThreads) hist_out[i] = hist[i];
     }
     if (tid == 0) {
+        (void)total_match;
         const uint32_t s1 = sub1_tok;
         const bool two = s1 < total_tok;  // tokens remain after the 8192nd match
         meta->ntok = total_tok;
@@ -1168,7 +1248,7 @@ void launch_candidates(const Config &cfg, const uint8_t *slab, uint64_t, uint32_
 
 void launch_match_parse(const Config &cfg, const uint8_t *slab, uint64_t, uint32_t nb,
                         const Scratch &s, hipStream_t stream) {
-    hipLaunchKernelGGL(k_match_parse, dim3(nb), dim3(256), 0, stream, cfg, slab, s.meta,
+    hipLaunchKernelGGL(k_match_parse, dim3(nb), dim3(kMpThreads), 0, stream, cfg, slab, s.meta,
                        (const uint32_t *)s.cand, s.tok, s.hist);
 }
 

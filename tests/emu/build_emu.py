@@ -20,7 +20,7 @@ def build(force=False):
     if (not force and os.path.exists(OUT)
             and os.path.getmtime(OUT) >= max(os.path.getmtime(d) for d in deps if os.path.exists(d))):
         return OUT
-    cmd = ["g++", "-O2", "-g", "-std=c++17", "-fPIC", "-shared", "-pthread", "-Wall", "-Wno-unused-function",
+    cmd = ["g++", "-O2", "-g", "-std=c++17", "-fPIC", "-shared", "-pthread", "-Wall", "-Wno-unused-function", "-Wno-unknown-pragmas",
            "-I", HERE, "-I", os.path.join(ROOT, "include"), "-x", "c++"] + srcs + ["-o", OUT]
     subprocess.check_call(cmd)
     return OUT

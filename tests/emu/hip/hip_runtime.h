@@ -31,6 +31,15 @@ struct uint3_emu {
     unsigned x, y, z;
 };
 
+struct uint2 {
+    unsigned x, y;
+};
+static inline uint2 make_uint2(unsigned x, unsigned y) { return uint2{x, y}; }
+struct uint4 {
+    unsigned x, y, z, w;
+};
+static inline uint4 make_uint4(unsigned x, unsigned y, unsigned z, unsigned w) { return uint4{x, y, z, w}; }
+
 namespace emu {
 struct ThreadCtx {
     uint3_emu tid;
