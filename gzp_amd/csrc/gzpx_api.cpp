@@ -513,6 +513,14 @@ int gzpx_debug_tokens(gzpx_ctx *ctx, size_t block, uint32_t *tokens, size_t max_
     return GZPX_OK;
 }
 
+int gzpx_debug_phase_cycles(const gzpx_ctx *ctx, uint64_t cycles[8]) {
+    if (!ctx || !cycles) return GZPX_ERR_INVALID_ARG;
+    for (int k = 0; k < 8; k++) cycles[k] = 0;
+    for (uint32_t b = 0; b < ctx->last_nb; b++)
+        for (int k = 0; k < 8; k++) cycles[k] += ctx->h_meta[b].phase_cycles[k];
+    return GZPX_OK;
+}
+
 const char *gzpx_strerror(int code) {
     switch (code) {
         case GZPX_OK: return "ok";

@@ -10,7 +10,7 @@
 namespace gzpx {
 
 constexpr unsigned kMaxUnit = 65536;       // max input bytes per block handled by the kernels
-constexpr unsigned kCandStride = kMaxUnit; // u32 per position
+constexpr unsigned kCandStride = kMaxUnit + 512;  // u32 per position (+ one super-step of padding)
 constexpr unsigned kTokStride = kMaxUnit;  // u32 per token (worst case: all literals)
 constexpr unsigned kMaxSub = 2;            // n <= 65536 => at most 2 sub-blocks (8192 matches each)
 constexpr unsigned kSeqPerSub = 8192;      // FAST_SEQ_STORE_LENGTH
@@ -51,6 +51,7 @@ struct BlockMeta {
     uint32_t crc;
     uint32_t status;
     SubMeta sub[kMaxSub];
+    uint32_t phase_cycles[8];  // k_match_parse: shader-clock cycles per phase (thread 0), diagnostics
 };
 
 struct CrcConsts {

@@ -151,6 +151,7 @@ __global__ void k_init_meta(Config cfg, uint64_t slab_len, uint32_t nb, uint32_t
         m.sub[s].hdr_bits = 0;
         m.sub[s].is_final = 0;
     }
+    for (unsigned k = 0; k < 8; k++) m.phase_cycles[k] = 0;
     meta[b] = m;
 }
 
@@ -172,13 +173,16 @@ __global__ void k_init_meta(Config cfg, uint64_t slab_len, uint32_t nb, uint32_t
 constexpr uint32_t kBuckets = 1u << 15;
 constexpr uint32_t kCandPrefetch = 8;  // steps of input kept in flight per lane (register ring)
 
-// aligned dword pair covering in[p .. p+3]; only issued for positions that are hashed
-__device__ __forceinline__ uint2 cand_fetch(const uint8_t *in, uint32_t p, uint32_t n) {
-    uint2 v = make_uint2(0u, 0u);
-    if (p + 5 <= n) {
-        const uintptr_t a = (uintptr_t)(in + p);
-        v = *(const uint2 *)(a & ~(uintptr_t)3);  // 4-byte aligned; bytes p..p+4 are inside it
-    }
+// aligned dword pair covering in[p .. p+3] (in32 = the block's bytes rounded down to a dword
+// boundary, mis = bytes skipped by that rounding); only issued for positions that are hashed
+// Unconditional (index clamped to the block's last dword) so that the number of loads in flight
+// is static and the compiler can wait with exact vmcnt values instead of vmcnt(0).
+__device__ __forceinline__ uint2 cand_fetch(const uint32_t *__restrict__ in32, uint32_t mis,
+                                            uint32_t p, uint32_t wmax) {
+    const uint32_t w = (p + mis) >> 2;  // bytes p..p+4 lie inside dwords w, w+1
+    uint2 v;
+    v.x = in32[w < wmax ? w : wmax];
+    v.y = in32[w + 1 < wmax ? w + 1 : wmax];
     return v;
 }
 
@@ -187,14 +191,14 @@ __device__ __forceinline__ uint2 cand_fetch(const uint8_t *in, uint32_t p, uint3
 // shared a bucket and the pre-step bucket contents are the candidates.  Otherwise (slow path)
 // the lanes are linked in position order with a 15-round ballot match-any and the shared
 // buckets are rewritten by the last lane of each group.
-__device__ __forceinline__ void cand_step(uint32_t *tab, const uint8_t *in, uint32_t base,
+__device__ __forceinline__ void cand_step(uint32_t *tab, uint32_t mis, uint32_t base,
                                           uint32_t lane, uint32_t n, uint2 raw,
                                           uint32_t *__restrict__ cand) {
     const uint32_t p = base + lane;
     const bool valid = p + 5 <= n;  // positions the matchfinder hashes (REQUIRED_NBYTES = 5)
     uint32_t h = 0;
     if (valid && p != 0)
-        h = lz_hash15(__builtin_amdgcn_alignbyte(raw.y, raw.x, (uint32_t)((uintptr_t)(in + p) & 3u)));
+        h = lz_hash15(__builtin_amdgcn_alignbyte(raw.y, raw.x, (p + mis) & 3u));
     const uint32_t t = tab[h];
     uint32_t c0 = t & 0xFFFFu, c1 = t >> 16;
     wave_sync();  // every lane has read its bucket before any lane rewrites one
@@ -229,7 +233,7 @@ __device__ __forceinline__ void cand_step(uint32_t *tab, const uint8_t *in, uint
     } else if (d1 == 0 || d1 > 32767u) {
         d1 = 0;
     }
-    if (p < n) cand[p] = valid ? (d0 | (d1 << 16)) : 0u;
+    cand[p] = valid ? (d0 | (d1 << 16)) : 0u;  // p < kCandStride always (padded stride)
 }
 
 __global__ __launch_bounds__(64) void k_candidates(Config cfg, const uint8_t *__restrict__ slab,
@@ -241,6 +245,9 @@ __global__ __launch_bounds__(64) void k_candidates(Config cfg, const uint8_t *__
     const uint32_t n = meta[b].n;
     if (n <= kPassthroughL1) return;  // stored-only path, no matchfinding
     const uint8_t *in = slab + (uint64_t)b * cfg.block_size;
+    const uint32_t mis = (uint32_t)((uintptr_t)in & 3u);
+    const uint32_t *in32 = (const uint32_t *)(in - mis);
+    const uint32_t wmax = (mis + n - 1) >> 2;  // last dword holding a byte of this block
     uint32_t *cand = cand_all + (uint64_t)b * kCandStride;
 
     for (uint32_t i = lane; i < kBuckets; i += 64) tab[i] = 0x80008000u;
@@ -250,7 +257,7 @@ __global__ __launch_bounds__(64) void k_candidates(Config cfg, const uint8_t *__
     // input in flight in a register ring
     uint2 ring[kCandPrefetch];
 #pragma unroll
-    for (uint32_t k = 0; k < kCandPrefetch; k++) ring[k] = cand_fetch(in, k * 64 + lane, n);
+    for (uint32_t k = 0; k < kCandPrefetch; k++) ring[k] = cand_fetch(in32, mis, k * 64 + lane, wmax);
 
     for (uint32_t base0 = 0; base0 < n; base0 += 64 * kCandPrefetch) {
         uint2 cur[kCandPrefetch];
@@ -258,12 +265,11 @@ __global__ __launch_bounds__(64) void k_candidates(Config cfg, const uint8_t *__
         for (uint32_t k = 0; k < kCandPrefetch; k++) cur[k] = ring[k];
 #pragma unroll
         for (uint32_t k = 0; k < kCandPrefetch; k++)
-            ring[k] = cand_fetch(in, base0 + (kCandPrefetch + k) * 64 + lane, n);
+            ring[k] = cand_fetch(in32, mis, base0 + (kCandPrefetch + k) * 64 + lane, wmax);
 #pragma unroll
         for (uint32_t k = 0; k < kCandPrefetch; k++) {
-            const uint32_t base = base0 + k * 64;
-            if (base >= n) break;
-            if (base != 0 && (base & 32767u) == 0) {
+            const uint32_t base = base0 + k * 64;  // steps past n only store zeros into padding
+            if (base != 0 && (base & 32767u) == 0 && base < n) {
                 // sweep: entries farther than 32767 behind `base` become "dead for the next
                 // 32768 positions" (the analogue of libdeflate's window slide)
                 const uint32_t dead = (base + 0x8000u) & 0xFFFFu;
@@ -277,7 +283,7 @@ __global__ __launch_bounds__(64) void k_candidates(Config cfg, const uint8_t *__
                 }
                 wave_sync();
             }
-            cand_step(tab, in, base, lane, n, cur[k], cand);
+            cand_step(tab, mis, base, lane, n, cur[k], cand);
         }
     }
 }
@@ -363,9 +369,10 @@ __global__ __launch_bounds__(kMpThreads) void k_match_parse(
     uint32_t *tok = tok_all + (uint64_t)b * kTokStride;
 
     // ---- phase 0: stage input
+    long long t_mark = clock64();
     const uint32_t mis = (uint32_t)((uintptr_t)in & 3u);
     {
-        const uint32_t *src = (const uint32_t *)((uintptr_t)in - mis);
+        const uint32_t *src = (const uint32_t *)(in - mis);
         const uint32_t ndw = (mis + n + 3) >> 2;
         for (uint32_t i = tid; i < ndw; i += kMpThreads) in_w[i] = src[i];
         for (uint32_t i = ndw + tid; i < ndw + 3 && i < kInWords; i += kMpThreads) in_w[i] = 0;
@@ -376,6 +383,11 @@ __global__ __launch_bounds__(kMpThreads) void k_match_parse(
         for (uint32_t i = tid; i < kMaxSub * kHistStride; i += kMpThreads) hist[i] = 0;
     }
     __syncthreads();
+    if (tid == 0) {
+        const long long t = clock64();
+        meta->phase_cycles[0] = (uint32_t)(t - t_mark);
+        t_mark = t;
+    }
 
     // ---- phase 1: longest match at every position (candidate loads batched 4 deep)
     for (uint32_t p0 = tid; p0 < n; p0 += 4 * kMpThreads) {
@@ -410,14 +422,20 @@ __global__ __launch_bounds__(kMpThreads) void k_match_parse(
         }
     }
     __syncthreads();
+    if (tid == 0) {
+        const long long t = clock64();
+        meta->phase_cycles[1] = (uint32_t)(t - t_mark);
+        t_mark = t;
+    }
 
     // ---- phase 2: greedy parse, speculative segment walk (threads 0..255 own segments)
     const uint32_t seg_begin = tid * kSeg;
     const bool active = tid < 256 && seg_begin < n;
     const uint32_t seg_end = active ? (seg_begin + kSeg < n ? seg_begin + kSeg : n) : 0;
-    uint32_t entry = seg_begin;
+    uint32_t entry = seg_begin, rounds = 0;
     if (active) seg_exit[tid] = walk_segment<false>(len8, entry, seg_end, tok_bits);
     for (;;) {
+        rounds++;
         __syncthreads();
         bool changed = false;
         uint32_t new_entry = entry;
@@ -432,8 +450,19 @@ __global__ __launch_bounds__(kMpThreads) void k_match_parse(
         }
         if (!__syncthreads_or(changed)) break;
     }
+    if (tid == 0) {
+        const long long t = clock64();
+        meta->phase_cycles[2] = (uint32_t)(t - t_mark);
+        meta->phase_cycles[6] = rounds;
+        t_mark = t;
+    }
     if (active) walk_segment<true>(len8, entry, seg_end, tok_bits);
     __syncthreads();
+    if (tid == 0) {
+        const long long t = clock64();
+        meta->phase_cycles[3] = (uint32_t)(t - t_mark);
+        t_mark = t;
+    }
 
     // ---- phase 3a: tokens / matches per (chunk, wave), then one workgroup-wide scan
     const uint32_t nchunks = (n + kMpThreads - 1) / kMpThreads;
@@ -481,6 +510,11 @@ __global__ __launch_bounds__(kMpThreads) void k_match_parse(
         }
     }
     __syncthreads();
+    if (tid == 0) {
+        const long long t = clock64();
+        meta->phase_cycles[4] = (uint32_t)(t - t_mark);
+        t_mark = t;
+    }
 
     // ---- phase 3b: build tokens in position order
     const uint64_t lane_below = (1ull << lane) - 1ull;
@@ -522,6 +556,7 @@ __global__ __launch_bounds__(kMpThreads) void k_match_parse(
     }
     if (tid == 0) {
         (void)total_match;
+        meta->phase_cycles[5] = (uint32_t)(clock64() - t_mark);
         const uint32_t s1 = sub1_tok;
         const bool two = s1 < total_tok;  // tokens remain after the 8192nd match
         meta->ntok = total_tok;

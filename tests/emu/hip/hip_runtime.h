@@ -113,6 +113,7 @@ static inline T __shfl_xor(T v, int mask, int width = 64) {
     int lane = (int)(emu::cur->flat & 63);
     return __shfl(v, (lane ^ mask) & 63);
 }
+static inline long long clock64() { return 0; }
 static inline unsigned __lane_id() { return emu::cur->flat & 63; }
 
 // ---------------------------------------------------------------- integer intrinsics

@@ -1,0 +1,20 @@
+"""GPU diagnostic: per-stage ms and k_match_parse per-phase cycles on a text slab."""
+import sys, os, json
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
+import numpy as np, torch
+from gzp_amd import _native, synth
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 576_716_800
+cls = sys.argv[2] if len(sys.argv) > 2 else "slab"
+a = synth.text_slab(n) if cls == "slab" else synth.make(cls, n, 3)
+d_in = torch.from_numpy(a).cuda()
+ctx = _native.Context(level=1, max_slab_bytes=n)
+cap = ctx.slab_bound(n)
+d_out = torch.empty(cap, dtype=torch.uint8, device="cuda")
+ctx.set_profiling(True)
+for i in range(3):
+    out_len, nb = ctx.compress_slab_device(d_in.data_ptr(), n, d_out.data_ptr(), cap, True)
+ms = ctx.last_stage_ms()
+cyc = ctx.debug_phase_cycles()
+print(json.dumps({"class": cls, "n": n, "ratio": out_len / n, "stage_ms": ms,
+                  "mp_phase_kcycles_per_block": [round(c / nb / 1e3, 1) for c in cyc[:6]],
+                  "mp_rounds_avg": cyc[6] / nb}))
