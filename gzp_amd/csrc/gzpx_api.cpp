@@ -284,6 +284,7 @@ int gzpx_ctx_create(const gzpx_config *cfg, gzpx_ctx **out) {
     ctx->dcfg.compat = (uint32_t)cfg->compat;
     ctx->dcfg.block_size = (uint32_t)cfg->buffer_size;
     ctx->dcfg.xfl = cfg->level >= 9 ? 2u : cfg->level <= 1 ? 4u : 0u;  // src/bgzf.rs:278-284
+    ctx->dcfg.debug = 0;
     for (unsigned l = 0; l < 8; l++) ctx->crc_consts.pow256[l] = x2k(11 + l);
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, cfg->device) == hipSuccess) {
@@ -510,6 +511,12 @@ int gzpx_debug_tokens(gzpx_ctx *ctx, size_t block, uint32_t *tokens, size_t max_
     if (tokens && ncopy)
         HIP_TRY(hipMemcpy(tokens, ctx->scratch.tok + block * (size_t)kTokStride, ncopy * 4,
                           hipMemcpyDeviceToHost));
+    return GZPX_OK;
+}
+
+int gzpx_debug_set_flags(gzpx_ctx *ctx, uint32_t flags) {
+    if (!ctx) return GZPX_ERR_INVALID_ARG;
+    ctx->dcfg.debug = flags;
     return GZPX_OK;
 }
 

@@ -52,6 +52,7 @@ struct BlockMeta {
     uint32_t status;
     SubMeta sub[kMaxSub];
     uint32_t phase_cycles[8];  // k_match_parse: shader-clock cycles per phase (thread 0), diagnostics
+    uint32_t cand_redo;        // k_candidates' LDS-order check failed: redo with k_candidates_safe
 };
 
 struct CrcConsts {
@@ -64,6 +65,7 @@ struct Config {
     uint32_t compat;      // 0: libdeflate >= 1.1x Huffman rule, 1: libdeflate 1.10
     uint32_t block_size;  // buffer_size of the reference's builder
     uint32_t xfl;         // gzip XFL byte derived from level (src/bgzf.rs:278-284)
+    uint32_t debug;       // diagnostics only: bit 0 = force k_candidates_safe on every block
 };
 
 // Device scratch for one batch of blocks.

@@ -13,7 +13,8 @@
 // the input ("the two most recent earlier positions with the same 15-bit hash, within 32767
 // bytes") and do not depend on the parse.  That turns the sequential compressor into a pipeline
 // of data-parallel stages, each a kernel over all blocks of a slab:
-//   k_candidates   one wave / block : LDS-resident 128 KiB bucket table, 64 positions per step
+//   k_candidates   one wave / block : LDS-resident 128 KiB bucket table, atomicMax chain,
+//                                     512 positions in flight per iteration
 //   k_match_parse  1024 thr / block : block input + per-position match length in LDS;
 //                                     lz_extend for every position, then the greedy parse as a
 //                                     segment-parallel pointer chase with speculative entries
@@ -152,31 +153,39 @@ __global__ void k_init_meta(Config cfg, uint64_t slab_len, uint32_t nb, uint32_t
         m.sub[s].is_final = 0;
     }
     for (unsigned k = 0; k < 8; k++) m.phase_cycles[k] = 0;
+    m.cand_redo = 0;
     meta[b] = m;
 }
 
 // ------------------------------------------------------------------------------------------
-// k_candidates: ht_matchfinder's bucket table (2^15 buckets x 2 entries), restated as
-// "previous two positions with the same hash".  One wave per block, 64 consecutive positions
-// per step:
-//   - hash of every position (position 0 is filed under bucket 0: libdeflate starts with
-//     next_hash = 0),
-//   - lanes of the step that share a bucket are linked in position order with a 15-round
-//     ballot "match-any",
-//   - one ds_read_b32 fetches both bucket entries (2 x u16 positions mod 65536), the last
-//     lane of each bucket group writes the new pair back with one ds_write_b32.
-// Entries are kept valid by distance: dist = (p - e) & 0xFFFF is a live candidate iff
-// 1 <= dist <= 32767 (libdeflate: cur_node > cutoff); every 32768 positions a sweep re-marks
-// stale entries so the 16-bit distance can never alias (the analogue of the window slide).
+// k_candidates: ht_matchfinder's bucket table (2^15 buckets x 2 entries), restated as "the
+// previous two positions with the same hash".  One wave per block, 128 KiB table in LDS.
+//
+// Table word per bucket: [ (last position + 1) << 16 | (that position's own predecessor + 1) ],
+// 0 = empty.  Positions of one block are < 65536 and only grow, so the newest position of a
+// bucket is an unsigned maximum, and liveness (libdeflate: cur_node > cutoff) is the plain
+// distance test p - c <= 32767 -- no window slide is needed below 64 KiB.
+//
+// Fast kernel (k_candidates): every lane does  old = atomicMax(&tab[h], (p+1) << 16).
+// The LDS applies same-address atomics of one instruction in ascending lane order (measured:
+// tools/probes/lds_atomic_order.hip, 2000/2000 patterns), so `old` already is the lane's
+// predecessor in its bucket -- whether that predecessor sits in an earlier step or in a lower
+// lane of the same instruction.  No cross-lane matching is needed, so kCandSteps steps
+// (kCandSteps * 64 positions) are kept in flight per iteration: all first atomics, one wait,
+// the older candidate c1 = "predecessor of the predecessor" from a small LDS staging array (or
+// from the low half of `old` when the predecessor is older than this iteration), then a second
+// atomicMax that files (p+1) << 16 | (c0+1).  The ordering assumption is CHECKED, never
+// trusted: a lane that is handed a predecessor >= its own position flags the block, and
+// k_candidates_safe (ballot match-any, order-independent) redoes flagged blocks.
 // Output: cand[p] = d0 | d1 << 16 (distances of the newer / older candidate, 0 = none).
 // ------------------------------------------------------------------------------------------
 constexpr uint32_t kBuckets = 1u << 15;
-constexpr uint32_t kCandPrefetch = 8;  // steps of input kept in flight per lane (register ring)
+constexpr uint32_t kCandSteps = 8;  // steps per iteration; also the depth of the input prefetch
 
 // aligned dword pair covering in[p .. p+3] (in32 = the block's bytes rounded down to a dword
-// boundary, mis = bytes skipped by that rounding); only issued for positions that are hashed
-// Unconditional (index clamped to the block's last dword) so that the number of loads in flight
-// is static and the compiler can wait with exact vmcnt values instead of vmcnt(0).
+// boundary, mis = bytes skipped by that rounding).  Unconditional (index clamped to the block's
+// last dword) so that the number of loads in flight is static and the compiler can wait with
+// exact vmcnt values instead of vmcnt(0).
 __device__ __forceinline__ uint2 cand_fetch(const uint32_t *__restrict__ in32, uint32_t mis,
                                             uint32_t p, uint32_t wmax) {
     const uint32_t w = (p + mis) >> 2;  // bytes p..p+4 lie inside dwords w, w+1
@@ -186,60 +195,19 @@ __device__ __forceinline__ uint2 cand_fetch(const uint32_t *__restrict__ in32, u
     return v;
 }
 
-// One 64-position step.  Fast path: every lane swaps its position into its bucket at once and
-// reads the bucket back; if each lane finds its own position there, no two lanes of the step
-// shared a bucket and the pre-step bucket contents are the candidates.  Otherwise (slow path)
-// the lanes are linked in position order with a 15-round ballot match-any and the shared
-// buckets are rewritten by the last lane of each group.
-__device__ __forceinline__ void cand_step(uint32_t *tab, uint32_t mis, uint32_t base,
-                                          uint32_t lane, uint32_t n, uint2 raw,
-                                          uint32_t *__restrict__ cand) {
-    const uint32_t p = base + lane;
-    const bool valid = p + 5 <= n;  // positions the matchfinder hashes (REQUIRED_NBYTES = 5)
-    uint32_t h = 0;
-    if (valid && p != 0)
-        h = lz_hash15(__builtin_amdgcn_alignbyte(raw.y, raw.x, (p + mis) & 3u));
-    const uint32_t t = tab[h];
-    uint32_t c0 = t & 0xFFFFu, c1 = t >> 16;
-    wave_sync();  // every lane has read its bucket before any lane rewrites one
-    if (valid) tab[h] = (p & 0xFFFFu) | (c0 << 16);
-    wave_sync();
-    const uint32_t chk = tab[h];
-    const bool lost = valid && (chk & 0xFFFFu) != (p & 0xFFFFu);
-    if (__ballot(lost)) {
-        // slow path: match-any over the 15-bit bucket index
-        uint64_t same = __ballot(valid);
-        for (int bit = 0; bit < 15; bit++) {
-            const bool one = (h >> bit) & 1u;
-            const uint64_t m = __ballot(one);
-            same &= one ? m : ~m;
-        }
-        const uint64_t below = same & ((1ull << lane) - 1ull);
-        const bool is_last_of_group = ((same >> lane) >> 1) == 0;
-        if (below) {
-            const uint32_t j1 = 63u - (uint32_t)__clzll((long long)below);
-            const uint64_t below2 = below & ~(1ull << j1);
-            c1 = below2 ? ((base + 63u - (uint32_t)__clzll((long long)below2)) & 0xFFFFu) : c0;
-            c0 = (base + j1) & 0xFFFFu;
-        }
-        wave_sync();
-        if (valid && is_last_of_group) tab[h] = (p & 0xFFFFu) | (c0 << 16);
-        wave_sync();
-    }
-    uint32_t d0 = (p - c0) & 0xFFFFu, d1 = (p - c1) & 0xFFFFu;
-    if (d0 == 0 || d0 > 32767u) {
-        d0 = 0;
-        d1 = 0;
-    } else if (d1 == 0 || d1 > 32767u) {
-        d1 = 0;
-    }
-    cand[p] = valid ? (d0 | (d1 << 16)) : 0u;  // p < kCandStride always (padded stride)
+__device__ __forceinline__ uint32_t cand_pack(uint32_t p, uint32_t c0p, uint32_t c1p) {
+    // c0p / c1p are positions + 1 (0 = none); candidates farther than 32767 are dead
+    uint32_t d0 = c0p ? p + 1 - c0p : 0, d1 = c1p ? p + 1 - c1p : 0;
+    if (d0 > 32767u) d0 = 0;
+    if (d0 == 0 || d1 > 32767u) d1 = 0;
+    return d0 | (d1 << 16);
 }
 
 __global__ __launch_bounds__(64) void k_candidates(Config cfg, const uint8_t *__restrict__ slab,
-                                                   const BlockMeta *__restrict__ meta,
+                                                   BlockMeta *__restrict__ meta,
                                                    uint32_t *__restrict__ cand_all) {
-    __shared__ uint32_t tab[kBuckets];  // 128 KiB: [e0 | e1 << 16]
+    __shared__ uint32_t tab[kBuckets];          // 128 KiB
+    __shared__ uint32_t stage[kCandSteps * 64];  // (c0 + 1) of every position of the iteration
     const uint32_t lane = threadIdx.x;
     const uint32_t b = blockIdx.x;
     const uint32_t n = meta[b].n;
@@ -250,26 +218,121 @@ __global__ __launch_bounds__(64) void k_candidates(Config cfg, const uint8_t *__
     const uint32_t wmax = (mis + n - 1) >> 2;  // last dword holding a byte of this block
     uint32_t *cand = cand_all + (uint64_t)b * kCandStride;
 
-    for (uint32_t i = lane; i < kBuckets; i += 64) tab[i] = 0x80008000u;
+    for (uint32_t i = lane; i < kBuckets; i += 64) tab[i] = 0;
     wave_sync();
 
-    // a single wave per CU has nobody to hide HBM latency behind: keep kCandPrefetch steps of
-    // input in flight in a register ring
-    uint2 ring[kCandPrefetch];
+    // a single wave per CU has nobody to hide HBM latency behind: the next iteration's input is
+    // always in flight
+    uint2 ring[kCandSteps];
 #pragma unroll
-    for (uint32_t k = 0; k < kCandPrefetch; k++) ring[k] = cand_fetch(in32, mis, k * 64 + lane, wmax);
+    for (uint32_t k = 0; k < kCandSteps; k++) ring[k] = cand_fetch(in32, mis, k * 64 + lane, wmax);
 
-    for (uint32_t base0 = 0; base0 < n; base0 += 64 * kCandPrefetch) {
-        uint2 cur[kCandPrefetch];
+    bool bad = false;
+    for (uint32_t base0 = 0; base0 < n; base0 += 64 * kCandSteps) {
+        uint32_t h[kCandSteps], old[kCandSteps];
 #pragma unroll
-        for (uint32_t k = 0; k < kCandPrefetch; k++) cur[k] = ring[k];
+        for (uint32_t k = 0; k < kCandSteps; k++) {
+            const uint32_t p = base0 + k * 64 + lane;
+            const uint32_t v = __builtin_amdgcn_alignbyte(ring[k].y, ring[k].x, (p + mis) & 3u);
+            h[k] = p != 0 ? lz_hash15(v) : 0;  // position 0 is filed under bucket 0 (next_hash = 0)
+        }
 #pragma unroll
-        for (uint32_t k = 0; k < kCandPrefetch; k++)
-            ring[k] = cand_fetch(in32, mis, base0 + (kCandPrefetch + k) * 64 + lane, wmax);
+        for (uint32_t k = 0; k < kCandSteps; k++)
+            ring[k] = cand_fetch(in32, mis, base0 + (kCandSteps + k) * 64 + lane, wmax);
+        // first atomics: newest position per bucket; the return value is the predecessor
 #pragma unroll
-        for (uint32_t k = 0; k < kCandPrefetch; k++) {
-            const uint32_t base = base0 + k * 64;  // steps past n only store zeros into padding
-            if (base != 0 && (base & 32767u) == 0 && base < n) {
+        for (uint32_t k = 0; k < kCandSteps; k++) {
+            const uint32_t p = base0 + k * 64 + lane;
+            old[k] = 0;
+            if (p + 5 <= n) old[k] = atomicMax(&tab[h[k]], (p + 1) << 16);
+        }
+#pragma unroll
+        for (uint32_t k = 0; k < kCandSteps; k++) {
+            const uint32_t p = base0 + k * 64 + lane;
+            const uint32_t c0p = old[k] >> 16;
+            bad |= c0p > p;  // handed a predecessor that is not earlier: LDS order assumption broken
+            stage[k * 64 + lane] = c0p;
+        }
+        wave_sync();
+        uint32_t c1s[kCandSteps];
+#pragma unroll
+        for (uint32_t k = 0; k < kCandSteps; k++) {  // all gathers in flight before the first use
+            const uint32_t c0p = old[k] >> 16;
+            c1s[k] = stage[c0p > base0 ? c0p - 1 - base0 : 0];
+        }
+#pragma unroll
+        for (uint32_t k = 0; k < kCandSteps; k++) {
+            const uint32_t p = base0 + k * 64 + lane;
+            const uint32_t c0p = old[k] >> 16;
+            // predecessor older than this iteration: its own predecessor was filed with it
+            const uint32_t c1p = c0p > base0 ? c1s[k] : (old[k] & 0xFFFFu);
+            if (p + 5 <= n) atomicMax(&tab[h[k]], ((p + 1) << 16) | c0p);
+            cand[p] = (p + 5 <= n) ? cand_pack(p, c0p, c1p) : 0u;  // p < kCandStride (padded)
+        }
+        wave_sync();
+    }
+    if (__ballot(bad) && lane == 0) meta[b].cand_redo = 1;
+}
+
+// Order-independent restatement used for blocks flagged by k_candidates (expected: never):
+// lanes of a step that share a bucket are linked in position order with a 15-round ballot
+// match-any; the last lane of each group rewrites the bucket.  Table word: [e0 | e1 << 16] as
+// positions mod 65536 with a dead marker (0x8000 behind), swept every 32768 positions.
+__device__ __forceinline__ void cand_step_safe(uint32_t *tab, uint32_t mis, uint32_t base,
+                                               uint32_t lane, uint32_t n, uint2 raw,
+                                               uint32_t *__restrict__ cand) {
+    const uint32_t p = base + lane;
+    const bool valid = p + 5 <= n;  // positions the matchfinder hashes (REQUIRED_NBYTES = 5)
+    uint32_t h = 0;
+    if (valid && p != 0) h = lz_hash15(__builtin_amdgcn_alignbyte(raw.y, raw.x, (p + mis) & 3u));
+    const uint32_t t = tab[h];
+    uint32_t c0 = t & 0xFFFFu, c1 = t >> 16;
+    uint64_t same = __ballot(valid);
+    for (int bit = 0; bit < 15; bit++) {
+        const bool one = (h >> bit) & 1u;
+        const uint64_t m = __ballot(one);
+        same &= one ? m : ~m;
+    }
+    const uint64_t below = same & ((1ull << lane) - 1ull);
+    const bool is_last_of_group = ((same >> lane) >> 1) == 0;
+    if (below) {
+        const uint32_t j1 = 63u - (uint32_t)__clzll((long long)below);
+        const uint64_t below2 = below & ~(1ull << j1);
+        c1 = below2 ? ((base + 63u - (uint32_t)__clzll((long long)below2)) & 0xFFFFu) : c0;
+        c0 = (base + j1) & 0xFFFFu;
+    }
+    wave_sync();  // every lane has read its bucket before any lane rewrites one
+    if (valid && is_last_of_group) tab[h] = (p & 0xFFFFu) | (c0 << 16);
+    wave_sync();
+    uint32_t d0 = (p - c0) & 0xFFFFu, d1 = (p - c1) & 0xFFFFu;
+    if (d0 == 0 || d0 > 32767u) {
+        d0 = 0;
+        d1 = 0;
+    } else if (d1 == 0 || d1 > 32767u) {
+        d1 = 0;
+    }
+    cand[p] = valid ? (d0 | (d1 << 16)) : 0u;
+}
+
+__global__ __launch_bounds__(64) void k_candidates_safe(Config cfg, const uint8_t *__restrict__ slab,
+                                                        BlockMeta *__restrict__ meta, uint32_t nb,
+                                                        uint32_t force,
+                                                        uint32_t *__restrict__ cand_all) {
+    __shared__ uint32_t tab[kBuckets];
+    const uint32_t lane = threadIdx.x;
+    for (uint32_t b = blockIdx.x; b < nb; b += gridDim.x) {
+        const uint32_t n = meta[b].n;
+        if (n <= kPassthroughL1 || !(force || meta[b].cand_redo)) continue;  // wave-uniform
+        const uint8_t *in = slab + (uint64_t)b * cfg.block_size;
+        const uint32_t mis = (uint32_t)((uintptr_t)in & 3u);
+        const uint32_t *in32 = (const uint32_t *)(in - mis);
+        const uint32_t wmax = (mis + n - 1) >> 2;
+        uint32_t *cand = cand_all + (uint64_t)b * kCandStride;
+        wave_sync();
+        for (uint32_t i = lane; i < kBuckets; i += 64) tab[i] = 0x80008000u;
+        wave_sync();
+        for (uint32_t base = 0; base < n; base += 64) {
+            if (base != 0 && (base & 32767u) == 0) {
                 // sweep: entries farther than 32767 behind `base` become "dead for the next
                 // 32768 positions" (the analogue of libdeflate's window slide)
                 const uint32_t dead = (base + 0x8000u) & 0xFFFFu;
@@ -283,8 +346,9 @@ __global__ __launch_bounds__(64) void k_candidates(Config cfg, const uint8_t *__
                 }
                 wave_sync();
             }
-            cand_step(tab, mis, base, lane, n, cur[k], cand);
+            cand_step_safe(tab, mis, base, lane, n, cand_fetch(in32, mis, base + lane, wmax), cand);
         }
+        if (lane == 0) meta[b].cand_redo = 0;
     }
 }
 
@@ -1277,8 +1341,13 @@ void launch_init_meta(const Config &cfg, uint64_t slab_len, uint32_t nb, int is_
 
 void launch_candidates(const Config &cfg, const uint8_t *slab, uint64_t, uint32_t nb, const Scratch &s,
                        hipStream_t stream) {
-    hipLaunchKernelGGL(k_candidates, dim3(nb), dim3(64), 0, stream, cfg, slab,
-                       (const BlockMeta *)s.meta, s.cand);
+    const uint32_t force_safe = cfg.debug & 1u;  // diagnostics: exercise the fallback on every block
+    if (!force_safe)
+        hipLaunchKernelGGL(k_candidates, dim3(nb), dim3(64), 0, stream, cfg, slab, s.meta, s.cand);
+    // blocks flagged by the order check (none expected) are redone order-independently
+    const uint32_t grid = force_safe ? nb : (nb < 256u ? nb : 256u);
+    hipLaunchKernelGGL(k_candidates_safe, dim3(grid), dim3(64), 0, stream, cfg, slab, s.meta, nb,
+                       force_safe, s.cand);
 }
 
 void launch_match_parse(const Config &cfg, const uint8_t *slab, uint64_t, uint32_t nb,

@@ -120,6 +120,10 @@ const char *gzpx_stage_name(int stage);
 int gzpx_debug_tokens(gzpx_ctx *ctx, size_t block, uint32_t *tokens, size_t max_tokens,
                       size_t *n_tokens, uint32_t *sub_first_token, size_t *n_sub);
 
+/* Diagnostics switches (0 in production): bit 0 = run the order-independent candidate kernel
+ * (k_candidates_safe) on every block instead of the atomic-chain kernel. */
+int gzpx_debug_set_flags(gzpx_ctx *ctx, uint32_t flags);
+
 /* k_match_parse diagnostics of the last batch: shader-clock cycles per phase summed over blocks
  * [stage-in, match, parse rounds, mark walk, rank scan, token build, parse rounds count, -]. */
 int gzpx_debug_phase_cycles(const gzpx_ctx *ctx, uint64_t cycles[8]);

@@ -120,3 +120,12 @@ def test_builder_validation(emu_lib):
     with pytest.raises(_native.GzpxError) as ei:
         _native.Context(level=6, lib=emu_lib)
     assert ei.value.code == _native.ERR_UNSUPPORTED
+
+
+def test_order_independent_candidate_kernel(emu_lib, oracle):
+    """k_candidates_safe (the fallback for a failed LDS-order check) forced on every block."""
+    with _native.Context(level=1, compat=_native.COMPAT_1_10, lib=emu_lib, max_slab_bytes=3 * 65280) as c:
+        c.debug_set_flags(1)
+        for cls in ("text", "zeros", "period2", "repeats", "random"):
+            a = synth.make(cls, 2 * 65280 + 99, 17)
+            assert c.compress_slab(a, True) == oracle.compress_stream(a, oracle.FMT_BGZF, 1, oracle.COMPAT_1_10, 65280), cls

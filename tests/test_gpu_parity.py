@@ -126,3 +126,13 @@ def test_device_resident_slab_and_properties(hip_lib, oracle):
         want = oracle.encode_block(a[b * 65280:(b + 1) * 65280], oracle.FMT_BGZF, 1, oracle.COMPAT_1_24,
                                    is_last=(b == nb - 1))
         assert out[offs[b]:offs[b + 1]].tobytes() == want, b
+
+
+def test_order_independent_candidate_kernel(hip_lib, oracle):
+    """k_candidates_safe (the fallback for a failed LDS-order check) forced on every block, and
+    the fast kernel never needing it on this hardware."""
+    with _native.Context(level=1, compat=_native.COMPAT_1_10, lib=hip_lib, max_slab_bytes=3 * 65280) as c:
+        c.debug_set_flags(1)
+        for cls in ("text", "zeros", "period2", "repeats", "random"):
+            a = synth.make(cls, 2 * 65280 + 99, 17)
+            assert c.compress_slab(a, True) == oracle.compress_stream(a, oracle.FMT_BGZF, 1, oracle.COMPAT_1_10, 65280), cls
