@@ -33,7 +33,7 @@ EXPORTS = [
     "gzpx_alloc_compressor", "gzpx_deflate_compress", "gzpx_deflate_compress_bound",
     "gzpx_free_compressor", "gzpx_compressor_set_compat", "gzpx_crc32",
     "gzpx_ctx_set_profiling", "gzpx_ctx_last_stage_ms", "gzpx_stage_name", "gzpx_debug_tokens",
-    "gzpx_debug_phase_cycles", "gzpx_debug_set_flags", "gzpx_strerror", "gzpx_device_name", "gzpx_version",
+    "gzpx_debug_phase_cycles", "gzpx_debug_cand_cycles", "gzpx_debug_set_flags", "gzpx_strerror", "gzpx_device_name", "gzpx_version",
 ]
 
 
@@ -103,6 +103,8 @@ class GzpxLib:
         L.gzpx_stage_name.argtypes = [i32]
         L.gzpx_debug_tokens.restype = i32
         L.gzpx_debug_tokens.argtypes = [vp, sz, vp, sz, psz, vp, psz]
+        L.gzpx_debug_cand_cycles.restype = i32
+        L.gzpx_debug_cand_cycles.argtypes = [vp, ctypes.POINTER(ctypes.c_uint64)]
         L.gzpx_debug_set_flags.restype = i32
         L.gzpx_debug_set_flags.argtypes = [vp, u32]
         L.gzpx_debug_phase_cycles.restype = i32
@@ -234,6 +236,11 @@ class Context:
         ms = (ctypes.c_float * N_STAGES)()
         self.lib.check(self.lib.L.gzpx_ctx_last_stage_ms(self.h, ms))
         return {self.lib.L.gzpx_stage_name(i).decode(): float(ms[i]) for i in range(N_STAGES)}
+
+    def debug_cand_cycles(self):
+        c = (ctypes.c_uint64 * 4)()
+        self.lib.check(self.lib.L.gzpx_debug_cand_cycles(self.h, c))
+        return [int(x) for x in c]
 
     def debug_set_flags(self, flags):
         self.lib.check(self.lib.L.gzpx_debug_set_flags(self.h, flags))

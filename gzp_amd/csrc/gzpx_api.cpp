@@ -528,6 +528,14 @@ int gzpx_debug_phase_cycles(const gzpx_ctx *ctx, uint64_t cycles[8]) {
     return GZPX_OK;
 }
 
+int gzpx_debug_cand_cycles(const gzpx_ctx *ctx, uint64_t cycles[4]) {
+    if (!ctx || !cycles) return GZPX_ERR_INVALID_ARG;
+    for (int k = 0; k < 4; k++) cycles[k] = 0;
+    for (uint32_t b = 0; b < ctx->last_nb; b++)
+        for (int k = 0; k < 4; k++) cycles[k] += ctx->h_meta[b].cand_cycles[k];
+    return GZPX_OK;
+}
+
 const char *gzpx_strerror(int code) {
     switch (code) {
         case GZPX_OK: return "ok";

@@ -53,6 +53,7 @@ struct BlockMeta {
     SubMeta sub[kMaxSub];
     uint32_t phase_cycles[8];  // k_match_parse: shader-clock cycles per phase (thread 0), diagnostics
     uint32_t cand_redo;        // k_candidates' LDS-order check failed: redo with k_candidates_safe
+    uint32_t cand_cycles[4];   // k_candidates: shader-clock cycles [hash+atomics, gather, file+store, total]
 };
 
 struct CrcConsts {

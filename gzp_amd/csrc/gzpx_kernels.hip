@@ -154,6 +154,7 @@ __global__ void k_init_meta(Config cfg, uint64_t slab_len, uint32_t nb, uint32_t
     }
     for (unsigned k = 0; k < 8; k++) m.phase_cycles[k] = 0;
     m.cand_redo = 0;
+    for (unsigned k = 0; k < 4; k++) m.cand_cycles[k] = 0;
     meta[b] = m;
 }
 
@@ -228,7 +229,10 @@ __global__ __launch_bounds__(64) void k_candidates(Config cfg, const uint8_t *__
     for (uint32_t k = 0; k < kCandSteps; k++) ring[k] = cand_fetch(in32, mis, k * 64 + lane, wmax);
 
     bool bad = false;
+    long long cyc_a = 0, cyc_b = 0, cyc_c = 0;
+    const long long t_begin = clock64();
     for (uint32_t base0 = 0; base0 < n; base0 += 64 * kCandSteps) {
+        const long long t0 = clock64();
         uint32_t h[kCandSteps], old[kCandSteps];
 #pragma unroll
         for (uint32_t k = 0; k < kCandSteps; k++) {
@@ -253,6 +257,7 @@ __global__ __launch_bounds__(64) void k_candidates(Config cfg, const uint8_t *__
             bad |= c0p > p;  // handed a predecessor that is not earlier: LDS order assumption broken
             stage[k * 64 + lane] = c0p;
         }
+        const long long t1 = clock64();
         wave_sync();
         uint32_t c1s[kCandSteps];
 #pragma unroll
@@ -260,6 +265,8 @@ __global__ __launch_bounds__(64) void k_candidates(Config cfg, const uint8_t *__
             const uint32_t c0p = old[k] >> 16;
             c1s[k] = stage[c0p > base0 ? c0p - 1 - base0 : 0];
         }
+        bad |= c1s[0] > 0x10000u;  // (never true) keeps the gathers ahead of the time stamp
+        const long long t2 = clock64();
 #pragma unroll
         for (uint32_t k = 0; k < kCandSteps; k++) {
             const uint32_t p = base0 + k * 64 + lane;
@@ -270,6 +277,16 @@ __global__ __launch_bounds__(64) void k_candidates(Config cfg, const uint8_t *__
             cand[p] = (p + 5 <= n) ? cand_pack(p, c0p, c1p) : 0u;  // p < kCandStride (padded)
         }
         wave_sync();
+        const long long t3 = clock64();
+        cyc_a += t1 - t0;
+        cyc_b += t2 - t1;
+        cyc_c += t3 - t2;
+    }
+    if (lane == 0) {
+        meta[b].cand_cycles[0] = (uint32_t)cyc_a;
+        meta[b].cand_cycles[1] = (uint32_t)cyc_b;
+        meta[b].cand_cycles[2] = (uint32_t)cyc_c;
+        meta[b].cand_cycles[3] = (uint32_t)(clock64() - t_begin);
     }
     if (__ballot(bad) && lane == 0) meta[b].cand_redo = 1;
 }

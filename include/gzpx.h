@@ -127,6 +127,8 @@ int gzpx_debug_set_flags(gzpx_ctx *ctx, uint32_t flags);
 /* k_match_parse diagnostics of the last batch: shader-clock cycles per phase summed over blocks
  * [stage-in, match, parse rounds, mark walk, rank scan, token build, parse rounds count, -]. */
 int gzpx_debug_phase_cycles(const gzpx_ctx *ctx, uint64_t cycles[8]);
+/* k_candidates diagnostics: cycles [hash + first atomics, stage gather, file + store, total]. */
+int gzpx_debug_cand_cycles(const gzpx_ctx *ctx, uint64_t cycles[4]);
 
 const char *gzpx_strerror(int code);
 const char *gzpx_device_name(const gzpx_ctx *ctx);
