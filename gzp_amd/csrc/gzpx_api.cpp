@@ -115,7 +115,7 @@ int alloc_scratch(gzpx_ctx *ctx) {
     const size_t nb = ctx->batch_blocks;
     Scratch &s = ctx->scratch;
     HIP_TRY(hipMalloc((void **)&s.meta, nb * sizeof(BlockMeta)));
-    HIP_TRY(hipMalloc((void **)&s.cand, nb * (size_t)kCandStride * 4));
+    HIP_TRY(hipMalloc((void **)&s.cand, nb * (size_t)kCandStride * sizeof(uint16_t)));
     HIP_TRY(hipMalloc((void **)&s.tok, nb * (size_t)kTokStride * 4));
     HIP_TRY(hipMalloc((void **)&s.hist, nb * (size_t)kMaxSub * kHistStride * 4));
     HIP_TRY(hipMalloc((void **)&s.codes, nb * (size_t)kMaxSub * kCodeWords * 4));

@@ -10,7 +10,7 @@
 namespace gzpx {
 
 constexpr unsigned kMaxUnit = 65536;       // max input bytes per block handled by the kernels
-constexpr unsigned kCandStride = kMaxUnit + 512;  // u32 per position (+ one super-step of padding)
+constexpr unsigned kCandStride = kMaxUnit + 512;  // u16 per position (+ one iteration of padding)
 constexpr unsigned kTokStride = kMaxUnit;  // u32 per token (worst case: all literals)
 constexpr unsigned kMaxSub = 2;            // n <= 65536 => at most 2 sub-blocks (8192 matches each)
 constexpr unsigned kSeqPerSub = 8192;      // FAST_SEQ_STORE_LENGTH
@@ -53,7 +53,7 @@ struct BlockMeta {
     SubMeta sub[kMaxSub];
     uint32_t phase_cycles[8];  // k_match_parse: shader-clock cycles per phase (thread 0), diagnostics
     uint32_t cand_redo;        // k_candidates' LDS-order check failed: redo with k_candidates_safe
-    uint32_t cand_cycles[4];   // k_candidates: shader-clock cycles [hash+atomics, gather, file+store, total]
+    uint32_t cand_cycles[4];   // k_candidates: shader-clock cycles [-, -, -, main loop total]
 };
 
 struct CrcConsts {
@@ -72,7 +72,7 @@ struct Config {
 // Device scratch for one batch of blocks.
 struct Scratch {
     BlockMeta *meta;      // [nb]
-    uint32_t *cand;       // [nb][kCandStride]   d0 | d1 << 16 (match distances, 0 = none)
+    uint16_t *cand;       // [nb][kCandStride]   d0: distance to the bucket predecessor (0 = none)
     uint32_t *tok;        // [nb][kTokStride]
     uint32_t *hist;       // [nb][kMaxSub][kHistStride]
     uint32_t *codes;      // [nb][kMaxSub][kCodeWords]

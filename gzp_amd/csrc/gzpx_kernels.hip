@@ -159,26 +159,26 @@ __global__ void k_init_meta(Config cfg, uint64_t slab_len, uint32_t nb, uint32_t
 }
 
 // ------------------------------------------------------------------------------------------
-// k_candidates: ht_matchfinder's bucket table (2^15 buckets x 2 entries), restated as "the
-// previous two positions with the same hash".  One wave per block, 128 KiB table in LDS.
+// k_candidates: ht_matchfinder's bucket table (2^15 buckets x 2 entries), restated as a chain:
+// the two entries of a bucket are always "the previous position with this hash" and "the one
+// before that", so it is enough to produce, for every position p, the distance d0[p] to its
+// predecessor in its bucket; the older candidate is the predecessor's predecessor
+// (d1 = d0[p] + d0[p - d0[p]]), which k_match_parse reads from the same array.
+// One wave per block, 128 KiB table in LDS, one word per bucket = (newest position + 1), 0 =
+// empty.  Positions of one block are < 65536 and only grow, so "newest" is an unsigned maximum
+// and liveness (libdeflate: cur_node > cutoff) is the plain distance test p - c <= 32767 -- no
+// window slide is needed below 64 KiB.
 //
-// Table word per bucket: [ (last position + 1) << 16 | (that position's own predecessor + 1) ],
-// 0 = empty.  Positions of one block are < 65536 and only grow, so the newest position of a
-// bucket is an unsigned maximum, and liveness (libdeflate: cur_node > cutoff) is the plain
-// distance test p - c <= 32767 -- no window slide is needed below 64 KiB.
-//
-// Fast kernel (k_candidates): every lane does  old = atomicMax(&tab[h], (p+1) << 16).
+// Fast kernel (k_candidates): every lane does  old = atomicMax(&tab[h], p + 1).
 // The LDS applies same-address atomics of one instruction in ascending lane order (measured:
 // tools/probes/lds_atomic_order.hip, 2000/2000 patterns), so `old` already is the lane's
 // predecessor in its bucket -- whether that predecessor sits in an earlier step or in a lower
-// lane of the same instruction.  No cross-lane matching is needed, so kCandSteps steps
-// (kCandSteps * 64 positions) are kept in flight per iteration: all first atomics, one wait,
-// the older candidate c1 = "predecessor of the predecessor" from a small LDS staging array (or
-// from the low half of `old` when the predecessor is older than this iteration), then a second
-// atomicMax that files (p+1) << 16 | (c0+1).  The ordering assumption is CHECKED, never
-// trusted: a lane that is handed a predecessor >= its own position flags the block, and
-// k_candidates_safe (ballot match-any, order-independent) redoes flagged blocks.
-// Output: cand[p] = d0 | d1 << 16 (distances of the newer / older candidate, 0 = none).
+// lane of the same instruction.  No cross-lane matching is needed, and kCandSteps steps
+// (kCandSteps * 64 positions) of atomics are kept in flight per iteration.  The ordering
+// assumption is CHECKED, never trusted: a lane that is handed a predecessor >= its own position
+// flags the block, and k_candidates_safe (ballot match-any, order-independent) redoes flagged
+// blocks.
+// Output: cand[p] = d0 (u16, 0 = no live predecessor).
 // ------------------------------------------------------------------------------------------
 constexpr uint32_t kBuckets = 1u << 15;
 constexpr uint32_t kCandSteps = 8;  // steps per iteration; also the depth of the input prefetch
@@ -196,19 +196,10 @@ __device__ __forceinline__ uint2 cand_fetch(const uint32_t *__restrict__ in32, u
     return v;
 }
 
-__device__ __forceinline__ uint32_t cand_pack(uint32_t p, uint32_t c0p, uint32_t c1p) {
-    // c0p / c1p are positions + 1 (0 = none); candidates farther than 32767 are dead
-    uint32_t d0 = c0p ? p + 1 - c0p : 0, d1 = c1p ? p + 1 - c1p : 0;
-    if (d0 > 32767u) d0 = 0;
-    if (d0 == 0 || d1 > 32767u) d1 = 0;
-    return d0 | (d1 << 16);
-}
-
 __global__ __launch_bounds__(64) void k_candidates(Config cfg, const uint8_t *__restrict__ slab,
                                                    BlockMeta *__restrict__ meta,
-                                                   uint32_t *__restrict__ cand_all) {
-    __shared__ uint32_t tab[kBuckets];          // 128 KiB
-    __shared__ uint32_t stage[kCandSteps * 64];  // (c0 + 1) of every position of the iteration
+                                                   uint16_t *__restrict__ cand_all) {
+    __shared__ uint32_t tab[kBuckets];  // 128 KiB
     const uint32_t lane = threadIdx.x;
     const uint32_t b = blockIdx.x;
     const uint32_t n = meta[b].n;
@@ -217,7 +208,7 @@ __global__ __launch_bounds__(64) void k_candidates(Config cfg, const uint8_t *__
     const uint32_t mis = (uint32_t)((uintptr_t)in & 3u);
     const uint32_t *in32 = (const uint32_t *)(in - mis);
     const uint32_t wmax = (mis + n - 1) >> 2;  // last dword holding a byte of this block
-    uint32_t *cand = cand_all + (uint64_t)b * kCandStride;
+    uint16_t *cand = cand_all + (uint64_t)b * kCandStride;
 
     for (uint32_t i = lane; i < kBuckets; i += 64) tab[i] = 0;
     wave_sync();
@@ -229,10 +220,8 @@ __global__ __launch_bounds__(64) void k_candidates(Config cfg, const uint8_t *__
     for (uint32_t k = 0; k < kCandSteps; k++) ring[k] = cand_fetch(in32, mis, k * 64 + lane, wmax);
 
     bool bad = false;
-    long long cyc_a = 0, cyc_b = 0, cyc_c = 0;
     const long long t_begin = clock64();
     for (uint32_t base0 = 0; base0 < n; base0 += 64 * kCandSteps) {
-        const long long t0 = clock64();
         uint32_t h[kCandSteps], old[kCandSteps];
 #pragma unroll
         for (uint32_t k = 0; k < kCandSteps; k++) {
@@ -243,67 +232,38 @@ __global__ __launch_bounds__(64) void k_candidates(Config cfg, const uint8_t *__
 #pragma unroll
         for (uint32_t k = 0; k < kCandSteps; k++)
             ring[k] = cand_fetch(in32, mis, base0 + (kCandSteps + k) * 64 + lane, wmax);
-        // first atomics: newest position per bucket; the return value is the predecessor
+        // newest position per bucket; the return value is the predecessor
 #pragma unroll
         for (uint32_t k = 0; k < kCandSteps; k++) {
             const uint32_t p = base0 + k * 64 + lane;
             old[k] = 0;
-            if (p + 5 <= n) old[k] = atomicMax(&tab[h[k]], (p + 1) << 16);
+            if (p + 5 <= n) old[k] = atomicMax(&tab[h[k]], p + 1);
         }
 #pragma unroll
         for (uint32_t k = 0; k < kCandSteps; k++) {
             const uint32_t p = base0 + k * 64 + lane;
-            const uint32_t c0p = old[k] >> 16;
-            bad |= c0p > p;  // handed a predecessor that is not earlier: LDS order assumption broken
-            stage[k * 64 + lane] = c0p;
+            bad |= old[k] > p;  // handed a predecessor that is not earlier: LDS order assumption broken
+            uint32_t d0 = old[k] ? p + 1 - old[k] : 0;
+            if (d0 > 32767u) d0 = 0;                // farther than the window: dead
+            cand[p] = (uint16_t)d0;                 // p < kCandStride (padded stride)
         }
-        const long long t1 = clock64();
-        wave_sync();
-        uint32_t c1s[kCandSteps];
-#pragma unroll
-        for (uint32_t k = 0; k < kCandSteps; k++) {  // all gathers in flight before the first use
-            const uint32_t c0p = old[k] >> 16;
-            c1s[k] = stage[c0p > base0 ? c0p - 1 - base0 : 0];
-        }
-        bad |= c1s[0] > 0x10000u;  // (never true) keeps the gathers ahead of the time stamp
-        const long long t2 = clock64();
-#pragma unroll
-        for (uint32_t k = 0; k < kCandSteps; k++) {
-            const uint32_t p = base0 + k * 64 + lane;
-            const uint32_t c0p = old[k] >> 16;
-            // predecessor older than this iteration: its own predecessor was filed with it
-            const uint32_t c1p = c0p > base0 ? c1s[k] : (old[k] & 0xFFFFu);
-            if (p + 5 <= n) atomicMax(&tab[h[k]], ((p + 1) << 16) | c0p);
-            cand[p] = (p + 5 <= n) ? cand_pack(p, c0p, c1p) : 0u;  // p < kCandStride (padded)
-        }
-        wave_sync();
-        const long long t3 = clock64();
-        cyc_a += t1 - t0;
-        cyc_b += t2 - t1;
-        cyc_c += t3 - t2;
     }
-    if (lane == 0) {
-        meta[b].cand_cycles[0] = (uint32_t)cyc_a;
-        meta[b].cand_cycles[1] = (uint32_t)cyc_b;
-        meta[b].cand_cycles[2] = (uint32_t)cyc_c;
-        meta[b].cand_cycles[3] = (uint32_t)(clock64() - t_begin);
-    }
+    if (lane == 0) meta[b].cand_cycles[3] = (uint32_t)(clock64() - t_begin);
     if (__ballot(bad) && lane == 0) meta[b].cand_redo = 1;
 }
 
 // Order-independent restatement used for blocks flagged by k_candidates (expected: never):
 // lanes of a step that share a bucket are linked in position order with a 15-round ballot
-// match-any; the last lane of each group rewrites the bucket.  Table word: [e0 | e1 << 16] as
-// positions mod 65536 with a dead marker (0x8000 behind), swept every 32768 positions.
+// match-any; the last lane of each group rewrites the bucket (position mod 65536, with a dead
+// marker 0x8000 behind that is refreshed every 32768 positions).
 __device__ __forceinline__ void cand_step_safe(uint32_t *tab, uint32_t mis, uint32_t base,
                                                uint32_t lane, uint32_t n, uint2 raw,
-                                               uint32_t *__restrict__ cand) {
+                                               uint16_t *__restrict__ cand) {
     const uint32_t p = base + lane;
     const bool valid = p + 5 <= n;  // positions the matchfinder hashes (REQUIRED_NBYTES = 5)
     uint32_t h = 0;
     if (valid && p != 0) h = lz_hash15(__builtin_amdgcn_alignbyte(raw.y, raw.x, (p + mis) & 3u));
-    const uint32_t t = tab[h];
-    uint32_t c0 = t & 0xFFFFu, c1 = t >> 16;
+    uint32_t c0 = tab[h];
     uint64_t same = __ballot(valid);
     for (int bit = 0; bit < 15; bit++) {
         const bool one = (h >> bit) & 1u;
@@ -312,29 +272,19 @@ __device__ __forceinline__ void cand_step_safe(uint32_t *tab, uint32_t mis, uint
     }
     const uint64_t below = same & ((1ull << lane) - 1ull);
     const bool is_last_of_group = ((same >> lane) >> 1) == 0;
-    if (below) {
-        const uint32_t j1 = 63u - (uint32_t)__clzll((long long)below);
-        const uint64_t below2 = below & ~(1ull << j1);
-        c1 = below2 ? ((base + 63u - (uint32_t)__clzll((long long)below2)) & 0xFFFFu) : c0;
-        c0 = (base + j1) & 0xFFFFu;
-    }
+    if (below) c0 = (base + 63u - (uint32_t)__clzll((long long)below)) & 0xFFFFu;
     wave_sync();  // every lane has read its bucket before any lane rewrites one
-    if (valid && is_last_of_group) tab[h] = (p & 0xFFFFu) | (c0 << 16);
+    if (valid && is_last_of_group) tab[h] = p & 0xFFFFu;
     wave_sync();
-    uint32_t d0 = (p - c0) & 0xFFFFu, d1 = (p - c1) & 0xFFFFu;
-    if (d0 == 0 || d0 > 32767u) {
-        d0 = 0;
-        d1 = 0;
-    } else if (d1 == 0 || d1 > 32767u) {
-        d1 = 0;
-    }
-    cand[p] = valid ? (d0 | (d1 << 16)) : 0u;
+    uint32_t d0 = (p - c0) & 0xFFFFu;
+    if (d0 > 32767u) d0 = 0;
+    cand[p] = (uint16_t)(valid ? d0 : 0u);
 }
 
 __global__ __launch_bounds__(64) void k_candidates_safe(Config cfg, const uint8_t *__restrict__ slab,
                                                         BlockMeta *__restrict__ meta, uint32_t nb,
                                                         uint32_t force,
-                                                        uint32_t *__restrict__ cand_all) {
+                                                        uint16_t *__restrict__ cand_all) {
     __shared__ uint32_t tab[kBuckets];
     const uint32_t lane = threadIdx.x;
     for (uint32_t b = blockIdx.x; b < nb; b += gridDim.x) {
@@ -344,9 +294,9 @@ __global__ __launch_bounds__(64) void k_candidates_safe(Config cfg, const uint8_
         const uint32_t mis = (uint32_t)((uintptr_t)in & 3u);
         const uint32_t *in32 = (const uint32_t *)(in - mis);
         const uint32_t wmax = (mis + n - 1) >> 2;
-        uint32_t *cand = cand_all + (uint64_t)b * kCandStride;
+        uint16_t *cand = cand_all + (uint64_t)b * kCandStride;
         wave_sync();
-        for (uint32_t i = lane; i < kBuckets; i += 64) tab[i] = 0x80008000u;
+        for (uint32_t i = lane; i < kBuckets; i += 64) tab[i] = 0x8000u;
         wave_sync();
         for (uint32_t base = 0; base < n; base += 64) {
             if (base != 0 && (base & 32767u) == 0) {
@@ -354,12 +304,9 @@ __global__ __launch_bounds__(64) void k_candidates_safe(Config cfg, const uint8_
                 // 32768 positions" (the analogue of libdeflate's window slide)
                 const uint32_t dead = (base + 0x8000u) & 0xFFFFu;
                 for (uint32_t i = lane; i < kBuckets; i += 64) {
-                    const uint32_t t = tab[i];
-                    uint32_t e0 = t & 0xFFFFu, e1 = t >> 16;
-                    const uint32_t a0 = (base - e0) & 0xFFFFu, a1 = (base - e1) & 0xFFFFu;
-                    if (a0 == 0 || a0 > 32767u) e0 = dead;
-                    if (a1 == 0 || a1 > 32767u) e1 = dead;
-                    tab[i] = e0 | (e1 << 16);
+                    const uint32_t e = tab[i];
+                    const uint32_t a = (base - e) & 0xFFFFu;
+                    if (a == 0 || a > 32767u) tab[i] = dead;
                 }
                 wave_sync();
             }
@@ -427,7 +374,7 @@ __device__ __forceinline__ uint32_t walk_segment(const uint8_t *len8, uint32_t p
 
 __global__ __launch_bounds__(kMpThreads) void k_match_parse(
     Config cfg, const uint8_t *__restrict__ slab, BlockMeta *__restrict__ meta_all,
-    const uint32_t *__restrict__ cand_all, uint32_t *__restrict__ tok_all,
+    const uint16_t *__restrict__ cand_all, uint32_t *__restrict__ tok_all,
     uint32_t *__restrict__ hist_all) {
     __shared__ uint32_t in_w[kInWords];             // block bytes (+ lead misalignment, + pad)
     __shared__ uint8_t len8[kMaxUnit];              // 0 = literal, else match length - 3
@@ -446,7 +393,7 @@ __global__ __launch_bounds__(kMpThreads) void k_match_parse(
     const uint32_t n = meta->n;
     if (n <= kPassthroughL1) return;  // uniform for the workgroup
     const uint8_t *in = slab + (uint64_t)b * cfg.block_size;
-    const uint32_t *cand = cand_all + (uint64_t)b * kCandStride;
+    const uint16_t *cand = cand_all + (uint64_t)b * kCandStride;
     uint32_t *tok = tok_all + (uint64_t)b * kTokStride;
 
     // ---- phase 0: stage input
@@ -470,20 +417,27 @@ __global__ __launch_bounds__(kMpThreads) void k_match_parse(
         t_mark = t;
     }
 
-    // ---- phase 1: longest match at every position (candidate loads batched 4 deep)
+    // ---- phase 1: longest match at every position.  Candidate distances are read 4 positions
+    // deep: d0 = distance to the bucket predecessor, d1 = d0 + the predecessor's own d0.
     for (uint32_t p0 = tid; p0 < n; p0 += 4 * kMpThreads) {
-        uint32_t cd[4];
+        uint32_t d0s[4], d1s[4];
 #pragma unroll
         for (uint32_t k = 0; k < 4; k++) {
             const uint32_t p = p0 + k * kMpThreads;
-            cd[k] = (p + 5 <= n) ? cand[p] : 0u;
+            d0s[k] = (p + 5 <= n) ? cand[p] : 0u;
+        }
+#pragma unroll
+        for (uint32_t k = 0; k < 4; k++) {
+            const uint32_t p = p0 + k * kMpThreads;
+            const uint32_t r = d0s[k] ? cand[p - d0s[k]] : 0u;
+            d1s[k] = (r && d0s[k] + r <= 32767u) ? d0s[k] + r : 0u;
         }
 #pragma unroll
         for (uint32_t k = 0; k < 4; k++) {
             const uint32_t p = p0 + k * kMpThreads;
             if (p >= n) break;
             uint32_t best = 0;
-            const uint32_t d0 = cd[k] & 0xFFFFu, d1 = cd[k] >> 16;
+            const uint32_t d0 = d0s[k], d1 = d1s[k];
             if (d0) {
                 const uint32_t rem = n - p;
                 const uint32_t max_len = rem < 258u ? rem : 258u;
@@ -611,8 +565,8 @@ __global__ __launch_bounds__(kMpThreads) void k_match_parse(
             uint32_t *h = hist + (mi >= kSeqPerSub ? kHistStride : 0);
             if (is_match) {
                 const uint32_t len = l + 3;
-                const uint32_t cd = cand[p];
-                const uint32_t off = ((which_bits[p >> 5] >> (p & 31u)) & 1u) ? (cd >> 16) : (cd & 0xFFFFu);
+                uint32_t off = cand[p];
+                if ((which_bits[p >> 5] >> (p & 31u)) & 1u) off += cand[p - off];  // the older candidate
                 uint32_t ls, le, lv, os, oe, ov;
                 length_slot(len, ls, le, lv);
                 offset_slot(off, os, oe, ov);
@@ -1088,9 +1042,11 @@ __global__ __launch_bounds__(64) void k_huffman(Config cfg, BlockMeta *__restric
 }
 
 // ------------------------------------------------------------------------------------------
-// k_crc32: gzip CRC-32 of every block.  Thread t owns the 256-byte segment that ENDS at
-// n - 256*(255 - t) (so only the first used segment is short), computes its CRC bytewise with
-// an LDS table, and the 256 CRCs are merged by a log-tree of zlib-style crc32_combine steps:
+// k_crc32: gzip CRC-32 of every block.  The block is staged in LDS with coalesced dword loads
+// (one HBM read of the input, no strided re-fetching).  Thread t owns the 256-byte segment that
+// ENDS at n - 256*(255 - t) (so only the first used segment is short), runs slice-by-4 over it
+// out of LDS (segments are laid out 65 dwords apart, so the 64 lanes of a wave hit 64 different
+// banks), and the 256 CRCs are merged by a log-tree of zlib-style crc32_combine steps:
 // crc(A||B) = crc(A) * x^(8|B|) mod P  xor  crc(B), with |B| = 256 * 2^level at every level.
 // ------------------------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t gf2_multmodp(uint32_t a, uint32_t bv) {
@@ -1103,28 +1059,66 @@ __device__ __forceinline__ uint32_t gf2_multmodp(uint32_t a, uint32_t bv) {
     return p;
 }
 
+constexpr uint32_t kCrcDataWords = (kMaxUnit / 4 + 2) + (kMaxUnit / 4 + 2) / 64 + 2;
+
+// dword index -> padded LDS index (one pad word after every 64)
+__device__ __forceinline__ uint32_t crc_pad(uint32_t w) { return w + (w >> 6); }
+
 __global__ __launch_bounds__(256) void k_crc32(Config cfg, const uint8_t *__restrict__ slab,
                                                BlockMeta *__restrict__ meta_all, CrcConsts cc) {
-    __shared__ uint32_t table[256];
+    __shared__ uint32_t table[4][256];
+    __shared__ uint32_t data[kCrcDataWords];
     __shared__ uint32_t part[256];
     const uint32_t tid = threadIdx.x;
     const uint32_t b = blockIdx.x;
     const uint32_t n = meta_all[b].n;
     const uint8_t *in = slab + (uint64_t)b * cfg.block_size;
+    const uint32_t mis = (uint32_t)((uintptr_t)in & 3u);
     {
         uint32_t c = tid;
         for (int k = 0; k < 8; k++) c = (c >> 1) ^ (0xEDB88320u & (0u - (c & 1u)));
-        table[tid] = c;
+        table[0][tid] = c;
+    }
+    if (n) {
+        const uint32_t *src = (const uint32_t *)(in - mis);
+        const uint32_t ndw = (mis + n + 3) >> 2;
+        for (uint32_t i = tid; i < ndw; i += 256) data[crc_pad(i)] = src[i];
     }
     __syncthreads();
-    // segment of thread t: [n - 256*(256 - t), n - 256*(255 - t)) clipped at 0
-    const int64_t seg_end = (int64_t)n - 256 * (int64_t)(255 - tid);
-    int64_t seg_begin = seg_end - 256;
+    {
+        const uint32_t t0 = table[0][tid];
+        const uint32_t t1 = (t0 >> 8) ^ table[0][t0 & 0xFFu];
+        const uint32_t t2 = (t1 >> 8) ^ table[0][t1 & 0xFFu];
+        const uint32_t t3 = (t2 >> 8) ^ table[0][t2 & 0xFFu];
+        table[1][tid] = t1;
+        table[2][tid] = t2;
+        table[3][tid] = t3;
+    }
+    __syncthreads();
+    // segment of thread t in block bytes: [n - 256*(256 - t), n - 256*(255 - t)) clipped at 0;
+    // LDS byte address of block byte i is i + mis (before padding)
+    const int32_t seg_end_i = (int32_t)n - 256 * (int32_t)(255 - tid);
     uint32_t crc = 0;
-    if (seg_end > 0) {
-        if (seg_begin < 0) seg_begin = 0;
+    if (seg_end_i > 0) {
+        const uint32_t seg_end = (uint32_t)seg_end_i + mis;
+        uint32_t pos = (seg_end_i > 256 ? (uint32_t)(seg_end_i - 256) : 0u) + mis;
         uint32_t c = 0xFFFFFFFFu;
-        for (int64_t i = seg_begin; i < seg_end; i++) c = (c >> 8) ^ table[(c ^ in[i]) & 0xFFu];
+        while (pos < seg_end && (pos & 3u)) {  // head bytes up to a dword boundary
+            const uint32_t byte = (data[crc_pad(pos >> 2)] >> (8u * (pos & 3u))) & 0xFFu;
+            c = (c >> 8) ^ table[0][(c ^ byte) & 0xFFu];
+            pos++;
+        }
+        while (pos + 4 <= seg_end) {  // slice-by-4
+            c ^= data[crc_pad(pos >> 2)];
+            c = table[3][c & 0xFFu] ^ table[2][(c >> 8) & 0xFFu] ^ table[1][(c >> 16) & 0xFFu] ^
+                table[0][c >> 24];
+            pos += 4;
+        }
+        while (pos < seg_end) {  // tail bytes
+            const uint32_t byte = (data[crc_pad(pos >> 2)] >> (8u * (pos & 3u))) & 0xFFu;
+            c = (c >> 8) ^ table[0][(c ^ byte) & 0xFFu];
+            pos++;
+        }
         crc = ~c;
     }
     part[tid] = crc;
@@ -1370,7 +1364,7 @@ void launch_candidates(const Config &cfg, const uint8_t *slab, uint64_t, uint32_
 void launch_match_parse(const Config &cfg, const uint8_t *slab, uint64_t, uint32_t nb,
                         const Scratch &s, hipStream_t stream) {
     hipLaunchKernelGGL(k_match_parse, dim3(nb), dim3(kMpThreads), 0, stream, cfg, slab, s.meta,
-                       (const uint32_t *)s.cand, s.tok, s.hist);
+                       (const uint16_t *)s.cand, s.tok, s.hist);
 }
 
 void launch_huffman(const Config &cfg, uint32_t nb, const Scratch &s, hipStream_t stream) {
