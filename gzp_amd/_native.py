@@ -20,6 +20,13 @@ ERR_BLOCK_SIZE_EXCEEDED = 5
 ERR_DEVICE = 6
 ERR_NO_DEVICE = 7
 ERR_UNSUPPORTED = 8
+ERR_NUM_THREADS = 9
+ERR_IO = 10
+ERR_CHANNEL = 11
+
+SLAB_FULL_BLOCKS = 0
+SLAB_LAST = 1
+SLAB_FLUSH = 2
 
 FORMAT_BGZF = 0
 FORMAT_MGZIP = 1
@@ -41,6 +48,15 @@ class GzpxConfig(ctypes.Structure):
     _fields_ = [("device", ctypes.c_int), ("format", ctypes.c_int), ("level", ctypes.c_int),
                 ("compat", ctypes.c_int), ("buffer_size", ctypes.c_size_t),
                 ("max_slab_bytes", ctypes.c_size_t)]
+
+
+class GzpxParConfig(ctypes.Structure):
+    _fields_ = [("format", ctypes.c_int), ("level", ctypes.c_int), ("compat", ctypes.c_int),
+                ("device", ctypes.c_int), ("buffer_size", ctypes.c_size_t),
+                ("num_threads", ctypes.c_size_t), ("batch_blocks", ctypes.c_size_t)]
+
+
+WRITE_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint8), ctypes.c_size_t)
 
 
 class GzpxError(RuntimeError):
@@ -115,6 +131,18 @@ class GzpxLib:
         L.gzpx_device_name.argtypes = [vp]
         L.gzpx_version.restype = ctypes.c_char_p
         L.gzpx_version.argtypes = []
+        L.gzpx_par_create.restype = i32
+        L.gzpx_par_create.argtypes = [ctypes.POINTER(GzpxParConfig), WRITE_FN, vp, ctypes.POINTER(vp)]
+        L.gzpx_par_write.restype = i32
+        L.gzpx_par_write.argtypes = [vp, vp, sz]
+        L.gzpx_par_flush.restype = i32
+        L.gzpx_par_flush.argtypes = [vp]
+        L.gzpx_par_finish.restype = i32
+        L.gzpx_par_finish.argtypes = [vp]
+        L.gzpx_par_destroy.restype = None
+        L.gzpx_par_destroy.argtypes = [vp]
+        L.gzpx_par_last_error.restype = ctypes.c_char_p
+        L.gzpx_par_last_error.argtypes = [vp]
 
     def strerror(self, code):
         return self.L.gzpx_strerror(code).decode()
@@ -188,8 +216,17 @@ class Context:
     def n_blocks(self, n):
         return 1 if n == 0 else -(-n // self.buffer_size)
 
+    @staticmethod
+    def _mode(is_last):
+        if is_last is True:
+            return SLAB_LAST
+        if is_last is False:
+            return SLAB_FULL_BLOCKS
+        return int(is_last)
+
     def compress_slab(self, data, is_last=True, return_block_sizes=False):
-        """Host buffer in, framed bytes out (gzpx_compress_slab)."""
+        """Host buffer in, framed bytes out (gzpx_compress_slab).  is_last: True = SLAB_LAST,
+        False = SLAB_FULL_BLOCKS, or an explicit SLAB_* mode."""
         a = _u8(data)
         cap = self.slab_bound(a.size)
         out = np.empty(cap, dtype=np.uint8)
@@ -197,7 +234,7 @@ class Context:
         sizes = np.zeros(nb_max, dtype=np.uint32)
         out_len = ctypes.c_size_t(0)
         nb = ctypes.c_size_t(0)
-        rc = self.lib.L.gzpx_compress_slab(self.h, a.ctypes.data, a.size, int(is_last),
+        rc = self.lib.L.gzpx_compress_slab(self.h, a.ctypes.data, a.size, self._mode(is_last),
                                            out.ctypes.data, cap, ctypes.byref(out_len),
                                            sizes.ctypes.data, nb_max, ctypes.byref(nb))
         self.lib.check(rc, nb.value if rc == ERR_BLOCK_SIZE_EXCEEDED else None)
@@ -214,7 +251,7 @@ class Context:
         bs_ptr, bs_n = (None, 0)
         if block_sizes is not None:
             bs_ptr, bs_n = block_sizes.ctypes.data, block_sizes.size
-        rc = self.lib.L.gzpx_compress_slab_device(self.h, d_in_ptr, in_len, int(is_last), d_out_ptr,
+        rc = self.lib.L.gzpx_compress_slab_device(self.h, d_in_ptr, in_len, self._mode(is_last), d_out_ptr,
                                                   out_cap, ctypes.byref(out_len), bs_ptr, bs_n,
                                                   ctypes.byref(nb), stream)
         self.lib.check(rc, nb.value if rc == ERR_BLOCK_SIZE_EXCEEDED else None)

@@ -192,11 +192,14 @@ int run_batch(gzpx_ctx *ctx, const uint8_t *d_in, size_t in_len, uint32_t nb, in
     return GZPX_OK;
 }
 
-int compress_device_locked(gzpx_ctx *ctx, const uint8_t *d_in, size_t in_len, int is_last,
+int compress_device_locked(gzpx_ctx *ctx, const uint8_t *d_in, size_t in_len, int mode,
                            uint8_t *d_out, size_t out_cap, size_t *out_len, uint32_t *block_sizes,
                            size_t max_blocks, size_t *n_blocks, hipStream_t stream) {
     const size_t bs = ctx->cfg.buffer_size;
-    if (!is_last && (in_len == 0 || in_len % bs != 0)) return GZPX_ERR_INVALID_ARG;
+    if (mode != GZPX_SLAB_FULL_BLOCKS && mode != GZPX_SLAB_LAST && mode != GZPX_SLAB_FLUSH)
+        return GZPX_ERR_INVALID_ARG;
+    if (mode == GZPX_SLAB_FULL_BLOCKS && (in_len == 0 || in_len % bs != 0)) return GZPX_ERR_INVALID_ARG;
+    const int is_last = mode == GZPX_SLAB_LAST;
     if ((in_len && !d_in) || !d_out || !out_len) return GZPX_ERR_INVALID_ARG;
     const uint64_t total_nb = blocks_of(ctx, in_len);
     if (block_sizes && max_blocks < total_nb) return GZPX_ERR_INVALID_ARG;
@@ -326,18 +329,18 @@ size_t gzpx_slab_bound(const gzpx_ctx *ctx, size_t in_len) {
     return (size_t)blocks_of(ctx, in_len) * framed_bound_per_block(ctx) + 28 + 64;
 }
 
-int gzpx_compress_slab_device(gzpx_ctx *ctx, const void *d_in, size_t in_len, int is_last,
+int gzpx_compress_slab_device(gzpx_ctx *ctx, const void *d_in, size_t in_len, int mode,
                               void *d_out, size_t out_cap, size_t *out_len, uint32_t *block_sizes,
                               size_t max_blocks, size_t *n_blocks, void *hip_stream) {
     if (!ctx) return GZPX_ERR_INVALID_ARG;
     std::lock_guard<std::mutex> lock(ctx->mu);
     if (hipSetDevice(ctx->cfg.device) != hipSuccess) return GZPX_ERR_DEVICE;
-    return compress_device_locked(ctx, (const uint8_t *)d_in, in_len, is_last, (uint8_t *)d_out,
+    return compress_device_locked(ctx, (const uint8_t *)d_in, in_len, mode, (uint8_t *)d_out,
                                   out_cap, out_len, block_sizes, max_blocks, n_blocks,
                                   (hipStream_t)hip_stream);
 }
 
-int gzpx_compress_slab(gzpx_ctx *ctx, const uint8_t *in, size_t in_len, int is_last, uint8_t *out,
+int gzpx_compress_slab(gzpx_ctx *ctx, const uint8_t *in, size_t in_len, int mode, uint8_t *out,
                        size_t out_cap, size_t *out_len, uint32_t *block_sizes, size_t max_blocks,
                        size_t *n_blocks) {
     if (!ctx || (in_len && !in) || !out || !out_len) return GZPX_ERR_INVALID_ARG;
@@ -348,7 +351,7 @@ int gzpx_compress_slab(gzpx_ctx *ctx, const uint8_t *in, size_t in_len, int is_l
     if (rc != GZPX_OK) return rc;
     if (in_len) HIP_TRY(hipMemcpyAsync(ctx->d_in, in, in_len, hipMemcpyHostToDevice, ctx->stream));
     size_t produced = 0;
-    rc = compress_device_locked(ctx, ctx->d_in, in_len, is_last, ctx->d_out, ctx->d_out_cap, &produced,
+    rc = compress_device_locked(ctx, ctx->d_in, in_len, mode, ctx->d_out, ctx->d_out_cap, &produced,
                                 block_sizes, max_blocks, n_blocks, ctx->stream);
     if (rc != GZPX_OK) return rc;
     if (produced > out_cap) return GZPX_ERR_INSUFFICIENT_SPACE;
@@ -362,15 +365,13 @@ int gzpx_encode_block(gzpx_ctx *ctx, const uint8_t *in, size_t n, int is_last, u
                       size_t out_cap, size_t *out_len) {
     if (!ctx) return GZPX_ERR_INVALID_ARG;
     if (n > ctx->cfg.buffer_size) return GZPX_ERR_INVALID_ARG;
-    // Bgzf::encode always runs on one block; EOF only when is_last (src/deflate.rs:613-626).
-    // A non-last block shorter than buffer_size (flush(), Q2) is still one block: run it as a
-    // "last" slab of a context-independent single block and strip nothing -- the EOF marker is
-    // the only is_last effect, so compress as last and drop the 28 trailing bytes if needed.
+    // Bgzf::encode runs on one block; the EOF marker is the only is_last effect
+    // (src/deflate.rs:613-626).  A non-last block may be short (flush()).
     std::vector<uint8_t> tmp(gzpx_slab_bound(ctx, n));
     size_t got = 0, nb = 0;
-    int rc = gzpx_compress_slab(ctx, in, n, 1, tmp.data(), tmp.size(), &got, nullptr, 0, &nb);
+    int rc = gzpx_compress_slab(ctx, in, n, is_last ? GZPX_SLAB_LAST : GZPX_SLAB_FLUSH, tmp.data(),
+                                tmp.size(), &got, nullptr, 0, &nb);
     if (rc != GZPX_OK) return rc;
-    if (!is_last && ctx->cfg.format == GZPX_FORMAT_BGZF) got -= 28;
     if (got > out_cap) return GZPX_ERR_INSUFFICIENT_SPACE;
     memcpy(out, tmp.data(), got);
     *out_len = got;
@@ -547,6 +548,9 @@ const char *gzpx_strerror(int code) {
         case GZPX_ERR_DEVICE: return "HIP runtime error";
         case GZPX_ERR_NO_DEVICE: return "no HIP device (no CPU fallback exists)";
         case GZPX_ERR_UNSUPPORTED: return "configuration valid in gzp but not built yet";
+        case GZPX_ERR_NUM_THREADS: return "number of threads must be > 0 (GzpError::NumThreads)";
+        case GZPX_ERR_IO: return "the wrapped writer failed (GzpError::Io)";
+        case GZPX_ERR_CHANNEL: return "compression pipeline already closed (GzpError::ChannelSend)";
         default: return "unknown error";
     }
 }

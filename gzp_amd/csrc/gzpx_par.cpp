@@ -1,0 +1,305 @@
+// gzpx_par.cpp -- ParCompress twin (see gzpx_par.hpp) + its C ABI (gzpx_par_* in include/gzpx.h).
+#include "gzpx_par.hpp"
+
+#include <cstring>
+
+namespace gzp {
+
+GzpError error_from_code(int code, size_t block) {
+    const std::string msg = std::string(gzpx_strerror(code));
+    switch (code) {
+        case GZPX_ERR_BUFFER_SIZE: return GzpError(GzpErrorKind::BufferSize, msg);
+        case GZPX_ERR_COMPRESSION_LEVEL: return GzpError(GzpErrorKind::LibDeflaterCompressionLvl, msg);
+        case GZPX_ERR_INSUFFICIENT_SPACE: return GzpError(GzpErrorKind::LibDeflaterCompress, msg);
+        case GZPX_ERR_BLOCK_SIZE_EXCEEDED:
+            return GzpError(GzpErrorKind::BlockSizeExceeded, msg + " (block " + std::to_string(block) + ")");
+        case GZPX_ERR_UNSUPPORTED: return GzpError(GzpErrorKind::Unsupported, msg);
+        default: return GzpError(GzpErrorKind::Device, msg);
+    }
+}
+
+ParCompress::ParCompress(const ParConfig &cfg, WriteFn writer) : cfg_(cfg), writer_(std::move(writer)) {
+    if (cfg_.buffer_size < DICT_SIZE) throw error_from_code(GZPX_ERR_BUFFER_SIZE);
+    if (cfg_.num_threads == 0) cfg_.num_threads = 1;
+    const size_t lanes = cfg_.num_threads < 2 ? 1 : 2;  // device lanes: one copies while one computes
+    if (cfg_.batch_blocks == 0) cfg_.batch_blocks = 1;
+    batch_bytes_ = cfg_.batch_blocks * cfg_.buffer_size;
+    q_cap_ = 2 * lanes;  // bounded(num_threads * 2), src/par/compress.rs:111-112
+    for (size_t i = 0; i < lanes; i++) {
+        gzpx_config c;
+        gzpx_config_default(&c, cfg_.format);
+        c.device = cfg_.device;
+        c.level = cfg_.compression_level.level();
+        c.compat = cfg_.compat;
+        c.buffer_size = cfg_.buffer_size;
+        c.max_slab_bytes = batch_bytes_;
+        gzpx_ctx *ctx = nullptr;
+        const int rc = gzpx_ctx_create(&c, &ctx);  // Bgzf::create_compressor, once per worker
+        if (rc != GZPX_OK) {
+            for (gzpx_ctx *x : ctxs_) gzpx_ctx_destroy(x);
+            ctxs_.clear();
+            throw error_from_code(rc);
+        }
+        ctxs_.push_back(ctx);
+    }
+    buffer_.reserve(batch_bytes_ + cfg_.buffer_size);
+    for (size_t i = 0; i < lanes; i++) workers_.emplace_back([this, i] { worker_main(i); });
+    writer_thread_ = std::thread([this] { writer_main(); });
+}
+
+ParCompress::~ParCompress() {
+    if (!finished_) {
+        try {
+            finish();
+        } catch (...) {
+            // Drop cannot report; the reference unwraps here (src/par/compress.rs:398)
+        }
+    }
+    for (gzpx_ctx *x : ctxs_) gzpx_ctx_destroy(x);
+}
+
+void ParCompress::raise_pipeline_error() {
+    std::exception_ptr e;
+    {
+        std::lock_guard<std::mutex> lk(mu_);
+        e = error_;
+    }
+    if (e) std::rethrow_exception(e);
+    throw GzpError(GzpErrorKind::ChannelSend, "compression pipeline is closed");
+}
+
+void ParCompress::dispatch(std::vector<uint8_t> &&input, int mode) {
+    auto job = std::make_unique<Job>();
+    job->input = std::move(input);
+    job->mode = mode;
+    std::unique_lock<std::mutex> lk(mu_);
+    cv_space_.wait(lk, [&] { return failed_ || closed_ || (work_q_.size() < q_cap_ && order_q_.size() < q_cap_); });
+    if (failed_ || closed_) {
+        lk.unlock();
+        raise_pipeline_error();
+    }
+    order_q_.push_back(job->result.get_future());  // order token FIRST (src/par/compress.rs:424-440)
+    work_q_.push_back(std::move(job));             // then the work item (:441-457)
+    cv_order_.notify_one();
+    cv_work_.notify_one();
+}
+
+size_t ParCompress::write(const uint8_t *buf, size_t n) {
+    if (finished_) throw GzpError(GzpErrorKind::ChannelSend, "write after finish");
+    buffer_.insert(buffer_.end(), buf, buf + n);
+    // `while buffer.len() > buffer_size` (strict): full blocks leave only while at least one byte
+    // stays behind.  Blocks are handed over batch_blocks at a time; the cut points are the same.
+    const size_t bs = cfg_.buffer_size;
+    while (buffer_.size() > batch_bytes_) {
+        size_t blocks = (buffer_.size() - 1) / bs;
+        if (blocks > cfg_.batch_blocks) blocks = cfg_.batch_blocks;
+        const size_t take = blocks * bs;
+        std::vector<uint8_t> slab(buffer_.begin(), buffer_.begin() + (ptrdiff_t)take);
+        buffer_.erase(buffer_.begin(), buffer_.begin() + (ptrdiff_t)take);
+        dispatch(std::move(slab), GZPX_SLAB_FULL_BLOCKS);
+    }
+    return n;
+}
+
+void ParCompress::flush_last(bool is_last) {
+    // everything buffered goes out cut at buffer_size; the final piece may be short and -- if the
+    // buffer is empty -- is an empty block (src/par/compress.rs:333-341 runs at least once)
+    const size_t bs = cfg_.buffer_size;
+    while (buffer_.size() > batch_bytes_) {
+        const size_t take = cfg_.batch_blocks * bs;
+        std::vector<uint8_t> slab(buffer_.begin(), buffer_.begin() + (ptrdiff_t)take);
+        buffer_.erase(buffer_.begin(), buffer_.begin() + (ptrdiff_t)take);
+        dispatch(std::move(slab), GZPX_SLAB_FULL_BLOCKS);
+    }
+    std::vector<uint8_t> rest;
+    rest.swap(buffer_);
+    dispatch(std::move(rest), is_last ? GZPX_SLAB_LAST : GZPX_SLAB_FLUSH);
+}
+
+void ParCompress::flush() {
+    if (finished_) throw GzpError(GzpErrorKind::ChannelSend, "flush after finish");
+    flush_last(false);
+}
+
+void ParCompress::finish() {
+    if (finished_) return;
+    finished_ = true;
+    std::exception_ptr first;
+    try {
+        flush_last(true);
+    } catch (...) {
+        first = std::current_exception();
+    }
+    {
+        std::lock_guard<std::mutex> lk(mu_);
+        closed_ = true;  // drop(tx_compressor), drop(tx_writer)
+    }
+    cv_work_.notify_all();
+    cv_order_.notify_all();
+    cv_space_.notify_all();
+    for (auto &t : workers_) t.join();
+    if (writer_thread_.joinable()) writer_thread_.join();
+    std::exception_ptr e;
+    {
+        std::lock_guard<std::mutex> lk(mu_);
+        e = error_;
+    }
+    if (e) std::rethrow_exception(e);  // the pipeline's own error wins (Io preserved)
+    if (first) std::rethrow_exception(first);
+}
+
+void ParCompress::worker_main(size_t lane) {
+    gzpx_ctx *ctx = ctxs_[lane];
+    for (;;) {
+        std::unique_ptr<Job> job;
+        {
+            std::unique_lock<std::mutex> lk(mu_);
+            cv_work_.wait(lk, [&] { return !work_q_.empty() || closed_ || failed_; });
+            if (work_q_.empty()) return;
+            job = std::move(work_q_.front());
+            work_q_.pop_front();
+            cv_space_.notify_all();
+        }
+        try {
+            const size_t n = job->input.size();
+            const int mode = job->mode;
+            std::vector<uint8_t> out(gzpx_slab_bound(ctx, n));
+            size_t out_len = 0, nb = 0;
+            const int rc = gzpx_compress_slab(ctx, job->input.data(), n, mode, out.data(), out.size(),
+                                              &out_len, nullptr, 0, &nb);
+            if (rc != GZPX_OK) throw error_from_code(rc, nb);
+            out.resize(out_len);
+            job->result.set_value(std::move(out));
+        } catch (...) {
+            job->result.set_exception(std::current_exception());
+        }
+    }
+}
+
+void ParCompress::writer_main() {
+    for (;;) {
+        std::future<std::vector<uint8_t>> fut;
+        {
+            std::unique_lock<std::mutex> lk(mu_);
+            cv_order_.wait(lk, [&] { return !order_q_.empty() || closed_; });
+            if (order_q_.empty()) return;
+            fut = std::move(order_q_.front());
+            order_q_.pop_front();
+            cv_space_.notify_all();
+        }
+        try {
+            std::vector<uint8_t> chunk = fut.get();  // blocks until THAT slab is done -> in order
+            std::string err;
+            bool ok;
+            {
+                std::lock_guard<std::mutex> lk(mu_);
+                ok = !failed_;
+            }
+            if (ok && !writer_(chunk.data(), chunk.size(), &err))
+                throw GzpError(GzpErrorKind::Io, err.empty() ? "write failed" : err);
+        } catch (...) {
+            std::lock_guard<std::mutex> lk(mu_);
+            if (!failed_) {
+                failed_ = true;
+                error_ = std::current_exception();
+            }
+            cv_space_.notify_all();
+            cv_work_.notify_all();
+        }
+    }
+}
+
+}  // namespace gzp
+
+// ---------------------------------------------------------------- C ABI of the twin
+struct gzpx_par {
+    std::unique_ptr<gzp::ParCompress> pc;
+    std::string last_error;
+    int last_kind = 0;
+};
+
+static int kind_to_code(gzp::GzpErrorKind k) {
+    using K = gzp::GzpErrorKind;
+    switch (k) {
+        case K::BufferSize: return GZPX_ERR_BUFFER_SIZE;
+        case K::NumThreads: return GZPX_ERR_NUM_THREADS;
+        case K::LibDeflaterCompressionLvl: return GZPX_ERR_COMPRESSION_LEVEL;
+        case K::LibDeflaterCompress: return GZPX_ERR_INSUFFICIENT_SPACE;
+        case K::BlockSizeExceeded: return GZPX_ERR_BLOCK_SIZE_EXCEEDED;
+        case K::Io: return GZPX_ERR_IO;
+        case K::ChannelSend:
+        case K::ChannelReceive: return GZPX_ERR_CHANNEL;
+        case K::Unsupported: return GZPX_ERR_UNSUPPORTED;
+        default: return GZPX_ERR_DEVICE;
+    }
+}
+
+template <class Fn>
+static int guarded(gzpx_par *p, Fn fn) {
+    try {
+        fn();
+        return GZPX_OK;
+    } catch (const gzp::GzpError &e) {
+        if (p) p->last_error = e.what();
+        return kind_to_code(e.kind);
+    } catch (const std::exception &e) {
+        if (p) p->last_error = e.what();
+        return GZPX_ERR_DEVICE;
+    }
+}
+
+extern "C" {
+
+int gzpx_par_create(const gzpx_par_config *cfg, gzpx_write_fn write_fn, void *user, gzpx_par **out) {
+    if (!cfg || !write_fn || !out) return GZPX_ERR_INVALID_ARG;
+    *out = nullptr;
+    if (cfg->num_threads == 0) return GZPX_ERR_NUM_THREADS;  // src/par/compress.rs:84-90
+    auto *p = new gzpx_par();
+    const int rc = guarded(p, [&] {
+        gzp::ParConfig c;
+        c.format = cfg->format;
+        c.buffer_size = cfg->buffer_size;
+        c.num_threads = cfg->num_threads;
+        c.compression_level = gzp::Compression(cfg->level);
+        c.device = cfg->device;
+        c.compat = cfg->compat;
+        c.batch_blocks = cfg->batch_blocks ? cfg->batch_blocks : 1024;
+        p->pc = std::make_unique<gzp::ParCompress>(
+            c, [write_fn, user](const uint8_t *d, size_t n, std::string *err) {
+                const int r = write_fn(user, d, n);
+                if (r != 0 && err) *err = "writer callback returned " + std::to_string(r);
+                return r == 0;
+            });
+    });
+    if (rc != GZPX_OK) {
+        delete p;
+        return rc;
+    }
+    *out = p;
+    return GZPX_OK;
+}
+
+int gzpx_par_write(gzpx_par *p, const uint8_t *buf, size_t n) {
+    if (!p || (!buf && n)) return GZPX_ERR_INVALID_ARG;
+    return guarded(p, [&] { p->pc->write(buf, n); });
+}
+
+int gzpx_par_flush(gzpx_par *p) {
+    if (!p) return GZPX_ERR_INVALID_ARG;
+    return guarded(p, [&] { p->pc->flush(); });
+}
+
+int gzpx_par_finish(gzpx_par *p) {
+    if (!p) return GZPX_ERR_INVALID_ARG;
+    return guarded(p, [&] { p->pc->finish(); });
+}
+
+void gzpx_par_destroy(gzpx_par *p) {
+    if (!p) return;
+    p->pc.reset();  // Drop: finishes if needed
+    delete p;
+}
+
+const char *gzpx_par_last_error(const gzpx_par *p) { return p ? p->last_error.c_str() : ""; }
+
+}  // extern "C"

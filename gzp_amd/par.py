@@ -1,0 +1,210 @@
+"""Python face of the ParCompress twin (gzp_amd/csrc/gzpx_par.{hpp,cpp}) -- same names and
+behaviour as the reference's builder/writer API for the block formats:
+
+    ParCompressBuilder / ParCompress   src/par/compress.rs:33-469
+    ZBuilder                           src/lib.rs:181-275
+    Compression                        flate2::Compression (src/lib.rs:81)
+    GzpError                           src/lib.rs:114-163
+
+    w = ParCompressBuilder(Bgzf).compression_level(Compression.fast()).from_writer(open(p, "wb"))
+    w.write_all(data); w.finish()
+
+All compression happens in the HIP library; this module only forwards bytes.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+from . import _native
+from ._native import GzpxError as GzpError  # noqa: F401  (the error type users catch)
+
+BUFSIZE = 64 * (1 << 10) * 2  # src/lib.rs:105
+DICT_SIZE = 32768             # src/lib.rs:108
+
+
+class Compression:
+    """flate2::Compression"""
+
+    def __init__(self, level=6):
+        self._level = int(level)
+
+    @staticmethod
+    def new(level):
+        return Compression(level)
+
+    @staticmethod
+    def none():
+        return Compression(0)
+
+    @staticmethod
+    def fast():
+        return Compression(1)
+
+    @staticmethod
+    def best():
+        return Compression(9)
+
+    def level(self):
+        return self._level
+
+
+class Bgzf:
+    DEFAULT_BUFSIZE = 65280  # src/deflate.rs:583
+    FORMAT = _native.FORMAT_BGZF
+
+
+class Mgzip:
+    DEFAULT_BUFSIZE = BUFSIZE  # src/lib.rs:330
+    FORMAT = _native.FORMAT_MGZIP
+
+
+class ParCompress:
+    """`Write` + `ZWriter` (src/par/compress.rs:221-469, src/lib.rs:166-170)."""
+
+    def __init__(self, cfg, writer, lib=None):
+        self._lib = lib or _native.load()
+        self._writer = writer
+        self._io_error = None
+
+        def _cb(user, data, n):
+            try:
+                self._writer.write(ctypes.string_at(data, n))
+                return 0
+            except Exception as e:  # the wrapped writer failed: GzpError::Io
+                self._io_error = e
+                return 1
+
+        self._cb = _native.WRITE_FN(_cb)  # keep alive
+        h = ctypes.c_void_p()
+        rc = self._lib.L.gzpx_par_create(ctypes.byref(cfg), self._cb, None, ctypes.byref(h))
+        self._lib.check(rc)
+        self._h = h
+        self._finished = False
+
+    def _check(self, rc):
+        if rc != _native.OK:
+            msg = self._lib.L.gzpx_par_last_error(self._h).decode() or self._lib.strerror(rc)
+            err = _native.GzpxError(rc, msg)
+            if rc == _native.ERR_IO and self._io_error is not None:
+                raise err from self._io_error
+            raise err
+
+    def write(self, buf):
+        a = _native._u8(buf)
+        self._check(self._lib.L.gzpx_par_write(self._h, a.ctypes.data, a.size))
+        return a.size
+
+    write_all = write
+
+    def flush(self):
+        self._check(self._lib.L.gzpx_par_flush(self._h))
+
+    def finish(self):
+        """Flush, append the trailer (BGZF EOF), join the pipeline; returns the wrapped writer."""
+        if not self._finished:
+            self._finished = True
+            self._check(self._lib.L.gzpx_par_finish(self._h))
+        return self._writer
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.L.gzpx_par_destroy(self._h)  # Drop: finishes if finish() was not called
+            self._h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, et, ev, tb):
+        if et is None:
+            self.finish()
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class ParCompressBuilder:
+    """ParCompressBuilder<F> (src/par/compress.rs:33-204)."""
+
+    def __init__(self, fmt=Bgzf, lib=None):
+        self._lib = lib
+        self._fmt = fmt
+        self._buffer_size = fmt.DEFAULT_BUFSIZE
+        self._num_threads = os.cpu_count() or 1
+        self._level = Compression(3)
+        self._pin = None
+        self._device = 0
+        self._compat = _native.COMPAT_1_24
+        self._batch_blocks = 1024
+
+    def buffer_size(self, n):
+        if n < DICT_SIZE:
+            raise _native.GzpxError(_native.ERR_BUFFER_SIZE,
+                                    "Invalid buffer size %d, must be >= %d" % (n, DICT_SIZE))
+        self._buffer_size = n
+        return self
+
+    def num_threads(self, n):
+        if n == 0:
+            raise _native.GzpxError(_native.ERR_NUM_THREADS, "Invalid number of threads 0")
+        self._num_threads = n
+        return self
+
+    def compression_level(self, c):
+        self._level = c if isinstance(c, Compression) else Compression(c)
+        return self
+
+    def pin_threads(self, p):
+        self._pin = p  # accepted for API parity; device lanes are not pinned
+        return self
+
+    # GPU-side knobs (no counterpart in the reference)
+    def device(self, d):
+        self._device = d
+        return self
+
+    def compat(self, c):
+        self._compat = c
+        return self
+
+    def batch_blocks(self, b):
+        self._batch_blocks = b
+        return self
+
+    def from_writer(self, writer):
+        cfg = _native.GzpxParConfig(self._fmt.FORMAT, self._level.level(), self._compat, self._device,
+                                    self._buffer_size, self._num_threads, self._batch_blocks)
+        return ParCompress(cfg, writer, self._lib)
+
+
+class ZBuilder:
+    """ZBuilder<F, W> (src/lib.rs:181-275).  num_threads <= 1 selects SyncZ in the reference; the
+    GPU path has no single-threaded variant, so both cases build a ParCompress with one lane."""
+
+    def __init__(self, fmt=Bgzf, lib=None):
+        self._b = ParCompressBuilder(fmt, lib)
+        self._threads = os.cpu_count() or 1
+
+    def buffer_size(self, n):
+        self._b.buffer_size(n)
+        return self
+
+    def num_threads(self, n):
+        self._threads = n
+        return self
+
+    def compression_level(self, c):
+        self._b.compression_level(c)
+        return self
+
+    def pin_threads(self, p):
+        self._b.pin_threads(p)
+        return self
+
+    def from_writer(self, writer):
+        self._b.num_threads(max(1, self._threads))
+        return self._b.from_writer(writer)

@@ -44,6 +44,14 @@ extern "C" {
 #define GZPX_ERR_DEVICE 6              /* HIP runtime error (the Io-like class)                       */
 #define GZPX_ERR_NO_DEVICE 7           /* no MI355X / HIP device: there is NO CPU fallback            */
 #define GZPX_ERR_UNSUPPORTED 8         /* valid in the reference, not built yet (level, block size)   */
+#define GZPX_ERR_NUM_THREADS 9         /* GzpError::NumThreads(0), src/par/compress.rs:84-90          */
+#define GZPX_ERR_IO 10                 /* GzpError::Io: the wrapped writer failed                     */
+#define GZPX_ERR_CHANNEL 11            /* GzpError::ChannelSend/Receive: pipeline already closed      */
+
+/* how a slab is cut (the `mode` argument of gzpx_compress_slab*) */
+#define GZPX_SLAB_FULL_BLOCKS 0 /* write(): only whole buffer_size blocks, in_len a non-zero multiple   */
+#define GZPX_SLAB_LAST 1        /* flush_last(true): final piece may be short/empty; BGZF EOF appended  */
+#define GZPX_SLAB_FLUSH 2       /* flush_last(false): final piece may be short/empty; no EOF marker     */
 
 #define GZPX_FORMAT_BGZF 0
 #define GZPX_FORMAT_MGZIP 1
@@ -78,20 +86,21 @@ size_t gzpx_slab_bound(const gzpx_ctx *ctx, size_t in_len);
 
 /*
  * Compress one slab held in HOST memory.  The slab is cut into buffer_size blocks exactly as
- * ParCompress::write does; when is_last == 0, in_len must be a non-zero multiple of
- * buffer_size (the caller keeps the remainder, as write() does); when is_last != 0 the final
- * piece may be short or empty and, for BGZF, is followed by the EOF marker.
+ * ParCompress::write does; `mode` is one of GZPX_SLAB_*: with FULL_BLOCKS, in_len must be a
+ * non-zero multiple of buffer_size (the caller keeps the remainder, as write() does); with LAST
+ * or FLUSH the final piece may be short or empty (flush_last), and LAST appends the BGZF EOF
+ * marker after it.
  * out receives the framed blocks back to back; block_sizes[i] (optional) the framed size of
  * block i.  On GZPX_ERR_BLOCK_SIZE_EXCEEDED, *n_blocks holds the index of the failing block.
  */
-int gzpx_compress_slab(gzpx_ctx *ctx, const uint8_t *in, size_t in_len, int is_last, uint8_t *out,
+int gzpx_compress_slab(gzpx_ctx *ctx, const uint8_t *in, size_t in_len, int mode, uint8_t *out,
                        size_t out_cap, size_t *out_len, uint32_t *block_sizes, size_t max_blocks,
                        size_t *n_blocks);
 
 /* Same, with the slab and the output already resident in DEVICE memory (d_in, d_out are device
  * pointers; hip_stream is a hipStream_t or NULL for the context's own stream).  Synchronous
  * with respect to the host on return. */
-int gzpx_compress_slab_device(gzpx_ctx *ctx, const void *d_in, size_t in_len, int is_last,
+int gzpx_compress_slab_device(gzpx_ctx *ctx, const void *d_in, size_t in_len, int mode,
                               void *d_out, size_t out_cap, size_t *out_len, uint32_t *block_sizes,
                               size_t max_blocks, size_t *n_blocks, void *hip_stream);
 
@@ -108,6 +117,26 @@ void gzpx_free_compressor(gzpx_compressor *c);
 /* compat / device knobs for the handle above (before first use) */
 int gzpx_compressor_set_compat(gzpx_compressor *c, int compat);
 uint32_t gzpx_crc32(uint32_t crc, const void *buf, size_t n);
+
+/* ---- ParCompress<Bgzf/Mgzip> twin: Write + ZWriter::finish over device lanes (C++ class
+ * gzp::ParCompress in gzp_amd/csrc/gzpx_par.hpp; src/par/compress.rs:33-469) ---- */
+typedef struct gzpx_par gzpx_par;
+typedef int (*gzpx_write_fn)(void *user, const uint8_t *data, size_t n); /* 0 = ok (the `W: Write`) */
+typedef struct gzpx_par_config {
+    int format;          /* GZPX_FORMAT_*                                               */
+    int level;           /* ParCompressBuilder::compression_level                       */
+    int compat;          /* GZPX_COMPAT_*                                               */
+    int device;          /* HIP device                                                  */
+    size_t buffer_size;  /* ParCompressBuilder::buffer_size (>= 32768)                  */
+    size_t num_threads;  /* ParCompressBuilder::num_threads (> 0); >= 2 -> two lanes    */
+    size_t batch_blocks; /* blocks per slab handed to a device lane (0 = default 1024)  */
+} gzpx_par_config;
+int gzpx_par_create(const gzpx_par_config *cfg, gzpx_write_fn write_fn, void *user, gzpx_par **out);
+int gzpx_par_write(gzpx_par *p, const uint8_t *buf, size_t n);
+int gzpx_par_flush(gzpx_par *p);
+int gzpx_par_finish(gzpx_par *p);
+void gzpx_par_destroy(gzpx_par *p);
+const char *gzpx_par_last_error(const gzpx_par *p);
 
 /* ---- measurement hooks (HIP events on the launching stream; bench.py roofline leg) ---- */
 #define GZPX_N_STAGES 7

@@ -4,6 +4,7 @@
 #include <sys/mman.h>
 
 #include <chrono>
+#include <mutex>
 #include <vector>
 
 namespace emu {
@@ -50,7 +51,6 @@ int cur_fiber = -1;
 int n_threads = 0;
 unsigned long progress = 0;
 const std::function<void()> *cur_body = nullptr;
-bool stacks_ready = false;
 
 extern "C" void emu_switch(void **save_sp, void *load_sp);
 asm(R"(
@@ -206,6 +206,9 @@ int sync_threads_count(int pred) {
 void set_lds_poison(bool) {}
 
 void launch(dim3 grid, dim3 block, const std::function<void()> &body) {
+    // one emulated "device": kernels from different host threads (device lanes) run one at a time
+    static std::mutex launch_mu;
+    std::lock_guard<std::mutex> launch_lock(launch_mu);
     n_threads = (int)(block.x * block.y * block.z);
     if (n_threads <= 0 || n_threads > kMaxThreads) {
         fprintf(stderr, "emu: unsupported block size %d\n", n_threads);
