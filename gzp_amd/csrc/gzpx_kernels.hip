@@ -164,7 +164,7 @@ __global__ void k_init_meta(Config cfg, uint64_t slab_len, uint32_t nb, uint32_t
 // before that", so it is enough to produce, for every position p, the distance d0[p] to its
 // predecessor in its bucket; the older candidate is the predecessor's predecessor
 // (d1 = d0[p] + d0[p - d0[p]]), which k_match_parse reads from the same array.
-// One wave per block, 128 KiB table in LDS, one word per bucket = (newest position + 1), 0 =
+// One workgroup per block, 128 KiB table in LDS, one word per bucket = (newest position + 1), 0 =
 // empty.  Positions of one block are < 65536 and only grow, so "newest" is an unsigned maximum
 // and liveness (libdeflate: cur_node > cutoff) is the plain distance test p - c <= 32767 -- no
 // window slide is needed below 64 KiB.
@@ -174,7 +174,8 @@ __global__ void k_init_meta(Config cfg, uint64_t slab_len, uint32_t nb, uint32_t
 // tools/probes/lds_atomic_order.hip, 2000/2000 patterns), so `old` already is the lane's
 // predecessor in its bucket -- whether that predecessor sits in an earlier step or in a lower
 // lane of the same instruction.  No cross-lane matching is needed, and kCandSteps steps
-// (kCandSteps * 64 positions) of atomics are kept in flight per iteration.  The ordering
+// (kCandSteps * 64 positions) of atomics are kept in flight per iteration; four waves (one per
+// SIMD) take turns at the table so that only the atomic phase is serial.  The ordering
 // assumption is CHECKED, never trusted: a lane that is handed a predecessor >= its own position
 // flags the block, and k_candidates_safe (ballot match-any, order-independent) redoes flagged
 // blocks.
@@ -196,32 +197,43 @@ __device__ __forceinline__ uint2 cand_fetch(const uint32_t *__restrict__ in32, u
     return v;
 }
 
-__global__ __launch_bounds__(64) void k_candidates(Config cfg, const uint8_t *__restrict__ slab,
-                                                   BlockMeta *__restrict__ meta,
-                                                   uint16_t *__restrict__ cand_all) {
+constexpr uint32_t kCandWaves = 4;  // one per SIMD; they take turns at the table
+
+__global__ __launch_bounds__(64 * kCandWaves) void k_candidates(Config cfg,
+                                                                 const uint8_t *__restrict__ slab,
+                                                                 BlockMeta *__restrict__ meta,
+                                                                 uint16_t *__restrict__ cand_all) {
     __shared__ uint32_t tab[kBuckets];  // 128 KiB
-    const uint32_t lane = threadIdx.x;
+    __shared__ uint32_t turn;           // index of the iteration whose atomics may go next
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint32_t b = blockIdx.x;
     const uint32_t n = meta[b].n;
-    if (n <= kPassthroughL1) return;  // stored-only path, no matchfinding
+    if (n <= kPassthroughL1) return;  // stored-only path, no matchfinding (uniform)
     const uint8_t *in = slab + (uint64_t)b * cfg.block_size;
     const uint32_t mis = (uint32_t)((uintptr_t)in & 3u);
     const uint32_t *in32 = (const uint32_t *)(in - mis);
     const uint32_t wmax = (mis + n - 1) >> 2;  // last dword holding a byte of this block
     uint16_t *cand = cand_all + (uint64_t)b * kCandStride;
 
-    for (uint32_t i = lane; i < kBuckets; i += 64) tab[i] = 0;
-    wave_sync();
+    for (uint32_t i = tid; i < kBuckets; i += 64 * kCandWaves) tab[i] = 0;
+    if (tid == 0) turn = 0;
+    __syncthreads();
 
-    // a single wave per CU has nobody to hide HBM latency behind: the next iteration's input is
-    // always in flight
+    // The table is one LDS array, so the atomics of iteration i+1 must reach it after those of
+    // iteration i -- but hashing / input prefetch before and distance / store work after are
+    // independent.  Wave w owns iterations w, w+4, ...; a ticket in LDS (`turn`) serialises only
+    // the atomic phase, so three waves hash, prefetch and store while the fourth is at the table.
+    constexpr uint32_t kIterPos = 64 * kCandSteps;
+    const uint32_t n_iters = (n + kIterPos - 1) / kIterPos;
     uint2 ring[kCandSteps];
 #pragma unroll
-    for (uint32_t k = 0; k < kCandSteps; k++) ring[k] = cand_fetch(in32, mis, k * 64 + lane, wmax);
+    for (uint32_t k = 0; k < kCandSteps; k++)
+        ring[k] = cand_fetch(in32, mis, wave * kIterPos + k * 64 + lane, wmax);
 
     bool bad = false;
     const long long t_begin = clock64();
-    for (uint32_t base0 = 0; base0 < n; base0 += 64 * kCandSteps) {
+    for (uint32_t it = wave; it < n_iters; it += kCandWaves) {
+        const uint32_t base0 = it * kIterPos;
         uint32_t h[kCandSteps], old[kCandSteps];
 #pragma unroll
         for (uint32_t k = 0; k < kCandSteps; k++) {
@@ -230,8 +242,11 @@ __global__ __launch_bounds__(64) void k_candidates(Config cfg, const uint8_t *__
             h[k] = p != 0 ? lz_hash15(v) : 0;  // position 0 is filed under bucket 0 (next_hash = 0)
         }
 #pragma unroll
-        for (uint32_t k = 0; k < kCandSteps; k++)
-            ring[k] = cand_fetch(in32, mis, base0 + (kCandSteps + k) * 64 + lane, wmax);
+        for (uint32_t k = 0; k < kCandSteps; k++)  // this wave's next iteration
+            ring[k] = cand_fetch(in32, mis, base0 + (kCandWaves * kCandSteps + k) * 64 + lane, wmax);
+        wave_sync();
+        while (__hip_atomic_load(&turn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != it)
+            __builtin_amdgcn_s_sleep(1);
         // newest position per bucket; the return value is the predecessor
 #pragma unroll
         for (uint32_t k = 0; k < kCandSteps; k++) {
@@ -239,16 +254,23 @@ __global__ __launch_bounds__(64) void k_candidates(Config cfg, const uint8_t *__
             old[k] = 0;
             if (p + 5 <= n) old[k] = atomicMax(&tab[h[k]], p + 1);
         }
+        // the returned values are in registers => every atomic of this iteration has been applied
+        uint32_t seen = 0;
+#pragma unroll
+        for (uint32_t k = 0; k < kCandSteps; k++) seen |= old[k];
+        bad |= seen > 0x7FFFFFFFu;  // (never) -- orders the ticket store after the atomics' return
+        wave_sync();
+        if (lane == 0) __hip_atomic_store(&turn, it + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 #pragma unroll
         for (uint32_t k = 0; k < kCandSteps; k++) {
             const uint32_t p = base0 + k * 64 + lane;
             bad |= old[k] > p;  // handed a predecessor that is not earlier: LDS order assumption broken
             uint32_t d0 = old[k] ? p + 1 - old[k] : 0;
-            if (d0 > 32767u) d0 = 0;                // farther than the window: dead
-            cand[p] = (uint16_t)d0;                 // p < kCandStride (padded stride)
+            if (d0 > 32767u) d0 = 0;  // farther than the window: dead
+            cand[p] = (uint16_t)d0;   // p < kCandStride (padded stride)
         }
     }
-    if (lane == 0) meta[b].cand_cycles[3] = (uint32_t)(clock64() - t_begin);
+    if (tid == 0) meta[b].cand_cycles[3] = (uint32_t)(clock64() - t_begin);
     if (__ballot(bad) && lane == 0) meta[b].cand_redo = 1;
 }
 
@@ -1354,7 +1376,8 @@ void launch_candidates(const Config &cfg, const uint8_t *slab, uint64_t, uint32_
                        hipStream_t stream) {
     const uint32_t force_safe = cfg.debug & 1u;  // diagnostics: exercise the fallback on every block
     if (!force_safe)
-        hipLaunchKernelGGL(k_candidates, dim3(nb), dim3(64), 0, stream, cfg, slab, s.meta, s.cand);
+        hipLaunchKernelGGL(k_candidates, dim3(nb), dim3(64 * kCandWaves), 0, stream, cfg, slab, s.meta,
+                           s.cand);
     // blocks flagged by the order check (none expected) are redone order-independently
     const uint32_t grid = force_safe ? nb : (nb < 256u ? nb : 256u);
     hipLaunchKernelGGL(k_candidates_safe, dim3(grid), dim3(64), 0, stream, cfg, slab, s.meta, nb,

@@ -204,6 +204,11 @@ int sync_threads_count(int pred) {
     return group.res_count;
 }
 void set_lds_poison(bool) {}
+static unsigned long spin_yields = 0;
+void yield_now() {
+    spin_yields++;
+    yield_to_scheduler();
+}
 
 void launch(dim3 grid, dim3 block, const std::function<void()> &body) {
     // one emulated "device": kernels from different host threads (device lanes) run one at a time
@@ -247,6 +252,15 @@ void launch(dim3 grid, dim3 block, const std::function<void()> &body) {
                         emu_switch(&sched_sp, f.sp);
                         if (f.done) remaining--;
                     }
+                    static unsigned idle_passes = 0;
+                    if (progress != before) idle_passes = 0;
+                    if (progress == before && remaining > 0 && spin_yields) {
+                        // only spinners ran: legal while another fiber still has to reach its
+                        // hand-off, so allow many passes before calling it a deadlock
+                        spin_yields = 0;
+                        if (++idle_passes < 100000) continue;
+                    }
+                    spin_yields = 0;
                     if (progress == before && remaining > 0) {
                         fprintf(stderr,
                                 "emu: deadlock in block (%u,%u,%u): %d threads blocked "

@@ -56,6 +56,7 @@ int sync_threads_count(int pred);
 unsigned long long wave_ballot(int pred);
 uint64_t wave_exchange(uint64_t v, int src_lane, int mode, int width);  // mode 0: idx
 void set_lds_poison(bool on);
+void yield_now();  // let the other fibers run (spin-wait loops)
 }  // namespace emu
 
 #define threadIdx (emu::cur->tid)
@@ -139,6 +140,13 @@ static inline unsigned __builtin_amdgcn_alignbit(unsigned hi, unsigned lo, unsig
 // wave-level ordering points: a rendezvous of the wave's live lanes in the emulator
 static inline void __builtin_amdgcn_wave_barrier() { (void)emu::wave_ballot(0); }
 #define __builtin_amdgcn_fence(order, scope) ((void)0)
+static inline void __builtin_amdgcn_s_sleep(int) { emu::yield_now(); }
+#define __HIP_MEMORY_SCOPE_WORKGROUP 2
+#define __HIP_MEMORY_SCOPE_AGENT 3
+template <typename T>
+static inline T __hip_atomic_load(const T *p, int, int) { return *(const volatile T *)p; }
+template <typename T, typename U>
+static inline void __hip_atomic_store(T *p, U v, int, int) { *(volatile T *)p = (T)v; }
 static inline unsigned __builtin_amdgcn_readfirstlane(unsigned v) { return __shfl(v, 0); }
 static inline unsigned min(unsigned a, unsigned b) { return a < b ? a : b; }
 static inline unsigned max(unsigned a, unsigned b) { return a > b ? a : b; }
