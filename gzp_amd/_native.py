@@ -32,7 +32,7 @@ FORMAT_BGZF = 0
 FORMAT_MGZIP = 1
 COMPAT_1_24 = 0
 COMPAT_1_10 = 1
-N_STAGES = 7
+N_STAGES = 8
 
 EXPORTS = [
     "gzpx_config_default", "gzpx_ctx_create", "gzpx_ctx_destroy", "gzpx_slab_bound",

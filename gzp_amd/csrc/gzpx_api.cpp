@@ -116,6 +116,8 @@ int alloc_scratch(gzpx_ctx *ctx) {
     Scratch &s = ctx->scratch;
     HIP_TRY(hipMalloc((void **)&s.meta, nb * sizeof(BlockMeta)));
     HIP_TRY(hipMalloc((void **)&s.cand, nb * (size_t)kCandStride * sizeof(uint16_t)));
+    HIP_TRY(hipMalloc((void **)&s.len8, nb * (size_t)kMaxUnit));
+    HIP_TRY(hipMalloc((void **)&s.which, nb * (size_t)(kMaxUnit / 32) * 4));
     HIP_TRY(hipMalloc((void **)&s.tok, nb * (size_t)kTokStride * 4));
     HIP_TRY(hipMalloc((void **)&s.hist, nb * (size_t)kMaxSub * kHistStride * 4));
     HIP_TRY(hipMalloc((void **)&s.codes, nb * (size_t)kMaxSub * kCodeWords * 4));
@@ -131,6 +133,8 @@ void free_scratch(gzpx_ctx *ctx) {
     if (s.meta) (void)hipFree(s.meta);
     if (s.cand) (void)hipFree(s.cand);
     if (s.tok) (void)hipFree(s.tok);
+    if (s.len8) (void)hipFree(s.len8);
+    if (s.which) (void)hipFree(s.which);
     if (s.hist) (void)hipFree(s.hist);
     if (s.codes) (void)hipFree(s.codes);
     if (s.hdr) (void)hipFree(s.hdr);
@@ -156,7 +160,9 @@ int run_batch(gzpx_ctx *ctx, const uint8_t *d_in, size_t in_len, uint32_t nb, in
     if (prof) HIP_TRY(hipEventRecord(ev[++k], stream));
     launch_candidates(c, d_in, in_len, nb, s, stream);
     if (prof) HIP_TRY(hipEventRecord(ev[++k], stream));
-    launch_match_parse(c, d_in, in_len, nb, s, stream);
+    launch_match(c, d_in, in_len, nb, s, stream);
+    if (prof) HIP_TRY(hipEventRecord(ev[++k], stream));
+    launch_parse(c, d_in, in_len, nb, s, stream);
     if (prof) HIP_TRY(hipEventRecord(ev[++k], stream));
     launch_huffman(c, nb, s, stream);
     if (prof) HIP_TRY(hipEventRecord(ev[++k], stream));
@@ -492,9 +498,8 @@ int gzpx_ctx_last_stage_ms(const gzpx_ctx *ctx, float ms[GZPX_N_STAGES]) {
 }
 
 const char *gzpx_stage_name(int stage) {
-    static const char *names[GZPX_N_STAGES] = {"k_init_meta", "k_candidates", "k_match_parse",
-                                               "k_huffman",   "k_crc32",      "k_scan",
-                                               "k_emit"};
+    static const char *names[GZPX_N_STAGES] = {"k_init_meta", "k_candidates", "k_match",  "k_parse",
+                                               "k_huffman",   "k_crc32",      "k_scan",   "k_emit"};
     return (stage >= 0 && stage < GZPX_N_STAGES) ? names[stage] : "?";
 }
 

@@ -51,7 +51,7 @@ struct BlockMeta {
     uint32_t crc;
     uint32_t status;
     SubMeta sub[kMaxSub];
-    uint32_t phase_cycles[8];  // k_match_parse: shader-clock cycles per phase (thread 0), diagnostics
+    uint32_t phase_cycles[8];  // k_match [0,1] / k_parse [2..5]: shader-clock cycles per phase, [6] parse rounds
     uint32_t cand_redo;        // k_candidates' LDS-order check failed: redo with k_candidates_safe
     uint32_t cand_cycles[4];   // k_candidates: shader-clock cycles [-, -, -, main loop total]
 };
@@ -73,6 +73,8 @@ struct Config {
 struct Scratch {
     BlockMeta *meta;      // [nb]
     uint16_t *cand;       // [nb][kCandStride]   d0: distance to the bucket predecessor (0 = none)
+    uint8_t *len8;        // [nb][kMaxUnit]      0 = no match at p, else match length - 3
+    uint32_t *which;      // [nb][kMaxUnit/32]   bit p: the older candidate won at p
     uint32_t *tok;        // [nb][kTokStride]
     uint32_t *hist;       // [nb][kMaxSub][kHistStride]
     uint32_t *codes;      // [nb][kMaxSub][kCodeWords]
@@ -85,8 +87,10 @@ void launch_init_meta(const Config &cfg, uint64_t slab_len, uint32_t nb, int is_
                       const Scratch &s, hipStream_t stream);
 void launch_candidates(const Config &cfg, const uint8_t *slab, uint64_t slab_len, uint32_t nb,
                        const Scratch &s, hipStream_t stream);
-void launch_match_parse(const Config &cfg, const uint8_t *slab, uint64_t slab_len, uint32_t nb,
-                        const Scratch &s, hipStream_t stream);
+void launch_match(const Config &cfg, const uint8_t *slab, uint64_t slab_len, uint32_t nb,
+                  const Scratch &s, hipStream_t stream);
+void launch_parse(const Config &cfg, const uint8_t *slab, uint64_t slab_len, uint32_t nb,
+                  const Scratch &s, hipStream_t stream);
 void launch_huffman(const Config &cfg, uint32_t nb, const Scratch &s, hipStream_t stream);
 void launch_crc32(const Config &cfg, const uint8_t *slab, uint64_t slab_len, uint32_t nb,
                   const Scratch &s, const CrcConsts &cc, hipStream_t stream);

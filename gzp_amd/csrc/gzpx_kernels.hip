@@ -15,9 +15,10 @@
 // of data-parallel stages, each a kernel over all blocks of a slab:
 //   k_candidates   one wave / block : LDS-resident 128 KiB bucket table, atomicMax chain,
 //                                     512 positions in flight per iteration
-//   k_match_parse  1024 thr / block : block input + per-position match length in LDS;
-//                                     lz_extend for every position, then the greedy parse as a
-//                                     segment-parallel pointer chase with speculative entries
+//   k_match        1024 thr / block : block input in LDS; lz_extend for every position
+//   k_parse        1024 thr / block : per-position match lengths in LDS; the greedy parse as a
+//                                     segment-parallel pointer chase with speculative entries,
+//                                     then the position-parallel token build
 //   k_huffman      one wave / block : libdeflate's length-limited Huffman construction, header
 //                                     RLE, exact cost comparison (dynamic / static / stored)
 //   k_crc32        256 thr  / block : per-segment CRC + GF(2) combine tree
@@ -339,18 +340,12 @@ __global__ __launch_bounds__(64) void k_candidates_safe(Config cfg, const uint8_
 }
 
 // ------------------------------------------------------------------------------------------
-// k_match_parse: per block (1024 threads, one workgroup per CU, ~156 KiB of LDS),
-//   phase 0  stage the block's bytes in LDS (coalesced dword loads),
-//   phase 1  ht_matchfinder_longest_match for EVERY position in parallel -> len8[p] (LDS),
-//   phase 2  deflate_compress_fastest's greedy parse as a segment-parallel pointer chase:
-//            272-byte segments (>= max match length, so a token leaving segment s lands in
-//            segment s+1), each thread walks its segment from a speculated entry, entries are
-//            corrected round by round until none changes (greedy chains re-synchronise within
-//            a few tokens, so this is 2-3 rounds in practice, <= #segments always); the final
-//            walk marks token starts in an LDS bitmap,
-//   phase 3  position-parallel token build: token / match ranks from wave ballots + one
-//            workgroup scan, coalesced candidate loads and token stores, litlen/offset
-//            histograms per sub-block (8192 matches each) with LDS atomics.
+// k_match: ht_matchfinder_longest_match for EVERY position of a block in parallel.
+//   1024 threads per block, 72 KiB of LDS (the block's bytes + one bit per position), so two
+//   workgroups = 32 waves share a CU and hide each other's LDS / L2 latency.
+//   d0 = distance to the bucket predecessor (from k_candidates), d1 = d0 + the predecessor's own
+//   d0; 4-byte check + lz_extend run out of LDS with aligned dword reads + v_alignbyte.
+//   Output: len8[p] (0 = no match, else length - 3) and which[p] (1 = the older candidate won).
 // ------------------------------------------------------------------------------------------
 constexpr uint32_t kSeg = 272;
 constexpr uint32_t kInWords = kMaxUnit / 4 + 4;
@@ -361,10 +356,6 @@ constexpr uint32_t kMpChunks = kMaxUnit / kMpThreads;  // 64 position chunks of 
 __device__ __forceinline__ uint32_t lds_le32(const uint32_t *in_w, uint32_t byte_addr) {
     const uint32_t w = byte_addr >> 2;
     return __builtin_amdgcn_alignbyte(in_w[w + 1], in_w[w], byte_addr & 3u);
-}
-
-__device__ __forceinline__ uint32_t lds_byte(const uint32_t *in_w, uint32_t byte_addr) {
-    return (in_w[byte_addr >> 2] >> (8u * (byte_addr & 3u))) & 0xFFu;
 }
 
 // lz_extend from 4 matched bytes, clamped to max_len
@@ -382,43 +373,23 @@ __device__ __forceinline__ uint32_t lds_extend(const uint32_t *in_w, uint32_t a,
     return len < max_len ? len : max_len;
 }
 
-// walk one segment from `pos`; optionally mark every token start in tok_bits
-template <bool kMark>
-__device__ __forceinline__ uint32_t walk_segment(const uint8_t *len8, uint32_t pos, uint32_t seg_end,
-                                                 uint32_t *tok_bits) {
-    while (pos < seg_end) {
-        const uint32_t l = len8[pos];
-        if (kMark) atomicOr(&tok_bits[pos >> 5], 1u << (pos & 31u));
-        pos += l ? l + 3 : 1;
-    }
-    return pos;
-}
-
-__global__ __launch_bounds__(kMpThreads) void k_match_parse(
-    Config cfg, const uint8_t *__restrict__ slab, BlockMeta *__restrict__ meta_all,
-    const uint16_t *__restrict__ cand_all, uint32_t *__restrict__ tok_all,
-    uint32_t *__restrict__ hist_all) {
+__global__ __launch_bounds__(kMpThreads) void k_match(Config cfg, const uint8_t *__restrict__ slab,
+                                                      BlockMeta *__restrict__ meta_all,
+                                                      const uint16_t *__restrict__ cand_all,
+                                                      uint8_t *__restrict__ len8_all,
+                                                      uint32_t *__restrict__ which_all) {
     __shared__ uint32_t in_w[kInWords];             // block bytes (+ lead misalignment, + pad)
-    __shared__ uint8_t len8[kMaxUnit];              // 0 = literal, else match length - 3
     __shared__ uint32_t which_bits[kMaxUnit / 32];  // 1 = the older candidate (c1) won
-    __shared__ uint32_t tok_bits[kMaxUnit / 32];    // 1 = a token starts here
-    __shared__ uint32_t hist[kMaxSub * kHistStride];
-    __shared__ uint32_t seg_exit[256];
-    __shared__ uint32_t tok_pre[kMpChunks * kMpWaves];  // tokens before (chunk, wave)
-    __shared__ uint32_t mat_pre[kMpChunks * kMpWaves];  // matches before (chunk, wave)
-    __shared__ uint32_t wsum_t[kMpWaves], wsum_m[kMpWaves];
-    __shared__ uint32_t sub1_tok, sub1_pos;
-
-    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t tid = threadIdx.x;
     const uint32_t b = blockIdx.x;
     BlockMeta *meta = meta_all + b;
     const uint32_t n = meta->n;
     if (n <= kPassthroughL1) return;  // uniform for the workgroup
     const uint8_t *in = slab + (uint64_t)b * cfg.block_size;
     const uint16_t *cand = cand_all + (uint64_t)b * kCandStride;
-    uint32_t *tok = tok_all + (uint64_t)b * kTokStride;
+    uint8_t *len8 = len8_all + (uint64_t)b * kMaxUnit;
+    uint32_t *which_out = which_all + (uint64_t)b * (kMaxUnit / 32);
 
-    // ---- phase 0: stage input
     long long t_mark = clock64();
     const uint32_t mis = (uint32_t)((uintptr_t)in & 3u);
     {
@@ -426,11 +397,7 @@ __global__ __launch_bounds__(kMpThreads) void k_match_parse(
         const uint32_t ndw = (mis + n + 3) >> 2;
         for (uint32_t i = tid; i < ndw; i += kMpThreads) in_w[i] = src[i];
         for (uint32_t i = ndw + tid; i < ndw + 3 && i < kInWords; i += kMpThreads) in_w[i] = 0;
-        for (uint32_t i = tid; i < kMaxUnit / 32; i += kMpThreads) {
-            which_bits[i] = 0;
-            tok_bits[i] = 0;
-        }
-        for (uint32_t i = tid; i < kMaxSub * kHistStride; i += kMpThreads) hist[i] = 0;
+        for (uint32_t i = tid; i < kMaxUnit / 32; i += kMpThreads) which_bits[i] = 0;
     }
     __syncthreads();
     if (tid == 0) {
@@ -439,8 +406,7 @@ __global__ __launch_bounds__(kMpThreads) void k_match_parse(
         t_mark = t;
     }
 
-    // ---- phase 1: longest match at every position.  Candidate distances are read 4 positions
-    // deep: d0 = distance to the bucket predecessor, d1 = d0 + the predecessor's own d0.
+    // candidate distances are read 4 positions deep (two dependent L2 reads per position)
     for (uint32_t p0 = tid; p0 < n; p0 += 4 * kMpThreads) {
         uint32_t d0s[4], d1s[4];
 #pragma unroll
@@ -479,11 +445,67 @@ __global__ __launch_bounds__(kMpThreads) void k_match_parse(
         }
     }
     __syncthreads();
-    if (tid == 0) {
-        const long long t = clock64();
-        meta->phase_cycles[1] = (uint32_t)(t - t_mark);
-        t_mark = t;
+    for (uint32_t i = tid; i < (n + 31) / 32; i += kMpThreads) which_out[i] = which_bits[i];
+    if (tid == 0) meta->phase_cycles[1] = (uint32_t)(clock64() - t_mark);
+}
+
+// ------------------------------------------------------------------------------------------
+// k_parse: deflate_compress_fastest's greedy parse + token stream, per block (1024 threads,
+// < 80 KiB of LDS so two workgroups share a CU):
+//   phase 2  the parse as a segment-parallel pointer chase over len8 (staged in LDS): 272-byte
+//            segments (>= max match length, so a token leaving segment s lands in segment s+1),
+//            each thread walks its segment from a speculated entry, entries are corrected round
+//            by round until none changes (greedy chains re-synchronise within a few tokens, so
+//            this is 2-3 rounds in practice, <= #segments always); the final walk marks token
+//            starts in an LDS bitmap,
+//   phase 3  position-parallel token build: token / match ranks from wave ballots + one
+//            workgroup scan, coalesced candidate loads and token stores, litlen/offset
+//            histograms per sub-block (8192 matches each) with LDS atomics.
+// ------------------------------------------------------------------------------------------
+// walk one segment from `pos`; optionally mark every token start in tok_bits
+template <bool kMark>
+__device__ __forceinline__ uint32_t walk_segment(const uint8_t *len8, uint32_t pos, uint32_t seg_end,
+                                                 uint32_t *tok_bits) {
+    while (pos < seg_end) {
+        const uint32_t l = len8[pos];
+        if (kMark) atomicOr(&tok_bits[pos >> 5], 1u << (pos & 31u));
+        pos += l ? l + 3 : 1;
     }
+    return pos;
+}
+
+__global__ __launch_bounds__(kMpThreads) void k_parse(
+    Config cfg, const uint8_t *__restrict__ slab, BlockMeta *__restrict__ meta_all,
+    const uint16_t *__restrict__ cand_all, const uint8_t *__restrict__ len8_all,
+    const uint32_t *__restrict__ which_all, uint32_t *__restrict__ tok_all,
+    uint32_t *__restrict__ hist_all) {
+    __shared__ uint32_t len8_w[kMaxUnit / 4];     // 0 = literal, else match length - 3 (bytes)
+    __shared__ uint32_t tok_bits[kMaxUnit / 32];  // 1 = a token starts here
+    __shared__ uint32_t hist[kMaxSub * kHistStride];
+    __shared__ uint32_t seg_exit[256];
+    __shared__ uint32_t rank_pre[kMpChunks * kMpWaves];  // (tokens | matches << 17) before (chunk, wave)
+    __shared__ uint32_t wsum_t[kMpWaves], wsum_m[kMpWaves];
+    __shared__ uint32_t sub1_tok, sub1_pos;
+    const uint8_t *len8 = (const uint8_t *)len8_w;
+
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t b = blockIdx.x;
+    BlockMeta *meta = meta_all + b;
+    const uint32_t n = meta->n;
+    if (n <= kPassthroughL1) return;  // uniform for the workgroup
+    const uint8_t *in = slab + (uint64_t)b * cfg.block_size;
+    const uint16_t *cand = cand_all + (uint64_t)b * kCandStride;
+    const uint32_t *which = which_all + (uint64_t)b * (kMaxUnit / 32);
+    uint32_t *tok = tok_all + (uint64_t)b * kTokStride;
+
+    long long t_mark = clock64();
+    {
+        const uint32_t *src = (const uint32_t *)(len8_all + (uint64_t)b * kMaxUnit);
+        for (uint32_t i = tid; i < (n + 3) / 4; i += kMpThreads) len8_w[i] = src[i];
+        for (uint32_t i = tid; i < kMaxUnit / 32; i += kMpThreads) tok_bits[i] = 0;
+        for (uint32_t i = tid; i < kMaxSub * kHistStride; i += kMpThreads) hist[i] = 0;
+    }
+    __syncthreads();
 
     // ---- phase 2: greedy parse, speculative segment walk (threads 0..255 own segments)
     const uint32_t seg_begin = tid * kSeg;
@@ -528,17 +550,15 @@ __global__ __launch_bounds__(kMpThreads) void k_match_parse(
         const bool is_tok = p < n && ((tok_bits[p >> 5] >> (p & 31u)) & 1u);
         const bool is_match = is_tok && len8[p] != 0;
         const uint64_t mt = __ballot(is_tok), mm = __ballot(is_match);
-        if (lane == 0) {
-            tok_pre[c * kMpWaves + wave] = (uint32_t)__popcll(mt);
-            mat_pre[c * kMpWaves + wave] = (uint32_t)__popcll(mm);
-        }
+        if (lane == 0) rank_pre[c * kMpWaves + wave] = (uint32_t)__popcll(mt) | ((uint32_t)__popcll(mm) << 17);
     }
     __syncthreads();
     uint32_t total_tok, total_match;
     {
         // entry e = chunk * 16 + wave is position order; thread e scans entry e
         const bool have = tid < nchunks * kMpWaves;
-        const uint32_t vt = have ? tok_pre[tid] : 0, vm = have ? mat_pre[tid] : 0;
+        const uint32_t v = have ? rank_pre[tid] : 0;
+        const uint32_t vt = v & 0x1FFFFu, vm = v >> 17;
         const uint32_t it = wave_inclusive_scan(vt, lane), im = wave_inclusive_scan(vm, lane);
         if (lane == 63) {
             wsum_t[wave] = it;
@@ -557,10 +577,8 @@ __global__ __launch_bounds__(kMpThreads) void k_match_parse(
         }
         total_tok = tt;
         total_match = tm;
-        if (have) {
-            tok_pre[tid] = bt + it - vt;
-            mat_pre[tid] = bm + im - vm;
-        }
+        // exclusive prefixes: tokens < 65536 + 1 fit 17 bits, matches <= 16384 fit 15 bits
+        if (have) rank_pre[tid] = (bt + it - vt) | ((bm + im - vm) << 17);
         if (tid == 0) {
             sub1_tok = total_tok;  // "no second sub-block"
             sub1_pos = n;
@@ -582,13 +600,14 @@ __global__ __launch_bounds__(kMpThreads) void k_match_parse(
         const bool is_match = l != 0;
         const uint64_t mt = __ballot(is_tok), mm = __ballot(is_match);
         if (is_tok) {
-            const uint32_t ti = tok_pre[c * kMpWaves + wave] + (uint32_t)__popcll(mt & lane_below);
-            const uint32_t mi = mat_pre[c * kMpWaves + wave] + (uint32_t)__popcll(mm & lane_below);
+            const uint32_t pre = rank_pre[c * kMpWaves + wave];
+            const uint32_t ti = (pre & 0x1FFFFu) + (uint32_t)__popcll(mt & lane_below);
+            const uint32_t mi = (pre >> 17) + (uint32_t)__popcll(mm & lane_below);
             uint32_t *h = hist + (mi >= kSeqPerSub ? kHistStride : 0);
             if (is_match) {
                 const uint32_t len = l + 3;
                 uint32_t off = cand[p];
-                if ((which_bits[p >> 5] >> (p & 31u)) & 1u) off += cand[p - off];  // the older candidate
+                if ((which[p >> 5] >> (p & 31u)) & 1u) off += cand[p - off];  // the older candidate
                 uint32_t ls, le, lv, os, oe, ov;
                 length_slot(len, ls, le, lv);
                 offset_slot(off, os, oe, ov);
@@ -600,7 +619,7 @@ __global__ __launch_bounds__(kMpThreads) void k_match_parse(
                     sub1_pos = p + len;
                 }
             } else {
-                const uint32_t lit = lds_byte(in_w, p + mis);
+                const uint32_t lit = in[p];
                 atomicAdd(&h[lit], 1u);
                 tok[ti] = lit;
             }
@@ -1384,10 +1403,17 @@ void launch_candidates(const Config &cfg, const uint8_t *slab, uint64_t, uint32_
                        force_safe, s.cand);
 }
 
-void launch_match_parse(const Config &cfg, const uint8_t *slab, uint64_t, uint32_t nb,
-                        const Scratch &s, hipStream_t stream) {
-    hipLaunchKernelGGL(k_match_parse, dim3(nb), dim3(kMpThreads), 0, stream, cfg, slab, s.meta,
-                       (const uint16_t *)s.cand, s.tok, s.hist);
+void launch_match(const Config &cfg, const uint8_t *slab, uint64_t, uint32_t nb, const Scratch &s,
+                  hipStream_t stream) {
+    hipLaunchKernelGGL(k_match, dim3(nb), dim3(kMpThreads), 0, stream, cfg, slab, s.meta,
+                       (const uint16_t *)s.cand, s.len8, s.which);
+}
+
+void launch_parse(const Config &cfg, const uint8_t *slab, uint64_t, uint32_t nb, const Scratch &s,
+                  hipStream_t stream) {
+    hipLaunchKernelGGL(k_parse, dim3(nb), dim3(kMpThreads), 0, stream, cfg, slab, s.meta,
+                       (const uint16_t *)s.cand, (const uint8_t *)s.len8, (const uint32_t *)s.which,
+                       s.tok, s.hist);
 }
 
 void launch_huffman(const Config &cfg, uint32_t nb, const Scratch &s, hipStream_t stream) {

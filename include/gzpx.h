@@ -139,8 +139,8 @@ void gzpx_par_destroy(gzpx_par *p);
 const char *gzpx_par_last_error(const gzpx_par *p);
 
 /* ---- measurement hooks (HIP events on the launching stream; bench.py roofline leg) ---- */
-#define GZPX_N_STAGES 7
-/* stage order: init_meta, candidates, match_parse, huffman, crc32, scan, emit */
+#define GZPX_N_STAGES 8
+/* stage order: init_meta, candidates, match, parse, huffman, crc32, scan, emit */
 int gzpx_ctx_set_profiling(gzpx_ctx *ctx, int on);
 int gzpx_ctx_last_stage_ms(const gzpx_ctx *ctx, float ms[GZPX_N_STAGES]);
 const char *gzpx_stage_name(int stage);
@@ -153,7 +153,7 @@ int gzpx_debug_tokens(gzpx_ctx *ctx, size_t block, uint32_t *tokens, size_t max_
  * (k_candidates_safe) on every block instead of the atomic-chain kernel. */
 int gzpx_debug_set_flags(gzpx_ctx *ctx, uint32_t flags);
 
-/* k_match_parse diagnostics of the last batch: shader-clock cycles per phase summed over blocks
+/* k_match / k_parse diagnostics of the last batch: shader-clock cycles per phase summed over blocks
  * [stage-in, match, parse rounds, mark walk, rank scan, token build, parse rounds count, -]. */
 int gzpx_debug_phase_cycles(const gzpx_ctx *ctx, uint64_t cycles[8]);
 /* k_candidates diagnostics: cycles [hash + first atomics, stage gather, file + store, total]. */
