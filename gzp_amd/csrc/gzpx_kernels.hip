@@ -456,22 +456,50 @@ __global__ __launch_bounds__(kMpThreads) void k_match(Config cfg, const uint8_t 
 //            segments (>= max match length, so a token leaving segment s lands in segment s+1),
 //            each thread walks its segment from a speculated entry, entries are corrected round
 //            by round until none changes (greedy chains re-synchronise within a few tokens, so
-//            this is 2-3 rounds in practice, <= #segments always); the final walk marks token
-//            starts in an LDS bitmap,
+//            this is 2-3 rounds in practice, <= #segments always); every walk marks its token
+//            starts in an LDS bitmap and a re-walk first clears its segment's marks,
 //   phase 3  position-parallel token build: token / match ranks from wave ballots + one
 //            workgroup scan, coalesced candidate loads and token stores, litlen/offset
 //            histograms per sub-block (8192 matches each) with LDS atomics.
 // ------------------------------------------------------------------------------------------
-// walk one segment from `pos`; optionally mark every token start in tok_bits
-template <bool kMark>
-__device__ __forceinline__ uint32_t walk_segment(const uint8_t *len8, uint32_t pos, uint32_t seg_end,
-                                                 uint32_t *tok_bits) {
+// Walk one segment from `pos`, marking every token start in tok_bits; returns the exit position.
+// len8 is read a dword (4 positions) at a time, so a run of literals costs one LDS read per four
+// tokens, and marks are merged per 32-position word before they go to LDS.
+__device__ __forceinline__ uint32_t walk_segment(const uint32_t *len8_w, uint32_t pos,
+                                                 uint32_t seg_end, uint32_t *tok_bits) {
+    uint32_t cur = 0xFFFFFFFFu, bits = 0;
     while (pos < seg_end) {
-        const uint32_t l = len8[pos];
-        if (kMark) atomicOr(&tok_bits[pos >> 5], 1u << (pos & 31u));
-        pos += l ? l + 3 : 1;
+        const uint32_t w = len8_w[pos >> 2];
+        for (;;) {
+            const uint32_t l = (w >> (8u * (pos & 3u))) & 0xFFu;
+            const uint32_t wi = pos >> 5;
+            if (wi != cur) {
+                if (bits) atomicOr(&tok_bits[cur], bits);
+                cur = wi;
+                bits = 0;
+            }
+            bits |= 1u << (pos & 31u);
+            if (l) {
+                pos += l + 3;
+                break;
+            }
+            pos++;
+            if ((pos & 3u) == 0 || pos >= seg_end) break;
+        }
     }
+    if (bits) atomicOr(&tok_bits[cur], bits);
     return pos;
+}
+
+// forget the marks of a walk that started from a wrong entry (a thread only marks positions of
+// its own segment, words at the segment edges are shared with the neighbours)
+__device__ __forceinline__ void clear_marks(uint32_t seg_begin, uint32_t seg_end, uint32_t *tok_bits) {
+    for (uint32_t wi = seg_begin >> 5; wi <= (seg_end - 1) >> 5; wi++) {
+        const uint32_t lo = wi * 32 < seg_begin ? seg_begin - wi * 32 : 0;
+        const uint32_t hi = (wi + 1) * 32 > seg_end ? seg_end - wi * 32 : 32;
+        const uint32_t mask = (hi >= 32 ? 0xFFFFFFFFu : (1u << hi) - 1u) & ~((1u << lo) - 1u);
+        atomicAnd(&tok_bits[wi], ~mask);
+    }
 }
 
 __global__ __launch_bounds__(kMpThreads) void k_parse(
@@ -512,7 +540,7 @@ __global__ __launch_bounds__(kMpThreads) void k_parse(
     const bool active = tid < 256 && seg_begin < n;
     const uint32_t seg_end = active ? (seg_begin + kSeg < n ? seg_begin + kSeg : n) : 0;
     uint32_t entry = seg_begin, rounds = 0;
-    if (active) seg_exit[tid] = walk_segment<false>(len8, entry, seg_end, tok_bits);
+    if (active) seg_exit[tid] = walk_segment(len8_w, entry, seg_end, tok_bits);
     for (;;) {
         rounds++;
         __syncthreads();
@@ -524,22 +552,17 @@ __global__ __launch_bounds__(kMpThreads) void k_parse(
         }
         __syncthreads();
         if (changed) {
+            clear_marks(seg_begin, seg_end, tok_bits);
             entry = new_entry;
-            seg_exit[tid] = walk_segment<false>(len8, entry, seg_end, tok_bits);
+            seg_exit[tid] = walk_segment(len8_w, entry, seg_end, tok_bits);
         }
         if (!__syncthreads_or(changed)) break;
     }
     if (tid == 0) {
         const long long t = clock64();
         meta->phase_cycles[2] = (uint32_t)(t - t_mark);
+        meta->phase_cycles[3] = 0;
         meta->phase_cycles[6] = rounds;
-        t_mark = t;
-    }
-    if (active) walk_segment<true>(len8, entry, seg_end, tok_bits);
-    __syncthreads();
-    if (tid == 0) {
-        const long long t = clock64();
-        meta->phase_cycles[3] = (uint32_t)(t - t_mark);
         t_mark = t;
     }
 
@@ -591,23 +614,36 @@ __global__ __launch_bounds__(kMpThreads) void k_parse(
         t_mark = t;
     }
 
-    // ---- phase 3b: build tokens in position order
+    // ---- phase 3b: build tokens in position order (global reads issued 4 chunks deep)
     const uint64_t lane_below = (1ull << lane) - 1ull;
-    for (uint32_t c = 0; c < nchunks; c++) {
-        const uint32_t p = c * kMpThreads + tid;
-        const bool is_tok = p < n && ((tok_bits[p >> 5] >> (p & 31u)) & 1u);
-        const uint32_t l = is_tok ? len8[p] : 0;
-        const bool is_match = l != 0;
-        const uint64_t mt = __ballot(is_tok), mm = __ballot(is_match);
-        if (is_tok) {
-            const uint32_t pre = rank_pre[c * kMpWaves + wave];
-            const uint32_t ti = (pre & 0x1FFFFu) + (uint32_t)__popcll(mt & lane_below);
-            const uint32_t mi = (pre >> 17) + (uint32_t)__popcll(mm & lane_below);
+    for (uint32_t c0 = 0; c0 < nchunks; c0 += 4) {
+        uint32_t lens[4], tis[4], mis_[4], offs[4], wbits[4], lits[4];
+#pragma unroll
+        for (uint32_t k = 0; k < 4; k++) {
+            const uint32_t c = c0 + k;
+            const uint32_t p = c * kMpThreads + tid;
+            const bool is_tok = c < nchunks && p < n && ((tok_bits[p >> 5] >> (p & 31u)) & 1u);
+            const uint32_t l = is_tok ? len8[p] : 0;
+            const bool is_match = l != 0;
+            const uint64_t mt = __ballot(is_tok), mm = __ballot(is_match);
+            const uint32_t pre = rank_pre[(c < nchunks ? c : 0) * kMpWaves + wave];
+            tis[k] = is_tok ? (pre & 0x1FFFFu) + (uint32_t)__popcll(mt & lane_below) : 0xFFFFFFFFu;
+            mis_[k] = (pre >> 17) + (uint32_t)__popcll(mm & lane_below);
+            lens[k] = l;
+            offs[k] = is_match ? cand[p] : 0u;
+            wbits[k] = is_match ? which[p >> 5] : 0u;
+            lits[k] = (is_tok && !is_match) ? in[p] : 0u;
+        }
+#pragma unroll
+        for (uint32_t k = 0; k < 4; k++) {
+            const uint32_t p = (c0 + k) * kMpThreads + tid;
+            if (tis[k] == 0xFFFFFFFFu) continue;
+            const uint32_t ti = tis[k], mi = mis_[k];
             uint32_t *h = hist + (mi >= kSeqPerSub ? kHistStride : 0);
-            if (is_match) {
-                const uint32_t len = l + 3;
-                uint32_t off = cand[p];
-                if ((which[p >> 5] >> (p & 31u)) & 1u) off += cand[p - off];  // the older candidate
+            if (lens[k]) {
+                const uint32_t len = lens[k] + 3;
+                uint32_t off = offs[k];
+                if ((wbits[k] >> (p & 31u)) & 1u) off += cand[p - off];  // the older candidate
                 uint32_t ls, le, lv, os, oe, ov;
                 length_slot(len, ls, le, lv);
                 offset_slot(off, os, oe, ov);
@@ -619,9 +655,8 @@ __global__ __launch_bounds__(kMpThreads) void k_parse(
                     sub1_pos = p + len;
                 }
             } else {
-                const uint32_t lit = in[p];
-                atomicAdd(&h[lit], 1u);
-                tok[ti] = lit;
+                atomicAdd(&h[lits[k]], 1u);
+                tok[ti] = lits[k];
             }
         }
     }

@@ -169,6 +169,12 @@ static inline T atomicOr(T *p, T v) {
     return o;
 }
 template <typename T>
+static inline T atomicAnd(T *p, T v) {
+    T o = *p;
+    *p = o & v;
+    return o;
+}
+template <typename T>
 static inline T atomicMax(T *p, T v) {
     T o = *p;
     if (v > o) *p = v;
