@@ -463,31 +463,14 @@ __global__ __launch_bounds__(kMpThreads) void k_match(Config cfg, const uint8_t 
 //            histograms per sub-block (8192 matches each) with LDS atomics.
 // ------------------------------------------------------------------------------------------
 // Walk one segment from `pos`, marking every token start in tok_bits; returns the exit position.
-// len8 is read a dword (4 positions) at a time, so a run of literals costs one LDS read per four
-// tokens, and marks are merged per 32-position word before they go to LDS.
-__device__ __forceinline__ uint32_t walk_segment(const uint32_t *len8_w, uint32_t pos,
-                                                 uint32_t seg_end, uint32_t *tok_bits) {
-    uint32_t cur = 0xFFFFFFFFu, bits = 0;
+// A latency chain (LDS read -> add -> LDS read ...); the mark is a fire-and-forget LDS atomic.
+__device__ __forceinline__ uint32_t walk_segment(const uint8_t *len8, uint32_t pos, uint32_t seg_end,
+                                                 uint32_t *tok_bits) {
     while (pos < seg_end) {
-        const uint32_t w = len8_w[pos >> 2];
-        for (;;) {
-            const uint32_t l = (w >> (8u * (pos & 3u))) & 0xFFu;
-            const uint32_t wi = pos >> 5;
-            if (wi != cur) {
-                if (bits) atomicOr(&tok_bits[cur], bits);
-                cur = wi;
-                bits = 0;
-            }
-            bits |= 1u << (pos & 31u);
-            if (l) {
-                pos += l + 3;
-                break;
-            }
-            pos++;
-            if ((pos & 3u) == 0 || pos >= seg_end) break;
-        }
+        const uint32_t l = len8[pos];
+        atomicOr(&tok_bits[pos >> 5], 1u << (pos & 31u));
+        pos += l ? l + 3 : 1;
     }
-    if (bits) atomicOr(&tok_bits[cur], bits);
     return pos;
 }
 
@@ -540,7 +523,7 @@ __global__ __launch_bounds__(kMpThreads) void k_parse(
     const bool active = tid < 256 && seg_begin < n;
     const uint32_t seg_end = active ? (seg_begin + kSeg < n ? seg_begin + kSeg : n) : 0;
     uint32_t entry = seg_begin, rounds = 0;
-    if (active) seg_exit[tid] = walk_segment(len8_w, entry, seg_end, tok_bits);
+    if (active) seg_exit[tid] = walk_segment(len8, entry, seg_end, tok_bits);
     for (;;) {
         rounds++;
         __syncthreads();
@@ -554,7 +537,7 @@ __global__ __launch_bounds__(kMpThreads) void k_parse(
         if (changed) {
             clear_marks(seg_begin, seg_end, tok_bits);
             entry = new_entry;
-            seg_exit[tid] = walk_segment(len8_w, entry, seg_end, tok_bits);
+            seg_exit[tid] = walk_segment(len8, entry, seg_end, tok_bits);
         }
         if (!__syncthreads_or(changed)) break;
     }
@@ -1363,35 +1346,58 @@ __global__ __launch_bounds__(256) void k_emit(Config cfg, const uint8_t *__restr
         for (uint32_t i = tid; i < nhw; i += 256) stage_or_bits(stage, bitpos + 32 * i, hw[i]);
         bitpos += sm.hdr_bits;
         __syncthreads();
-        for (uint32_t tb = sm.tok_begin; tb < sm.tok_end; tb += 256) {
-            const uint32_t ti = tb + tid;
-            uint64_t bits = 0;
-            uint32_t nbits = 0;
-            if (ti < sm.tok_end) {
-                const uint32_t t = tok[ti];
-                if (t & kTokMatch) {
-                    const uint32_t len = t & 0x1FFu, off = (t >> 9) & 0xFFFFu;
-                    uint32_t ls, le, lv, os, oe, ov;
-                    length_slot(len, ls, le, lv);
-                    offset_slot(off, os, oe, ov);
-                    const uint32_t lc = codes[257 + ls], oc = codes[kNumLitlen + os];
-                    bits = lc & 0xFFFFu;
-                    nbits = lc >> 16;
-                    bits |= (uint64_t)lv << nbits;
-                    nbits += le;
-                    bits |= (uint64_t)(oc & 0xFFFFu) << nbits;
-                    nbits += oc >> 16;
-                    bits |= (uint64_t)ov << nbits;
-                    nbits += oe;
-                } else {
-                    const uint32_t lc = codes[t];
-                    bits = lc & 0xFFFFu;
-                    nbits = lc >> 16;
+        // 4 consecutive tokens per thread: one workgroup scan per 1024 tokens, and neighbouring
+        // codewords are merged into <= 64-bit pieces before they are OR-ed into the staging buffer
+        for (uint32_t tb = sm.tok_begin; tb < sm.tok_end; tb += 1024) {
+            const uint32_t t0 = tb + 4 * tid;
+            uint64_t bits[4];
+            uint32_t nbits[4], sum = 0;
+#pragma unroll
+            for (uint32_t j = 0; j < 4; j++) {
+                bits[j] = 0;
+                nbits[j] = 0;
+                if (t0 + j < sm.tok_end) {
+                    const uint32_t t = tok[t0 + j];
+                    if (t & kTokMatch) {
+                        const uint32_t len = t & 0x1FFu, off = (t >> 9) & 0xFFFFu;
+                        uint32_t ls, le, lv, os, oe, ov;
+                        length_slot(len, ls, le, lv);
+                        offset_slot(off, os, oe, ov);
+                        const uint32_t lc = codes[257 + ls], oc = codes[kNumLitlen + os];
+                        uint64_t v = lc & 0xFFFFu;
+                        uint32_t nb = lc >> 16;
+                        v |= (uint64_t)lv << nb;
+                        nb += le;
+                        v |= (uint64_t)(oc & 0xFFFFu) << nb;
+                        nb += oc >> 16;
+                        v |= (uint64_t)ov << nb;
+                        nb += oe;
+                        bits[j] = v;
+                        nbits[j] = nb;
+                    } else {
+                        const uint32_t lc = codes[t];
+                        bits[j] = lc & 0xFFFFu;
+                        nbits[j] = lc >> 16;
+                    }
+                    sum += nbits[j];
                 }
             }
             uint32_t total;
-            const uint32_t ex = block_exclusive_scan256(nbits, wsum, &total);
-            if (nbits) stage_or_bits(stage, bitpos + ex, bits);
+            const uint32_t ex = block_exclusive_scan256(sum, wsum, &total);
+            uint32_t off_bits = bitpos + ex, accn = 0;
+            uint64_t acc = 0;
+#pragma unroll
+            for (uint32_t j = 0; j < 4; j++) {
+                if (accn + nbits[j] > 64) {
+                    stage_or_bits(stage, off_bits, acc);
+                    off_bits += accn;
+                    acc = 0;
+                    accn = 0;
+                }
+                acc |= bits[j] << accn;
+                accn += nbits[j];
+            }
+            if (accn) stage_or_bits(stage, off_bits, acc);
             bitpos += total;
         }
         if (tid == 0) {
