@@ -118,6 +118,7 @@ int alloc_scratch(gzpx_ctx *ctx) {
     HIP_TRY(hipMalloc((void **)&s.cand, nb * (size_t)kCandStride * sizeof(uint16_t)));
     HIP_TRY(hipMalloc((void **)&s.len8, nb * (size_t)kMaxUnit));
     HIP_TRY(hipMalloc((void **)&s.which, nb * (size_t)(kMaxUnit / 32) * 4));
+    HIP_TRY(hipMalloc((void **)&s.alt, nb * (size_t)kMaxUnit * sizeof(uint16_t)));
     HIP_TRY(hipMalloc((void **)&s.tok, nb * (size_t)kTokStride * 4));
     HIP_TRY(hipMalloc((void **)&s.hist, nb * (size_t)kMaxSub * kHistStride * 4));
     HIP_TRY(hipMalloc((void **)&s.codes, nb * (size_t)kMaxSub * kCodeWords * 4));
@@ -135,6 +136,7 @@ void free_scratch(gzpx_ctx *ctx) {
     if (s.tok) (void)hipFree(s.tok);
     if (s.len8) (void)hipFree(s.len8);
     if (s.which) (void)hipFree(s.which);
+    if (s.alt) (void)hipFree(s.alt);
     if (s.hist) (void)hipFree(s.hist);
     if (s.codes) (void)hipFree(s.codes);
     if (s.hdr) (void)hipFree(s.hdr);

@@ -75,6 +75,7 @@ struct Scratch {
     uint16_t *cand;       // [nb][kCandStride]   d0: distance to the bucket predecessor (0 = none)
     uint8_t *len8;        // [nb][kMaxUnit]      0 = no match at p, else match length - 3
     uint32_t *which;      // [nb][kMaxUnit/32]   bit p: the older candidate won at p
+    uint16_t *alt;        // [nb][kMaxUnit]      match distance at p where that bit is set
     uint32_t *tok;        // [nb][kTokStride]
     uint32_t *hist;       // [nb][kMaxSub][kHistStride]
     uint32_t *codes;      // [nb][kMaxSub][kCodeWords]

@@ -345,7 +345,8 @@ __global__ __launch_bounds__(64) void k_candidates_safe(Config cfg, const uint8_
 //   workgroups = 32 waves share a CU and hide each other's LDS / L2 latency.
 //   d0 = distance to the bucket predecessor (from k_candidates), d1 = d0 + the predecessor's own
 //   d0; 4-byte check + lz_extend run out of LDS with aligned dword reads + v_alignbyte.
-//   Output: len8[p] (0 = no match, else length - 3) and which[p] (1 = the older candidate won).
+//   Output: len8[p] (0 = no match, else length - 3), which[p] (1 = the older candidate won) and,
+//   for those positions only, alt[p] = the winning distance d1.
 // ------------------------------------------------------------------------------------------
 constexpr uint32_t kSeg = 272;
 constexpr uint32_t kInWords = kMaxUnit / 4 + 4;
@@ -377,7 +378,8 @@ __global__ __launch_bounds__(kMpThreads) void k_match(Config cfg, const uint8_t 
                                                       BlockMeta *__restrict__ meta_all,
                                                       const uint16_t *__restrict__ cand_all,
                                                       uint8_t *__restrict__ len8_all,
-                                                      uint32_t *__restrict__ which_all) {
+                                                      uint32_t *__restrict__ which_all,
+                                                      uint16_t *__restrict__ alt_all) {
     __shared__ uint32_t in_w[kInWords];             // block bytes (+ lead misalignment, + pad)
     __shared__ uint32_t which_bits[kMaxUnit / 32];  // 1 = the older candidate (c1) won
     const uint32_t tid = threadIdx.x;
@@ -389,6 +391,7 @@ __global__ __launch_bounds__(kMpThreads) void k_match(Config cfg, const uint8_t 
     const uint16_t *cand = cand_all + (uint64_t)b * kCandStride;
     uint8_t *len8 = len8_all + (uint64_t)b * kMaxUnit;
     uint32_t *which_out = which_all + (uint64_t)b * (kMaxUnit / 32);
+    uint16_t *alt = alt_all + (uint64_t)b * kMaxUnit;
 
     long long t_mark = clock64();
     const uint32_t mis = (uint32_t)((uintptr_t)in & 3u);
@@ -438,6 +441,7 @@ __global__ __launch_bounds__(kMpThreads) void k_match(Config cfg, const uint8_t 
                     if (l1 > best) {
                         best = l1;
                         atomicOr(&which_bits[p >> 5], 1u << (p & 31u));
+                        alt[p] = (uint16_t)d1;  // the match distance when the older candidate won
                     }
                 }
             }
@@ -488,8 +492,8 @@ __device__ __forceinline__ void clear_marks(uint32_t seg_begin, uint32_t seg_end
 __global__ __launch_bounds__(kMpThreads) void k_parse(
     Config cfg, const uint8_t *__restrict__ slab, BlockMeta *__restrict__ meta_all,
     const uint16_t *__restrict__ cand_all, const uint8_t *__restrict__ len8_all,
-    const uint32_t *__restrict__ which_all, uint32_t *__restrict__ tok_all,
-    uint32_t *__restrict__ hist_all) {
+    const uint32_t *__restrict__ which_all, const uint16_t *__restrict__ alt_all,
+    uint32_t *__restrict__ tok_all, uint32_t *__restrict__ hist_all) {
     __shared__ uint32_t len8_w[kMaxUnit / 4];     // 0 = literal, else match length - 3 (bytes)
     __shared__ uint32_t tok_bits[kMaxUnit / 32];  // 1 = a token starts here
     __shared__ uint32_t hist[kMaxSub * kHistStride];
@@ -507,6 +511,7 @@ __global__ __launch_bounds__(kMpThreads) void k_parse(
     const uint8_t *in = slab + (uint64_t)b * cfg.block_size;
     const uint16_t *cand = cand_all + (uint64_t)b * kCandStride;
     const uint32_t *which = which_all + (uint64_t)b * (kMaxUnit / 32);
+    const uint16_t *alt = alt_all + (uint64_t)b * kMaxUnit;
     uint32_t *tok = tok_all + (uint64_t)b * kTokStride;
 
     long long t_mark = clock64();
@@ -600,7 +605,7 @@ __global__ __launch_bounds__(kMpThreads) void k_parse(
     // ---- phase 3b: build tokens in position order (global reads issued 4 chunks deep)
     const uint64_t lane_below = (1ull << lane) - 1ull;
     for (uint32_t c0 = 0; c0 < nchunks; c0 += 4) {
-        uint32_t lens[4], tis[4], mis_[4], offs[4], wbits[4], lits[4];
+        uint32_t lens[4], tis[4], mis_[4], offs[4], alts[4], wbits[4], lits[4];
 #pragma unroll
         for (uint32_t k = 0; k < 4; k++) {
             const uint32_t c = c0 + k;
@@ -614,6 +619,7 @@ __global__ __launch_bounds__(kMpThreads) void k_parse(
             mis_[k] = (pre >> 17) + (uint32_t)__popcll(mm & lane_below);
             lens[k] = l;
             offs[k] = is_match ? cand[p] : 0u;
+            alts[k] = is_match ? alt[p] : 0u;  // only meaningful where the which bit is set
             wbits[k] = is_match ? which[p >> 5] : 0u;
             lits[k] = (is_tok && !is_match) ? in[p] : 0u;
         }
@@ -625,8 +631,7 @@ __global__ __launch_bounds__(kMpThreads) void k_parse(
             uint32_t *h = hist + (mi >= kSeqPerSub ? kHistStride : 0);
             if (lens[k]) {
                 const uint32_t len = lens[k] + 3;
-                uint32_t off = offs[k];
-                if ((wbits[k] >> (p & 31u)) & 1u) off += cand[p - off];  // the older candidate
+                const uint32_t off = ((wbits[k] >> (p & 31u)) & 1u) ? alts[k] : offs[k];
                 uint32_t ls, le, lv, os, oe, ov;
                 length_slot(len, ls, le, lv);
                 offset_slot(off, os, oe, ov);
@@ -1447,14 +1452,14 @@ void launch_candidates(const Config &cfg, const uint8_t *slab, uint64_t, uint32_
 void launch_match(const Config &cfg, const uint8_t *slab, uint64_t, uint32_t nb, const Scratch &s,
                   hipStream_t stream) {
     hipLaunchKernelGGL(k_match, dim3(nb), dim3(kMpThreads), 0, stream, cfg, slab, s.meta,
-                       (const uint16_t *)s.cand, s.len8, s.which);
+                       (const uint16_t *)s.cand, s.len8, s.which, s.alt);
 }
 
 void launch_parse(const Config &cfg, const uint8_t *slab, uint64_t, uint32_t nb, const Scratch &s,
                   hipStream_t stream) {
     hipLaunchKernelGGL(k_parse, dim3(nb), dim3(kMpThreads), 0, stream, cfg, slab, s.meta,
                        (const uint16_t *)s.cand, (const uint8_t *)s.len8, (const uint32_t *)s.which,
-                       s.tok, s.hist);
+                       (const uint16_t *)s.alt, s.tok, s.hist);
 }
 
 void launch_huffman(const Config &cfg, uint32_t nb, const Scratch &s, hipStream_t stream) {
