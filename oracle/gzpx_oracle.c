@@ -80,21 +80,30 @@ static const uint8_t extra_precode_bits[NUM_PRECODE_SYMS] = {0, 0, 0, 0, 0, 0, 0
 static const uint8_t precode_lens_permutation[NUM_PRECODE_SYMS] = {
     16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
 
-static unsigned length_slot(unsigned len)
+/* slot lookup tables (libdeflate keeps the same kind of tables), built on first use */
+static uint8_t length_slot_tab[MAX_MATCH_LEN + 1];
+static uint8_t offset_slot_tab[32768 + 1];
+static int slot_tabs_ready;
+
+static void init_slot_tabs(void)
 {
-    unsigned s = 28;
-    while (length_slot_base[s] > len)
-        s--;
-    return s;
+    for (unsigned len = MIN_MATCH_LEN; len <= MAX_MATCH_LEN; len++) {
+        unsigned s = 28;
+        while (length_slot_base[s] > len)
+            s--;
+        length_slot_tab[len] = (uint8_t)s;
+    }
+    for (unsigned off = 1; off <= 32768; off++) {
+        unsigned s = 29;
+        while (offset_slot_base[s] > off)
+            s--;
+        offset_slot_tab[off] = (uint8_t)s;
+    }
+    slot_tabs_ready = 1;
 }
 
-static unsigned offset_slot(unsigned off)
-{
-    unsigned s = 29;
-    while (offset_slot_base[s] > off)
-        s--;
-    return s;
-}
+static inline unsigned length_slot(unsigned len) { return length_slot_tab[len]; }
+static inline unsigned offset_slot(unsigned off) { return offset_slot_tab[off]; }
 
 /* ------------------------------------------------------------------ output bitstream */
 
@@ -378,6 +387,8 @@ static void flush_block(struct bitwriter *w, int compat, const uint8_t *block_be
 
     if (!static_codes_ready)
         init_static_codes();
+    if (!slot_tabs_ready)
+        init_slot_tabs();
 
     fr->litlen[END_OF_BLOCK]++;
     gzpx_oracle_make_huffman_code(NUM_LITLEN_SYMS, MAX_LITLEN_CODEWORD_LEN, compat, fr->litlen,
@@ -499,6 +510,14 @@ static void ht_slide(struct ht_mf *mf)
 
 static unsigned lz_extend(const uint8_t *a, const uint8_t *b, unsigned len, unsigned max_len)
 {
+    while (len + 8 <= max_len) {
+        uint64_t x, y;
+        memcpy(&x, a + len, 8);
+        memcpy(&y, b + len, 8);
+        if (x != y)
+            return len + (unsigned)(__builtin_ctzll(x ^ y) >> 3);
+        len += 8;
+    }
     while (len < max_len && a[len] == b[len])
         len++;
     return len;
@@ -608,20 +627,31 @@ static void tally_match(struct freqs *fr, uint32_t *tokens, size_t *nt, unsigned
     tokens[(*nt)++] = TOKEN_MATCH | (off << 9) | len;
 }
 
+/* The compressor object of the reference lives as long as its worker thread
+ * (src/par/compress.rs:278); its big arrays are likewise kept per thread here instead of being
+ * re-allocated for every block. */
+static __thread struct ht_mf *tl_mf;
+static __thread uint32_t *tl_tokens;
+
 /* deflate_compress_fastest: greedy parse with ht_matchfinder; sub-block per 8192 sequences. */
 static int compress_fastest(const uint8_t *in, size_t n, block_sink_fn sink, void *ctx)
 {
     const uint8_t *in_next = in, *in_end = in + n, *in_cur_base = in;
     unsigned max_len = MAX_MATCH_LEN, nice_len = 32;
     uint32_t next_hash = 0;
-    struct ht_mf *mf = (struct ht_mf *)malloc(sizeof(*mf));
+    struct ht_mf *mf;
+    uint32_t *tokens;
+    if (!slot_tabs_ready)
+        init_slot_tabs();
+    if (!tl_mf)
+        tl_mf = (struct ht_mf *)malloc(sizeof(*tl_mf));
     /* worst case one token per byte in a sub-block of <= 65535+5000 bytes */
-    uint32_t *tokens = (uint32_t *)malloc(sizeof(uint32_t) * (FAST_SOFT_MAX_BLOCK_LENGTH + MIN_BLOCK_LENGTH + 300));
-    if (!mf || !tokens) {
-        free(mf);
-        free(tokens);
+    if (!tl_tokens)
+        tl_tokens = (uint32_t *)malloc(sizeof(uint32_t) * (FAST_SOFT_MAX_BLOCK_LENGTH + MIN_BLOCK_LENGTH + 300));
+    mf = tl_mf;
+    tokens = tl_tokens;
+    if (!mf || !tokens)
         return -1;
-    }
     for (size_t i = 0; i < (1u << HT_HASH_ORDER); i++)
         mf->tab[i][0] = mf->tab[i][1] = -WINDOW_SIZE;
 
@@ -662,8 +692,6 @@ static int compress_fastest(const uint8_t *in, size_t n, block_sink_fn sink, voi
         } while (in_next < max_block_end && nseq < FAST_SEQ_STORE_LENGTH);
         sink(ctx, block_begin, (size_t)(in_next - block_begin), tokens, nt, &fr, in_next == in_end);
     } while (in_next != in_end);
-    free(mf);
-    free(tokens);
     return 0;
 }
 
