@@ -32,7 +32,7 @@ FORMAT_BGZF = 0
 FORMAT_MGZIP = 1
 COMPAT_1_24 = 0
 COMPAT_1_10 = 1
-N_STAGES = 8
+N_STAGES = 9
 
 EXPORTS = [
     "gzpx_config_default", "gzpx_ctx_create", "gzpx_ctx_destroy", "gzpx_slab_bound",
@@ -288,8 +288,8 @@ class Context:
         return [int(x) for x in c]
 
     def debug_tokens(self, block):
-        toks = np.empty(65536, dtype=np.uint32)
-        first = np.zeros(4, dtype=np.uint32)
+        toks = np.empty(max(65536, int(self.buffer_size)), dtype=np.uint32)
+        first = np.zeros(int(self.buffer_size) // 32768 + 4, dtype=np.uint32)
         n = ctypes.c_size_t(0)
         ns = ctypes.c_size_t(0)
         self.lib.check(self.lib.L.gzpx_debug_tokens(self.h, block, toks.ctypes.data, toks.size,

@@ -21,6 +21,7 @@ namespace {
 
 constexpr size_t kDictSize = 32768;  // DICT_SIZE, src/lib.rs:108
 constexpr uint32_t kMaxBatchBlocks = 16384;
+constexpr size_t kMaxScratchBytes = (size_t)24 << 30;  // per-context cap of the per-block scratch
 
 // ---- GF(2) polynomial helpers for CRC-32 combination (reflected representation) ----
 uint32_t multmodp(uint32_t a, uint32_t b) {
@@ -78,6 +79,7 @@ struct gzpx_ctx {
     uint8_t *d_out = nullptr;
     size_t d_out_cap = 0;
     BlockMeta *h_meta = nullptr;  // pinned, batch_blocks entries
+    SubMeta *h_sub = nullptr;     // pinned, batch_blocks * max_sub entries (debug hooks)
     uint64_t *h_total = nullptr;  // pinned
     StageEvents events;
     bool profiling = false;
@@ -111,20 +113,30 @@ uint64_t blocks_of(const gzpx_ctx *ctx, size_t in_len) {
     return in_len == 0 ? 1 : (in_len + bs - 1) / bs;
 }
 
+// bytes of device scratch one block needs (see gzpx_device.h Scratch)
+size_t scratch_bytes_per_block(const Config &c) {
+    return (size_t)c.stride * (2 + 1 + 2 + 4) + c.stride / 8 +
+           (size_t)c.max_sub * (sizeof(SubMeta) + (kHistStride + kCodeWords + kHdrWords) * 4) +
+           sizeof(BlockMeta) + 8;
+}
+
 int alloc_scratch(gzpx_ctx *ctx) {
     const size_t nb = ctx->batch_blocks;
+    const Config &c = ctx->dcfg;
     Scratch &s = ctx->scratch;
     HIP_TRY(hipMalloc((void **)&s.meta, nb * sizeof(BlockMeta)));
-    HIP_TRY(hipMalloc((void **)&s.cand, nb * (size_t)kCandStride * sizeof(uint16_t)));
-    HIP_TRY(hipMalloc((void **)&s.len8, nb * (size_t)kMaxUnit));
-    HIP_TRY(hipMalloc((void **)&s.which, nb * (size_t)(kMaxUnit / 32) * 4));
-    HIP_TRY(hipMalloc((void **)&s.alt, nb * (size_t)kMaxUnit * sizeof(uint16_t)));
-    HIP_TRY(hipMalloc((void **)&s.tok, nb * (size_t)kTokStride * 4));
-    HIP_TRY(hipMalloc((void **)&s.hist, nb * (size_t)kMaxSub * kHistStride * 4));
-    HIP_TRY(hipMalloc((void **)&s.codes, nb * (size_t)kMaxSub * kCodeWords * 4));
-    HIP_TRY(hipMalloc((void **)&s.hdr, nb * (size_t)kMaxSub * kHdrWords * 4));
+    HIP_TRY(hipMalloc((void **)&s.sub, nb * (size_t)c.max_sub * sizeof(SubMeta)));
+    HIP_TRY(hipMalloc((void **)&s.cand, nb * (size_t)c.stride * sizeof(uint16_t)));
+    HIP_TRY(hipMalloc((void **)&s.len8, nb * (size_t)c.stride));
+    HIP_TRY(hipMalloc((void **)&s.which, nb * (size_t)(c.stride / 32) * 4));
+    HIP_TRY(hipMalloc((void **)&s.alt, nb * (size_t)c.stride * sizeof(uint16_t)));
+    HIP_TRY(hipMalloc((void **)&s.tok, nb * (size_t)c.stride * 4));
+    HIP_TRY(hipMalloc((void **)&s.hist, nb * (size_t)c.max_sub * kHistStride * 4));
+    HIP_TRY(hipMalloc((void **)&s.codes, nb * (size_t)c.max_sub * kCodeWords * 4));
+    HIP_TRY(hipMalloc((void **)&s.hdr, nb * (size_t)c.max_sub * kHdrWords * 4));
     HIP_TRY(hipMalloc((void **)&s.out_off, (nb + 1) * sizeof(uint64_t)));
     HIP_TRY(hipHostMalloc((void **)&ctx->h_meta, nb * sizeof(BlockMeta), hipHostMallocDefault));
+    HIP_TRY(hipHostMalloc((void **)&ctx->h_sub, nb * (size_t)c.max_sub * sizeof(SubMeta), hipHostMallocDefault));
     HIP_TRY(hipHostMalloc((void **)&ctx->h_total, 64, hipHostMallocDefault));
     return GZPX_OK;
 }
@@ -132,6 +144,8 @@ int alloc_scratch(gzpx_ctx *ctx) {
 void free_scratch(gzpx_ctx *ctx) {
     Scratch &s = ctx->scratch;
     if (s.meta) (void)hipFree(s.meta);
+    if (s.sub) (void)hipFree(s.sub);
+    if (ctx->h_sub) (void)hipHostFree(ctx->h_sub);
     if (s.cand) (void)hipFree(s.cand);
     if (s.tok) (void)hipFree(s.tok);
     if (s.len8) (void)hipFree(s.len8);
@@ -165,6 +179,8 @@ int run_batch(gzpx_ctx *ctx, const uint8_t *d_in, size_t in_len, uint32_t nb, in
     launch_match(c, d_in, in_len, nb, s, stream);
     if (prof) HIP_TRY(hipEventRecord(ev[++k], stream));
     launch_parse(c, d_in, in_len, nb, s, stream);
+    if (prof) HIP_TRY(hipEventRecord(ev[++k], stream));
+    launch_hist(c, nb, s, stream);
     if (prof) HIP_TRY(hipEventRecord(ev[++k], stream));
     launch_huffman(c, nb, s, stream);
     if (prof) HIP_TRY(hipEventRecord(ev[++k], stream));
@@ -281,7 +297,7 @@ int gzpx_ctx_create(const gzpx_config *cfg, gzpx_ctx **out) {
     if (cfg->compat != GZPX_COMPAT_LIBDEFLATE_1_24 && cfg->compat != GZPX_COMPAT_LIBDEFLATE_1_10)
         return GZPX_ERR_INVALID_ARG;
     if (cfg->level != 1) return GZPX_ERR_UNSUPPORTED;             // levels 0, 2..12: not built yet
-    if (cfg->buffer_size > kMaxUnit) return GZPX_ERR_UNSUPPORTED;  // > 64 KiB blocks: not built yet
+    if (cfg->buffer_size > kMaxBlockSize) return GZPX_ERR_UNSUPPORTED;  // > 16 MiB blocks: not built
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return GZPX_ERR_NO_DEVICE;
     if (cfg->device < 0 || cfg->device >= ndev) return GZPX_ERR_INVALID_ARG;
@@ -296,7 +312,11 @@ int gzpx_ctx_create(const gzpx_config *cfg, gzpx_ctx **out) {
     ctx->dcfg.block_size = (uint32_t)cfg->buffer_size;
     ctx->dcfg.xfl = cfg->level >= 9 ? 2u : cfg->level <= 1 ? 4u : 0u;  // src/bgzf.rs:278-284
     ctx->dcfg.debug = 0;
+    // per-block strides: padding for k_candidates' last iteration / dword-wide tile loads
+    ctx->dcfg.stride = (uint32_t)((cfg->buffer_size + 1023) / 1024 * 1024 + 1024);
+    ctx->dcfg.max_sub = (uint32_t)(cfg->buffer_size / 32768 + 2);
     for (unsigned l = 0; l < 8; l++) ctx->crc_consts.pow256[l] = x2k(11 + l);
+    ctx->crc_consts.pow_tile = x2k(19);  // x^(8 * 65536) = x^(2^19)
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, cfg->device) == hipSuccess) {
         snprintf(ctx->devname, sizeof(ctx->devname), "%s (%s, %d CUs)", prop.name, prop.gcnArchName,
@@ -304,6 +324,10 @@ int gzpx_ctx_create(const gzpx_config *cfg, gzpx_ctx **out) {
     }
     const uint64_t want = blocks_of(ctx, cfg->max_slab_bytes ? cfg->max_slab_bytes : 1);
     ctx->batch_blocks = (uint32_t)(want < kMaxBatchBlocks ? want : kMaxBatchBlocks);
+    {
+        const size_t fit = kMaxScratchBytes / scratch_bytes_per_block(ctx->dcfg);
+        if (ctx->batch_blocks > fit) ctx->batch_blocks = (uint32_t)fit;
+    }
     if (ctx->batch_blocks == 0) ctx->batch_blocks = 1;
     int rc = GZPX_OK;
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) rc = GZPX_ERR_DEVICE;
@@ -410,25 +434,29 @@ int gzpx_compressor_set_compat(gzpx_compressor *c, int compat) {
     return GZPX_OK;
 }
 
-static int compressor_ctx(gzpx_compressor *c) {
-    if (c->ctx) return GZPX_OK;
+static int compressor_ctx(gzpx_compressor *c, size_t n) {
+    if (c->ctx && n <= c->ctx->cfg.buffer_size) return GZPX_OK;
+    if (c->ctx) gzpx_ctx_destroy(c->ctx);
+    c->ctx = nullptr;
     gzpx_config cfg;
     gzpx_config_default(&cfg, GZPX_FORMAT_MGZIP);  // Mgzip framing has no payload size limit
     cfg.level = c->level;
     cfg.compat = c->compat;
-    cfg.buffer_size = kMaxUnit;
-    cfg.max_slab_bytes = kMaxUnit;
+    size_t bs = 65536;  // one whole-buffer DEFLATE call = one "block" of that size
+    while (bs < n) bs *= 2;
+    cfg.buffer_size = bs;
+    cfg.max_slab_bytes = bs;
     return gzpx_ctx_create(&cfg, &c->ctx);
 }
 
 size_t gzpx_deflate_compress(gzpx_compressor *c, const void *in, size_t n, void *out, size_t cap) {
     if (!c || (!in && n) || !out) return 0;
-    if (n > kMaxUnit) return 0;  // TODO(next): inputs above one 64 KiB unit
-    if (compressor_ctx(c) != GZPX_OK) return 0;
+    if (n > kMaxBlockSize) return 0;  // whole-buffer inputs above 16 MiB: not built
+    if (compressor_ctx(c, n) != GZPX_OK) return 0;
     c->tmp.resize(gzpx_slab_bound(c->ctx, n));
     size_t got = 0, nb = 0;
-    if (gzpx_compress_slab(c->ctx, (const uint8_t *)in, n, 1, c->tmp.data(), c->tmp.size(), &got,
-                           nullptr, 0, &nb) != GZPX_OK)
+    if (gzpx_compress_slab(c->ctx, (const uint8_t *)in, n, GZPX_SLAB_LAST, c->tmp.data(), c->tmp.size(),
+                           &got, nullptr, 0, &nb) != GZPX_OK)
         return 0;
     const size_t payload = got - 20 - 8;
     if (payload > cap) return 0;  // libdeflate: 0 when the output does not fit
@@ -458,7 +486,7 @@ uint32_t gzpx_crc32(uint32_t crc, const void *buf, size_t n) {
         gzpx_config cfg;
         gzpx_config_default(&cfg, GZPX_FORMAT_MGZIP);
         cfg.level = 1;
-        cfg.buffer_size = kMaxUnit;
+        cfg.buffer_size = kTile;
         cfg.max_slab_bytes = (size_t)64 << 20;
         if (gzpx_ctx_create(&cfg, &ctx) != GZPX_OK) return 0;
     }
@@ -466,11 +494,11 @@ uint32_t gzpx_crc32(uint32_t crc, const void *buf, size_t n) {
     std::lock_guard<std::mutex> lock2(ctx->mu);
     if (hipSetDevice(ctx->cfg.device) != hipSuccess) return 0;
     const uint8_t *p = (const uint8_t *)buf;
-    const size_t slab_max = (size_t)ctx->batch_blocks * kMaxUnit;
+    const size_t slab_max = (size_t)ctx->batch_blocks * kTile;
     while (n) {
         const size_t take = n < slab_max ? n : slab_max;
         if (ensure_buffers(ctx, take, 64) != GZPX_OK) return 0;
-        const uint32_t nb = (uint32_t)((take + kMaxUnit - 1) / kMaxUnit);
+        const uint32_t nb = (uint32_t)((take + kTile - 1) / kTile);
         if (hipMemcpyAsync(ctx->d_in, p, take, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) return 0;
         launch_init_meta(ctx->dcfg, take, nb, 0, ctx->scratch, ctx->stream);
         launch_crc32(ctx->dcfg, ctx->d_in, take, nb, ctx->scratch, ctx->crc_consts, ctx->stream);
@@ -500,8 +528,8 @@ int gzpx_ctx_last_stage_ms(const gzpx_ctx *ctx, float ms[GZPX_N_STAGES]) {
 }
 
 const char *gzpx_stage_name(int stage) {
-    static const char *names[GZPX_N_STAGES] = {"k_init_meta", "k_candidates", "k_match",  "k_parse",
-                                               "k_huffman",   "k_crc32",      "k_scan",   "k_emit"};
+    static const char *names[GZPX_N_STAGES] = {"k_init_meta", "k_candidates", "k_match", "k_parse", "k_hist",
+                                               "k_huffman",   "k_crc32",      "k_scan",  "k_emit"};
     return (stage >= 0 && stage < GZPX_N_STAGES) ? names[stage] : "?";
 }
 
@@ -511,13 +539,17 @@ int gzpx_debug_tokens(gzpx_ctx *ctx, size_t block, uint32_t *tokens, size_t max_
     std::lock_guard<std::mutex> lock(ctx->mu);
     if (hipSetDevice(ctx->cfg.device) != hipSuccess) return GZPX_ERR_DEVICE;
     const BlockMeta &m = ctx->h_meta[block];
+    const uint32_t max_sub = ctx->dcfg.max_sub;
     *n_tokens = m.ntok;
     if (n_sub) *n_sub = m.nsub;
-    if (sub_first_token)
-        for (uint32_t s = 0; s < m.nsub && s < kMaxSub; s++) sub_first_token[s] = m.sub[s].tok_begin;
+    if (sub_first_token && m.nsub) {
+        HIP_TRY(hipMemcpy(ctx->h_sub, ctx->scratch.sub + block * (size_t)max_sub,
+                          (size_t)m.nsub * sizeof(SubMeta), hipMemcpyDeviceToHost));
+        for (uint32_t s = 0; s < m.nsub && s < max_sub; s++) sub_first_token[s] = ctx->h_sub[s].tok_begin;
+    }
     const size_t ncopy = m.ntok < max_tokens ? m.ntok : max_tokens;
     if (tokens && ncopy)
-        HIP_TRY(hipMemcpy(tokens, ctx->scratch.tok + block * (size_t)kTokStride, ncopy * 4,
+        HIP_TRY(hipMemcpy(tokens, ctx->scratch.tok + block * (size_t)ctx->dcfg.stride, ncopy * 4,
                           hipMemcpyDeviceToHost));
     return GZPX_OK;
 }

@@ -9,11 +9,11 @@
 
 namespace gzpx {
 
-constexpr unsigned kMaxUnit = 65536;       // max input bytes per block handled by the kernels
-constexpr unsigned kCandStride = kMaxUnit + 512;  // u16 per position (+ one iteration of padding)
-constexpr unsigned kTokStride = kMaxUnit;  // u32 per token (worst case: all literals)
-constexpr unsigned kMaxSub = 2;            // n <= 65536 => at most 2 sub-blocks (8192 matches each)
+constexpr unsigned kTile = 65536;         // positions handled per LDS tile (k_parse) / stage window
+constexpr unsigned kMaxBlockSize = 1u << 24;  // largest buffer_size the kernels accept (16 MiB)
 constexpr unsigned kSeqPerSub = 8192;      // FAST_SEQ_STORE_LENGTH
+constexpr unsigned kSoftMaxSub = 65535;    // FAST_SOFT_MAX_BLOCK_LENGTH
+constexpr unsigned kMinBlockLen = 5000;    // MIN_BLOCK_LENGTH
 constexpr unsigned kNumLitlen = 288;
 constexpr unsigned kNumOffset = 32;
 constexpr unsigned kHistStride = kNumLitlen + kNumOffset;  // 320 u32 per sub-block
@@ -50,7 +50,6 @@ struct BlockMeta {
     uint32_t framed_bytes;   // header + c + footer (+ EOF)
     uint32_t crc;
     uint32_t status;
-    SubMeta sub[kMaxSub];
     uint32_t phase_cycles[8];  // k_match [0,1] / k_parse [2..5]: shader-clock cycles per phase, [6] parse rounds
     uint32_t cand_redo;        // k_candidates' LDS-order check failed: redo with k_candidates_safe
     uint32_t cand_cycles[4];   // k_candidates: shader-clock cycles [-, -, -, main loop total]
@@ -58,6 +57,7 @@ struct BlockMeta {
 
 struct CrcConsts {
     uint32_t pow256[8];  // x^(8*256*2^l) mod P (reflected), l = 0..7
+    uint32_t pow_tile;   // x^(8*65536) mod P: appends one full 64 KiB chunk
 };
 
 struct Config {
@@ -67,19 +67,22 @@ struct Config {
     uint32_t block_size;  // buffer_size of the reference's builder
     uint32_t xfl;         // gzip XFL byte derived from level (src/bgzf.rs:278-284)
     uint32_t debug;       // diagnostics only: bit 0 = force k_candidates_safe on every block
+    uint32_t stride;      // per-block stride (positions) of cand / len8 / alt / tok: >= block_size + 1024
+    uint32_t max_sub;     // per-block capacity of sub / hist / codes / hdr (sub-blocks >= 32768 bytes)
 };
 
 // Device scratch for one batch of blocks.
 struct Scratch {
     BlockMeta *meta;      // [nb]
-    uint16_t *cand;       // [nb][kCandStride]   d0: distance to the bucket predecessor (0 = none)
-    uint8_t *len8;        // [nb][kMaxUnit]      0 = no match at p, else match length - 3
-    uint32_t *which;      // [nb][kMaxUnit/32]   bit p: the older candidate won at p
-    uint16_t *alt;        // [nb][kMaxUnit]      match distance at p where that bit is set
-    uint32_t *tok;        // [nb][kTokStride]
-    uint32_t *hist;       // [nb][kMaxSub][kHistStride]
-    uint32_t *codes;      // [nb][kMaxSub][kCodeWords]
-    uint32_t *hdr;        // [nb][kMaxSub][kHdrWords]
+    SubMeta *sub;         // [nb][max_sub]
+    uint16_t *cand;       // [nb][stride]        d0: distance to the bucket predecessor (0 = none)
+    uint8_t *len8;        // [nb][stride]        0 = no match at p, else match length - 3
+    uint32_t *which;      // [nb][stride/32]     bit p: the older candidate won at p
+    uint16_t *alt;        // [nb][stride]        match distance at p where that bit is set
+    uint32_t *tok;        // [nb][stride]        worst case one token per byte
+    uint32_t *hist;       // [nb][max_sub][kHistStride]
+    uint32_t *codes;      // [nb][max_sub][kCodeWords]
+    uint32_t *hdr;        // [nb][max_sub][kHdrWords]
     uint64_t *out_off;    // [nb + 1] byte offset of each framed block in the output
 };
 
@@ -92,6 +95,7 @@ void launch_match(const Config &cfg, const uint8_t *slab, uint64_t slab_len, uin
                   const Scratch &s, hipStream_t stream);
 void launch_parse(const Config &cfg, const uint8_t *slab, uint64_t slab_len, uint32_t nb,
                   const Scratch &s, hipStream_t stream);
+void launch_hist(const Config &cfg, uint32_t nb, const Scratch &s, hipStream_t stream);
 void launch_huffman(const Config &cfg, uint32_t nb, const Scratch &s, hipStream_t stream);
 void launch_crc32(const Config &cfg, const uint8_t *slab, uint64_t slab_len, uint32_t nb,
                   const Scratch &s, const CrcConsts &cc, hipStream_t stream);

@@ -143,16 +143,6 @@ __global__ void k_init_meta(Config cfg, uint64_t slab_len, uint32_t nb, uint32_t
     m.framed_bytes = 0;
     m.crc = 0;
     m.status = kStatusOk;
-    for (unsigned s = 0; s < kMaxSub; s++) {
-        m.sub[s].type = 0;
-        m.sub[s].tok_begin = 0;
-        m.sub[s].tok_end = 0;
-        m.sub[s].byte_begin = 0;
-        m.sub[s].byte_len = 0;
-        m.sub[s].bit_begin = 0;
-        m.sub[s].hdr_bits = 0;
-        m.sub[s].is_final = 0;
-    }
     for (unsigned k = 0; k < 8; k++) m.phase_cycles[k] = 0;
     m.cand_redo = 0;
     for (unsigned k = 0; k < 4; k++) m.cand_cycles[k] = 0;
@@ -166,9 +156,9 @@ __global__ void k_init_meta(Config cfg, uint64_t slab_len, uint32_t nb, uint32_t
 // predecessor in its bucket; the older candidate is the predecessor's predecessor
 // (d1 = d0[p] + d0[p - d0[p]]), which k_match_parse reads from the same array.
 // One workgroup per block, 128 KiB table in LDS, one word per bucket = (newest position + 1), 0 =
-// empty.  Positions of one block are < 65536 and only grow, so "newest" is an unsigned maximum
-// and liveness (libdeflate: cur_node > cutoff) is the plain distance test p - c <= 32767 -- no
-// window slide is needed below 64 KiB.
+// empty.  Positions only grow, so "newest" is an unsigned maximum, and liveness (libdeflate:
+// cur_node > cutoff) is the plain distance test p - c <= 32767 on 32-bit positions -- the window
+// slide of the reference never changes the outcome of a lookup, so none is needed.
 //
 // Fast kernel (k_candidates): every lane does  old = atomicMax(&tab[h], p + 1).
 // The LDS applies same-address atomics of one instruction in ascending lane order (measured:
@@ -214,7 +204,7 @@ __global__ __launch_bounds__(64 * kCandWaves) void k_candidates(Config cfg,
     const uint32_t mis = (uint32_t)((uintptr_t)in & 3u);
     const uint32_t *in32 = (const uint32_t *)(in - mis);
     const uint32_t wmax = (mis + n - 1) >> 2;  // last dword holding a byte of this block
-    uint16_t *cand = cand_all + (uint64_t)b * kCandStride;
+    uint16_t *cand = cand_all + (uint64_t)b * cfg.stride;
 
     for (uint32_t i = tid; i < kBuckets; i += 64 * kCandWaves) tab[i] = 0;
     if (tid == 0) turn = 0;
@@ -268,7 +258,7 @@ __global__ __launch_bounds__(64 * kCandWaves) void k_candidates(Config cfg,
             bad |= old[k] > p;  // handed a predecessor that is not earlier: LDS order assumption broken
             uint32_t d0 = old[k] ? p + 1 - old[k] : 0;
             if (d0 > 32767u) d0 = 0;  // farther than the window: dead
-            cand[p] = (uint16_t)d0;   // p < kCandStride (padded stride)
+            cand[p] = (uint16_t)d0;   // p < cfg.stride (padded by >= one iteration)
         }
     }
     if (tid == 0) meta[b].cand_cycles[3] = (uint32_t)(clock64() - t_begin);
@@ -317,7 +307,7 @@ __global__ __launch_bounds__(64) void k_candidates_safe(Config cfg, const uint8_
         const uint32_t mis = (uint32_t)((uintptr_t)in & 3u);
         const uint32_t *in32 = (const uint32_t *)(in - mis);
         const uint32_t wmax = (mis + n - 1) >> 2;
-        uint16_t *cand = cand_all + (uint64_t)b * kCandStride;
+        uint16_t *cand = cand_all + (uint64_t)b * cfg.stride;
         wave_sync();
         for (uint32_t i = lane; i < kBuckets; i += 64) tab[i] = 0x8000u;
         wave_sync();
@@ -341,18 +331,20 @@ __global__ __launch_bounds__(64) void k_candidates_safe(Config cfg, const uint8_
 
 // ------------------------------------------------------------------------------------------
 // k_match: ht_matchfinder_longest_match for EVERY position of a block in parallel.
-//   1024 threads per block, 72 KiB of LDS (the block's bytes + one bit per position), so two
-//   workgroups = 32 waves share a CU and hide each other's LDS / L2 latency.
+//   1024 threads per block, ~74 KiB of LDS (a window of the block's bytes + one bit per
+//   position), so two workgroups = 32 waves share a CU and hide each other's LDS / L2 latency.
+//   Blocks up to 64 KiB are one tile; larger blocks are walked in 32 KiB tiles whose LDS window
+//   also holds the 32 KiB of history a match may reach back into.
 //   d0 = distance to the bucket predecessor (from k_candidates), d1 = d0 + the predecessor's own
 //   d0; 4-byte check + lz_extend run out of LDS with aligned dword reads + v_alignbyte.
 //   Output: len8[p] (0 = no match, else length - 3), which[p] (1 = the older candidate won) and,
 //   for those positions only, alt[p] = the winning distance d1.
 // ------------------------------------------------------------------------------------------
 constexpr uint32_t kSeg = 272;
-constexpr uint32_t kInWords = kMaxUnit / 4 + 4;
+constexpr uint32_t kInWords = kTile / 4 + 132;  // 64 KiB window + max match + alignment slack
 constexpr uint32_t kMpThreads = 1024;
 constexpr uint32_t kMpWaves = kMpThreads / 64;
-constexpr uint32_t kMpChunks = kMaxUnit / kMpThreads;  // 64 position chunks of 1024
+constexpr uint32_t kMpChunks = kTile / kMpThreads;  // 64 position chunks of 1024
 
 __device__ __forceinline__ uint32_t lds_le32(const uint32_t *in_w, uint32_t byte_addr) {
     const uint32_t w = byte_addr >> 2;
@@ -374,100 +366,109 @@ __device__ __forceinline__ uint32_t lds_extend(const uint32_t *in_w, uint32_t a,
     return len < max_len ? len : max_len;
 }
 
-__global__ __launch_bounds__(kMpThreads) void k_match(Config cfg, const uint8_t *__restrict__ slab,
+__global__ __launch_bounds__(kMpThreads, 8) void k_match(Config cfg, const uint8_t *__restrict__ slab,
                                                       BlockMeta *__restrict__ meta_all,
                                                       const uint16_t *__restrict__ cand_all,
                                                       uint8_t *__restrict__ len8_all,
                                                       uint32_t *__restrict__ which_all,
                                                       uint16_t *__restrict__ alt_all) {
-    __shared__ uint32_t in_w[kInWords];             // block bytes (+ lead misalignment, + pad)
-    __shared__ uint32_t which_bits[kMaxUnit / 32];  // 1 = the older candidate (c1) won
+    __shared__ uint32_t in_w[kInWords];          // window bytes (+ lead misalignment, + pad)
+    __shared__ uint32_t which_bits[kTile / 32];  // 1 = the older candidate (c1) won (per tile)
     const uint32_t tid = threadIdx.x;
     const uint32_t b = blockIdx.x;
     BlockMeta *meta = meta_all + b;
     const uint32_t n = meta->n;
     if (n <= kPassthroughL1) return;  // uniform for the workgroup
     const uint8_t *in = slab + (uint64_t)b * cfg.block_size;
-    const uint16_t *cand = cand_all + (uint64_t)b * kCandStride;
-    uint8_t *len8 = len8_all + (uint64_t)b * kMaxUnit;
-    uint32_t *which_out = which_all + (uint64_t)b * (kMaxUnit / 32);
-    uint16_t *alt = alt_all + (uint64_t)b * kMaxUnit;
+    const uint16_t *cand = cand_all + (uint64_t)b * cfg.stride;
+    uint8_t *len8 = len8_all + (uint64_t)b * cfg.stride;
+    uint32_t *which_out = which_all + (uint64_t)b * (cfg.stride / 32);
+    uint16_t *alt = alt_all + (uint64_t)b * cfg.stride;
 
-    long long t_mark = clock64();
-    const uint32_t mis = (uint32_t)((uintptr_t)in & 3u);
-    {
-        const uint32_t *src = (const uint32_t *)(in - mis);
-        const uint32_t ndw = (mis + n + 3) >> 2;
-        for (uint32_t i = tid; i < ndw; i += kMpThreads) in_w[i] = src[i];
-        for (uint32_t i = ndw + tid; i < ndw + 3 && i < kInWords; i += kMpThreads) in_w[i] = 0;
-        for (uint32_t i = tid; i < kMaxUnit / 32; i += kMpThreads) which_bits[i] = 0;
-    }
-    __syncthreads();
-    if (tid == 0) {
-        const long long t = clock64();
-        meta->phase_cycles[0] = (uint32_t)(t - t_mark);
-        t_mark = t;
-    }
+    const long long t_begin = clock64();
+    const uint32_t tile_step = n <= kTile ? kTile : kTile / 2;
+    for (uint32_t tile_begin = 0; tile_begin < n; tile_begin += tile_step) {
+        const uint32_t tile_end = tile_begin + tile_step < n ? tile_begin + tile_step : n;
+        const uint32_t win_begin = tile_begin >= 32768u ? tile_begin - 32768u : 0;  // history
+        const uint32_t win_end = tile_end + 264 < n ? tile_end + 264 : n;           // look-ahead
+        // LDS byte address of block byte i is (i - win_begin) + mis
+        const uint32_t mis = (uint32_t)((uintptr_t)(in + win_begin) & 3u);
+        __syncthreads();  // the previous tile is done with in_w / which_bits
+        {
+            const uint32_t *src = (const uint32_t *)(in + win_begin - mis);
+            const uint32_t ndw = (mis + (win_end - win_begin) + 3) >> 2;
+            for (uint32_t i = tid; i < ndw; i += kMpThreads) in_w[i] = src[i];
+            for (uint32_t i = ndw + tid; i < ndw + 3 && i < kInWords; i += kMpThreads) in_w[i] = 0;
+            for (uint32_t i = tid; i < kTile / 32; i += kMpThreads) which_bits[i] = 0;
+        }
+        __syncthreads();
 
-    // candidate distances are read 4 positions deep (two dependent L2 reads per position)
-    for (uint32_t p0 = tid; p0 < n; p0 += 4 * kMpThreads) {
-        uint32_t d0s[4], d1s[4];
+        // candidate distances are read 4 positions deep (two dependent L2 reads per position)
+        for (uint32_t p0 = tile_begin + tid; p0 < tile_end; p0 += 4 * kMpThreads) {
+            uint32_t d0s[4], d1s[4];
 #pragma unroll
-        for (uint32_t k = 0; k < 4; k++) {
-            const uint32_t p = p0 + k * kMpThreads;
-            d0s[k] = (p + 5 <= n) ? cand[p] : 0u;
-        }
+            for (uint32_t k = 0; k < 4; k++) {
+                const uint32_t p = p0 + k * kMpThreads;
+                d0s[k] = (p < tile_end && p + 5 <= n) ? cand[p] : 0u;
+            }
 #pragma unroll
-        for (uint32_t k = 0; k < 4; k++) {
-            const uint32_t p = p0 + k * kMpThreads;
-            const uint32_t r = d0s[k] ? cand[p - d0s[k]] : 0u;
-            d1s[k] = (r && d0s[k] + r <= 32767u) ? d0s[k] + r : 0u;
-        }
+            for (uint32_t k = 0; k < 4; k++) {
+                const uint32_t p = p0 + k * kMpThreads;
+                const uint32_t r = d0s[k] ? cand[p - d0s[k]] : 0u;
+                d1s[k] = (r && d0s[k] + r <= 32767u) ? d0s[k] + r : 0u;
+            }
 #pragma unroll
-        for (uint32_t k = 0; k < 4; k++) {
-            const uint32_t p = p0 + k * kMpThreads;
-            if (p >= n) break;
-            uint32_t best = 0;
-            const uint32_t d0 = d0s[k], d1 = d1s[k];
-            if (d0) {
-                const uint32_t rem = n - p;
-                const uint32_t max_len = rem < 258u ? rem : 258u;
-                const uint32_t nice_len = max_len < 32u ? max_len : 32u;
-                const uint32_t a = p + mis;
-                const uint32_t seq = lds_le32(in_w, a);
-                if (lds_le32(in_w, a - d0) == seq) best = lds_extend(in_w, a, a - d0, max_len);
-                if (d1 && best < nice_len && lds_le32(in_w, a - d1) == seq) {
-                    const uint32_t l1 = lds_extend(in_w, a, a - d1, max_len);
-                    if (l1 > best) {
-                        best = l1;
-                        atomicOr(&which_bits[p >> 5], 1u << (p & 31u));
-                        alt[p] = (uint16_t)d1;  // the match distance when the older candidate won
+            for (uint32_t k = 0; k < 4; k++) {
+                const uint32_t p = p0 + k * kMpThreads;
+                if (p >= tile_end) break;
+                uint32_t best = 0;
+                const uint32_t d0 = d0s[k], d1 = d1s[k];
+                if (d0) {
+                    const uint32_t rem = n - p;
+                    const uint32_t max_len = rem < 258u ? rem : 258u;
+                    const uint32_t nice_len = max_len < 32u ? max_len : 32u;
+                    const uint32_t a = p - win_begin + mis;
+                    const uint32_t seq = lds_le32(in_w, a);
+                    if (lds_le32(in_w, a - d0) == seq) best = lds_extend(in_w, a, a - d0, max_len);
+                    if (d1 && best < nice_len && lds_le32(in_w, a - d1) == seq) {
+                        const uint32_t l1 = lds_extend(in_w, a, a - d1, max_len);
+                        if (l1 > best) {
+                            best = l1;
+                            const uint32_t r = p - tile_begin;
+                            atomicOr(&which_bits[r >> 5], 1u << (r & 31u));
+                            alt[p] = (uint16_t)d1;  // the match distance when the older candidate won
+                        }
                     }
                 }
+                len8[p] = (uint8_t)(best ? best - 3 : 0);
             }
-            len8[p] = (uint8_t)(best ? best - 3 : 0);
         }
+        __syncthreads();
+        // tile_begin is a multiple of 32, so the tile's bit words are whole words of the block's
+        for (uint32_t i = tid; i < (tile_end - tile_begin + 31) / 32; i += kMpThreads)
+            which_out[tile_begin / 32 + i] = which_bits[i];
     }
-    __syncthreads();
-    for (uint32_t i = tid; i < (n + 31) / 32; i += kMpThreads) which_out[i] = which_bits[i];
-    if (tid == 0) meta->phase_cycles[1] = (uint32_t)(clock64() - t_mark);
+    if (tid == 0) meta->phase_cycles[1] = (uint32_t)(clock64() - t_begin);
 }
 
 // ------------------------------------------------------------------------------------------
-// k_parse: deflate_compress_fastest's greedy parse + token stream, per block (1024 threads,
-// < 80 KiB of LDS so two workgroups share a CU):
-//   phase 2  the parse as a segment-parallel pointer chase over len8 (staged in LDS): 272-byte
-//            segments (>= max match length, so a token leaving segment s lands in segment s+1),
-//            each thread walks its segment from a speculated entry, entries are corrected round
-//            by round until none changes (greedy chains re-synchronise within a few tokens, so
-//            this is 2-3 rounds in practice, <= #segments always); every walk marks its token
-//            starts in an LDS bitmap and a re-walk first clears its segment's marks,
+// k_parse: deflate_compress_fastest's greedy parse + token stream + sub-block boundaries, per
+// block (1024 threads, < 80 KiB of LDS so two workgroups share a CU), in tiles of 64 KiB
+// positions whose len8 bytes are staged in LDS:
+//   phase 2  the parse as a segment-parallel pointer chase: 272-byte segments (>= max match
+//            length, so a token leaving segment s lands in segment s+1), each thread walks its
+//            segment from a speculated entry, entries are corrected round by round until none
+//            changes (greedy chains re-synchronise within a few tokens, so this is 2-3 rounds in
+//            practice, <= #segments always); every walk marks its token starts in an LDS bitmap
+//            and a re-walk first clears its segment's marks,
 //   phase 3  position-parallel token build: token / match ranks from wave ballots + one
-//            workgroup scan, coalesced candidate loads and token stores, litlen/offset
-//            histograms per sub-block (8192 matches each) with LDS atomics.
+//            workgroup scan, coalesced reads and token stores; the same pass finds where the
+//            current DEFLATE sub-block ends (8192 matches, or the 65535-byte soft limit of
+//            choose_max_block_end).
 // ------------------------------------------------------------------------------------------
-// Walk one segment from `pos`, marking every token start in tok_bits; returns the exit position.
-// A latency chain (LDS read -> add -> LDS read ...); the mark is a fire-and-forget LDS atomic.
+// Walk one segment (tile-relative positions) from `pos`, marking every token start in tok_bits;
+// returns the exit position.  A latency chain (LDS read -> add -> LDS read ...); the mark is a
+// fire-and-forget LDS atomic.
 __device__ __forceinline__ uint32_t walk_segment(const uint8_t *len8, uint32_t pos, uint32_t seg_end,
                                                  uint32_t *tok_bits) {
     while (pos < seg_end) {
@@ -489,189 +490,269 @@ __device__ __forceinline__ void clear_marks(uint32_t seg_begin, uint32_t seg_end
     }
 }
 
-__global__ __launch_bounds__(kMpThreads) void k_parse(
+// choose_max_block_end (FAST_SOFT_MAX_BLOCK_LENGTH, MIN_BLOCK_LENGTH): where a sub-block that
+// starts at `start` must end at the latest
+__device__ __forceinline__ uint32_t sub_limit_of(uint32_t start, uint32_t n) {
+    return (n - start < kSoftMaxSub + kMinBlockLen) ? n : start + kSoftMaxSub;
+}
+
+__global__ __launch_bounds__(kMpThreads, 8) void k_parse(
     Config cfg, const uint8_t *__restrict__ slab, BlockMeta *__restrict__ meta_all,
-    const uint16_t *__restrict__ cand_all, const uint8_t *__restrict__ len8_all,
-    const uint32_t *__restrict__ which_all, const uint16_t *__restrict__ alt_all,
-    uint32_t *__restrict__ tok_all, uint32_t *__restrict__ hist_all) {
-    __shared__ uint32_t len8_w[kMaxUnit / 4];     // 0 = literal, else match length - 3 (bytes)
-    __shared__ uint32_t tok_bits[kMaxUnit / 32];  // 1 = a token starts here
-    __shared__ uint32_t hist[kMaxSub * kHistStride];
+    SubMeta *__restrict__ sub_all, const uint16_t *__restrict__ cand_all,
+    const uint8_t *__restrict__ len8_all, const uint32_t *__restrict__ which_all,
+    const uint16_t *__restrict__ alt_all, uint32_t *__restrict__ tok_all) {
+    __shared__ uint32_t len8_w[kTile / 4];     // 0 = literal, else match length - 3 (bytes)
+    __shared__ uint32_t tok_bits[kTile / 32];  // 1 = a token starts here (tile-relative)
     __shared__ uint32_t seg_exit[256];
     __shared__ uint32_t rank_pre[kMpChunks * kMpWaves];  // (tokens | matches << 17) before (chunk, wave)
     __shared__ uint32_t wsum_t[kMpWaves], wsum_m[kMpWaves];
-    __shared__ uint32_t sub1_tok, sub1_pos;
+    __shared__ unsigned long long bnd;  // (position << 32 | token index) of the sub-block boundary
+    __shared__ uint32_t bnd_mat;        // matches before that boundary
     const uint8_t *len8 = (const uint8_t *)len8_w;
 
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint32_t b = blockIdx.x;
     BlockMeta *meta = meta_all + b;
+    SubMeta *sub = sub_all + (uint64_t)b * cfg.max_sub;
     const uint32_t n = meta->n;
     if (n <= kPassthroughL1) return;  // uniform for the workgroup
     const uint8_t *in = slab + (uint64_t)b * cfg.block_size;
-    const uint16_t *cand = cand_all + (uint64_t)b * kCandStride;
-    const uint32_t *which = which_all + (uint64_t)b * (kMaxUnit / 32);
-    const uint16_t *alt = alt_all + (uint64_t)b * kMaxUnit;
-    uint32_t *tok = tok_all + (uint64_t)b * kTokStride;
+    const uint16_t *cand = cand_all + (uint64_t)b * cfg.stride;
+    const uint32_t *which = which_all + (uint64_t)b * (cfg.stride / 32);
+    const uint16_t *alt = alt_all + (uint64_t)b * cfg.stride;
+    uint32_t *tok = tok_all + (uint64_t)b * cfg.stride;
 
-    long long t_mark = clock64();
-    {
-        const uint32_t *src = (const uint32_t *)(len8_all + (uint64_t)b * kMaxUnit);
-        for (uint32_t i = tid; i < (n + 3) / 4; i += kMpThreads) len8_w[i] = src[i];
-        for (uint32_t i = tid; i < kMaxUnit / 32; i += kMpThreads) tok_bits[i] = 0;
-        for (uint32_t i = tid; i < kMaxSub * kHistStride; i += kMpThreads) hist[i] = 0;
-    }
-    __syncthreads();
-
-    // ---- phase 2: greedy parse, speculative segment walk (threads 0..255 own segments)
-    const uint32_t seg_begin = tid * kSeg;
-    const bool active = tid < 256 && seg_begin < n;
-    const uint32_t seg_end = active ? (seg_begin + kSeg < n ? seg_begin + kSeg : n) : 0;
-    uint32_t entry = seg_begin, rounds = 0;
-    if (active) seg_exit[tid] = walk_segment(len8, entry, seg_end, tok_bits);
-    for (;;) {
-        rounds++;
-        __syncthreads();
-        bool changed = false;
-        uint32_t new_entry = entry;
-        if (active && tid > 0) {
-            new_entry = seg_exit[tid - 1];
-            changed = new_entry != entry;
-        }
-        __syncthreads();
-        if (changed) {
-            clear_marks(seg_begin, seg_end, tok_bits);
-            entry = new_entry;
-            seg_exit[tid] = walk_segment(len8, entry, seg_end, tok_bits);
-        }
-        if (!__syncthreads_or(changed)) break;
-    }
-    if (tid == 0) {
-        const long long t = clock64();
-        meta->phase_cycles[2] = (uint32_t)(t - t_mark);
-        meta->phase_cycles[3] = 0;
-        meta->phase_cycles[6] = rounds;
-        t_mark = t;
-    }
-
-    // ---- phase 3a: tokens / matches per (chunk, wave), then one workgroup-wide scan
-    const uint32_t nchunks = (n + kMpThreads - 1) / kMpThreads;
-    for (uint32_t c = 0; c < nchunks; c++) {
-        const uint32_t p = c * kMpThreads + tid;
-        const bool is_tok = p < n && ((tok_bits[p >> 5] >> (p & 31u)) & 1u);
-        const bool is_match = is_tok && len8[p] != 0;
-        const uint64_t mt = __ballot(is_tok), mm = __ballot(is_match);
-        if (lane == 0) rank_pre[c * kMpWaves + wave] = (uint32_t)__popcll(mt) | ((uint32_t)__popcll(mm) << 17);
-    }
-    __syncthreads();
-    uint32_t total_tok, total_match;
-    {
-        // entry e = chunk * 16 + wave is position order; thread e scans entry e
-        const bool have = tid < nchunks * kMpWaves;
-        const uint32_t v = have ? rank_pre[tid] : 0;
-        const uint32_t vt = v & 0x1FFFFu, vm = v >> 17;
-        const uint32_t it = wave_inclusive_scan(vt, lane), im = wave_inclusive_scan(vm, lane);
-        if (lane == 63) {
-            wsum_t[wave] = it;
-            wsum_m[wave] = im;
-        }
-        __syncthreads();
-        uint32_t bt = 0, bm = 0, tt = 0, tm = 0;
-        for (uint32_t w = 0; w < kMpWaves; w++) {
-            const uint32_t st = wsum_t[w], sm = wsum_m[w];
-            if (w < wave) {
-                bt += st;
-                bm += sm;
-            }
-            tt += st;
-            tm += sm;
-        }
-        total_tok = tt;
-        total_match = tm;
-        // exclusive prefixes: tokens < 65536 + 1 fit 17 bits, matches <= 16384 fit 15 bits
-        if (have) rank_pre[tid] = (bt + it - vt) | ((bm + im - vm) << 17);
-        if (tid == 0) {
-            sub1_tok = total_tok;  // "no second sub-block"
-            sub1_pos = n;
-        }
-    }
-    __syncthreads();
-    if (tid == 0) {
-        const long long t = clock64();
-        meta->phase_cycles[4] = (uint32_t)(t - t_mark);
-        t_mark = t;
-    }
-
-    // ---- phase 3b: build tokens in position order (global reads issued 4 chunks deep)
+    const long long t_begin = clock64();
+    // state carried from tile to tile (uniform across the workgroup)
+    uint32_t entry_carry = 0;            // where the parse enters the next tile
+    uint32_t tok_carry = 0, mat_carry = 0;
+    uint32_t cur_sub = 0, sub_start = 0, sub_start_tok = 0, sub_start_mat = 0;
+    uint32_t sub_limit = sub_limit_of(0, n);
+    uint32_t rounds_total = 0;
     const uint64_t lane_below = (1ull << lane) - 1ull;
-    for (uint32_t c0 = 0; c0 < nchunks; c0 += 4) {
-        uint32_t lens[4], tis[4], mis_[4], offs[4], alts[4], wbits[4], lits[4];
-#pragma unroll
-        for (uint32_t k = 0; k < 4; k++) {
-            const uint32_t c = c0 + k;
-            const uint32_t p = c * kMpThreads + tid;
-            const bool is_tok = c < nchunks && p < n && ((tok_bits[p >> 5] >> (p & 31u)) & 1u);
-            const uint32_t l = is_tok ? len8[p] : 0;
-            const bool is_match = l != 0;
-            const uint64_t mt = __ballot(is_tok), mm = __ballot(is_match);
-            const uint32_t pre = rank_pre[(c < nchunks ? c : 0) * kMpWaves + wave];
-            tis[k] = is_tok ? (pre & 0x1FFFFu) + (uint32_t)__popcll(mt & lane_below) : 0xFFFFFFFFu;
-            mis_[k] = (pre >> 17) + (uint32_t)__popcll(mm & lane_below);
-            lens[k] = l;
-            offs[k] = is_match ? cand[p] : 0u;
-            alts[k] = is_match ? alt[p] : 0u;  // only meaningful where the which bit is set
-            wbits[k] = is_match ? which[p >> 5] : 0u;
-            lits[k] = (is_tok && !is_match) ? in[p] : 0u;
+
+    for (uint32_t tile_begin = 0; tile_begin < n; tile_begin += kTile) {
+        const uint32_t tile_len = n - tile_begin < kTile ? n - tile_begin : kTile;
+        __syncthreads();  // previous tile fully consumed
+        {
+            const uint32_t *src = (const uint32_t *)(len8_all + (uint64_t)b * cfg.stride + tile_begin);
+            for (uint32_t i = tid; i < (tile_len + 3) / 4; i += kMpThreads) len8_w[i] = src[i];
+            for (uint32_t i = tid; i < kTile / 32; i += kMpThreads) tok_bits[i] = 0;
+            if (tid == 0) bnd = ~0ull;
         }
-#pragma unroll
-        for (uint32_t k = 0; k < 4; k++) {
-            const uint32_t p = (c0 + k) * kMpThreads + tid;
-            if (tis[k] == 0xFFFFFFFFu) continue;
-            const uint32_t ti = tis[k], mi = mis_[k];
-            uint32_t *h = hist + (mi >= kSeqPerSub ? kHistStride : 0);
-            if (lens[k]) {
-                const uint32_t len = lens[k] + 3;
-                const uint32_t off = ((wbits[k] >> (p & 31u)) & 1u) ? alts[k] : offs[k];
-                uint32_t ls, le, lv, os, oe, ov;
-                length_slot(len, ls, le, lv);
-                offset_slot(off, os, oe, ov);
-                atomicAdd(&h[257 + ls], 1u);
-                atomicAdd(&h[kNumLitlen + os], 1u);
-                tok[ti] = kTokMatch | (off << 9) | len;
-                if (mi + 1 == kSeqPerSub) {  // the 8192nd match closes sub-block 0
-                    sub1_tok = ti + 1;
-                    sub1_pos = p + len;
-                }
-            } else {
-                atomicAdd(&h[lits[k]], 1u);
-                tok[ti] = lits[k];
+        __syncthreads();
+
+        // ---- phase 2: greedy parse, speculative segment walk (threads 0..255 own segments)
+        const uint32_t seg_begin = tid * kSeg;  // tile-relative
+        const bool active = tid < 256 && seg_begin < tile_len;
+        const uint32_t seg_end = active ? (seg_begin + kSeg < tile_len ? seg_begin + kSeg : tile_len) : 0;
+        // the tile's true entry is known (thread 0); the others speculate "at my segment start"
+        uint32_t entry = tid == 0 ? entry_carry - tile_begin : seg_begin;
+        if (active) seg_exit[tid] = walk_segment(len8, entry, seg_end, tok_bits);
+        for (;;) {
+            rounds_total++;
+            __syncthreads();
+            bool changed = false;
+            uint32_t new_entry = entry;
+            if (active && tid > 0) {
+                new_entry = seg_exit[tid - 1];
+                changed = new_entry != entry;
             }
+            __syncthreads();
+            if (changed) {
+                clear_marks(seg_begin, seg_end, tok_bits);
+                entry = new_entry;
+                seg_exit[tid] = walk_segment(len8, entry, seg_end, tok_bits);
+            }
+            if (!__syncthreads_or(changed)) break;
         }
-    }
-    __syncthreads();
-    {
-        uint32_t *hist_out = hist_all + (uint64_t)b * (kMaxSub * kHistStride);
-        for (uint32_t i = tid; i < kMaxSub * kHistStride; i += kMpThreads) hist_out[i] = hist[i];
+        // where the parse leaves this tile (a match may overhang the tile end)
+        const uint32_t n_seg = (tile_len + kSeg - 1) / kSeg;
+        const uint32_t exit_rel = seg_exit[n_seg - 1];
+
+        // ---- phase 3a: tokens / matches per (chunk, wave), then one workgroup-wide scan
+        const uint32_t nchunks = (tile_len + kMpThreads - 1) / kMpThreads;
+        for (uint32_t c = 0; c < nchunks; c++) {
+            const uint32_t r = c * kMpThreads + tid;
+            const bool is_tok = r < tile_len && ((tok_bits[r >> 5] >> (r & 31u)) & 1u);
+            const bool is_match = is_tok && len8[r] != 0;
+            const uint64_t mt = __ballot(is_tok), mm = __ballot(is_match);
+            if (lane == 0)
+                rank_pre[c * kMpWaves + wave] = (uint32_t)__popcll(mt) | ((uint32_t)__popcll(mm) << 17);
+        }
+        __syncthreads();
+        uint32_t tile_tok, tile_mat;
+        {
+            // entry e = chunk * 16 + wave is position order; thread e scans entry e
+            const bool have = tid < nchunks * kMpWaves;
+            const uint32_t v = have ? rank_pre[tid] : 0;
+            const uint32_t vt = v & 0x1FFFFu, vm = v >> 17;
+            const uint32_t it = wave_inclusive_scan(vt, lane), im = wave_inclusive_scan(vm, lane);
+            if (lane == 63) {
+                wsum_t[wave] = it;
+                wsum_m[wave] = im;
+            }
+            __syncthreads();
+            uint32_t bt = 0, bm = 0, tt = 0, tm = 0;
+            for (uint32_t w = 0; w < kMpWaves; w++) {
+                const uint32_t st = wsum_t[w], sm = wsum_m[w];
+                if (w < wave) {
+                    bt += st;
+                    bm += sm;
+                }
+                tt += st;
+                tm += sm;
+            }
+            tile_tok = tt;
+            tile_mat = tm;
+            // exclusive prefixes: tokens <= 65536 fit 17 bits, matches <= 16384 fit 15 bits
+            if (have) rank_pre[tid] = (bt + it - vt) | ((bm + im - vm) << 17);
+        }
+        __syncthreads();
+
+        // ---- phase 3b: build tokens in position order (global reads issued 4 chunks deep) and
+        // look for the end of the current sub-block.  A second boundary inside one tile needs
+        // another 8192 matches after the first, so the search is repeated only in that case.
+        bool build = true;
+        for (;;) {
+            for (uint32_t c0 = 0; c0 < nchunks; c0 += 4) {
+                uint32_t lens[4], tis[4], mis_[4], offs[4], alts[4], wbits[4], lits[4];
+#pragma unroll
+                for (uint32_t k = 0; k < 4; k++) {
+                    const uint32_t c = c0 + k;
+                    const uint32_t r = c * kMpThreads + tid;
+                    const uint32_t p = tile_begin + r;
+                    const bool is_tok = c < nchunks && r < tile_len && ((tok_bits[r >> 5] >> (r & 31u)) & 1u);
+                    const uint32_t l = is_tok ? len8[r] : 0;
+                    const bool is_match = l != 0;
+                    const uint64_t mt = __ballot(is_tok), mm = __ballot(is_match);
+                    const uint32_t pre = rank_pre[(c < nchunks ? c : 0) * kMpWaves + wave];
+                    tis[k] = is_tok ? tok_carry + (pre & 0x1FFFFu) + (uint32_t)__popcll(mt & lane_below)
+                                    : 0xFFFFFFFFu;
+                    mis_[k] = mat_carry + (pre >> 17) + (uint32_t)__popcll(mm & lane_below);
+                    lens[k] = l;
+                    offs[k] = (build && is_match) ? cand[p] : 0u;
+                    alts[k] = (build && is_match) ? alt[p] : 0u;  // only meaningful where `which` is set
+                    wbits[k] = (build && is_match) ? which[p >> 5] : 0u;
+                    lits[k] = (build && is_tok && !is_match) ? in[p] : 0u;
+                }
+#pragma unroll
+                for (uint32_t k = 0; k < 4; k++) {
+                    const uint32_t p = tile_begin + (c0 + k) * kMpThreads + tid;
+                    if (tis[k] == 0xFFFFFFFFu) continue;
+                    const uint32_t ti = tis[k], mi = mis_[k];
+                    // sub-block boundary: this token would start past the soft limit, or 8192
+                    // matches precede it in the current sub-block (src: deflate_compress_fastest)
+                    if (p > sub_start && (p >= sub_limit || mi - sub_start_mat >= kSeqPerSub))
+                        atomicMin(&bnd, ((unsigned long long)p << 32) | ti);
+                    if (!build) continue;
+                    if (lens[k]) {
+                        const uint32_t len = lens[k] + 3;
+                        const uint32_t off = ((wbits[k] >> (p & 31u)) & 1u) ? alts[k] : offs[k];
+                        tok[ti] = kTokMatch | (off << 9) | len;
+                    } else {
+                        tok[ti] = lits[k];
+                    }
+                }
+            }
+            __syncthreads();
+            const unsigned long long bv = bnd;
+            if (bv == ~0ull) break;  // the current sub-block runs past this tile
+            // the boundary token's match rank: recomputed by the wave that owns its position
+            const uint32_t bp = (uint32_t)(bv >> 32), bti = (uint32_t)bv;
+            {
+                const uint32_t r = bp - tile_begin;
+                const uint32_t c = r / kMpThreads;
+                if (wave == (r % kMpThreads) / 64) {
+                    const uint32_t rr = c * kMpThreads + tid;
+                    const bool is_tok = rr < tile_len && ((tok_bits[rr >> 5] >> (rr & 31u)) & 1u);
+                    const bool is_match = is_tok && len8[rr] != 0;
+                    const uint64_t mm = __ballot(is_match);
+                    if (rr == r)
+                        bnd_mat = mat_carry + (rank_pre[c * kMpWaves + wave] >> 17) +
+                                  (uint32_t)__popcll(mm & lane_below);
+                }
+            }
+            __syncthreads();
+            const uint32_t bm = bnd_mat;
+            if (tid == 0) {
+                sub[cur_sub].tok_begin = sub_start_tok;
+                sub[cur_sub].tok_end = bti;
+                sub[cur_sub].byte_begin = sub_start;
+                sub[cur_sub].byte_len = bp - sub_start;
+                sub[cur_sub].is_final = 0;
+                bnd = ~0ull;
+            }
+            cur_sub++;
+            sub_start = bp;
+            sub_start_tok = bti;
+            sub_start_mat = bm;
+            sub_limit = sub_limit_of(bp, n);
+            __syncthreads();
+            // another boundary in this tile is only possible through the match-count rule
+            if (mat_carry + tile_mat - bm < kSeqPerSub) break;
+            build = false;
+        }
+        tok_carry += tile_tok;
+        mat_carry += tile_mat;
+        entry_carry = tile_begin + exit_rel;
     }
     if (tid == 0) {
-        (void)total_match;
-        meta->phase_cycles[5] = (uint32_t)(clock64() - t_mark);
-        const uint32_t s1 = sub1_tok;
-        const bool two = s1 < total_tok;  // tokens remain after the 8192nd match
-        meta->ntok = total_tok;
-        meta->nsub = two ? 2u : 1u;
-        meta->sub[0].tok_begin = 0;
-        meta->sub[0].tok_end = two ? s1 : total_tok;
-        meta->sub[0].byte_begin = 0;
-        meta->sub[0].byte_len = two ? sub1_pos : n;
-        meta->sub[0].is_final = two ? 0u : 1u;
-        if (two) {
-            meta->sub[1].tok_begin = s1;
-            meta->sub[1].tok_end = total_tok;
-            meta->sub[1].byte_begin = sub1_pos;
-            meta->sub[1].byte_len = n - sub1_pos;
-            meta->sub[1].is_final = 1u;
+        sub[cur_sub].tok_begin = sub_start_tok;
+        sub[cur_sub].tok_end = tok_carry;
+        sub[cur_sub].byte_begin = sub_start;
+        sub[cur_sub].byte_len = n - sub_start;
+        sub[cur_sub].is_final = 1;
+        meta->ntok = tok_carry;
+        meta->nsub = cur_sub + 1;
+        meta->phase_cycles[2] = (uint32_t)(clock64() - t_begin);
+        meta->phase_cycles[6] = rounds_total;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// k_hist: litlen / offset symbol frequencies of every DEFLATE sub-block (deflate_choose_literal /
+// deflate_choose_match tallies), from the token stream.  256 threads per block, LDS atomics.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_hist(Config cfg, const BlockMeta *__restrict__ meta_all,
+                                              const SubMeta *__restrict__ sub_all,
+                                              const uint32_t *__restrict__ tok_all,
+                                              uint32_t *__restrict__ hist_all) {
+    __shared__ uint32_t hist[kHistStride];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t b = blockIdx.x;
+    const BlockMeta *meta = meta_all + b;
+    if (meta->n <= kPassthroughL1) return;
+    const SubMeta *sub = sub_all + (uint64_t)b * cfg.max_sub;
+    const uint32_t *tok = tok_all + (uint64_t)b * cfg.stride;
+    const uint32_t nsub = meta->nsub;
+    for (uint32_t s = 0; s < nsub; s++) {
+        for (uint32_t i = tid; i < kHistStride; i += 256) hist[i] = 0;
+        __syncthreads();
+        const uint32_t t_end = sub[s].tok_end;
+        for (uint32_t t0 = sub[s].tok_begin + tid; t0 < t_end; t0 += 4 * 256) {
+            uint32_t tk[4];
+#pragma unroll
+            for (uint32_t k = 0; k < 4; k++) tk[k] = t0 + k * 256 < t_end ? tok[t0 + k * 256] : 0xFFFFFFFFu;
+#pragma unroll
+            for (uint32_t k = 0; k < 4; k++) {
+                const uint32_t t = tk[k];
+                if (t == 0xFFFFFFFFu) continue;  // (never a real token: offset field < 32768)
+                if (t & kTokMatch) {
+                    uint32_t ls, le, lv, os, oe, ov;
+                    length_slot(t & 0x1FFu, ls, le, lv);
+                    offset_slot((t >> 9) & 0xFFFFu, os, oe, ov);
+                    atomicAdd(&hist[257 + ls], 1u);
+                    atomicAdd(&hist[kNumLitlen + os], 1u);
+                } else {
+                    atomicAdd(&hist[t], 1u);
+                }
+            }
         }
+        __syncthreads();
+        uint32_t *out = hist_all + ((uint64_t)b * cfg.max_sub + s) * kHistStride;
+        for (uint32_t i = tid; i < kHistStride; i += 256) out[i] = hist[i];
+        __syncthreads();
     }
 }
 
@@ -837,6 +918,7 @@ __device__ __forceinline__ void hdr_put(uint32_t *hdr, uint32_t &bitpos, uint32_
 }
 
 __global__ __launch_bounds__(64) void k_huffman(Config cfg, BlockMeta *__restrict__ meta_all,
+                                                SubMeta *__restrict__ sub_all,
                                                 const uint32_t *__restrict__ hist_all,
                                                 uint32_t *__restrict__ codes_all,
                                                 uint32_t *__restrict__ hdr_all) {
@@ -844,6 +926,7 @@ __global__ __launch_bounds__(64) void k_huffman(Config cfg, BlockMeta *__restric
     const uint32_t lane = threadIdx.x;
     const uint32_t b = blockIdx.x;
     BlockMeta *meta = meta_all + b;
+    SubMeta *sub = sub_all + (uint64_t)b * cfg.max_sub;
     const uint32_t n = meta->n;
     const uint32_t hdr_len = hdr_len_of(cfg.format);
     const uint32_t eof_len = (meta->is_last && cfg.format == 0) ? 28u : 0u;
@@ -853,14 +936,14 @@ __global__ __launch_bounds__(64) void k_huffman(Config cfg, BlockMeta *__restric
         if (lane == 0) {
             meta->nsub = 1;
             meta->ntok = 0;
-            meta->sub[0].type = kStored;
-            meta->sub[0].tok_begin = 0;
-            meta->sub[0].tok_end = 0;
-            meta->sub[0].byte_begin = 0;
-            meta->sub[0].byte_len = n;
-            meta->sub[0].bit_begin = 0;
-            meta->sub[0].hdr_bits = 0;
-            meta->sub[0].is_final = 1;
+            sub[0].type = kStored;
+            sub[0].tok_begin = 0;
+            sub[0].tok_end = 0;
+            sub[0].byte_begin = 0;
+            sub[0].byte_len = n;
+            sub[0].bit_begin = 0;
+            sub[0].hdr_bits = 0;
+            sub[0].is_final = 1;
             meta->payload_bytes = 5 + n;
             meta->framed_bytes = hdr_len + 5 + n + 8 + eof_len;
         }
@@ -870,11 +953,11 @@ __global__ __launch_bounds__(64) void k_huffman(Config cfg, BlockMeta *__restric
     const uint32_t nsub = meta->nsub;
     uint32_t bitpos = 0;  // bits of payload emitted so far (wave-uniform)
     for (uint32_t s = 0; s < nsub; s++) {
-        const uint32_t *hist = hist_all + ((uint64_t)b * kMaxSub + s) * kHistStride;
-        uint32_t *codes = codes_all + ((uint64_t)b * kMaxSub + s) * kCodeWords;
-        uint32_t *hdr_out = hdr_all + ((uint64_t)b * kMaxSub + s) * kHdrWords;
-        const uint32_t block_length = meta->sub[s].byte_len;
-        const uint32_t is_final = meta->sub[s].is_final;
+        const uint32_t *hist = hist_all + ((uint64_t)b * cfg.max_sub + s) * kHistStride;
+        uint32_t *codes = codes_all + ((uint64_t)b * cfg.max_sub + s) * kCodeWords;
+        uint32_t *hdr_out = hdr_all + ((uint64_t)b * cfg.max_sub + s) * kHdrWords;
+        const uint32_t block_length = sub[s].byte_len;
+        const uint32_t is_final = sub[s].is_final;
 
         // ---- litlen code (EOB tallied once), offset code
         for (uint32_t i = lane; i < kNumLitlen; i += 64) h.freq[i] = hist[i] + (i == 256 ? 1u : 0u);
@@ -1090,9 +1173,9 @@ __global__ __launch_bounds__(64) void k_huffman(Config cfg, BlockMeta *__restric
         }
         for (uint32_t i = lane; i < kHdrWords; i += 64) hdr_out[i] = h.hdr[i];
         if (lane == 0) {
-            meta->sub[s].type = type;
-            meta->sub[s].bit_begin = bitpos;
-            meta->sub[s].hdr_bits = hdr_bits;
+            sub[s].type = type;
+            sub[s].bit_begin = bitpos;
+            sub[s].hdr_bits = hdr_bits;
         }
         bitpos += sub_bits;
         wave_sync();
@@ -1123,7 +1206,7 @@ __device__ __forceinline__ uint32_t gf2_multmodp(uint32_t a, uint32_t bv) {
     return p;
 }
 
-constexpr uint32_t kCrcDataWords = (kMaxUnit / 4 + 2) + (kMaxUnit / 4 + 2) / 64 + 2;
+constexpr uint32_t kCrcDataWords = (kTile / 4 + 2) + (kTile / 4 + 2) / 64 + 2;
 
 // dword index -> padded LDS index (one pad word after every 64)
 __device__ __forceinline__ uint32_t crc_pad(uint32_t w) { return w + (w >> 6); }
@@ -1137,16 +1220,10 @@ __global__ __launch_bounds__(256) void k_crc32(Config cfg, const uint8_t *__rest
     const uint32_t b = blockIdx.x;
     const uint32_t n = meta_all[b].n;
     const uint8_t *in = slab + (uint64_t)b * cfg.block_size;
-    const uint32_t mis = (uint32_t)((uintptr_t)in & 3u);
     {
         uint32_t c = tid;
         for (int k = 0; k < 8; k++) c = (c >> 1) ^ (0xEDB88320u & (0u - (c & 1u)));
         table[0][tid] = c;
-    }
-    if (n) {
-        const uint32_t *src = (const uint32_t *)(in - mis);
-        const uint32_t ndw = (mis + n + 3) >> 2;
-        for (uint32_t i = tid; i < ndw; i += 256) data[crc_pad(i)] = src[i];
     }
     __syncthreads();
     {
@@ -1158,45 +1235,63 @@ __global__ __launch_bounds__(256) void k_crc32(Config cfg, const uint8_t *__rest
         table[2][tid] = t2;
         table[3][tid] = t3;
     }
-    __syncthreads();
-    // segment of thread t in block bytes: [n - 256*(256 - t), n - 256*(255 - t)) clipped at 0;
-    // LDS byte address of block byte i is i + mis (before padding)
-    const int32_t seg_end_i = (int32_t)n - 256 * (int32_t)(255 - tid);
-    uint32_t crc = 0;
-    if (seg_end_i > 0) {
-        const uint32_t seg_end = (uint32_t)seg_end_i + mis;
-        uint32_t pos = (seg_end_i > 256 ? (uint32_t)(seg_end_i - 256) : 0u) + mis;
-        uint32_t c = 0xFFFFFFFFu;
-        while (pos < seg_end && (pos & 3u)) {  // head bytes up to a dword boundary
-            const uint32_t byte = (data[crc_pad(pos >> 2)] >> (8u * (pos & 3u))) & 0xFFu;
-            c = (c >> 8) ^ table[0][(c ^ byte) & 0xFFu];
-            pos++;
+    // Blocks above 64 KiB are cut into 64 KiB chunks aligned to the END of the block (only the
+    // first chunk is short), so every chunk-to-chunk combine uses the same x^(8*65536) constant.
+    uint32_t total = 0;
+    const uint32_t first_len = n ? ((n - 1) % kTile) + 1 : 0;
+    for (uint32_t cb = 0; cb < n || cb == 0; cb += (cb == 0 ? first_len : kTile)) {
+        const uint32_t clen = n == 0 ? 0 : (cb == 0 ? first_len : kTile);
+        const uint8_t *cin = in + cb;
+        const uint32_t mis = (uint32_t)((uintptr_t)cin & 3u);
+        __syncthreads();  // tables ready / previous chunk consumed
+        if (clen) {
+            const uint32_t *src = (const uint32_t *)(cin - mis);
+            const uint32_t ndw = (mis + clen + 3) >> 2;
+            for (uint32_t i = tid; i < ndw; i += 256) data[crc_pad(i)] = src[i];
         }
-        while (pos + 4 <= seg_end) {  // slice-by-4
-            c ^= data[crc_pad(pos >> 2)];
-            c = table[3][c & 0xFFu] ^ table[2][(c >> 8) & 0xFFu] ^ table[1][(c >> 16) & 0xFFu] ^
-                table[0][c >> 24];
-            pos += 4;
-        }
-        while (pos < seg_end) {  // tail bytes
-            const uint32_t byte = (data[crc_pad(pos >> 2)] >> (8u * (pos & 3u))) & 0xFFu;
-            c = (c >> 8) ^ table[0][(c ^ byte) & 0xFFu];
-            pos++;
-        }
-        crc = ~c;
-    }
-    part[tid] = crc;
-    __syncthreads();
-    for (uint32_t level = 0; level < 8; level++) {
-        const uint32_t stride = 1u << level;
-        uint32_t merged = 0;
-        const bool act = (tid & (2 * stride - 1)) == 0;
-        if (act) merged = gf2_multmodp(cc.pow256[level], part[tid]) ^ part[tid + stride];
         __syncthreads();
-        if (act) part[tid] = merged;
+        // segment of thread t in chunk bytes: [clen - 256*(256 - t), clen - 256*(255 - t)) clipped
+        // at 0; LDS byte address of chunk byte i is i + mis (before padding)
+        const int32_t seg_end_i = (int32_t)clen - 256 * (int32_t)(255 - tid);
+        uint32_t crc = 0;
+        if (seg_end_i > 0) {
+            const uint32_t seg_end = (uint32_t)seg_end_i + mis;
+            uint32_t pos = (seg_end_i > 256 ? (uint32_t)(seg_end_i - 256) : 0u) + mis;
+            uint32_t c = 0xFFFFFFFFu;
+            while (pos < seg_end && (pos & 3u)) {  // head bytes up to a dword boundary
+                const uint32_t byte = (data[crc_pad(pos >> 2)] >> (8u * (pos & 3u))) & 0xFFu;
+                c = (c >> 8) ^ table[0][(c ^ byte) & 0xFFu];
+                pos++;
+            }
+            while (pos + 4 <= seg_end) {  // slice-by-4
+                c ^= data[crc_pad(pos >> 2)];
+                c = table[3][c & 0xFFu] ^ table[2][(c >> 8) & 0xFFu] ^ table[1][(c >> 16) & 0xFFu] ^
+                    table[0][c >> 24];
+                pos += 4;
+            }
+            while (pos < seg_end) {  // tail bytes
+                const uint32_t byte = (data[crc_pad(pos >> 2)] >> (8u * (pos & 3u))) & 0xFFu;
+                c = (c >> 8) ^ table[0][(c ^ byte) & 0xFFu];
+                pos++;
+            }
+            crc = ~c;
+        }
+        part[tid] = crc;
         __syncthreads();
+        for (uint32_t level = 0; level < 8; level++) {
+            const uint32_t stride = 1u << level;
+            uint32_t merged = 0;
+            const bool act = (tid & (2 * stride - 1)) == 0;
+            if (act) merged = gf2_multmodp(cc.pow256[level], part[tid]) ^ part[tid + stride];
+            __syncthreads();
+            if (act) part[tid] = merged;
+            __syncthreads();
+        }
+        // crc(A || chunk) = crc(A) * x^(8 * 65536) + crc(chunk); the first chunk has no A
+        total = cb == 0 ? part[0] : (gf2_multmodp(cc.pow_tile, total) ^ part[0]);
+        if (n == 0) break;
     }
-    if (tid == 0) meta_all[b].crc = part[0];
+    if (tid == 0) meta_all[b].crc = total;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1229,7 +1324,9 @@ __global__ __launch_bounds__(256) void k_scan(uint32_t nb, const BlockMeta *__re
 // CRC32 + ISIZE footer, BGZF_EOF after the last block) in LDS at the byte alignment it will
 // have in the output stream, then write it out with aligned dword stores.
 // ------------------------------------------------------------------------------------------
-constexpr uint32_t kStageWords = (kMaxUnit + 1024) / 4;  // >= 3 + 20 + 65535 + 8 + 28 bytes
+// The stage window must hold one whole sub-block (<= 65535 + 5000 bytes of input, stored worst
+// case + 10 header bytes) plus the footer and the EOF marker.
+constexpr uint32_t kStageWords = 18432;  // 72 KiB
 
 __device__ __forceinline__ void stage_or_bits(uint32_t *stage, uint32_t bitpos, uint64_t v) {
     const uint32_t w = bitpos >> 5, sh = bitpos & 31u;
@@ -1245,8 +1342,29 @@ __device__ __forceinline__ void stage_put_byte(uint32_t *stage, uint32_t byte_id
     atomicOr(&stage[byte_idx >> 2], (v & 0xFFu) << (8u * (byte_idx & 3u)));
 }
 
+// Write the window's bytes [win_base, upto) (coordinates: bytes from the 4-byte-aligned address
+// just below the block's first output byte) to global memory: whole dwords where every byte
+// belongs to this block, single bytes at the block's two edges.
+__device__ __forceinline__ void stage_flush(const uint32_t *stage, uint8_t *dst_aligned,
+                                            uint32_t win_base, uint32_t upto, uint32_t lead,
+                                            uint32_t end_byte, uint32_t tid) {
+    const uint32_t words = (upto - win_base + 3) >> 2;
+    for (uint32_t w = tid; w < words; w += 256) {
+        const uint32_t v = stage[w];
+        const uint32_t b0 = win_base + 4 * w;
+        if (b0 >= lead && b0 + 4 <= end_byte && b0 + 4 <= upto) {
+            *(uint32_t *)(dst_aligned + b0) = v;
+        } else {
+            for (uint32_t k = 0; k < 4; k++)
+                if (b0 + k >= lead && b0 + k < end_byte && b0 + k < upto)
+                    dst_aligned[b0 + k] = (uint8_t)(v >> (8 * k));
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void k_emit(Config cfg, const uint8_t *__restrict__ slab,
                                               const BlockMeta *__restrict__ meta_all,
+                                              const SubMeta *__restrict__ sub_all,
                                               const uint32_t *__restrict__ tok_all,
                                               const uint32_t *__restrict__ codes_all,
                                               const uint32_t *__restrict__ hdr_all,
@@ -1258,6 +1376,7 @@ __global__ __launch_bounds__(256) void k_emit(Config cfg, const uint8_t *__restr
     const uint32_t tid = threadIdx.x;
     const uint32_t b = blockIdx.x;
     const BlockMeta *meta = meta_all + b;
+    const SubMeta *sub = sub_all + (uint64_t)b * cfg.max_sub;
     const uint32_t n = meta->n;
     const uint32_t framed = meta->framed_bytes;
     const uint32_t c = meta->payload_bytes;
@@ -1265,13 +1384,17 @@ __global__ __launch_bounds__(256) void k_emit(Config cfg, const uint8_t *__restr
     if (meta->status != kStatusOk || dst_off + framed > out_cap) return;  // host reports the error
     const uint8_t *in = slab + (uint64_t)b * cfg.block_size;
     const uint32_t hdr_len = hdr_len_of(cfg.format);
+    // "aligned coordinates": byte i of the framed block lives at lead + i, so that dword
+    // boundaries of the stage are dword boundaries of the output address
     const uint32_t lead = (uint32_t)(((uintptr_t)out + dst_off) & 3u);
-    const uint32_t total_words = (lead + framed + 3) >> 2;
+    uint8_t *dst_aligned = out + dst_off - lead;
+    const uint32_t end_byte = lead + framed;
+    uint32_t win_base = 0;  // aligned coordinate of stage[0] (multiple of 4)
 
-    for (uint32_t i = tid; i < total_words; i += 256) stage[i] = 0;
+    for (uint32_t i = tid; i < kStageWords; i += 256) stage[i] = 0;
     __syncthreads();
 
-    // ---- gzip member header (src/bgzf.rs:274-303 / src/mgzip.rs:246-275) and footer
+    // ---- gzip member header (src/bgzf.rs:274-303 / src/mgzip.rs:246-275)
     if (tid == 0) {
         const uint32_t hb = lead;
         stage_put_byte(stage, hb + 0, 0x1f);
@@ -1299,25 +1422,32 @@ __global__ __launch_bounds__(256) void k_emit(Config cfg, const uint8_t *__restr
             stage_put_byte(stage, hb + 18, tot >> 16);
             stage_put_byte(stage, hb + 19, tot >> 24);
         }
-        const uint32_t fb = lead + hdr_len + c;
-        const uint32_t crc = meta->crc;
-        for (uint32_t k = 0; k < 4; k++) {
-            stage_put_byte(stage, fb + k, crc >> (8 * k));
-            stage_put_byte(stage, fb + 4 + k, n >> (8 * k));
-        }
-        if (meta->is_last && cfg.format == 0) {
-            // BGZF_EOF (src/bgzf.rs:24-38), appended inside the last block by Bgzf::encode
-            const uint8_t eof[28] = {0x1f, 0x8b, 0x08, 0x04, 0, 0, 0, 0, 0x00, 0xff, 0x06, 0x00, 0x42, 0x43,
-                                     0x02, 0x00, 0x1b, 0x00, 0x03, 0x00, 0, 0, 0, 0, 0, 0, 0, 0};
-            for (uint32_t k = 0; k < 28; k++) stage_put_byte(stage, fb + 8 + k, eof[k]);
-        }
     }
 
-    const uint32_t payload_bit0 = 8u * (lead + hdr_len);
-    const uint32_t *tok = tok_all + (uint64_t)b * kTokStride;
-    for (uint32_t s = 0; s < meta->nsub; s++) {
-        const SubMeta sm = meta->sub[s];
-        uint32_t bitpos = payload_bit0 + sm.bit_begin;
+    const uint32_t payload_bit0 = 8u * (lead + hdr_len);  // aligned coordinates, in bits
+    const uint32_t *tok = tok_all + (uint64_t)b * cfg.stride;
+    const uint32_t nsub = meta->nsub;
+    for (uint32_t s = 0; s < nsub; s++) {
+        const SubMeta sm = sub[s];
+        // everything this sub-block (and, after the last one, the footer + EOF) will touch must
+        // lie inside the window; if not, write out what is complete and slide the window
+        {
+            const uint32_t sub_end_bits = payload_bit0 + (s + 1 < nsub ? sub[s + 1].bit_begin : 8u * c);
+            const uint32_t need_end = ((sub_end_bits + 7) >> 3) + (s + 1 == nsub ? 8u + 28u : 0u) + 16u;
+            if (need_end > win_base + 4 * kStageWords) {
+                const uint32_t upto = ((payload_bit0 + sm.bit_begin) >> 3) & ~3u;
+                __syncthreads();
+                stage_flush(stage, dst_aligned, win_base, upto, lead, end_byte, tid);
+                const uint32_t keep = stage[(upto - win_base) >> 2];  // the dword being filled
+                __syncthreads();
+                for (uint32_t i = tid; i < kStageWords; i += 256) stage[i] = 0;
+                __syncthreads();
+                if (tid == 0) stage[0] = keep;
+                win_base = upto;
+                __syncthreads();
+            }
+        }
+        uint32_t bitpos = payload_bit0 + sm.bit_begin - 8u * win_base;  // window-relative
         if (sm.type == kStored) {
             uint32_t left = sm.byte_len, src = sm.byte_begin;
             do {
@@ -1344,9 +1474,9 @@ __global__ __launch_bounds__(256) void k_emit(Config cfg, const uint8_t *__restr
             continue;
         }
         // ---- Huffman-coded sub-block: header bits, tokens, end-of-block
-        const uint32_t *cd = codes_all + ((uint64_t)b * kMaxSub + s) * kCodeWords;
+        const uint32_t *cd = codes_all + ((uint64_t)b * cfg.max_sub + s) * kCodeWords;
         for (uint32_t i = tid; i < kCodeWords; i += 256) codes[i] = cd[i];
-        const uint32_t *hw = hdr_all + ((uint64_t)b * kMaxSub + s) * kHdrWords;
+        const uint32_t *hw = hdr_all + ((uint64_t)b * cfg.max_sub + s) * kHdrWords;
         const uint32_t nhw = (sm.hdr_bits + 31) >> 5;
         for (uint32_t i = tid; i < nhw; i += 256) stage_or_bits(stage, bitpos + 32 * i, hw[i]);
         bitpos += sm.hdr_bits;
@@ -1411,21 +1541,24 @@ __global__ __launch_bounds__(256) void k_emit(Config cfg, const uint8_t *__restr
         }
         __syncthreads();
     }
-    __syncthreads();
 
-    // ---- write out: whole dwords aligned to the output address, edge bytes individually
-    uint8_t *dst_aligned = out + dst_off - lead;
-    const uint32_t end_byte = lead + framed;
-    for (uint32_t w = tid; w < total_words; w += 256) {
-        const uint32_t v = stage[w];
-        const uint32_t b0 = 4 * w;
-        if (b0 >= lead && b0 + 4 <= end_byte) {
-            *(uint32_t *)(dst_aligned + b0) = v;
-        } else {
-            for (uint32_t k = 0; k < 4; k++)
-                if (b0 + k >= lead && b0 + k < end_byte) dst_aligned[b0 + k] = (uint8_t)(v >> (8 * k));
+    // ---- footer (src/bgzf.rs:233-234) and, after the stream's last block, BGZF_EOF
+    if (tid == 0) {
+        const uint32_t fb = lead + hdr_len + c - win_base;
+        const uint32_t crc = meta->crc;
+        for (uint32_t k = 0; k < 4; k++) {
+            stage_put_byte(stage, fb + k, crc >> (8 * k));
+            stage_put_byte(stage, fb + 4 + k, n >> (8 * k));
+        }
+        if (meta->is_last && cfg.format == 0) {
+            // BGZF_EOF (src/bgzf.rs:24-38), appended inside the last block by Bgzf::encode
+            const uint8_t eof[28] = {0x1f, 0x8b, 0x08, 0x04, 0, 0, 0, 0, 0x00, 0xff, 0x06, 0x00, 0x42, 0x43,
+                                     0x02, 0x00, 0x1b, 0x00, 0x03, 0x00, 0, 0, 0, 0, 0, 0, 0, 0};
+            for (uint32_t k = 0; k < 28; k++) stage_put_byte(stage, fb + 8 + k, eof[k]);
         }
     }
+    __syncthreads();
+    stage_flush(stage, dst_aligned, win_base, end_byte, lead, end_byte, tid);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1457,13 +1590,18 @@ void launch_match(const Config &cfg, const uint8_t *slab, uint64_t, uint32_t nb,
 
 void launch_parse(const Config &cfg, const uint8_t *slab, uint64_t, uint32_t nb, const Scratch &s,
                   hipStream_t stream) {
-    hipLaunchKernelGGL(k_parse, dim3(nb), dim3(kMpThreads), 0, stream, cfg, slab, s.meta,
+    hipLaunchKernelGGL(k_parse, dim3(nb), dim3(kMpThreads), 0, stream, cfg, slab, s.meta, s.sub,
                        (const uint16_t *)s.cand, (const uint8_t *)s.len8, (const uint32_t *)s.which,
-                       (const uint16_t *)s.alt, s.tok, s.hist);
+                       (const uint16_t *)s.alt, s.tok);
+}
+
+void launch_hist(const Config &cfg, uint32_t nb, const Scratch &s, hipStream_t stream) {
+    hipLaunchKernelGGL(k_hist, dim3(nb), dim3(256), 0, stream, cfg, (const BlockMeta *)s.meta,
+                       (const SubMeta *)s.sub, (const uint32_t *)s.tok, s.hist);
 }
 
 void launch_huffman(const Config &cfg, uint32_t nb, const Scratch &s, hipStream_t stream) {
-    hipLaunchKernelGGL(k_huffman, dim3(nb), dim3(64), 0, stream, cfg, s.meta,
+    hipLaunchKernelGGL(k_huffman, dim3(nb), dim3(64), 0, stream, cfg, s.meta, s.sub,
                        (const uint32_t *)s.hist, s.codes, s.hdr);
 }
 
@@ -1480,8 +1618,8 @@ void launch_scan(uint32_t nb, const Scratch &s, hipStream_t stream) {
 void launch_emit(const Config &cfg, const uint8_t *slab, uint64_t, uint32_t nb, const Scratch &s,
                  uint8_t *out, uint64_t out_cap, hipStream_t stream) {
     hipLaunchKernelGGL(k_emit, dim3(nb), dim3(256), 0, stream, cfg, slab, (const BlockMeta *)s.meta,
-                       (const uint32_t *)s.tok, (const uint32_t *)s.codes, (const uint32_t *)s.hdr,
-                       (const uint64_t *)s.out_off, out, out_cap);
+                       (const SubMeta *)s.sub, (const uint32_t *)s.tok, (const uint32_t *)s.codes,
+                       (const uint32_t *)s.hdr, (const uint64_t *)s.out_off, out, out_cap);
 }
 
 }  // namespace gzpx

@@ -139,8 +139,8 @@ void gzpx_par_destroy(gzpx_par *p);
 const char *gzpx_par_last_error(const gzpx_par *p);
 
 /* ---- measurement hooks (HIP events on the launching stream; bench.py roofline leg) ---- */
-#define GZPX_N_STAGES 8
-/* stage order: init_meta, candidates, match, parse, huffman, crc32, scan, emit */
+#define GZPX_N_STAGES 9
+/* stage order: init_meta, candidates, match, parse, hist, huffman, crc32, scan, emit */
 int gzpx_ctx_set_profiling(gzpx_ctx *ctx, int on);
 int gzpx_ctx_last_stage_ms(const gzpx_ctx *ctx, float ms[GZPX_N_STAGES]);
 const char *gzpx_stage_name(int stage);

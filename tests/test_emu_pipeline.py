@@ -129,3 +129,43 @@ def test_order_independent_candidate_kernel(emu_lib, oracle):
         for cls in ("text", "zeros", "period2", "repeats", "random"):
             a = synth.make(cls, 2 * 65280 + 99, 17)
             assert c.compress_slab(a, True) == oracle.compress_stream(a, oracle.FMT_BGZF, 1, oracle.COMPAT_1_10, 65280), cls
+
+
+def test_golden_streams_large_blocks(emu_lib, golden):
+    """Mgzip with buffer sizes above one 64 KiB tile (incl. the 1 MiB blocks of BASELINE config 3)."""
+    seen = 0
+    for e in golden["streams"]:
+        if e["buffer_size"] <= 65536:
+            continue
+        a = synth.make(e["class"], e["n"], e["seed"])
+        fmt = _native.FORMAT_BGZF if e["fmt"] == "bgzf" else _native.FORMAT_MGZIP
+        with _native.Context(format=fmt, level=1, buffer_size=e["buffer_size"], compat=_native.COMPAT_1_10,
+                             lib=emu_lib, max_slab_bytes=a.size) as c:
+            out, sizes = c.compress_slab(a, True, return_block_sizes=True)
+        assert hashlib.sha256(out).hexdigest() == e["sha256"], e
+        assert list(sizes) == e["block_sizes"]
+        seen += 1
+    assert seen >= 2
+
+
+def test_golden_raw_deflate_large_inputs(emu_lib, golden):
+    comp = _native.Compressor(1, _native.COMPAT_1_10, lib=emu_lib)
+    seen = 0
+    for e in golden["raw_deflate"]:
+        if e["n"] <= 65536:
+            continue
+        a = synth.make(e["class"], e["n"], e["seed"])
+        assert hashlib.sha256(comp.deflate_compress(a)).hexdigest() == e["sha256"], e
+        seen += 1
+    comp.close()
+    assert seen >= 8
+
+
+@pytest.mark.parametrize("cls", ["text", "repeats", "zeros", "random", "fastq", "runs"])
+def test_large_mgzip_blocks_vs_oracle(emu_lib, oracle, cls):
+    for bs, n in [(131072, 131072), (131072, 300001), (100000, 250000), (1 << 20, (1 << 20) + 77)]:
+        a = synth.make(cls, n, 40 + n % 97)
+        with _native.Context(format=_native.FORMAT_MGZIP, level=1, buffer_size=bs, compat=_native.COMPAT_1_10,
+                             lib=emu_lib, max_slab_bytes=a.size) as c:
+            got = c.compress_slab(a, True)
+        assert got == oracle.compress_stream(a, oracle.FMT_MGZIP, 1, oracle.COMPAT_1_10, bs), (cls, bs, n)

@@ -33,8 +33,6 @@ def test_native_library_is_the_hip_build(hip_lib, ctx10):
 
 def test_golden_streams(hip_lib, golden):
     for e in golden["streams"]:
-        if e["buffer_size"] > 65536:
-            continue
         a = (np.frombuffer(bytes.fromhex(e["input_hex"]), dtype=np.uint8) if "input_hex" in e
              else synth.make(e["class"], e["n"], e["seed"]))
         fmt = _native.FORMAT_BGZF if e["fmt"] == "bgzf" else _native.FORMAT_MGZIP
@@ -48,8 +46,6 @@ def test_golden_streams(hip_lib, golden):
 def test_golden_raw_deflate_via_libdeflate_shaped_abi(hip_lib, golden):
     comp = _native.Compressor(1, _native.COMPAT_1_10, lib=hip_lib)
     for e in golden["raw_deflate"] + golden["raw_deflate_literal_inputs"]:
-        if e.get("n", 0) > 65536:
-            continue
         a = (np.frombuffer(bytes.fromhex(e["input_hex"]), dtype=np.uint8) if "input_hex" in e
              else synth.make(e["class"], e["n"], e["seed"]))
         out = comp.deflate_compress(a)
@@ -136,3 +132,15 @@ def test_order_independent_candidate_kernel(hip_lib, oracle):
         for cls in ("text", "zeros", "period2", "repeats", "random"):
             a = synth.make(cls, 2 * 65280 + 99, 17)
             assert c.compress_slab(a, True) == oracle.compress_stream(a, oracle.FMT_BGZF, 1, oracle.COMPAT_1_10, 65280), cls
+
+
+@pytest.mark.parametrize("cls", ["text", "repeats", "zeros", "random", "fastq"])
+def test_large_mgzip_blocks_vs_oracle(hip_lib, oracle, cls):
+    """Mgzip at its default 128 KiB buffer and at the 1 MiB blocks of BASELINE config 3 (level 1)."""
+    for bs, n in [(131072, 5 * 131072 + 4321), (1 << 20, 3 * (1 << 20) + 77)]:
+        a = synth.make(cls, n, 40 + n % 97)
+        with _native.Context(format=_native.FORMAT_MGZIP, level=1, buffer_size=bs, compat=_native.COMPAT_1_10,
+                             lib=hip_lib, max_slab_bytes=a.size) as c:
+            got = c.compress_slab(a, True)
+        assert got == oracle.compress_stream(a, oracle.FMT_MGZIP, 1, oracle.COMPAT_1_10, bs), (cls, bs, n)
+        assert gzip.decompress(got) == a.tobytes()
