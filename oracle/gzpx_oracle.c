@@ -695,6 +695,302 @@ static int compress_fastest(const uint8_t *in, size_t n, block_sink_fn sink, voi
     return 0;
 }
 
+/* ------------------------------------------------------------------ levels 2-4: hc_matchfinder, greedy (A.8) */
+
+#define SOFT_MAX_BLOCK_LENGTH 300000
+#define SEQ_STORE_LENGTH 50000
+#define HC_HASH3_ORDER 15
+#define HC_HASH4_ORDER 16
+#define NUM_LITERAL_OBSERVATION_TYPES 8
+#define NUM_MATCH_OBSERVATION_TYPES 2
+#define NUM_OBSERVATION_TYPES (NUM_LITERAL_OBSERVATION_TYPES + NUM_MATCH_OBSERVATION_TYPES)
+#define NUM_OBSERVATIONS_PER_BLOCK_CHECK 512
+
+struct hc_mf {
+    int16_t hash3_tab[1u << HC_HASH3_ORDER];
+    int16_t hash4_tab[1u << HC_HASH4_ORDER];
+    int16_t next_tab[WINDOW_SIZE];
+};
+
+struct split_stats {
+    uint32_t new_observations[NUM_OBSERVATION_TYPES];
+    uint32_t observations[NUM_OBSERVATION_TYPES];
+    uint32_t num_new_observations;
+    uint32_t num_observations;
+};
+
+static void hc_slide(struct hc_mf *mf)
+{
+    int16_t *t = (int16_t *)mf;
+    const size_t cnt = sizeof(*mf) / sizeof(int16_t);
+    for (size_t i = 0; i < cnt; i++)
+        t[i] = (int16_t)(t[i] >= 0 ? t[i] - WINDOW_SIZE : -WINDOW_SIZE);
+}
+
+static unsigned hc_longest_match(struct hc_mf *mf, const uint8_t **in_base_p, const uint8_t *in_next,
+                                 unsigned best_len, unsigned max_len, unsigned nice_len,
+                                 unsigned max_search_depth, uint32_t next_hashes[2], unsigned *offset_ret)
+{
+    unsigned depth_remaining = max_search_depth;
+    const uint8_t *best_matchptr = in_next;
+    int16_t cur_node3, cur_node4;
+    uint32_t hash3, hash4, next_hashseq, seq4;
+    const uint8_t *matchptr;
+    unsigned len;
+    uint32_t cur_pos = (uint32_t)(in_next - *in_base_p);
+    const uint8_t *in_base;
+    int32_t cutoff;
+
+    if (cur_pos == WINDOW_SIZE) {
+        hc_slide(mf);
+        *in_base_p += WINDOW_SIZE;
+        cur_pos = 0;
+    }
+    in_base = *in_base_p;
+    cutoff = (int32_t)cur_pos - WINDOW_SIZE;
+
+    if (max_len < 5) /* cannot read 4 bytes from in_next + 1 */
+        goto out;
+
+    hash3 = next_hashes[0];
+    hash4 = next_hashes[1];
+    cur_node3 = mf->hash3_tab[hash3];
+    cur_node4 = mf->hash4_tab[hash4];
+    mf->hash3_tab[hash3] = (int16_t)cur_pos;
+    mf->hash4_tab[hash4] = (int16_t)cur_pos;
+    mf->next_tab[cur_pos] = cur_node4;
+
+    next_hashseq = le32(in_next + 1);
+    next_hashes[0] = lz_hash(next_hashseq & 0xFFFFFF, HC_HASH3_ORDER);
+    next_hashes[1] = lz_hash(next_hashseq, HC_HASH4_ORDER);
+
+    if (best_len < 4) {
+        if (cur_node3 <= cutoff)
+            goto out;
+        seq4 = le32(in_next);
+        if (best_len < 3) {
+            matchptr = in_base + cur_node3;
+            if ((le32(matchptr) & 0xFFFFFF) == (seq4 & 0xFFFFFF)) {
+                best_len = 3;
+                best_matchptr = matchptr;
+            }
+        }
+        if (cur_node4 <= cutoff)
+            goto out;
+        for (;;) {
+            matchptr = in_base + cur_node4;
+            if (le32(matchptr) == seq4)
+                break;
+            cur_node4 = mf->next_tab[cur_node4 & (WINDOW_SIZE - 1)];
+            if (cur_node4 <= cutoff || !--depth_remaining)
+                goto out;
+        }
+        best_matchptr = matchptr;
+        best_len = lz_extend(in_next, best_matchptr, 4, max_len);
+        if (best_len >= nice_len)
+            goto out;
+        cur_node4 = mf->next_tab[cur_node4 & (WINDOW_SIZE - 1)];
+        if (cur_node4 <= cutoff || !--depth_remaining)
+            goto out;
+    } else {
+        if (cur_node4 <= cutoff || best_len >= nice_len)
+            goto out;
+    }
+
+    for (;;) {
+        for (;;) {
+            matchptr = in_base + cur_node4;
+            if (le32(matchptr + best_len - 3) == le32(in_next + best_len - 3) &&
+                le32(matchptr) == le32(in_next))
+                break;
+            cur_node4 = mf->next_tab[cur_node4 & (WINDOW_SIZE - 1)];
+            if (cur_node4 <= cutoff || !--depth_remaining)
+                goto out;
+        }
+        len = lz_extend(in_next, matchptr, 4, max_len);
+        if (len > best_len) {
+            best_len = len;
+            best_matchptr = matchptr;
+            if (best_len >= nice_len)
+                goto out;
+        }
+        cur_node4 = mf->next_tab[cur_node4 & (WINDOW_SIZE - 1)];
+        if (cur_node4 <= cutoff || !--depth_remaining)
+            goto out;
+    }
+out:
+    *offset_ret = (unsigned)(in_next - best_matchptr);
+    return best_len;
+}
+
+static void hc_skip_bytes(struct hc_mf *mf, const uint8_t **in_base_p, const uint8_t *in_next,
+                          const uint8_t *in_end, unsigned count, uint32_t next_hashes[2])
+{
+    uint32_t cur_pos, hash3, hash4, next_hashseq;
+    unsigned remaining = count;
+
+    if ((size_t)count + 5 > (size_t)(in_end - in_next))
+        return;
+    cur_pos = (uint32_t)(in_next - *in_base_p);
+    hash3 = next_hashes[0];
+    hash4 = next_hashes[1];
+    do {
+        if (cur_pos == WINDOW_SIZE) {
+            hc_slide(mf);
+            *in_base_p += WINDOW_SIZE;
+            cur_pos = 0;
+        }
+        mf->hash3_tab[hash3] = (int16_t)cur_pos;
+        mf->next_tab[cur_pos] = mf->hash4_tab[hash4];
+        mf->hash4_tab[hash4] = (int16_t)cur_pos;
+        next_hashseq = le32(++in_next);
+        hash3 = lz_hash(next_hashseq & 0xFFFFFF, HC_HASH3_ORDER);
+        hash4 = lz_hash(next_hashseq, HC_HASH4_ORDER);
+        cur_pos++;
+    } while (--remaining);
+    next_hashes[0] = hash3;
+    next_hashes[1] = hash4;
+}
+
+static unsigned choose_min_match_len(unsigned num_used_literals, unsigned max_search_depth)
+{
+    static const uint8_t min_lens[] = {
+        9, 9, 9, 9, 9, 9, 8, 8, 7, 7, 6, 6, 6, 6, 6, 6, 5, 5, 5, 5, 5, 5, 5, 5, 5, 5, 5,
+        5, 5, 5, 5, 5, 5, 5, 5, 5, 5, 5, 5, 5, 5, 5, 5, 5, 5, 4, 4, 4, 4, 4, 4, 4, 4, 4,
+        4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4,
+    };
+    unsigned min_len = MIN_MATCH_LEN;
+    if (num_used_literals < sizeof(min_lens))
+        min_len = min_lens[num_used_literals];
+    if (max_search_depth < 16) {
+        unsigned cap = max_search_depth < 5 ? 4 : max_search_depth < 10 ? 5 : 7;
+        if (min_len > cap)
+            min_len = cap;
+    }
+    return min_len;
+}
+
+static unsigned calculate_min_match_len(const uint8_t *data, size_t data_len, unsigned max_search_depth,
+                                        int compat)
+{
+    uint8_t used[256];
+    unsigned num_used = 0;
+    memset(used, 0, sizeof(used));
+    /* libdeflate >= 1.1x: a scan shorter than 512 bytes always uses 3 (SURVEY A.7 delta 2) */
+    if (compat != GZPX_ORACLE_COMPAT_1_10 && data_len < 512)
+        return MIN_MATCH_LEN;
+    if (data_len > 4096)
+        data_len = 4096;
+    for (size_t i = 0; i < data_len; i++)
+        used[data[i]] = 1;
+    for (unsigned i = 0; i < 256; i++)
+        num_used += used[i];
+    return choose_min_match_len(num_used, max_search_depth);
+}
+
+static int do_end_block_check(struct split_stats *st, uint32_t block_length)
+{
+    if (st->num_observations > 0) {
+        uint32_t total_delta = 0, num_items, cutoff;
+        for (int i = 0; i < NUM_OBSERVATION_TYPES; i++) {
+            uint32_t expected = st->observations[i] * st->num_new_observations;
+            uint32_t actual = st->new_observations[i] * st->num_observations;
+            total_delta += actual > expected ? actual - expected : expected - actual;
+        }
+        num_items = st->num_observations + st->num_new_observations;
+        cutoff = st->num_new_observations * 200 / 512 * st->num_observations;
+        if (block_length < 10000 && num_items < 8192)
+            cutoff += (uint32_t)((uint64_t)cutoff * (8192 - num_items) / 8192);
+        if (total_delta + (block_length / 4096) * st->num_observations >= cutoff)
+            return 1;
+    }
+    for (int i = 0; i < NUM_OBSERVATION_TYPES; i++) {
+        st->num_observations += st->new_observations[i];
+        st->observations[i] += st->new_observations[i];
+        st->new_observations[i] = 0;
+    }
+    st->num_new_observations = 0;
+    return 0;
+}
+
+static __thread struct hc_mf *tl_hc;
+static __thread uint32_t *tl_tokens_hc;
+
+/* deflate_compress_greedy */
+static int compress_greedy(const uint8_t *in, size_t n, unsigned nice_match_length,
+                           unsigned max_search_depth, int compat, block_sink_fn sink, void *ctx)
+{
+    const uint8_t *in_next = in, *in_end = in + n, *in_cur_base = in;
+    unsigned max_len = MAX_MATCH_LEN;
+    unsigned nice_len = nice_match_length < max_len ? nice_match_length : max_len;
+    uint32_t next_hashes[2] = {0, 0};
+    struct hc_mf *mf;
+    uint32_t *tokens;
+    if (!slot_tabs_ready)
+        init_slot_tabs();
+    if (!tl_hc)
+        tl_hc = (struct hc_mf *)malloc(sizeof(*tl_hc));
+    if (!tl_tokens_hc)
+        tl_tokens_hc = (uint32_t *)malloc(sizeof(uint32_t) * (SOFT_MAX_BLOCK_LENGTH + MIN_BLOCK_LENGTH + 300));
+    mf = tl_hc;
+    tokens = tl_tokens_hc;
+    if (!mf || !tokens)
+        return -1;
+    {
+        int16_t *t = (int16_t *)mf;
+        for (size_t i = 0; i < sizeof(*mf) / sizeof(int16_t); i++)
+            t[i] = -WINDOW_SIZE;
+    }
+    do {
+        const uint8_t *block_begin = in_next;
+        const uint8_t *max_block_end =
+            ((size_t)(in_end - in_next) < SOFT_MAX_BLOCK_LENGTH + MIN_BLOCK_LENGTH)
+                ? in_end
+                : in_next + SOFT_MAX_BLOCK_LENGTH;
+        struct freqs fr;
+        struct split_stats st;
+        size_t nt = 0;
+        unsigned nseq = 0, min_len;
+        memset(&fr, 0, sizeof(fr));
+        memset(&st, 0, sizeof(st));
+        min_len = calculate_min_match_len(in_next, (size_t)(max_block_end - in_next), max_search_depth,
+                                          compat);
+        for (;;) {
+            unsigned length, offset;
+            size_t remaining = (size_t)(in_end - in_next);
+            if (remaining < MAX_MATCH_LEN) {
+                max_len = (unsigned)remaining;
+                if (nice_len > max_len)
+                    nice_len = max_len;
+            }
+            length = hc_longest_match(mf, &in_cur_base, in_next, min_len - 1, max_len, nice_len,
+                                      max_search_depth, next_hashes, &offset);
+            if (length >= min_len && (length > MIN_MATCH_LEN || offset <= 4096)) {
+                tally_match(&fr, tokens, &nt, length, offset);
+                nseq++;
+                st.new_observations[NUM_LITERAL_OBSERVATION_TYPES + (length >= 9)]++;
+                st.num_new_observations++;
+                hc_skip_bytes(mf, &in_cur_base, in_next + 1, in_end, length - 1, next_hashes);
+                in_next += length;
+            } else {
+                uint8_t lit = *in_next++;
+                tally_literal(&fr, tokens, &nt, lit);
+                st.new_observations[((lit >> 5) & 0x6) | (lit & 1)]++;
+                st.num_new_observations++;
+            }
+            if (!(in_next < max_block_end && nseq < SEQ_STORE_LENGTH))
+                break;
+            if (st.num_new_observations >= NUM_OBSERVATIONS_PER_BLOCK_CHECK &&
+                (size_t)(in_next - block_begin) >= MIN_BLOCK_LENGTH &&
+                (size_t)(in_end - in_next) >= MIN_BLOCK_LENGTH &&
+                do_end_block_check(&st, (uint32_t)(in_next - block_begin)))
+                break;
+        }
+        sink(ctx, block_begin, (size_t)(in_next - block_begin), tokens, nt, &fr, in_next == in_end);
+    } while (in_next != in_end);
+    return 0;
+}
+
 /* ------------------------------------------------------------------ entry points */
 
 struct emit_ctx {
@@ -726,13 +1022,19 @@ size_t gzpx_oracle_deflate_compress(int level, int compat, const uint8_t *in, si
     c.w.out = out;
     c.w.cap = cap;
     c.compat = compat;
-    if (level < 0 || level > 1)
-        return 0; /* levels 2..12: not restated yet */
+    if (level < 0 || level > 4)
+        return 0; /* levels 5..12 (lazy / near-optimal parsers): not restated */
     /* A.0: very short inputs (and level 0) are emitted as stored blocks only */
     if (level == 0 || n <= (size_t)(55 - 4 * level)) {
         write_stored(&c.w, in, n, 1);
-    } else {
+    } else if (level == 1) {
         if (compress_fastest(in, n, emit_sink, &c) != 0)
+            return 0;
+        bw_align(&c.w);
+    } else {
+        /* level 2: depth 6 nice 10; level 3: depth 12 nice 14; level 4: depth 16 nice 30 */
+        static const unsigned depth[5] = {0, 0, 6, 12, 16}, nice[5] = {0, 0, 10, 14, 30};
+        if (compress_greedy(in, n, nice[level], depth[level], compat, emit_sink, &c) != 0)
             return 0;
         bw_align(&c.w);
     }

@@ -17,6 +17,6 @@ ms = ctx.last_stage_ms()
 cyc = ctx.debug_phase_cycles()
 cc = ctx.debug_cand_cycles()
 print(json.dumps({"class": cls, "n": n, "ratio": out_len / n, "stage_ms": ms,
-                  "match[stage,match]+parse[rounds,mark,rank,build]_kcycles_per_block": [round(c / nb / 1e3, 1) for c in cyc[:6]],
+                  "kcycles_per_block[-,k_match,k_parse]": [round(c / nb / 1e3, 1) for c in cyc[:6]],
                   "mp_rounds_avg": cyc[6] / nb,
                   "cand_kcycles_per_block[hash+atomics,gather,file+store,total]": [round(c / nb / 1e3, 1) for c in cc]}))
