@@ -289,7 +289,7 @@ class Context:
 
     def debug_tokens(self, block):
         toks = np.empty(max(65536, int(self.buffer_size)), dtype=np.uint32)
-        first = np.zeros(int(self.buffer_size) // 32768 + 4, dtype=np.uint32)
+        first = np.zeros(int(self.buffer_size) // 5000 + 4, dtype=np.uint32)
         n = ctypes.c_size_t(0)
         ns = ctypes.c_size_t(0)
         self.lib.check(self.lib.L.gzpx_debug_tokens(self.h, block, toks.ctypes.data, toks.size,

@@ -115,7 +115,7 @@ uint64_t blocks_of(const gzpx_ctx *ctx, size_t in_len) {
 
 // bytes of device scratch one block needs (see gzpx_device.h Scratch)
 size_t scratch_bytes_per_block(const Config &c) {
-    return (size_t)c.stride * (2 + 1 + 2 + 4) + c.stride / 8 +
+    return (size_t)c.stride * (2 + 1 + 2 + 4 + (c.level >= 2 ? 2 : 0)) + c.stride / 8 +
            (size_t)c.max_sub * (sizeof(SubMeta) + (kHistStride + kCodeWords + kHdrWords) * 4) +
            sizeof(BlockMeta) + 8;
 }
@@ -131,6 +131,11 @@ int alloc_scratch(gzpx_ctx *ctx) {
     HIP_TRY(hipMalloc((void **)&s.which, nb * (size_t)(c.stride / 32) * 4));
     HIP_TRY(hipMalloc((void **)&s.alt, nb * (size_t)c.stride * sizeof(uint16_t)));
     HIP_TRY(hipMalloc((void **)&s.tok, nb * (size_t)c.stride * 4));
+    if (c.level >= 2) {  // hc_matchfinder levels: hash4 chain links + per-block parse state
+        HIP_TRY(hipMalloc((void **)&s.d4, nb * (size_t)c.stride * sizeof(uint16_t)));
+        HIP_TRY(hipMalloc((void **)&s.hc, nb * sizeof(HcState)));
+        HIP_TRY(hipMalloc((void **)&s.pending, 64));
+    }
     HIP_TRY(hipMalloc((void **)&s.hist, nb * (size_t)c.max_sub * kHistStride * 4));
     HIP_TRY(hipMalloc((void **)&s.codes, nb * (size_t)c.max_sub * kCodeWords * 4));
     HIP_TRY(hipMalloc((void **)&s.hdr, nb * (size_t)c.max_sub * kHdrWords * 4));
@@ -151,6 +156,9 @@ void free_scratch(gzpx_ctx *ctx) {
     if (s.len8) (void)hipFree(s.len8);
     if (s.which) (void)hipFree(s.which);
     if (s.alt) (void)hipFree(s.alt);
+    if (s.d4) (void)hipFree(s.d4);
+    if (s.hc) (void)hipFree(s.hc);
+    if (s.pending) (void)hipFree(s.pending);
     if (s.hist) (void)hipFree(s.hist);
     if (s.codes) (void)hipFree(s.codes);
     if (s.hdr) (void)hipFree(s.hdr);
@@ -176,10 +184,24 @@ int run_batch(gzpx_ctx *ctx, const uint8_t *d_in, size_t in_len, uint32_t nb, in
     if (prof) HIP_TRY(hipEventRecord(ev[++k], stream));
     launch_candidates(c, d_in, in_len, nb, s, stream);
     if (prof) HIP_TRY(hipEventRecord(ev[++k], stream));
-    launch_match(c, d_in, in_len, nb, s, stream);
-    if (prof) HIP_TRY(hipEventRecord(ev[++k], stream));
-    launch_parse(c, d_in, in_len, nb, s, stream);
-    if (prof) HIP_TRY(hipEventRecord(ev[++k], stream));
+    if (c.level == 1) {
+        launch_match(c, d_in, in_len, nb, s, stream);
+        if (prof) HIP_TRY(hipEventRecord(ev[++k], stream));
+        launch_parse(c, d_in, in_len, nb, s, stream);
+        if (prof) HIP_TRY(hipEventRecord(ev[++k], stream));
+    } else {
+        // levels 2-4: match + parse rounds until no block needs its tail redone with another
+        // min_len (one round unless should_end_block splits a block into unlike halves)
+        for (uint32_t round = 0;; round++) {
+            launch_hc_round(c, d_in, nb, s, round == 0, stream);
+            HIP_TRY(hipMemcpyAsync(ctx->h_total, s.pending, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+            HIP_TRY(hipStreamSynchronize(stream));
+            if (*(const uint32_t *)ctx->h_total == 0) break;
+            if (round > c.max_sub + 2) return GZPX_ERR_DEVICE;  // cannot happen: one sub-block per round
+        }
+        if (prof) HIP_TRY(hipEventRecord(ev[++k], stream));
+        if (prof) HIP_TRY(hipEventRecord(ev[++k], stream));
+    }
     launch_hist(c, nb, s, stream);
     if (prof) HIP_TRY(hipEventRecord(ev[++k], stream));
     launch_huffman(c, nb, s, stream);
@@ -296,7 +318,7 @@ int gzpx_ctx_create(const gzpx_config *cfg, gzpx_ctx **out) {
     if (cfg->level < 0 || cfg->level > 12) return GZPX_ERR_COMPRESSION_LEVEL;
     if (cfg->compat != GZPX_COMPAT_LIBDEFLATE_1_24 && cfg->compat != GZPX_COMPAT_LIBDEFLATE_1_10)
         return GZPX_ERR_INVALID_ARG;
-    if (cfg->level != 1) return GZPX_ERR_UNSUPPORTED;             // levels 0, 2..12: not built yet
+    if (cfg->level < 1 || cfg->level > 4) return GZPX_ERR_UNSUPPORTED;  // 0, 5..12: not built yet
     if (cfg->buffer_size > kMaxBlockSize) return GZPX_ERR_UNSUPPORTED;  // > 16 MiB blocks: not built
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return GZPX_ERR_NO_DEVICE;
@@ -314,7 +336,15 @@ int gzpx_ctx_create(const gzpx_config *cfg, gzpx_ctx **out) {
     ctx->dcfg.debug = 0;
     // per-block strides: padding for k_candidates' last iteration / dword-wide tile loads
     ctx->dcfg.stride = (uint32_t)((cfg->buffer_size + 1023) / 1024 * 1024 + 1024);
-    ctx->dcfg.max_sub = (uint32_t)(cfg->buffer_size / 32768 + 2);
+    // level 1 sub-blocks hold 8192 matches (>= 32768 bytes); the block splitter of levels 2-4 may
+    // cut every MIN_BLOCK_LENGTH = 5000 bytes
+    ctx->dcfg.max_sub = (uint32_t)(cfg->buffer_size / (cfg->level == 1 ? 32768 : 5000) + 2);
+    ctx->dcfg.passthrough = (uint32_t)(55 - 4 * cfg->level);
+    {
+        static const uint32_t depth[5] = {0, 0, 6, 12, 16}, nice[5] = {0, 0, 10, 14, 30};
+        ctx->dcfg.hc_depth = depth[cfg->level];
+        ctx->dcfg.hc_nice = nice[cfg->level];
+    }
     for (unsigned l = 0; l < 8; l++) ctx->crc_consts.pow256[l] = x2k(11 + l);
     ctx->crc_consts.pow_tile = x2k(19);  // x^(8 * 65536) = x^(2^19)
     hipDeviceProp_t prop;

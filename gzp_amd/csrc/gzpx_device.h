@@ -19,7 +19,6 @@ constexpr unsigned kNumOffset = 32;
 constexpr unsigned kHistStride = kNumLitlen + kNumOffset;  // 320 u32 per sub-block
 constexpr unsigned kHdrWords = 160;                        // dynamic header bit string, <= 4554 bits
 constexpr unsigned kCodeWords = kNumLitlen + kNumOffset;   // (codeword | len << 16) per symbol
-constexpr unsigned kPassthroughL1 = 51;                    // n <= 55 - 4*level => stored only
 
 constexpr uint32_t kTokMatch = 0x80000000u;  // token = kTokMatch | offset << 9 | length
 
@@ -55,6 +54,19 @@ struct BlockMeta {
     uint32_t cand_cycles[4];   // k_candidates: shader-clock cycles [-, -, -, main loop total]
 };
 
+// Levels 2-4: per-block parse state carried between tiles and between match/parse rounds (a
+// round ends early when a new DEFLATE sub-block needs another minimum match length).
+struct HcState {
+    uint32_t done;        // the block's token stream is complete
+    uint32_t min_len;     // min_len of the sub-block that starts at resume_pos (0 = not computed yet)
+    uint32_t resume_pos;  // where match results must be (re)computed and the parse resumes
+    uint32_t tok_carry;   // tokens emitted before resume_pos
+    uint32_t mat_carry;   // matches emitted before resume_pos
+    uint32_t cur_sub;     // index of the sub-block that starts at resume_pos
+    uint32_t rounds;      // diagnostics
+    uint32_t pad;
+};
+
 struct CrcConsts {
     uint32_t pow256[8];  // x^(8*256*2^l) mod P (reflected), l = 0..7
     uint32_t pow_tile;   // x^(8*65536) mod P: appends one full 64 KiB chunk
@@ -69,6 +81,9 @@ struct Config {
     uint32_t debug;       // diagnostics only: bit 0 = force k_candidates_safe on every block
     uint32_t stride;      // per-block stride (positions) of cand / len8 / alt / tok: >= block_size + 1024
     uint32_t max_sub;     // per-block capacity of sub / hist / codes / hdr (sub-blocks >= 32768 bytes)
+    uint32_t passthrough; // n <= 55 - 4*level is emitted as stored blocks only (deflate_compress_none)
+    uint32_t hc_depth;    // levels 2-4: max_search_depth
+    uint32_t hc_nice;     // levels 2-4: nice_match_length
 };
 
 // Device scratch for one batch of blocks.
@@ -79,6 +94,9 @@ struct Scratch {
     uint8_t *len8;        // [nb][stride]        0 = no match at p, else match length - 3
     uint32_t *which;      // [nb][stride/32]     bit p: the older candidate won at p
     uint16_t *alt;        // [nb][stride]        match distance at p where that bit is set
+    uint16_t *d4;         // [nb][stride]        levels 2-4: distance to the hash4 chain predecessor
+    HcState *hc;          // [nb]                levels 2-4: parse state
+    uint32_t *pending;    // [1]                 levels 2-4: blocks that need another round
     uint32_t *tok;        // [nb][stride]        worst case one token per byte
     uint32_t *hist;       // [nb][max_sub][kHistStride]
     uint32_t *codes;      // [nb][max_sub][kCodeWords]
@@ -95,6 +113,8 @@ void launch_match(const Config &cfg, const uint8_t *slab, uint64_t slab_len, uin
                   const Scratch &s, hipStream_t stream);
 void launch_parse(const Config &cfg, const uint8_t *slab, uint64_t slab_len, uint32_t nb,
                   const Scratch &s, hipStream_t stream);
+void launch_hc_round(const Config &cfg, const uint8_t *slab, uint32_t nb, const Scratch &s, int first,
+                     hipStream_t stream);
 void launch_hist(const Config &cfg, uint32_t nb, const Scratch &s, hipStream_t stream);
 void launch_huffman(const Config &cfg, uint32_t nb, const Scratch &s, hipStream_t stream);
 void launch_crc32(const Config &cfg, const uint8_t *slab, uint64_t slab_len, uint32_t nb,

@@ -190,6 +190,29 @@ __device__ __forceinline__ uint2 cand_fetch(const uint32_t *__restrict__ in32, u
 
 constexpr uint32_t kCandWaves = 4;  // one per SIMD; they take turns at the table
 
+// Which chain a candidate pass builds (MODE):
+//   0  level 1, ht_matchfinder: 15-bit hash of 4 bytes
+//   1  levels 2-4, hc_matchfinder hash3_tab: 15-bit hash of 3 bytes (single previous position)
+//   2  levels 2-4, hc_matchfinder hash4_tab / next_tab: 16-bit hash of 4 bytes, buckets 0..32767
+//   3  same, buckets 32768..65535 (the 2^16-bucket table does not fit LDS, so it takes two passes;
+//      every position belongs to exactly one of them)
+// Position 0 is filed under bucket 0 in every table (libdeflate starts with next_hash(es) = 0).
+template <int MODE>
+__device__ __forceinline__ bool cand_bucket(uint32_t v, uint32_t p, uint32_t &h) {
+    if (MODE == 0) {
+        h = p != 0 ? lz_hash15(v) : 0;
+        return true;
+    } else if (MODE == 1) {
+        h = p != 0 ? lz_hash15(v & 0xFFFFFFu) : 0;
+        return true;
+    } else {
+        const uint32_t h16 = p != 0 ? (v * 0x1E35A7BDu) >> 16 : 0;
+        h = h16 & 32767u;
+        return MODE == 2 ? h16 < 32768u : h16 >= 32768u;
+    }
+}
+
+template <int MODE>
 __global__ __launch_bounds__(64 * kCandWaves) void k_candidates(Config cfg,
                                                                  const uint8_t *__restrict__ slab,
                                                                  BlockMeta *__restrict__ meta,
@@ -199,7 +222,7 @@ __global__ __launch_bounds__(64 * kCandWaves) void k_candidates(Config cfg,
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint32_t b = blockIdx.x;
     const uint32_t n = meta[b].n;
-    if (n <= kPassthroughL1) return;  // stored-only path, no matchfinding (uniform)
+    if (n <= cfg.passthrough) return;  // stored-only path, no matchfinding (uniform)
     const uint8_t *in = slab + (uint64_t)b * cfg.block_size;
     const uint32_t mis = (uint32_t)((uintptr_t)in & 3u);
     const uint32_t *in32 = (const uint32_t *)(in - mis);
@@ -226,11 +249,12 @@ __global__ __launch_bounds__(64 * kCandWaves) void k_candidates(Config cfg,
     for (uint32_t it = wave; it < n_iters; it += kCandWaves) {
         const uint32_t base0 = it * kIterPos;
         uint32_t h[kCandSteps], old[kCandSteps];
+        bool mine[kCandSteps];  // this pass owns the position's bucket
 #pragma unroll
         for (uint32_t k = 0; k < kCandSteps; k++) {
             const uint32_t p = base0 + k * 64 + lane;
             const uint32_t v = __builtin_amdgcn_alignbyte(ring[k].y, ring[k].x, (p + mis) & 3u);
-            h[k] = p != 0 ? lz_hash15(v) : 0;  // position 0 is filed under bucket 0 (next_hash = 0)
+            mine[k] = cand_bucket<MODE>(v, p, h[k]) && p + 5 <= n;
         }
 #pragma unroll
         for (uint32_t k = 0; k < kCandSteps; k++)  // this wave's next iteration
@@ -243,7 +267,7 @@ __global__ __launch_bounds__(64 * kCandWaves) void k_candidates(Config cfg,
         for (uint32_t k = 0; k < kCandSteps; k++) {
             const uint32_t p = base0 + k * 64 + lane;
             old[k] = 0;
-            if (p + 5 <= n) old[k] = atomicMax(&tab[h[k]], p + 1);
+            if (mine[k]) old[k] = atomicMax(&tab[h[k]], p + 1);
         }
         // the returned values are in registers => every atomic of this iteration has been applied
         uint32_t seen = 0;
@@ -258,24 +282,28 @@ __global__ __launch_bounds__(64 * kCandWaves) void k_candidates(Config cfg,
             bad |= old[k] > p;  // handed a predecessor that is not earlier: LDS order assumption broken
             uint32_t d0 = old[k] ? p + 1 - old[k] : 0;
             if (d0 > 32767u) d0 = 0;  // farther than the window: dead
-            cand[p] = (uint16_t)d0;   // p < cfg.stride (padded by >= one iteration)
+            // p < cfg.stride (padded by >= one iteration).  The two hash4 passes own disjoint
+            // positions; positions that are never hashed are zeroed by the first of them.
+            if (MODE < 2 || mine[k] || (MODE == 2 && p + 5 > n)) cand[p] = (uint16_t)d0;
         }
     }
-    if (tid == 0) meta[b].cand_cycles[3] = (uint32_t)(clock64() - t_begin);
-    if (__ballot(bad) && lane == 0) meta[b].cand_redo = 1;
+    if (tid == 0 && MODE == 0) meta[b].cand_cycles[3] = (uint32_t)(clock64() - t_begin);
+    if (__ballot(bad) && lane == 0) atomicOr(&meta[b].cand_redo, 1u << MODE);
 }
 
 // Order-independent restatement used for blocks flagged by k_candidates (expected: never):
 // lanes of a step that share a bucket are linked in position order with a 15-round ballot
 // match-any; the last lane of each group rewrites the bucket (position mod 65536, with a dead
 // marker 0x8000 behind that is refreshed every 32768 positions).
+template <int MODE>
 __device__ __forceinline__ void cand_step_safe(uint32_t *tab, uint32_t mis, uint32_t base,
                                                uint32_t lane, uint32_t n, uint2 raw,
                                                uint16_t *__restrict__ cand) {
     const uint32_t p = base + lane;
-    const bool valid = p + 5 <= n;  // positions the matchfinder hashes (REQUIRED_NBYTES = 5)
     uint32_t h = 0;
-    if (valid && p != 0) h = lz_hash15(__builtin_amdgcn_alignbyte(raw.y, raw.x, (p + mis) & 3u));
+    const bool owns = cand_bucket<MODE>(__builtin_amdgcn_alignbyte(raw.y, raw.x, (p + mis) & 3u), p, h);
+    const bool valid = owns && p + 5 <= n;  // positions the matchfinder hashes (REQUIRED_NBYTES = 5)
+    if (!valid) h = 0;
     uint32_t c0 = tab[h];
     uint64_t same = __ballot(valid);
     for (int bit = 0; bit < 15; bit++) {
@@ -291,9 +319,10 @@ __device__ __forceinline__ void cand_step_safe(uint32_t *tab, uint32_t mis, uint
     wave_sync();
     uint32_t d0 = (p - c0) & 0xFFFFu;
     if (d0 > 32767u) d0 = 0;
-    cand[p] = (uint16_t)(valid ? d0 : 0u);
+    if (MODE < 2 || valid || (MODE == 2 && p + 5 > n)) cand[p] = (uint16_t)(valid ? d0 : 0u);
 }
 
+template <int MODE>
 __global__ __launch_bounds__(64) void k_candidates_safe(Config cfg, const uint8_t *__restrict__ slab,
                                                         BlockMeta *__restrict__ meta, uint32_t nb,
                                                         uint32_t force,
@@ -302,7 +331,7 @@ __global__ __launch_bounds__(64) void k_candidates_safe(Config cfg, const uint8_
     const uint32_t lane = threadIdx.x;
     for (uint32_t b = blockIdx.x; b < nb; b += gridDim.x) {
         const uint32_t n = meta[b].n;
-        if (n <= kPassthroughL1 || !(force || meta[b].cand_redo)) continue;  // wave-uniform
+        if (n <= cfg.passthrough || !(force || (meta[b].cand_redo >> MODE) & 1u)) continue;  // wave-uniform
         const uint8_t *in = slab + (uint64_t)b * cfg.block_size;
         const uint32_t mis = (uint32_t)((uintptr_t)in & 3u);
         const uint32_t *in32 = (const uint32_t *)(in - mis);
@@ -323,9 +352,8 @@ __global__ __launch_bounds__(64) void k_candidates_safe(Config cfg, const uint8_
                 }
                 wave_sync();
             }
-            cand_step_safe(tab, mis, base, lane, n, cand_fetch(in32, mis, base + lane, wmax), cand);
+            cand_step_safe<MODE>(tab, mis, base, lane, n, cand_fetch(in32, mis, base + lane, wmax), cand);
         }
-        if (lane == 0) meta[b].cand_redo = 0;
     }
 }
 
@@ -378,7 +406,7 @@ __global__ __launch_bounds__(kMpThreads, 8) void k_match(Config cfg, const uint8
     const uint32_t b = blockIdx.x;
     BlockMeta *meta = meta_all + b;
     const uint32_t n = meta->n;
-    if (n <= kPassthroughL1) return;  // uniform for the workgroup
+    if (n <= cfg.passthrough) return;  // uniform for the workgroup
     const uint8_t *in = slab + (uint64_t)b * cfg.block_size;
     const uint16_t *cand = cand_all + (uint64_t)b * cfg.stride;
     uint8_t *len8 = len8_all + (uint64_t)b * cfg.stride;
@@ -515,7 +543,7 @@ __global__ __launch_bounds__(kMpThreads, 8) void k_parse(
     BlockMeta *meta = meta_all + b;
     SubMeta *sub = sub_all + (uint64_t)b * cfg.max_sub;
     const uint32_t n = meta->n;
-    if (n <= kPassthroughL1) return;  // uniform for the workgroup
+    if (n <= cfg.passthrough) return;  // uniform for the workgroup
     const uint8_t *in = slab + (uint64_t)b * cfg.block_size;
     const uint16_t *cand = cand_all + (uint64_t)b * cfg.stride;
     const uint32_t *which = which_all + (uint64_t)b * (cfg.stride / 32);
@@ -711,6 +739,578 @@ __global__ __launch_bounds__(kMpThreads, 8) void k_parse(
 }
 
 // ------------------------------------------------------------------------------------------
+// Levels 2-4: deflate_compress_greedy with hc_matchfinder (max_search_depth / nice_match_length:
+// 6/10, 12/14, 16/30).  Like the level-1 table, hc_matchfinder inserts every position, so its
+// state is parse independent: hash3_tab = "previous position with the same 3-byte hash" (d3) and
+// hash4_tab + next_tab = a chain of previous positions with the same 4-byte hash (d4 links).
+//
+// k_match_hc: hc_matchfinder_longest_match + the greedy acceptance rule for every position of a
+// block, in 16 KiB tiles whose LDS window also holds the 32 KiB of history: input bytes (48 KiB)
+// and the d4 links of every position a chain can visit (96 KiB), so the whole chain walk (up to
+// max_search_depth hops, each a 4-byte check and maybe an lz_extend) runs out of LDS.
+//   best_len starts at min_len - 1, where min_len comes from calculate_min_match_len over the
+//   first 4096 bytes of the DEFLATE sub-block -- so results depend on the sub-block a position
+//   belongs to; HcState.resume_pos / min_len say from where and with which min_len to compute.
+// Output: len8[p] = length - 3, which[p] (bit: a match was accepted at p), alt[p] = its distance.
+// ------------------------------------------------------------------------------------------
+constexpr uint32_t kHcTile = 16384;
+constexpr uint32_t kHcInWords = (32768 + kHcTile + 264) / 4 + 8;
+constexpr uint32_t kHcSoftMaxSub = 300000;  // SOFT_MAX_BLOCK_LENGTH
+constexpr uint32_t kHcSeqPerSub = 50000;    // SEQ_STORE_LENGTH
+
+__device__ __forceinline__ uint32_t hc_sub_limit_of(uint32_t start, uint32_t n) {
+    return (n - start < kHcSoftMaxSub + kMinBlockLen) ? n : start + kHcSoftMaxSub;
+}
+
+// choose_min_match_len
+__device__ __forceinline__ uint32_t hc_choose_min_len(uint32_t num_used, uint32_t depth) {
+    uint32_t m = num_used < 6 ? 9 : num_used < 8 ? 8 : num_used < 10 ? 7 : num_used < 16 ? 6
+               : num_used < 45 ? 5 : num_used < 80 ? 4 : 3;
+    if (depth < 16) {
+        const uint32_t cap = depth < 5 ? 4 : depth < 10 ? 5 : 7;
+        if (m > cap) m = cap;
+    }
+    return m;
+}
+
+// calculate_min_match_len for the sub-block that starts at `start`; all threads of the workgroup
+// call it (two barriers), `used` is 8 words of LDS.
+__device__ uint32_t hc_calc_min_len(const Config &cfg, const uint8_t *in, uint32_t start, uint32_t n,
+                                    uint32_t *used, uint32_t tid, uint32_t nthreads) {
+    uint32_t data_len = hc_sub_limit_of(start, n) - start;
+    __syncthreads();
+    if (tid < 8) used[tid] = 0;
+    __syncthreads();
+    const bool short_scan = cfg.compat == 0 && data_len < 512;  // libdeflate >= 1.1x
+    if (data_len > 4096) data_len = 4096;
+    for (uint32_t i = tid; i < data_len; i += nthreads) {
+        const uint32_t v = in[start + i];
+        atomicOr(&used[v >> 5], 1u << (v & 31u));
+    }
+    __syncthreads();
+    uint32_t num_used = 0;
+    for (uint32_t k = 0; k < 8; k++) num_used += (uint32_t)__popc(used[k]);
+    return short_scan ? 3u : hc_choose_min_len(num_used, cfg.hc_depth);
+}
+
+// hc_matchfinder_longest_match for the position at LDS byte address a / link index li.
+__device__ __forceinline__ uint32_t hc_search(const uint32_t *in_w, const uint16_t *link, uint32_t a,
+                                              uint32_t li, uint32_t d3v, uint32_t min_len,
+                                              uint32_t max_len, uint32_t nice_len, uint32_t depth,
+                                              uint32_t &dist_out) {
+    uint32_t best_len = min_len - 1, best_dist = 0;
+    uint32_t cur = link[li];  // distance to the next chain node (0 = end of chain)
+    uint32_t tot = cur;       // distance from p to that node; it is alive while tot <= 32767
+    const uint32_t seq4 = lds_le32(in_w, a);
+    bool more = true;
+    if (best_len < 4) {
+        if (d3v == 0) {
+            more = false;
+        } else {
+            if (best_len < 3 && ((lds_le32(in_w, a - d3v) ^ seq4) & 0xFFFFFFu) == 0) {
+                best_len = 3;
+                best_dist = d3v;
+            }
+            if (cur == 0 || tot > 32767u) {
+                more = false;
+            } else {
+                for (;;) {  // first node whose 4 bytes match
+                    if (lds_le32(in_w, a - tot) == seq4) break;
+                    cur = link[li - tot];
+                    tot += cur;
+                    if (cur == 0 || tot > 32767u || !--depth) {
+                        more = false;
+                        break;
+                    }
+                }
+                if (more) {
+                    best_dist = tot;
+                    best_len = lds_extend(in_w, a, a - tot, max_len);
+                    if (best_len >= nice_len) {
+                        more = false;
+                    } else {
+                        cur = link[li - tot];
+                        tot += cur;
+                        if (cur == 0 || tot > 32767u || !--depth) more = false;
+                    }
+                }
+            }
+        }
+    } else if (cur == 0 || tot > 32767u || best_len >= nice_len) {
+        more = false;
+    }
+    while (more) {  // look for something longer than best_len
+        for (;;) {
+            if (lds_le32(in_w, a - tot + best_len - 3) == lds_le32(in_w, a + best_len - 3) &&
+                lds_le32(in_w, a - tot) == seq4)
+                break;
+            cur = link[li - tot];
+            tot += cur;
+            if (cur == 0 || tot > 32767u || !--depth) {
+                more = false;
+                break;
+            }
+        }
+        if (!more) break;
+        const uint32_t len = lds_extend(in_w, a, a - tot, max_len);
+        if (len > best_len) {
+            best_len = len;
+            best_dist = tot;
+            if (best_len >= nice_len) break;
+        }
+        cur = link[li - tot];
+        tot += cur;
+        if (cur == 0 || tot > 32767u || !--depth) break;
+    }
+    dist_out = best_dist;
+    return best_len;
+}
+
+__global__ __launch_bounds__(1024) void k_match_hc(Config cfg, const uint8_t *__restrict__ slab,
+                                                   const BlockMeta *__restrict__ meta_all,
+                                                   HcState *__restrict__ hc_all,
+                                                   const uint16_t *__restrict__ d3_all,
+                                                   const uint16_t *__restrict__ d4_all,
+                                                   uint8_t *__restrict__ len8_all,
+                                                   uint32_t *__restrict__ mbits_all,
+                                                   uint16_t *__restrict__ dist_all) {
+    __shared__ uint32_t in_w[kHcInWords];                // 48 KiB window of the block's bytes
+    __shared__ uint32_t link_w[(32768 + kHcTile) / 2];  // d4 of every position in the window (u16)
+    __shared__ uint32_t mbits[kHcTile / 32];
+    __shared__ uint32_t used[8];
+    const uint16_t *link = (const uint16_t *)link_w;
+    const uint32_t tid = threadIdx.x;
+    const uint32_t b = blockIdx.x;
+    const uint32_t n = meta_all[b].n;
+    HcState *st = hc_all + b;
+    if (n <= cfg.passthrough || st->done) return;  // uniform
+    const uint8_t *in = slab + (uint64_t)b * cfg.block_size;
+    const uint16_t *d3 = d3_all + (uint64_t)b * cfg.stride;
+    const uint16_t *d4 = d4_all + (uint64_t)b * cfg.stride;
+    uint8_t *len8 = len8_all + (uint64_t)b * cfg.stride;
+    uint32_t *mbits_out = mbits_all + (uint64_t)b * (cfg.stride / 32);
+    uint16_t *dist = dist_all + (uint64_t)b * cfg.stride;
+
+    const uint32_t resume = st->resume_pos;
+    uint32_t min_len = st->min_len;
+    if (min_len == 0) {  // first round: the sub-block that starts the block
+        min_len = hc_calc_min_len(cfg, in, 0, n, used, tid, 1024);
+        __syncthreads();
+        if (tid == 0) st->min_len = min_len;
+    }
+    const uint32_t nice_level = cfg.hc_nice, depth = cfg.hc_depth;
+
+    for (uint32_t tile_begin = resume / kHcTile * kHcTile; tile_begin < n; tile_begin += kHcTile) {
+        const uint32_t tile_end = tile_begin + kHcTile < n ? tile_begin + kHcTile : n;
+        const uint32_t win_begin = tile_begin >= 32768u ? tile_begin - 32768u : 0;
+        const uint32_t win_end = tile_end + 264 < n ? tile_end + 264 : n;
+        const uint32_t mis = (uint32_t)((uintptr_t)(in + win_begin) & 3u);
+        __syncthreads();
+        {
+            const uint32_t *src = (const uint32_t *)(in + win_begin - mis);
+            const uint32_t ndw = (mis + (win_end - win_begin) + 3) >> 2;
+            for (uint32_t i = tid; i < ndw; i += 1024) in_w[i] = src[i];
+            for (uint32_t i = ndw + tid; i < ndw + 3 && i < kHcInWords; i += 1024) in_w[i] = 0;
+            // win_begin is a multiple of 16384 and the stride of 1024: dword-aligned u16 pairs
+            const uint32_t *lsrc = (const uint32_t *)(d4 + win_begin);
+            for (uint32_t i = tid; i < (tile_end - win_begin + 1) / 2; i += 1024) link_w[i] = lsrc[i];
+            for (uint32_t i = tid; i < kHcTile / 32; i += 1024) mbits[i] = 0;
+        }
+        __syncthreads();
+        for (uint32_t p = tile_begin + tid; p < tile_end; p += 1024) {
+            uint32_t len = 0, dst = 0;
+            if (p + 5 <= n) {  // max_len >= 5, otherwise hc_matchfinder_longest_match bails out
+                const uint32_t rem = n - p;
+                const uint32_t max_len = rem < 258u ? rem : 258u;
+                const uint32_t nice_len = max_len < nice_level ? max_len : nice_level;
+                const uint32_t a = p - win_begin + mis;
+                len = hc_search(in_w, link, a, p - win_begin, d3[p], min_len, max_len, nice_len, depth, dst);
+            }
+            // deflate_compress_greedy: a length-3 match is only worth it at a short distance
+            const bool take = len >= min_len && (len > 3 || dst <= 4096u);
+            len8[p] = (uint8_t)(take ? len - 3 : 0);
+            if (take) {
+                const uint32_t r = p - tile_begin;
+                atomicOr(&mbits[r >> 5], 1u << (r & 31u));
+                dist[p] = (uint16_t)dst;
+            }
+        }
+        __syncthreads();
+        for (uint32_t i = tid; i < (tile_end - tile_begin + 31) / 32; i += 1024)
+            mbits_out[tile_begin / 32 + i] = mbits[i];
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// k_parse_hc: the greedy parse, token stream and sub-block boundaries of deflate_compress_greedy,
+// per block in tiles of 48 KiB positions.  Walkers / ranks / token build as in k_parse (a match
+// is flagged by a bit, because length 3 shares len8 == 0 with "literal").  A sub-block ends at
+//   - the 300000-byte soft limit (choose_max_block_end) or after 50000 matches, or
+//   - where should_end_block says so: every 512 tokens (once 5000 bytes are in and 5000 remain)
+//     the histogram of 10 observation classes since the last check is compared with the
+//     block's so far (do_end_block_check).
+// The checks are a short sequential recurrence over per-512-token class counts, which are
+// gathered in parallel.  When the sub-block that follows a boundary needs a different min_len,
+// the match results from there on are stale: the state is saved, `pending` is bumped and the
+// host runs another k_match_hc / k_parse_hc round for this block.
+// ------------------------------------------------------------------------------------------
+constexpr uint32_t kHpTile = 49152;
+constexpr uint32_t kHpChunks = kHpTile / kMpThreads;  // 48
+constexpr uint32_t kHpMaxBins = kHpTile / 512 + 3;
+constexpr uint32_t kNoCheckYet = 0xFFFFFFFFu, kNoMoreChecks = 0xFFFFFFFEu;
+
+__device__ __forceinline__ uint32_t walk_segment_hc(const uint8_t *len8, const uint32_t *mb, uint32_t pos,
+                                                    uint32_t seg_end, uint32_t *tok_bits) {
+    while (pos < seg_end) {
+        const uint32_t l = len8[pos];
+        const uint32_t m = (mb[pos >> 5] >> (pos & 31u)) & 1u;
+        atomicOr(&tok_bits[pos >> 5], 1u << (pos & 31u));
+        pos += m ? l + 3 : 1;
+    }
+    return pos;
+}
+
+__global__ __launch_bounds__(kMpThreads, 8) void k_parse_hc(
+    Config cfg, const uint8_t *__restrict__ slab, BlockMeta *__restrict__ meta_all,
+    SubMeta *__restrict__ sub_all, HcState *__restrict__ hc_all, const uint8_t *__restrict__ len8_all,
+    const uint32_t *__restrict__ mbits_all, const uint16_t *__restrict__ dist_all,
+    uint32_t *__restrict__ tok_all, uint32_t *__restrict__ pending) {
+    __shared__ uint32_t len8_w[kHpTile / 4];
+    __shared__ uint32_t tok_bits[kHpTile / 32];
+    __shared__ uint32_t mb[kHpTile / 32];
+    __shared__ uint32_t seg_exit[256];
+    __shared__ uint32_t rank_pre[kHpChunks * kMpWaves];
+    __shared__ uint32_t wsum_t[kMpWaves], wsum_m[kMpWaves];
+    __shared__ unsigned long long bnd;  // limit / sequence-count boundary: (position << 32 | token)
+    __shared__ uint32_t bnd_tok, bnd_mat;
+    __shared__ uint32_t first_check;                // candidate for the first split check (token index)
+    __shared__ uint32_t bins[kHpMaxBins][10];       // observation classes per 512-token bin
+    __shared__ uint32_t chk_end[kHpMaxBins];        // end position of every check token
+    __shared__ uint32_t split_pos;                  // where should_end_block ended the sub-block
+    __shared__ uint32_t s_next_check, s_num_obs, s_num_new, s_obs[10], s_new[10];
+    __shared__ uint32_t used[8];
+    const uint8_t *len8 = (const uint8_t *)len8_w;
+
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t b = blockIdx.x;
+    BlockMeta *meta = meta_all + b;
+    SubMeta *sub = sub_all + (uint64_t)b * cfg.max_sub;
+    HcState *st = hc_all + b;
+    const uint32_t n = meta->n;
+    if (n <= cfg.passthrough || st->done) return;  // uniform
+    const uint8_t *in = slab + (uint64_t)b * cfg.block_size;
+    const uint16_t *dist = dist_all + (uint64_t)b * cfg.stride;
+    const uint32_t *mbits_g = mbits_all + (uint64_t)b * (cfg.stride / 32);
+    uint32_t *tok = tok_all + (uint64_t)b * cfg.stride;
+
+    // state (uniform across the workgroup)
+    uint32_t entry_carry = st->resume_pos;
+    uint32_t tok_carry = st->tok_carry, mat_carry = st->mat_carry;
+    uint32_t cur_sub = st->cur_sub;
+    uint32_t sub_start = st->resume_pos, sub_start_tok = tok_carry, sub_start_mat = mat_carry;
+    uint32_t sub_limit = hc_sub_limit_of(sub_start, n);
+    const uint32_t min_len = st->min_len;
+    const uint64_t lane_below = (1ull << lane) - 1ull;
+    if (tid == 0) {
+        s_next_check = kNoCheckYet;
+        s_num_obs = 0;
+        s_num_new = 0;
+        for (int k = 0; k < 10; k++) {
+            s_obs[k] = 0;
+            s_new[k] = 0;
+        }
+    }
+
+    for (uint32_t tile_begin = entry_carry / kHpTile * kHpTile; tile_begin < n; tile_begin += kHpTile) {
+        const uint32_t tile_len = n - tile_begin < kHpTile ? n - tile_begin : kHpTile;
+        __syncthreads();
+        {
+            const uint32_t *src = (const uint32_t *)(len8_all + (uint64_t)b * cfg.stride + tile_begin);
+            for (uint32_t i = tid; i < (tile_len + 3) / 4; i += kMpThreads) len8_w[i] = src[i];
+            for (uint32_t i = tid; i < kHpTile / 32; i += kMpThreads) {
+                tok_bits[i] = 0;
+                mb[i] = i < (tile_len + 31) / 32 ? mbits_g[tile_begin / 32 + i] : 0u;
+            }
+        }
+        __syncthreads();
+
+        // ---- greedy parse: speculative segment walk
+        const uint32_t seg_begin = tid * kSeg;
+        const bool active = tid < 256 && seg_begin < tile_len;
+        const uint32_t seg_end = active ? (seg_begin + kSeg < tile_len ? seg_begin + kSeg : tile_len) : 0;
+        const uint32_t entry_rel = entry_carry - tile_begin;
+        // the segment that holds the true entry knows it; segments before it have no tokens
+        uint32_t entry = seg_begin;
+        if (active && entry_rel >= seg_begin) entry = entry_rel < seg_end ? entry_rel : seg_end;
+        const bool fixed_entry = entry_rel >= seg_begin;  // (covers thread 0 always)
+        if (active) seg_exit[tid] = walk_segment_hc(len8, mb, entry, seg_end, tok_bits);
+        for (;;) {
+            __syncthreads();
+            bool changed = false;
+            uint32_t new_entry = entry;
+            if (active && !fixed_entry) {
+                new_entry = seg_exit[tid - 1];
+                changed = new_entry != entry;
+            }
+            __syncthreads();
+            if (changed) {
+                clear_marks(seg_begin, seg_end, tok_bits);
+                entry = new_entry;
+                seg_exit[tid] = walk_segment_hc(len8, mb, entry, seg_end, tok_bits);
+            }
+            if (!__syncthreads_or(changed)) break;
+        }
+        const uint32_t n_seg = (tile_len + kSeg - 1) / kSeg;
+        const uint32_t exit_rel = seg_exit[n_seg - 1];
+
+        // ---- ranks
+        const uint32_t nchunks = (tile_len + kMpThreads - 1) / kMpThreads;
+        for (uint32_t c = 0; c < nchunks; c++) {
+            const uint32_t r = c * kMpThreads + tid;
+            const bool is_tok = r < tile_len && ((tok_bits[r >> 5] >> (r & 31u)) & 1u);
+            const bool is_match = is_tok && ((mb[r >> 5] >> (r & 31u)) & 1u);
+            const uint64_t mt = __ballot(is_tok), mm = __ballot(is_match);
+            if (lane == 0)
+                rank_pre[c * kMpWaves + wave] = (uint32_t)__popcll(mt) | ((uint32_t)__popcll(mm) << 17);
+        }
+        __syncthreads();
+        uint32_t tile_tok, tile_mat;
+        {
+            const bool have = tid < nchunks * kMpWaves;
+            const uint32_t v = have ? rank_pre[tid] : 0;
+            const uint32_t vt = v & 0x1FFFFu, vm = v >> 17;
+            const uint32_t it = wave_inclusive_scan(vt, lane), im = wave_inclusive_scan(vm, lane);
+            if (lane == 63) {
+                wsum_t[wave] = it;
+                wsum_m[wave] = im;
+            }
+            __syncthreads();
+            uint32_t bt = 0, bm = 0, tt = 0, tm = 0;
+            for (uint32_t w = 0; w < kMpWaves; w++) {
+                const uint32_t st_ = wsum_t[w], sm_ = wsum_m[w];
+                if (w < wave) {
+                    bt += st_;
+                    bm += sm_;
+                }
+                tt += st_;
+                tm += sm_;
+            }
+            tile_tok = tt;
+            tile_mat = tm;
+            if (have) rank_pre[tid] = (bt + it - vt) | ((bm + im - vm) << 17);
+        }
+        __syncthreads();
+
+        // ---- tokens, then (per sub-block that starts or continues in this tile) the boundaries
+        bool build = true;
+        uint32_t stat_from = sub_start_tok > tok_carry ? sub_start_tok : tok_carry;  // first token not yet tallied
+        for (;;) {
+            if (tid == 0) {
+                bnd = ~0ull;
+                first_check = 0xFFFFFFFFu;
+                split_pos = 0xFFFFFFFFu;
+            }
+            __syncthreads();
+            const uint32_t next_check0 = s_next_check;
+            // pass 1: build tokens (first time), soft-limit / sequence-count boundary, first check
+            for (uint32_t c = 0; c < nchunks; c++) {
+                const uint32_t r = c * kMpThreads + tid;
+                const uint32_t p = tile_begin + r;
+                const bool is_tok = r < tile_len && ((tok_bits[r >> 5] >> (r & 31u)) & 1u);
+                const bool is_match = is_tok && ((mb[r >> 5] >> (r & 31u)) & 1u);
+                const uint64_t mt = __ballot(is_tok), mm = __ballot(is_match);
+                if (!is_tok) continue;
+                const uint32_t pre = rank_pre[c * kMpWaves + wave];
+                const uint32_t ti = tok_carry + (pre & 0x1FFFFu) + (uint32_t)__popcll(mt & lane_below);
+                const uint32_t mi = mat_carry + (pre >> 17) + (uint32_t)__popcll(mm & lane_below);
+                const uint32_t len = is_match ? (uint32_t)len8[r] + 3u : 1u;
+                if (build) tok[ti] = is_match ? (kTokMatch | ((uint32_t)dist[p] << 9) | len) : (uint32_t)in[p];
+                if (p > sub_start && (p >= sub_limit || mi - sub_start_mat >= kHcSeqPerSub))
+                    atomicMin(&bnd, ((unsigned long long)p << 32) | ti);
+                // should_end_block's preconditions for the first check of this sub-block
+                if (next_check0 == kNoCheckYet && ti >= sub_start_tok && ti - sub_start_tok >= 511u &&
+                    p + len - sub_start >= kMinBlockLen)
+                    atomicMin(&first_check, ti);
+            }
+            __syncthreads();
+            const unsigned long long bv = bnd;
+            const uint32_t lim_tok = bv == ~0ull ? 0xFFFFFFFFu : (uint32_t)bv;  // tokens from here are in the next sub-block
+            if (tid == 0 && s_next_check == kNoCheckYet && first_check != 0xFFFFFFFFu) s_next_check = first_check;
+            for (uint32_t i = tid; i < kHpMaxBins * 10; i += kMpThreads) (&bins[0][0])[i] = 0;
+            __syncthreads();
+            const uint32_t nc = s_next_check;  // token index of the first check from here, or a sentinel
+            // pass 2: observation classes per bin (bin 0 = up to and including the first check token)
+            for (uint32_t c = 0; c < nchunks; c++) {
+                const uint32_t r = c * kMpThreads + tid;
+                const uint32_t p = tile_begin + r;
+                const bool is_tok = r < tile_len && ((tok_bits[r >> 5] >> (r & 31u)) & 1u);
+                const bool is_match = is_tok && ((mb[r >> 5] >> (r & 31u)) & 1u);
+                const uint64_t mt = __ballot(is_tok);
+                if (!is_tok) continue;
+                const uint32_t pre = rank_pre[c * kMpWaves + wave];
+                const uint32_t ti = tok_carry + (pre & 0x1FFFFu) + (uint32_t)__popcll(mt & lane_below);
+                if (ti < stat_from || ti >= lim_tok) continue;
+                const uint32_t len = is_match ? (uint32_t)len8[r] + 3u : 1u;
+                uint32_t cls;
+                if (is_match) {
+                    cls = 8u + (len >= 9u ? 1u : 0u);
+                } else {
+                    const uint32_t lit = in[p];
+                    cls = ((lit >> 5) & 6u) | (lit & 1u);
+                }
+                uint32_t bin = 0;
+                if (nc < kNoMoreChecks && ti > nc) bin = 1u + (ti - nc - 1u) / 512u;
+                if (bin < kHpMaxBins) atomicAdd(&bins[bin][cls], 1u);
+                if (nc < kNoMoreChecks && ti >= nc && (ti - nc) % 512u == 0 && (ti - nc) / 512u < kHpMaxBins)
+                    chk_end[(ti - nc) / 512u] = p + len;
+            }
+            __syncthreads();
+            // the checks themselves: a short recurrence (thread 0)
+            if (tid == 0) {
+                const uint32_t last_tok = (lim_tok < tok_carry + tile_tok ? lim_tok : tok_carry + tile_tok);  // exclusive
+                uint32_t nck = s_next_check;
+                for (uint32_t k = 0; k < kHpMaxBins; k++) {
+                    uint32_t cnt = 0;
+                    for (int c = 0; c < 10; c++) {
+                        s_new[c] += bins[k][c];
+                        cnt += bins[k][c];
+                    }
+                    s_num_new += cnt;
+                    if (nck >= kNoMoreChecks || nck >= last_tok) break;  // no check token in range
+                    const uint32_t e = chk_end[k];
+                    const uint32_t blen = e - sub_start;
+                    if (n - e < kMinBlockLen) {  // in_end - in_next < MIN_BLOCK_LENGTH: never again
+                        nck = kNoMoreChecks;
+                        continue;
+                    }
+                    // do_end_block_check
+                    bool end_block = false;
+                    if (s_num_obs > 0) {
+                        uint32_t total_delta = 0;
+                        for (int c = 0; c < 10; c++) {
+                            const uint32_t expected = s_obs[c] * s_num_new, actual = s_new[c] * s_num_obs;
+                            total_delta += actual > expected ? actual - expected : expected - actual;
+                        }
+                        const uint32_t num_items = s_num_obs + s_num_new;
+                        uint32_t cutoff = s_num_new * 200u / 512u * s_num_obs;
+                        if (blen < 10000u && num_items < 8192u)
+                            cutoff += (uint32_t)((unsigned long long)cutoff * (8192u - num_items) / 8192u);
+                        end_block = total_delta + (blen / 4096u) * s_num_obs >= cutoff;
+                    }
+                    if (end_block) {
+                        split_pos = e;
+                        bnd_tok = nck + 1;
+                        break;
+                    }
+                    for (int c = 0; c < 10; c++) {
+                        s_obs[c] += s_new[c];
+                        s_num_obs += s_new[c];
+                        s_new[c] = 0;
+                    }
+                    s_num_new = 0;
+                    nck += 512;
+                }
+                s_next_check = nck;
+            }
+            __syncthreads();
+            // which boundary, if any, ends the sub-block inside this tile
+            uint32_t bp = 0xFFFFFFFFu, bti = 0;
+            if (split_pos != 0xFFFFFFFFu) {
+                bp = split_pos;
+                bti = bnd_tok;
+            } else if (bv != ~0ull) {
+                bp = (uint32_t)(bv >> 32);
+                bti = (uint32_t)bv;
+            }
+            if (bp == 0xFFFFFFFFu) break;  // the sub-block continues in the next tile
+            // matches before the boundary token
+            if (bp >= tile_begin + tile_len) {
+                if (tid == 0) bnd_mat = mat_carry + tile_mat;  // it starts in the next tile
+            } else {
+                const uint32_t r = bp - tile_begin;
+                const uint32_t c = r / kMpThreads;
+                if (wave == (r % kMpThreads) / 64) {
+                    const uint32_t rr = c * kMpThreads + tid;
+                    const bool is_tok = rr < tile_len && ((tok_bits[rr >> 5] >> (rr & 31u)) & 1u);
+                    const bool is_match = is_tok && ((mb[rr >> 5] >> (rr & 31u)) & 1u);
+                    const uint64_t mm = __ballot(is_match);
+                    if (rr == r)
+                        bnd_mat = mat_carry + (rank_pre[c * kMpWaves + wave] >> 17) +
+                                  (uint32_t)__popcll(mm & lane_below);
+                }
+            }
+            __syncthreads();
+            const uint32_t bm = bnd_mat;
+            if (tid == 0) {
+                sub[cur_sub].tok_begin = sub_start_tok;
+                sub[cur_sub].tok_end = bti;
+                sub[cur_sub].byte_begin = sub_start;
+                sub[cur_sub].byte_len = bp - sub_start;
+                sub[cur_sub].is_final = 0;
+                s_next_check = kNoCheckYet;
+                s_num_obs = 0;
+                s_num_new = 0;
+                for (int k = 0; k < 10; k++) {
+                    s_obs[k] = 0;
+                    s_new[k] = 0;
+                }
+            }
+            cur_sub++;
+            sub_start = bp;
+            sub_start_tok = bti;
+            sub_start_mat = bm;
+            sub_limit = hc_sub_limit_of(bp, n);
+            stat_from = bti;
+            const uint32_t new_min_len = hc_calc_min_len(cfg, in, bp, n, used, tid, kMpThreads);
+            __syncthreads();
+            if (new_min_len != min_len) {
+                // match results from bp on were computed with the wrong min_len: another round
+                if (tid == 0) {
+                    st->min_len = new_min_len;
+                    st->resume_pos = bp;
+                    st->tok_carry = bti;
+                    st->mat_carry = bm;
+                    st->cur_sub = cur_sub;
+                    st->rounds++;
+                    atomicAdd(pending, 1u);
+                }
+                return;
+            }
+            build = false;
+        }
+        tok_carry += tile_tok;
+        mat_carry += tile_mat;
+        entry_carry = tile_begin + exit_rel;
+    }
+    if (tid == 0) {
+        sub[cur_sub].tok_begin = sub_start_tok;
+        sub[cur_sub].tok_end = tok_carry;
+        sub[cur_sub].byte_begin = sub_start;
+        sub[cur_sub].byte_len = n - sub_start;
+        sub[cur_sub].is_final = 1;
+        meta->ntok = tok_carry;
+        meta->nsub = cur_sub + 1;
+        st->done = 1;
+    }
+}
+
+__global__ void k_hc_init(uint32_t nb, HcState *hc, uint32_t *pending) {
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b == 0) *pending = 0;
+    if (b >= nb) return;
+    HcState s;
+    s.done = 0;
+    s.min_len = 0;
+    s.resume_pos = 0;
+    s.tok_carry = 0;
+    s.mat_carry = 0;
+    s.cur_sub = 0;
+    s.rounds = 0;
+    s.pad = 0;
+    hc[b] = s;
+}
+
+// ------------------------------------------------------------------------------------------
 // k_hist: litlen / offset symbol frequencies of every DEFLATE sub-block (deflate_choose_literal /
 // deflate_choose_match tallies), from the token stream.  256 threads per block, LDS atomics.
 // ------------------------------------------------------------------------------------------
@@ -722,7 +1322,7 @@ __global__ __launch_bounds__(256) void k_hist(Config cfg, const BlockMeta *__res
     const uint32_t tid = threadIdx.x;
     const uint32_t b = blockIdx.x;
     const BlockMeta *meta = meta_all + b;
-    if (meta->n <= kPassthroughL1) return;
+    if (meta->n <= cfg.passthrough) return;
     const SubMeta *sub = sub_all + (uint64_t)b * cfg.max_sub;
     const uint32_t *tok = tok_all + (uint64_t)b * cfg.stride;
     const uint32_t nsub = meta->nsub;
@@ -931,7 +1531,7 @@ __global__ __launch_bounds__(64) void k_huffman(Config cfg, BlockMeta *__restric
     const uint32_t hdr_len = hdr_len_of(cfg.format);
     const uint32_t eof_len = (meta->is_last && cfg.format == 0) ? 28u : 0u;
 
-    if (n <= kPassthroughL1) {
+    if (n <= cfg.passthrough) {
         // deflate_compress_none: one final stored block
         if (lane == 0) {
             meta->nsub = 1;
@@ -1324,8 +1924,9 @@ __global__ __launch_bounds__(256) void k_scan(uint32_t nb, const BlockMeta *__re
 // CRC32 + ISIZE footer, BGZF_EOF after the last block) in LDS at the byte alignment it will
 // have in the output stream, then write it out with aligned dword stores.
 // ------------------------------------------------------------------------------------------
-// The stage window must hold one whole sub-block (<= 65535 + 5000 bytes of input, stored worst
-// case + 10 header bytes) plus the footer and the EOF marker.
+// The stage is a sliding window over the block's output: when the next piece (a header, 1024
+// tokens, 16 KiB of stored bytes, the footer) might not fit, everything complete is written out
+// and the window moves on.  A 64 KiB BGZF block never needs to slide.
 constexpr uint32_t kStageWords = 18432;  // 72 KiB
 
 __device__ __forceinline__ void stage_or_bits(uint32_t *stage, uint32_t bitpos, uint64_t v) {
@@ -1424,49 +2025,54 @@ __global__ __launch_bounds__(256) void k_emit(Config cfg, const uint8_t *__restr
         }
     }
 
-    const uint32_t payload_bit0 = 8u * (lead + hdr_len);  // aligned coordinates, in bits
     const uint32_t *tok = tok_all + (uint64_t)b * cfg.stride;
     const uint32_t nsub = meta->nsub;
+    // bit cursor, relative to the window (stage[0] = aligned coordinate win_base)
+    uint32_t bitpos = 8u * (lead + hdr_len);
+    // Make room for `need_bits` more bits (+ slack for the 3-word OR) by writing out every
+    // complete dword and sliding the window so that the dword being filled becomes stage[0].
+    // Uniform: all threads call it at the same points.
+    auto ensure = [&](uint32_t need_bits) {
+        if (((bitpos + need_bits + 7) >> 3) + 16u <= 4u * kStageWords) return;
+        __syncthreads();
+        const uint32_t upto_rel = (bitpos >> 3) & ~3u;
+        stage_flush(stage, dst_aligned, win_base, win_base + upto_rel, lead, end_byte, tid);
+        const uint32_t keep = stage[upto_rel >> 2];
+        __syncthreads();
+        for (uint32_t i = tid; i < kStageWords; i += 256) stage[i] = 0;
+        __syncthreads();
+        if (tid == 0) stage[0] = keep;
+        win_base += upto_rel;
+        bitpos -= 8u * upto_rel;
+        __syncthreads();
+    };
     for (uint32_t s = 0; s < nsub; s++) {
         const SubMeta sm = sub[s];
-        // everything this sub-block (and, after the last one, the footer + EOF) will touch must
-        // lie inside the window; if not, write out what is complete and slide the window
-        {
-            const uint32_t sub_end_bits = payload_bit0 + (s + 1 < nsub ? sub[s + 1].bit_begin : 8u * c);
-            const uint32_t need_end = ((sub_end_bits + 7) >> 3) + (s + 1 == nsub ? 8u + 28u : 0u) + 16u;
-            if (need_end > win_base + 4 * kStageWords) {
-                const uint32_t upto = ((payload_bit0 + sm.bit_begin) >> 3) & ~3u;
-                __syncthreads();
-                stage_flush(stage, dst_aligned, win_base, upto, lead, end_byte, tid);
-                const uint32_t keep = stage[(upto - win_base) >> 2];  // the dword being filled
-                __syncthreads();
-                for (uint32_t i = tid; i < kStageWords; i += 256) stage[i] = 0;
-                __syncthreads();
-                if (tid == 0) stage[0] = keep;
-                win_base = upto;
-                __syncthreads();
-            }
-        }
-        uint32_t bitpos = payload_bit0 + sm.bit_begin - 8u * win_base;  // window-relative
+        // (sm.bit_begin is where this sub-block starts inside the payload; the cursor is there)
         if (sm.type == kStored) {
             uint32_t left = sm.byte_len, src = sm.byte_begin;
             do {
                 const uint32_t chunk = left > 65535u ? 65535u : left;
                 const bool last_chunk = chunk == left;
-                if (tid == 0) {
-                    stage_or_bits(stage, bitpos, (sm.is_final && last_chunk) ? 1u : 0u);
-                }
+                ensure(64);
+                if (tid == 0) stage_or_bits(stage, bitpos, (sm.is_final && last_chunk) ? 1u : 0u);
                 bitpos = (bitpos + 3 + 7u) & ~7u;
-                const uint32_t bytepos = bitpos >> 3;
                 if (tid == 0) {
+                    const uint32_t bytepos = bitpos >> 3;
                     stage_put_byte(stage, bytepos + 0, chunk);
                     stage_put_byte(stage, bytepos + 1, chunk >> 8);
                     stage_put_byte(stage, bytepos + 2, ~chunk);
                     stage_put_byte(stage, bytepos + 3, (~chunk) >> 8);
                 }
-                for (uint32_t i = tid; i < chunk; i += 256)
-                    stage_put_byte(stage, bytepos + 4 + i, in[src + i]);
-                bitpos += 32 + 8 * chunk;
+                bitpos += 32;
+                for (uint32_t done = 0; done < chunk; done += 16384u) {  // raw bytes, 16 KiB at a time
+                    const uint32_t piece = chunk - done < 16384u ? chunk - done : 16384u;
+                    ensure(8u * piece);
+                    const uint32_t bytepos = bitpos >> 3;
+                    for (uint32_t i = tid; i < piece; i += 256)
+                        stage_put_byte(stage, bytepos + i, in[src + done + i]);
+                    bitpos += 8u * piece;
+                }
                 src += chunk;
                 left -= chunk;
             } while (left);
@@ -1474,16 +2080,19 @@ __global__ __launch_bounds__(256) void k_emit(Config cfg, const uint8_t *__restr
             continue;
         }
         // ---- Huffman-coded sub-block: header bits, tokens, end-of-block
+        __syncthreads();  // the previous sub-block is done with `codes`
         const uint32_t *cd = codes_all + ((uint64_t)b * cfg.max_sub + s) * kCodeWords;
         for (uint32_t i = tid; i < kCodeWords; i += 256) codes[i] = cd[i];
         const uint32_t *hw = hdr_all + ((uint64_t)b * cfg.max_sub + s) * kHdrWords;
         const uint32_t nhw = (sm.hdr_bits + 31) >> 5;
+        ensure(32u * kHdrWords);
         for (uint32_t i = tid; i < nhw; i += 256) stage_or_bits(stage, bitpos + 32 * i, hw[i]);
         bitpos += sm.hdr_bits;
         __syncthreads();
         // 4 consecutive tokens per thread: one workgroup scan per 1024 tokens, and neighbouring
         // codewords are merged into <= 64-bit pieces before they are OR-ed into the staging buffer
         for (uint32_t tb = sm.tok_begin; tb < sm.tok_end; tb += 1024) {
+            ensure(1024u * 48u);
             const uint32_t t0 = tb + 4 * tid;
             uint64_t bits[4];
             uint32_t nbits[4], sum = 0;
@@ -1535,14 +2144,17 @@ __global__ __launch_bounds__(256) void k_emit(Config cfg, const uint8_t *__restr
             if (accn) stage_or_bits(stage, off_bits, acc);
             bitpos += total;
         }
+        ensure(64);
         if (tid == 0) {
             const uint32_t ec = codes[256];
             stage_or_bits(stage, bitpos, ec & 0xFFFFu);
         }
+        bitpos += codes[256] >> 16;
         __syncthreads();
     }
 
     // ---- footer (src/bgzf.rs:233-234) and, after the stream's last block, BGZF_EOF
+    ensure(8u * (8u + 28u + 8u));
     if (tid == 0) {
         const uint32_t fb = lead + hdr_len + c - win_base;
         const uint32_t crc = meta->crc;
@@ -1570,16 +2182,27 @@ void launch_init_meta(const Config &cfg, uint64_t slab_len, uint32_t nb, int is_
                        (uint32_t)(is_last ? 1 : 0), s.meta);
 }
 
-void launch_candidates(const Config &cfg, const uint8_t *slab, uint64_t, uint32_t nb, const Scratch &s,
-                       hipStream_t stream) {
+template <int MODE>
+static void launch_candidates_mode(const Config &cfg, const uint8_t *slab, uint32_t nb, BlockMeta *meta,
+                                   uint16_t *out, hipStream_t stream) {
     const uint32_t force_safe = cfg.debug & 1u;  // diagnostics: exercise the fallback on every block
     if (!force_safe)
-        hipLaunchKernelGGL(k_candidates, dim3(nb), dim3(64 * kCandWaves), 0, stream, cfg, slab, s.meta,
-                           s.cand);
+        hipLaunchKernelGGL(k_candidates<MODE>, dim3(nb), dim3(64 * kCandWaves), 0, stream, cfg, slab, meta, out);
     // blocks flagged by the order check (none expected) are redone order-independently
     const uint32_t grid = force_safe ? nb : (nb < 256u ? nb : 256u);
-    hipLaunchKernelGGL(k_candidates_safe, dim3(grid), dim3(64), 0, stream, cfg, slab, s.meta, nb,
-                       force_safe, s.cand);
+    hipLaunchKernelGGL(k_candidates_safe<MODE>, dim3(grid), dim3(64), 0, stream, cfg, slab, meta, nb,
+                       force_safe, out);
+}
+
+void launch_candidates(const Config &cfg, const uint8_t *slab, uint64_t, uint32_t nb, const Scratch &s,
+                       hipStream_t stream) {
+    if (cfg.level == 1) {
+        launch_candidates_mode<0>(cfg, slab, nb, s.meta, s.cand, stream);
+    } else {  // hc_matchfinder: hash3 predecessor in cand, hash4 chain links in d4
+        launch_candidates_mode<1>(cfg, slab, nb, s.meta, s.cand, stream);
+        launch_candidates_mode<2>(cfg, slab, nb, s.meta, s.d4, stream);
+        launch_candidates_mode<3>(cfg, slab, nb, s.meta, s.d4, stream);
+    }
 }
 
 void launch_match(const Config &cfg, const uint8_t *slab, uint64_t, uint32_t nb, const Scratch &s,
@@ -1593,6 +2216,17 @@ void launch_parse(const Config &cfg, const uint8_t *slab, uint64_t, uint32_t nb,
     hipLaunchKernelGGL(k_parse, dim3(nb), dim3(kMpThreads), 0, stream, cfg, slab, s.meta, s.sub,
                        (const uint16_t *)s.cand, (const uint8_t *)s.len8, (const uint32_t *)s.which,
                        (const uint16_t *)s.alt, s.tok);
+}
+
+void launch_hc_round(const Config &cfg, const uint8_t *slab, uint32_t nb, const Scratch &s, int first,
+                     hipStream_t stream) {
+    if (first) hipLaunchKernelGGL(k_hc_init, dim3((nb + 255) / 256), dim3(256), 0, stream, nb, s.hc, s.pending);
+    else (void)hipMemsetAsync(s.pending, 0, sizeof(uint32_t), stream);
+    hipLaunchKernelGGL(k_match_hc, dim3(nb), dim3(1024), 0, stream, cfg, slab, (const BlockMeta *)s.meta, s.hc,
+                       (const uint16_t *)s.cand, (const uint16_t *)s.d4, s.len8, s.which, s.alt);
+    hipLaunchKernelGGL(k_parse_hc, dim3(nb), dim3(kMpThreads), 0, stream, cfg, slab, s.meta, s.sub, s.hc,
+                       (const uint8_t *)s.len8, (const uint32_t *)s.which, (const uint16_t *)s.alt, s.tok,
+                       s.pending);
 }
 
 void launch_hist(const Config &cfg, uint32_t nb, const Scratch &s, hipStream_t stream) {

@@ -171,6 +171,45 @@ def main():
         e.update(entry(s))
         streams.append(e)
 
+    # ---- levels 2-4 (greedy hc_matchfinder): gzp's DEFAULT level is 3 (src/par/compress.rs:54-62)
+    hc_raw = []
+    for level in (2, 3, 4):
+        for cls in synth.CLASSES:
+            for n in (0, 43, 44, 47, 48, 300, 512, 4096, 5000, 32769, 65280):
+                seed = 2000 + n
+                a = synth.make(cls, n, seed)
+                e = {"class": cls, "n": n, "seed": seed, "level": level}
+                e.update(entry(ld_deflate(a, level)))
+                hc_raw.append(e)
+    for level, cls, n in [(3, "text", 1 << 20), (3, "ascii", 1 << 20), (3, "fastq", 1 << 20), (3, "mixed", 700000),
+                          (2, "text", 400000), (4, "repeats", 400000), (3, "dna", 305001), (3, "text", 304999)]:
+        a = synth.make(cls, n, 78)
+        e = {"class": cls, "n": n, "seed": 78, "level": level}
+        e.update(entry(ld_deflate(a, level)))
+        hc_raw.append(e)
+    hc_streams = []
+    for fmt, bs, level, cases in [
+        ("bgzf", 65280, 3, [("text", 0), ("text", 65280), ("text", 3 * 65280 + 1234), ("mixed", 300000),
+                            ("fastq", 200000), ("random", 70000)]),
+        ("bgzf", 65280, 2, [("text", 200000)]),
+        ("bgzf", 65280, 4, [("repeats", 200000)]),
+        ("mgzip", 1 << 20, 3, [("ascii", (1 << 20) + 7), ("text", 2 * (1 << 20))]),  # BASELINE config 3 shape
+        ("mgzip", 131072, 3, [("mixed", 500000)]),
+    ]:
+        for cls, n in cases:
+            a = synth.make(cls, n, 4343)
+            st, blk = frame_stream(a, level, fmt, bs)
+            e = {"fmt": fmt, "buffer_size": bs, "class": cls, "n": n, "seed": 4343, "level": level,
+                 "block_sizes": blk}
+            e.update(entry(st))
+            hc_streams.append(e)
+    with open(os.path.join(HERE, "l234_vectors.json"), "w") as f:
+        json.dump({"generator": "tests/golden/make_golden.py",
+                   "libdeflate": "v1.10 binary (Ubuntu libdeflate0 1.10-2), compat=1.10",
+                   "raw_deflate": hc_raw, "streams": hc_streams}, f, indent=0, separators=(",", ":"))
+        f.write("\n")
+    print("wrote %d raw, %d stream vectors for levels 2-4" % (len(hc_raw), len(hc_streams)))
+
     doc = {
         "generator": "tests/golden/make_golden.py",
         "libdeflate": "v1.10 binary (Ubuntu libdeflate0 1.10-2), compat=1.10",

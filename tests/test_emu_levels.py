@@ -1,0 +1,67 @@
+"""Levels 2-4 (greedy hc_matchfinder; 3 is gzp's default level) through the emulated kernels:
+golden vectors of the libdeflate 1.10 binary + oracle comparisons.  No GPU."""
+import hashlib
+
+import numpy as np
+import pytest
+
+from gzp_amd import _native, synth
+
+
+def hetero(n, seed):
+    """Unlike segments back to back: makes should_end_block split sub-blocks and the split-off
+    part need another min_len (a second match/parse round)."""
+    rng = np.random.default_rng(seed)
+    names = ["dna", "random", "text", "zeros", "lowent", "fastq", "ascii", "runs"]
+    parts, size = [], 0
+    while size < n:
+        ln = int(rng.integers(3000, 60000))
+        parts.append(synth.make(names[rng.integers(len(names))], ln, int(rng.integers(1 << 30))))
+        size += ln
+    return np.ascontiguousarray(np.concatenate(parts)[:n])
+
+
+def test_golden_raw_deflate_levels(emu_lib, golden_hc):
+    comps = {L: _native.Compressor(L, _native.COMPAT_1_10, lib=emu_lib) for L in (2, 3, 4)}
+    for e in golden_hc["raw_deflate"]:
+        if e["n"] > 400000 and e["level"] != 3:
+            continue
+        a = synth.make(e["class"], e["n"], e["seed"])
+        assert hashlib.sha256(comps[e["level"]].deflate_compress(a)).hexdigest() == e["sha256"], e
+    for c in comps.values():
+        c.close()
+
+
+def test_golden_streams_levels(emu_lib, golden_hc):
+    for e in golden_hc["streams"]:
+        a = synth.make(e["class"], e["n"], e["seed"])
+        fmt = _native.FORMAT_BGZF if e["fmt"] == "bgzf" else _native.FORMAT_MGZIP
+        with _native.Context(format=fmt, level=e["level"], buffer_size=e["buffer_size"],
+                             compat=_native.COMPAT_1_10, lib=emu_lib, max_slab_bytes=max(a.size, 1)) as c:
+            out, sizes = c.compress_slab(a, True, return_block_sizes=True)
+        assert hashlib.sha256(out).hexdigest() == e["sha256"], e
+        assert list(sizes) == e["block_sizes"]
+
+
+@pytest.mark.parametrize("level", [2, 3, 4])
+def test_heterogeneous_blocks_vs_oracle(emu_lib, oracle, level):
+    for fmt, ofmt, bs, n in [(_native.FORMAT_BGZF, 0, 65280, 4 * 65280 + 99), (_native.FORMAT_MGZIP, 1, 1 << 20, (1 << 20) + 4321),
+                             (_native.FORMAT_MGZIP, 1, 300001, 700000)]:
+        a = hetero(n, 10 * level + bs % 7)
+        for compat in (_native.COMPAT_1_10, _native.COMPAT_1_24):
+            with _native.Context(format=fmt, level=level, buffer_size=bs, compat=compat, lib=emu_lib,
+                                 max_slab_bytes=n) as c:
+                got = c.compress_slab(a, True)
+            assert got == oracle.compress_stream(a, ofmt, level, compat, bs), (level, fmt, bs, compat)
+
+
+def test_default_level_of_the_builder_is_3(emu_lib, oracle):
+    import io
+    from gzp_amd import par
+    a = synth.make("text", 150000, 8)
+    sink = io.BytesIO()
+    w = par.ParCompressBuilder(par.Bgzf, lib=emu_lib).compat(_native.COMPAT_1_10).from_writer(sink)  # level 3
+    w.write_all(a)
+    w.finish()
+    w.close()
+    assert sink.getvalue() == oracle.compress_stream(a, oracle.FMT_BGZF, 3, oracle.COMPAT_1_10, 65280)

@@ -1,0 +1,70 @@
+"""Levels 2-4 (greedy hc_matchfinder; gzp's default level is 3) on the real HIP library."""
+import gzip
+import hashlib
+import io
+
+import numpy as np
+import pytest
+
+from gzp_amd import _native, par, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def hetero(n, seed):
+    rng = np.random.default_rng(seed)
+    names = ["dna", "random", "text", "zeros", "lowent", "fastq", "ascii", "runs"]
+    parts, size = [], 0
+    while size < n:
+        ln = int(rng.integers(3000, 60000))
+        parts.append(synth.make(names[rng.integers(len(names))], ln, int(rng.integers(1 << 30))))
+        size += ln
+    return np.ascontiguousarray(np.concatenate(parts)[:n])
+
+
+def test_golden_vectors_levels(hip_lib, golden_hc):
+    comps = {L: _native.Compressor(L, _native.COMPAT_1_10, lib=hip_lib) for L in (2, 3, 4)}
+    for e in golden_hc["raw_deflate"]:
+        a = synth.make(e["class"], e["n"], e["seed"])
+        assert hashlib.sha256(comps[e["level"]].deflate_compress(a)).hexdigest() == e["sha256"], e
+    for c in comps.values():
+        c.close()
+    for e in golden_hc["streams"]:
+        a = synth.make(e["class"], e["n"], e["seed"])
+        fmt = _native.FORMAT_BGZF if e["fmt"] == "bgzf" else _native.FORMAT_MGZIP
+        with _native.Context(format=fmt, level=e["level"], buffer_size=e["buffer_size"],
+                             compat=_native.COMPAT_1_10, lib=hip_lib, max_slab_bytes=max(a.size, 1)) as c:
+            out, sizes = c.compress_slab(a, True, return_block_sizes=True)
+        assert hashlib.sha256(out).hexdigest() == e["sha256"], e
+        assert list(sizes) == e["block_sizes"]
+
+
+@pytest.mark.parametrize("level", [2, 3, 4])
+def test_heterogeneous_blocks_vs_oracle(hip_lib, oracle, level):
+    for fmt, ofmt, bs, n in [(_native.FORMAT_BGZF, 0, 65280, 40 * 65280 + 99),
+                             (_native.FORMAT_MGZIP, 1, 1 << 20, 5 * (1 << 20) + 4321)]:
+        a = hetero(n, 10 * level + bs % 7)
+        with _native.Context(format=fmt, level=level, buffer_size=bs, compat=_native.COMPAT_1_24, lib=hip_lib,
+                             max_slab_bytes=n) as c:
+            got = c.compress_slab(a, True)
+        assert got == oracle.compress_stream(a, ofmt, level, oracle.COMPAT_1_24, bs), (level, fmt, bs)
+        assert gzip.decompress(got) == a.tobytes()
+
+
+def test_config3_shape_mgzip_1mib_level3(hip_lib, oracle):
+    """BASELINE config 3 in small: Mgzip, 1 MiB blocks, level 3, ASCII noise (0x20 + u8 % 95)."""
+    a = synth.ascii_random(16 * (1 << 20) + 5, 99)
+    with _native.Context(format=_native.FORMAT_MGZIP, level=3, buffer_size=1 << 20, lib=hip_lib,
+                         max_slab_bytes=a.size) as c:
+        got = c.compress_slab(a, True)
+    assert got == oracle.compress_stream(a, oracle.FMT_MGZIP, 3, oracle.COMPAT_1_24, 1 << 20)
+
+
+def test_builder_default_level(hip_lib, oracle):
+    a = synth.text_slab(20 * 65280 + 5, 2_000_000, 3)
+    sink = io.BytesIO()
+    w = par.ParCompressBuilder(par.Bgzf, lib=hip_lib).batch_blocks(4).from_writer(sink)  # level 3
+    w.write_all(a)
+    w.finish()
+    w.close()
+    assert sink.getvalue() == oracle.compress_stream(a, oracle.FMT_BGZF, 3, oracle.COMPAT_1_24, 65280)

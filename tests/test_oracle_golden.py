@@ -80,3 +80,17 @@ def test_huffman_code_is_prefix_free_and_length_limited(oracle):
         used = lens[lens > 0].astype(np.int64)
         if (f > 0).sum() >= 2:
             assert np.sum(2.0 ** -used) == pytest.approx(1.0)  # complete code
+
+
+def test_levels_2_to_4_match_libdeflate_vectors(oracle, golden_hc):
+    for e in golden_hc["raw_deflate"]:
+        a = synth.make(e["class"], e["n"], e["seed"])
+        out = oracle.deflate_compress(a, e["level"], oracle.COMPAT_1_10)
+        assert hashlib.sha256(out).hexdigest() == e["sha256"], e
+        assert zlib.decompress(out, -15) == a.tobytes()
+    for e in golden_hc["streams"]:
+        a = synth.make(e["class"], e["n"], e["seed"])
+        fmt = oracle.FMT_BGZF if e["fmt"] == "bgzf" else oracle.FMT_MGZIP
+        out, sizes = oracle.compress_stream(a, fmt, e["level"], oracle.COMPAT_1_10, e["buffer_size"], True)
+        assert hashlib.sha256(out).hexdigest() == e["sha256"], e
+        assert list(sizes) == e["block_sizes"]
