@@ -23,6 +23,9 @@ ERR_UNSUPPORTED = 8
 ERR_NUM_THREADS = 9
 ERR_IO = 10
 ERR_CHANNEL = 11
+ERR_INVALID_HEADER = 12
+ERR_INVALID_CHECK = 13
+ERR_BAD_DATA = 14
 
 SLAB_FULL_BLOCKS = 0
 SLAB_LAST = 1
@@ -56,6 +59,11 @@ class GzpxParConfig(ctypes.Structure):
                 ("num_threads", ctypes.c_size_t), ("batch_blocks", ctypes.c_size_t)]
 
 
+class GzpxCheckInfo(ctypes.Structure):
+    _fields_ = [("block", ctypes.c_size_t), ("found", ctypes.c_uint32), ("expected", ctypes.c_uint32)]
+
+
+READ_FN = ctypes.CFUNCTYPE(ctypes.c_long, ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint8), ctypes.c_size_t)
 WRITE_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint8), ctypes.c_size_t)
 
 
@@ -143,6 +151,31 @@ class GzpxLib:
         L.gzpx_par_destroy.argtypes = [vp]
         L.gzpx_par_last_error.restype = ctypes.c_char_p
         L.gzpx_par_last_error.argtypes = [vp]
+        pinfo = ctypes.POINTER(GzpxCheckInfo)
+        L.gzpx_dctx_create.restype = i32
+        L.gzpx_dctx_create.argtypes = [i32, i32, ctypes.POINTER(vp)]
+        L.gzpx_dctx_destroy.restype = None
+        L.gzpx_dctx_destroy.argtypes = [vp]
+        L.gzpx_scan_blocks.restype = i32
+        L.gzpx_scan_blocks.argtypes = [i32, vp, sz, vp, vp, sz, psz, psz]
+        L.gzpx_decompress_blocks.restype = i32
+        L.gzpx_decompress_blocks.argtypes = [vp, vp, sz, vp, vp, sz, vp, sz, psz, pinfo]
+        L.gzpx_decompress_blocks_device.restype = i32
+        L.gzpx_decompress_blocks_device.argtypes = [vp, vp, sz, vp, vp, sz, vp, sz, psz, pinfo, vp]
+        L.gzpx_alloc_decompressor.restype = vp
+        L.gzpx_alloc_decompressor.argtypes = []
+        L.gzpx_deflate_decompress.restype = i32
+        L.gzpx_deflate_decompress.argtypes = [vp, vp, sz, vp, sz, psz]
+        L.gzpx_free_decompressor.restype = None
+        L.gzpx_free_decompressor.argtypes = [vp]
+        L.gzpx_pard_create.restype = i32
+        L.gzpx_pard_create.argtypes = [i32, i32, sz, READ_FN, vp, ctypes.POINTER(vp)]
+        L.gzpx_pard_read.restype = i32
+        L.gzpx_pard_read.argtypes = [vp, vp, sz, psz]
+        L.gzpx_pard_destroy.restype = None
+        L.gzpx_pard_destroy.argtypes = [vp]
+        L.gzpx_pard_last_error.restype = ctypes.c_char_p
+        L.gzpx_pard_last_error.argtypes = [vp]
 
     def strerror(self, code):
         return self.L.gzpx_strerror(code).decode()
@@ -334,3 +367,109 @@ def crc32(data, crc=0, lib=None):
     lib = lib or load()
     a = _u8(data)
     return int(lib.L.gzpx_crc32(crc, a.ctypes.data, a.size))
+
+
+class DContext:
+    """gzpx_dctx: the GPU side of ParDecompress<Bgzf/Mgzip> (create_decompressor + decode_block +
+    the per-block CRC check, for every block of a slab at once)."""
+
+    def __init__(self, format=FORMAT_BGZF, device=0, lib=None):
+        self.lib = lib or load()
+        self.format = format
+        h = ctypes.c_void_p()
+        self.lib.check(self.lib.L.gzpx_dctx_create(device, format, ctypes.byref(h)))
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.L.gzpx_dctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def scan_blocks(self, data):
+        """(offsets uint64[], sizes uint32[], consumed) of the complete blocks in `data`."""
+        a = _u8(data)
+        nb = ctypes.c_size_t(0)
+        used = ctypes.c_size_t(0)
+        self.lib.check(self.lib.L.gzpx_scan_blocks(self.format, a.ctypes.data, a.size, None, None, 0,
+                                                   ctypes.byref(nb), ctypes.byref(used)))
+        offs = np.zeros(max(nb.value, 1), dtype=np.uint64)
+        sizes = np.zeros(max(nb.value, 1), dtype=np.uint32)
+        self.lib.check(self.lib.L.gzpx_scan_blocks(self.format, a.ctypes.data, a.size, offs.ctypes.data,
+                                                   sizes.ctypes.data, offs.size, ctypes.byref(nb),
+                                                   ctypes.byref(used)))
+        return offs[:nb.value], sizes[:nb.value], used.value
+
+    def _raise(self, rc, info):
+        if rc == ERR_INVALID_CHECK:
+            raise GzpxError(rc, "InvalidCheck { found: %d, expected: %d }" % (info.found, info.expected), info.block)
+        raise GzpxError(rc, self.lib.strerror(rc), info.block)
+
+    def decompress(self, data):
+        """Host bytes of whole blocks in, inflated bytes out."""
+        a = _u8(data)
+        offs, sizes, used = self.scan_blocks(a)
+        if used != a.size:
+            raise GzpxError(ERR_INVALID_ARG, "trailing partial block (%d bytes)" % (a.size - used))
+        isz = 0
+        for o, s_ in zip(offs, sizes):
+            e = int(o) + int(s_)
+            isz += int.from_bytes(a[e - 4:e].tobytes(), "little")
+        out = np.empty(max(isz, 1), dtype=np.uint8)
+        out_len = ctypes.c_size_t(0)
+        info = GzpxCheckInfo()
+        rc = self.lib.L.gzpx_decompress_blocks(self.h, a.ctypes.data, a.size, offs.ctypes.data,
+                                               sizes.ctypes.data, offs.size, out.ctypes.data, isz,
+                                               ctypes.byref(out_len), ctypes.byref(info))
+        if rc != OK:
+            self._raise(rc, info)
+        return out[:out_len.value].tobytes()
+
+    def decompress_device(self, d_in_ptr, in_len, offsets, sizes, d_out_ptr, out_cap, stream=None):
+        out_len = ctypes.c_size_t(0)
+        info = GzpxCheckInfo()
+        rc = self.lib.L.gzpx_decompress_blocks_device(self.h, d_in_ptr, in_len, offsets.ctypes.data,
+                                                      sizes.ctypes.data, offsets.size, d_out_ptr, out_cap,
+                                                      ctypes.byref(out_len), ctypes.byref(info), stream)
+        if rc != OK:
+            self._raise(rc, info)
+        return out_len.value
+
+
+class Decompressor:
+    """libdeflater::Decompressor shape: deflate_decompress(raw, out_size)."""
+
+    def __init__(self, lib=None):
+        self.lib = lib or load()
+        self.h = self.lib.L.gzpx_alloc_decompressor()
+
+    def deflate_decompress(self, data, out_size):
+        a = _u8(data)
+        out = np.empty(max(out_size, 1), dtype=np.uint8)
+        actual = ctypes.c_size_t(0)
+        rc = self.lib.L.gzpx_deflate_decompress(self.h, a.ctypes.data, a.size, out.ctypes.data, out_size,
+                                                ctypes.byref(actual))
+        self.lib.check(rc)
+        return out[:actual.value].tobytes()
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.L.gzpx_free_decompressor(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

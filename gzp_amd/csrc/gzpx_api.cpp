@@ -544,6 +544,260 @@ uint32_t gzpx_crc32(uint32_t crc, const void *buf, size_t n) {
     return crc;
 }
 
+// ---------------------------------------------------------------- ParDecompress side
+struct gzpx_dctx {
+    int device = 0;
+    int format = 0;
+    CrcConsts cc;
+    hipStream_t stream = nullptr;
+    size_t cap_blocks = 0;
+    uint64_t *d_offsets = nullptr, *d_out_off = nullptr;
+    uint32_t *d_sizes = nullptr, *d_crc = nullptr;
+    DBlockHost *d_blk = nullptr;
+    DBlockHost *h_blk = nullptr;
+    uint32_t *h_crc = nullptr;
+    uint64_t *h_total = nullptr;
+    uint8_t *d_in = nullptr, *d_out = nullptr;
+    size_t d_in_cap = 0, d_out_cap = 0;
+    std::mutex mu;
+};
+
+namespace {
+
+void dctx_free_tables(gzpx_dctx *c) {
+    if (c->d_offsets) (void)hipFree(c->d_offsets);
+    if (c->d_out_off) (void)hipFree(c->d_out_off);
+    if (c->d_sizes) (void)hipFree(c->d_sizes);
+    if (c->d_crc) (void)hipFree(c->d_crc);
+    if (c->d_blk) (void)hipFree(c->d_blk);
+    if (c->h_blk) (void)hipHostFree(c->h_blk);
+    if (c->h_crc) (void)hipHostFree(c->h_crc);
+    c->d_offsets = c->d_out_off = nullptr;
+    c->d_sizes = c->d_crc = nullptr;
+    c->d_blk = c->h_blk = nullptr;
+    c->h_crc = nullptr;
+    c->cap_blocks = 0;
+}
+
+int dctx_reserve(gzpx_dctx *c, size_t nb) {
+    if (nb <= c->cap_blocks) return GZPX_OK;
+    dctx_free_tables(c);
+    const size_t cap = nb + nb / 4 + 64;
+    HIP_TRY(hipMalloc((void **)&c->d_offsets, cap * 8));
+    HIP_TRY(hipMalloc((void **)&c->d_out_off, (cap + 1) * 8));
+    HIP_TRY(hipMalloc((void **)&c->d_sizes, cap * 4));
+    HIP_TRY(hipMalloc((void **)&c->d_crc, cap * 4));
+    HIP_TRY(hipMalloc((void **)&c->d_blk, cap * sizeof(DBlockHost)));
+    HIP_TRY(hipHostMalloc((void **)&c->h_blk, cap * sizeof(DBlockHost), hipHostMallocDefault));
+    HIP_TRY(hipHostMalloc((void **)&c->h_crc, cap * 4, hipHostMallocDefault));
+    c->cap_blocks = cap;
+    return GZPX_OK;
+}
+
+int decompress_device_locked(gzpx_dctx *c, const uint8_t *d_in, size_t in_len, const uint64_t *offsets,
+                             const uint32_t *sizes, size_t nb, uint8_t *d_out, size_t out_cap,
+                             size_t *out_len, gzpx_check_info *info, hipStream_t stream) {
+    if (!out_len || (nb && (!offsets || !sizes || !d_in))) return GZPX_ERR_INVALID_ARG;
+    *out_len = 0;
+    if (nb == 0) return GZPX_OK;
+    const uint32_t hdr_len = c->format == GZPX_FORMAT_BGZF ? 18 : 20;
+    for (size_t b = 0; b < nb; b++)
+        if (sizes[b] < hdr_len + 8 || offsets[b] + sizes[b] > in_len) return GZPX_ERR_INVALID_ARG;
+    int rc = dctx_reserve(c, nb);
+    if (rc != GZPX_OK) return rc;
+    if (!stream) stream = c->stream;
+    HIP_TRY(hipMemcpyAsync(c->d_offsets, offsets, nb * 8, hipMemcpyHostToDevice, stream));
+    HIP_TRY(hipMemcpyAsync(c->d_sizes, sizes, nb * 4, hipMemcpyHostToDevice, stream));
+    launch_inflate(hdr_len, d_in, c->d_offsets, c->d_sizes, (uint32_t)nb, c->d_blk, c->d_out_off, d_out, out_cap,
+                   c->d_crc, c->cc, stream);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(c->h_blk, c->d_blk, nb * sizeof(DBlockHost), hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipMemcpyAsync(c->h_crc, c->d_crc, nb * 4, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipMemcpyAsync(c->h_total, c->d_out_off + nb, 8, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    for (size_t b = 0; b < nb; b++) {  // first failing block, in stream order (src/par/decompress.rs:162-186)
+        const DBlockHost &d = c->h_blk[b];
+        int err = GZPX_OK;
+        if (d.status == 1) err = GZPX_ERR_BAD_DATA;
+        else if (d.status == 2) err = GZPX_ERR_INSUFFICIENT_SPACE;
+        else if (c->h_crc[b] != d.crc) err = GZPX_ERR_INVALID_CHECK;
+        if (err != GZPX_OK) {
+            if (info) {
+                info->block = b;
+                info->found = c->h_crc[b];
+                info->expected = d.crc;
+            }
+            return err;
+        }
+    }
+    *out_len = (size_t)*c->h_total;
+    return GZPX_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int gzpx_dctx_create(int device, int format, gzpx_dctx **out) {
+    if (!out || (format != GZPX_FORMAT_BGZF && format != GZPX_FORMAT_MGZIP)) return GZPX_ERR_INVALID_ARG;
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return GZPX_ERR_NO_DEVICE;
+    if (device < 0 || device >= ndev) return GZPX_ERR_INVALID_ARG;
+    if (hipSetDevice(device) != hipSuccess) return GZPX_ERR_DEVICE;
+    gzpx_dctx *c = new (std::nothrow) gzpx_dctx();
+    if (!c) return GZPX_ERR_DEVICE;
+    c->device = device;
+    c->format = format;
+    for (unsigned l = 0; l < 8; l++) c->cc.pow256[l] = x2k(11 + l);
+    c->cc.pow_tile = x2k(19);
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipHostMalloc((void **)&c->h_total, 64, hipHostMallocDefault) != hipSuccess) {
+        gzpx_dctx_destroy(c);
+        return GZPX_ERR_DEVICE;
+    }
+    *out = c;
+    return GZPX_OK;
+}
+
+void gzpx_dctx_destroy(gzpx_dctx *c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    dctx_free_tables(c);
+    if (c->h_total) (void)hipHostFree(c->h_total);
+    if (c->d_in) (void)hipFree(c->d_in);
+    if (c->d_out) (void)hipFree(c->d_out);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int gzpx_scan_blocks(int format, const uint8_t *in, size_t in_len, uint64_t *offsets, uint32_t *sizes,
+                     size_t max_blocks, size_t *n_blocks, size_t *consumed) {
+    if ((!in && in_len) || !n_blocks || !consumed) return GZPX_ERR_INVALID_ARG;
+    const size_t hdr = format == GZPX_FORMAT_BGZF ? 18 : 20;  // BlockFormatSpec::HEADER_SIZE
+    size_t pos = 0, nb = 0;
+    *n_blocks = 0;
+    *consumed = 0;
+    while (in_len - pos >= hdr) {  // read_exact(header) succeeds
+        const uint8_t *h = in + pos;
+        if ((h[3] & 4) != 4) return GZPX_ERR_INVALID_HEADER;  // "Extra field flag not set"
+        if (format == GZPX_FORMAT_BGZF ? (h[12] != 'B' || h[13] != 'C') : (h[12] != 'I' || h[13] != 'G'))
+            return GZPX_ERR_INVALID_HEADER;  // "Bad SID"
+        const size_t size = format == GZPX_FORMAT_BGZF
+                                ? (size_t)(h[16] | (h[17] << 8)) + 1
+                                : (size_t)h[16] | ((size_t)h[17] << 8) | ((size_t)h[18] << 16) | ((size_t)h[19] << 24);
+        if (size < hdr + 8) return GZPX_ERR_INVALID_HEADER;
+        if (in_len - pos < size) break;  // read_exact(remainder) would wait for more input
+        if (offsets && sizes) {
+            if (nb >= max_blocks) break;
+            offsets[nb] = pos;
+            sizes[nb] = (uint32_t)size;
+        }
+        nb++;
+        pos += size;
+    }
+    *n_blocks = nb;
+    *consumed = pos;
+    return GZPX_OK;
+}
+
+int gzpx_decompress_blocks_device(gzpx_dctx *c, const void *d_in, size_t in_len, const uint64_t *offsets,
+                                  const uint32_t *sizes, size_t n_blocks, void *d_out, size_t out_cap,
+                                  size_t *out_len, gzpx_check_info *info, void *hip_stream) {
+    if (!c) return GZPX_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lock(c->mu);
+    if (hipSetDevice(c->device) != hipSuccess) return GZPX_ERR_DEVICE;
+    return decompress_device_locked(c, (const uint8_t *)d_in, in_len, offsets, sizes, n_blocks, (uint8_t *)d_out,
+                                    out_cap, out_len, info, (hipStream_t)hip_stream);
+}
+
+int gzpx_decompress_blocks(gzpx_dctx *c, const uint8_t *in, size_t in_len, const uint64_t *offsets,
+                           const uint32_t *sizes, size_t n_blocks, uint8_t *out, size_t out_cap,
+                           size_t *out_len, gzpx_check_info *info) {
+    if (!c || (!in && in_len) || (!out && out_cap) || !out_len) return GZPX_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lock(c->mu);
+    if (hipSetDevice(c->device) != hipSuccess) return GZPX_ERR_DEVICE;
+    if (in_len + 16 > c->d_in_cap) {
+        if (c->d_in) (void)hipFree(c->d_in);
+        c->d_in = nullptr;
+        c->d_in_cap = 0;
+        HIP_TRY(hipMalloc((void **)&c->d_in, in_len + in_len / 8 + 4096));
+        c->d_in_cap = in_len + in_len / 8 + 4096;
+    }
+    if (out_cap + 16 > c->d_out_cap) {
+        if (c->d_out) (void)hipFree(c->d_out);
+        c->d_out = nullptr;
+        c->d_out_cap = 0;
+        HIP_TRY(hipMalloc((void **)&c->d_out, out_cap + out_cap / 8 + 4096));
+        c->d_out_cap = out_cap + out_cap / 8 + 4096;
+    }
+    if (in_len) HIP_TRY(hipMemcpyAsync(c->d_in, in, in_len, hipMemcpyHostToDevice, c->stream));
+    size_t produced = 0;
+    const int rc = decompress_device_locked(c, c->d_in, in_len, offsets, sizes, n_blocks, c->d_out, out_cap,
+                                            &produced, info, c->stream);
+    if (rc != GZPX_OK) return rc;
+    if (produced) HIP_TRY(hipMemcpyAsync(out, c->d_out, produced, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    *out_len = produced;
+    return GZPX_OK;
+}
+
+struct gzpx_decompressor {
+    gzpx_dctx *ctx;
+    std::vector<uint8_t> framed;
+};
+
+gzpx_decompressor *gzpx_alloc_decompressor(void) {
+    gzpx_decompressor *d = new (std::nothrow) gzpx_decompressor();
+    if (d) d->ctx = nullptr;
+    return d;
+}
+
+int gzpx_deflate_decompress(gzpx_decompressor *d, const void *in, size_t n, void *out, size_t cap, size_t *actual) {
+    if (!d || (!in && n) || (!out && cap)) return GZPX_ERR_INVALID_ARG;
+    if (!d->ctx) {
+        const int rc = gzpx_dctx_create(0, GZPX_FORMAT_MGZIP, &d->ctx);
+        if (rc != GZPX_OK) return rc;
+    }
+    // the kernels work on framed members: wrap the raw stream with a header and a footer whose
+    // ISIZE is the caller's capacity (libdeflate semantics: at most `cap` bytes may come out)
+    d->framed.assign(20 + n + 8, 0);
+    memcpy(d->framed.data() + 20, in, n);
+    uint8_t *f = d->framed.data() + 20 + n;
+    const uint32_t isz = (uint32_t)cap;
+    f[4] = (uint8_t)isz;
+    f[5] = (uint8_t)(isz >> 8);
+    f[6] = (uint8_t)(isz >> 16);
+    f[7] = (uint8_t)(isz >> 24);
+    const uint64_t off = 0;
+    const uint32_t size = (uint32_t)d->framed.size();
+    std::vector<uint8_t> tmp(cap ? cap : 1);
+    size_t produced = 0;
+    gzpx_check_info info = {0, 0, 0};
+    gzpx_dctx *c = d->ctx;
+    int rc = gzpx_decompress_blocks(c, d->framed.data(), d->framed.size(), &off, &size, 1, tmp.data(), cap,
+                                    &produced, &info);
+    if (rc == GZPX_ERR_INVALID_CHECK) rc = GZPX_OK;  // a raw stream carries no checksum
+    if (rc != GZPX_OK) return rc;
+    const size_t got = cap ? c->h_blk[0].produced : 0;
+    if (cap) {
+        // on the InvalidCheck path nothing was copied back: fetch the bytes now
+        if (hipMemcpy(tmp.data(), c->d_out, got, hipMemcpyDeviceToHost) != hipSuccess) return GZPX_ERR_DEVICE;
+        memcpy(out, tmp.data(), got);
+    }
+    if (actual) *actual = got;
+    return GZPX_OK;
+}
+
+void gzpx_free_decompressor(gzpx_decompressor *d) {
+    if (!d) return;
+    if (d->ctx) gzpx_dctx_destroy(d->ctx);
+    delete d;
+}
+
+}  // extern "C"
+
 // ---------------------------------------------------------------- measurement / debug hooks
 int gzpx_ctx_set_profiling(gzpx_ctx *ctx, int on) {
     if (!ctx) return GZPX_ERR_INVALID_ARG;
@@ -620,6 +874,9 @@ const char *gzpx_strerror(int code) {
         case GZPX_ERR_NUM_THREADS: return "number of threads must be > 0 (GzpError::NumThreads)";
         case GZPX_ERR_IO: return "the wrapped writer failed (GzpError::Io)";
         case GZPX_ERR_CHANNEL: return "compression pipeline already closed (GzpError::ChannelSend)";
+        case GZPX_ERR_INVALID_HEADER: return "invalid block header (GzpError::InvalidHeader)";
+        case GZPX_ERR_INVALID_CHECK: return "checksum mismatch (GzpError::InvalidCheck)";
+        case GZPX_ERR_BAD_DATA: return "invalid DEFLATE stream (GzpError::LibDelfaterDecompress(BadData))";
         default: return "unknown error";
     }
 }

@@ -123,4 +123,13 @@ void launch_scan(uint32_t nb, const Scratch &s, hipStream_t stream);
 void launch_emit(const Config &cfg, const uint8_t *slab, uint64_t slab_len, uint32_t nb,
                  const Scratch &s, uint8_t *out, uint64_t out_cap, hipStream_t stream);
 
+// ParDecompress side: one record per block (filled by k_dinit / k_inflate)
+struct DBlockHost {
+    uint64_t in_off;
+    uint32_t size, isize, crc, status, produced, pad;
+};
+void launch_inflate(uint32_t hdr_len, const uint8_t *d_in, const uint64_t *d_offsets, const uint32_t *d_sizes,
+                    uint32_t nb, void *d_blk, uint64_t *d_out_off, uint8_t *d_out, uint64_t out_cap,
+                    uint32_t *d_crc_found, const CrcConsts &cc, hipStream_t stream);
+
 }  // namespace gzpx

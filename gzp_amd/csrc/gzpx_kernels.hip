@@ -1811,29 +1811,29 @@ constexpr uint32_t kCrcDataWords = (kTile / 4 + 2) + (kTile / 4 + 2) / 64 + 2;
 // dword index -> padded LDS index (one pad word after every 64)
 __device__ __forceinline__ uint32_t crc_pad(uint32_t w) { return w + (w >> 6); }
 
-__global__ __launch_bounds__(256) void k_crc32(Config cfg, const uint8_t *__restrict__ slab,
-                                               BlockMeta *__restrict__ meta_all, CrcConsts cc) {
-    __shared__ uint32_t table[4][256];
-    __shared__ uint32_t data[kCrcDataWords];
-    __shared__ uint32_t part[256];
-    const uint32_t tid = threadIdx.x;
-    const uint32_t b = blockIdx.x;
-    const uint32_t n = meta_all[b].n;
-    const uint8_t *in = slab + (uint64_t)b * cfg.block_size;
+struct CrcLds {
+    uint32_t table[4][256];
+    uint32_t data[kCrcDataWords];
+    uint32_t part[256];
+};
+
+// CRC-32 of in[0..n) by a 256-thread workgroup; the result is valid in every thread.
+__device__ uint32_t crc32_workgroup(CrcLds &l, const uint8_t *__restrict__ in, uint32_t n,
+                                    const CrcConsts &cc, uint32_t tid) {
     {
         uint32_t c = tid;
         for (int k = 0; k < 8; k++) c = (c >> 1) ^ (0xEDB88320u & (0u - (c & 1u)));
-        table[0][tid] = c;
+        l.table[0][tid] = c;
     }
     __syncthreads();
     {
-        const uint32_t t0 = table[0][tid];
-        const uint32_t t1 = (t0 >> 8) ^ table[0][t0 & 0xFFu];
-        const uint32_t t2 = (t1 >> 8) ^ table[0][t1 & 0xFFu];
-        const uint32_t t3 = (t2 >> 8) ^ table[0][t2 & 0xFFu];
-        table[1][tid] = t1;
-        table[2][tid] = t2;
-        table[3][tid] = t3;
+        const uint32_t t0 = l.table[0][tid];
+        const uint32_t t1 = (t0 >> 8) ^ l.table[0][t0 & 0xFFu];
+        const uint32_t t2 = (t1 >> 8) ^ l.table[0][t1 & 0xFFu];
+        const uint32_t t3 = (t2 >> 8) ^ l.table[0][t2 & 0xFFu];
+        l.table[1][tid] = t1;
+        l.table[2][tid] = t2;
+        l.table[3][tid] = t3;
     }
     // Blocks above 64 KiB are cut into 64 KiB chunks aligned to the END of the block (only the
     // first chunk is short), so every chunk-to-chunk combine uses the same x^(8*65536) constant.
@@ -1847,7 +1847,7 @@ __global__ __launch_bounds__(256) void k_crc32(Config cfg, const uint8_t *__rest
         if (clen) {
             const uint32_t *src = (const uint32_t *)(cin - mis);
             const uint32_t ndw = (mis + clen + 3) >> 2;
-            for (uint32_t i = tid; i < ndw; i += 256) data[crc_pad(i)] = src[i];
+            for (uint32_t i = tid; i < ndw; i += 256) l.data[crc_pad(i)] = src[i];
         }
         __syncthreads();
         // segment of thread t in chunk bytes: [clen - 256*(256 - t), clen - 256*(255 - t)) clipped
@@ -1859,39 +1859,47 @@ __global__ __launch_bounds__(256) void k_crc32(Config cfg, const uint8_t *__rest
             uint32_t pos = (seg_end_i > 256 ? (uint32_t)(seg_end_i - 256) : 0u) + mis;
             uint32_t c = 0xFFFFFFFFu;
             while (pos < seg_end && (pos & 3u)) {  // head bytes up to a dword boundary
-                const uint32_t byte = (data[crc_pad(pos >> 2)] >> (8u * (pos & 3u))) & 0xFFu;
-                c = (c >> 8) ^ table[0][(c ^ byte) & 0xFFu];
+                const uint32_t byte = (l.data[crc_pad(pos >> 2)] >> (8u * (pos & 3u))) & 0xFFu;
+                c = (c >> 8) ^ l.table[0][(c ^ byte) & 0xFFu];
                 pos++;
             }
             while (pos + 4 <= seg_end) {  // slice-by-4
-                c ^= data[crc_pad(pos >> 2)];
-                c = table[3][c & 0xFFu] ^ table[2][(c >> 8) & 0xFFu] ^ table[1][(c >> 16) & 0xFFu] ^
-                    table[0][c >> 24];
+                c ^= l.data[crc_pad(pos >> 2)];
+                c = l.table[3][c & 0xFFu] ^ l.table[2][(c >> 8) & 0xFFu] ^ l.table[1][(c >> 16) & 0xFFu] ^
+                    l.table[0][c >> 24];
                 pos += 4;
             }
             while (pos < seg_end) {  // tail bytes
-                const uint32_t byte = (data[crc_pad(pos >> 2)] >> (8u * (pos & 3u))) & 0xFFu;
-                c = (c >> 8) ^ table[0][(c ^ byte) & 0xFFu];
+                const uint32_t byte = (l.data[crc_pad(pos >> 2)] >> (8u * (pos & 3u))) & 0xFFu;
+                c = (c >> 8) ^ l.table[0][(c ^ byte) & 0xFFu];
                 pos++;
             }
             crc = ~c;
         }
-        part[tid] = crc;
+        l.part[tid] = crc;
         __syncthreads();
         for (uint32_t level = 0; level < 8; level++) {
             const uint32_t stride = 1u << level;
             uint32_t merged = 0;
             const bool act = (tid & (2 * stride - 1)) == 0;
-            if (act) merged = gf2_multmodp(cc.pow256[level], part[tid]) ^ part[tid + stride];
+            if (act) merged = gf2_multmodp(cc.pow256[level], l.part[tid]) ^ l.part[tid + stride];
             __syncthreads();
-            if (act) part[tid] = merged;
+            if (act) l.part[tid] = merged;
             __syncthreads();
         }
         // crc(A || chunk) = crc(A) * x^(8 * 65536) + crc(chunk); the first chunk has no A
-        total = cb == 0 ? part[0] : (gf2_multmodp(cc.pow_tile, total) ^ part[0]);
+        total = cb == 0 ? l.part[0] : (gf2_multmodp(cc.pow_tile, total) ^ l.part[0]);
         if (n == 0) break;
     }
-    if (tid == 0) meta_all[b].crc = total;
+    return total;
+}
+
+__global__ __launch_bounds__(256) void k_crc32(Config cfg, const uint8_t *__restrict__ slab,
+                                               BlockMeta *__restrict__ meta_all, CrcConsts cc) {
+    __shared__ CrcLds l;
+    const uint32_t b = blockIdx.x;
+    const uint32_t total = crc32_workgroup(l, slab + (uint64_t)b * cfg.block_size, meta_all[b].n, cc, threadIdx.x);
+    if (threadIdx.x == 0) meta_all[b].crc = total;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -2174,6 +2182,486 @@ __global__ __launch_bounds__(256) void k_emit(Config cfg, const uint8_t *__restr
 }
 
 // ------------------------------------------------------------------------------------------
+// ParDecompress<Bgzf/Mgzip> (src/par/decompress.rs:132-220): every block is an independent gzip
+// member, so a slab of blocks is inflated by one launch.
+//   k_dinit    footer (CRC32, ISIZE) of every block -> DBlock
+//   k_dscan    exclusive scan of ISIZE -> output offsets
+//   k_inflate  libdeflate_deflate_decompress for every block: one wave per block; the wave keeps
+//              the last 32 KiB of output in an LDS ring (the DEFLATE window) and streams finished
+//              output to HBM in coalesced 16 KiB pieces; the compressed bytes come through a
+//              512-byte register ring (two dwords per lane, refilled by cross-lane reads), Huffman
+//              decode tables (10-bit / 8-bit direct lookup + canonical fallback) are rebuilt in LDS
+//              for every dynamic sub-block by all 64 lanes.  The symbol loop itself is the
+//              sequential part: its state is wave-uniform.
+//   k_crc32    (shared with the compressor) CRC-32 of the inflated bytes, checked against the footer
+// ------------------------------------------------------------------------------------------
+struct InfLds {
+    uint32_t win[8192];     // 32 KiB ring of the most recent output bytes
+    uint16_t lfast[1024];   // litlen: sym | len << 9 for codes of <= 10 bits, 0 = longer code
+    uint16_t ofast[256];    // offset: sym | len << 9 for codes of <= 8 bits
+    uint16_t lsorted[288];  // symbols in canonical order
+    uint16_t osorted[32];
+    uint8_t lens[320];      // code lengths: litlen then offset
+    uint32_t lcount[16], lfirst[16], loffs[16];
+    uint32_t ocount[16], ofirst[16], ooffs[16];
+};
+
+enum InflateStatus : uint32_t { kInfOk = 0, kInfBadData = 1, kInfInsufficientSpace = 2, kInfShortOutput = 3 };
+
+// Build the decode tables of one code from h.lens[base .. base + nsyms): counts, canonical first
+// codes, symbols in canonical order, and the direct-lookup table for codes of <= fast_bits bits.
+// All 64 lanes call it.  Returns false for an over-subscribed code.
+__device__ bool inflate_build(const uint8_t *lens, uint32_t nsyms, uint32_t fast_bits, uint16_t *fast,
+                              uint16_t *sorted, uint32_t *count, uint32_t *first, uint32_t *offs,
+                              uint32_t lane) {
+    const uint64_t lane_below = (1ull << lane) - 1ull;
+    uint32_t cnt[16];
+    for (uint32_t l = 0; l < 16; l++) cnt[l] = 0;
+    for (uint32_t base = 0; base < nsyms; base += 64) {
+        const uint32_t s = base + lane;
+        const uint32_t myl = s < nsyms ? lens[s] : 0;
+        for (uint32_t l = 1; l <= 15; l++) cnt[l] += (uint32_t)__popcll(__ballot(myl == l));
+    }
+    uint32_t code = 0, idx = 0, kraft = 0;
+    uint32_t fst[16], off[16];
+    for (uint32_t l = 1; l <= 15; l++) {
+        code <<= 1;
+        fst[l] = code;
+        off[l] = idx;
+        code += cnt[l];
+        idx += cnt[l];
+        kraft += cnt[l] << (15 - l);
+    }
+    if (kraft > (1u << 15)) return false;
+    wave_sync();
+    if (lane < 16) {
+        count[lane] = lane ? cnt[lane] : 0;
+        first[lane] = lane ? fst[lane] : 0;
+        offs[lane] = lane ? off[lane] : 0;
+    }
+    for (uint32_t i = lane; i < (1u << fast_bits); i += 64) fast[i] = 0;
+    wave_sync();
+    uint32_t run[16];
+    for (uint32_t l = 0; l < 16; l++) run[l] = 0;
+    for (uint32_t base = 0; base < nsyms; base += 64) {
+        const uint32_t s = base + lane;
+        const uint32_t myl = s < nsyms ? lens[s] : 0;
+        uint32_t rank = 0;
+        for (uint32_t l = 1; l <= 15; l++) {
+            const uint64_t m = __ballot(myl == l);
+            if (myl == l) rank = run[l] + (uint32_t)__popcll(m & lane_below);
+            run[l] += (uint32_t)__popcll(m);
+        }
+        if (myl) {
+            sorted[off[myl] + rank] = (uint16_t)s;
+            if (myl <= fast_bits) {
+                const uint32_t cw = __brev(fst[myl] + rank) >> (32 - myl);  // LSB-first codeword
+                const uint16_t e = (uint16_t)(s | (myl << 9));
+                for (uint32_t k = cw; k < (1u << fast_bits); k += 1u << myl) fast[k] = e;
+            }
+        }
+    }
+    wave_sync();
+    return true;
+}
+
+// One symbol of a canonical Huffman code from the low bits of `bits` (LSB first).  Returns the
+// symbol and its length, or len = 0 when no codeword matches (bad data).
+__device__ __forceinline__ uint32_t inflate_sym(uint32_t bits, const uint16_t *fast, uint32_t fast_bits,
+                                                const uint16_t *sorted, const uint32_t *count,
+                                                const uint32_t *first, const uint32_t *offs, uint32_t &len) {
+    const uint32_t e = fast[bits & ((1u << fast_bits) - 1u)];
+    if (e) {
+        len = e >> 9;
+        return e & 0x1FFu;
+    }
+    uint32_t code = 0;
+    for (uint32_t l = 1; l <= 15; l++) {
+        code = (code << 1) | ((bits >> (l - 1)) & 1u);
+        const uint32_t c = count[l];
+        if (code - first[l] < c) {
+            len = l;
+            return sorted[offs[l] + code - first[l]];
+        }
+    }
+    len = 0;
+    return 0;
+}
+
+struct DBlock {
+    uint64_t in_off;    // offset of the block (its gzip header) in the compressed slab
+    uint32_t size;      // total block size (header + payload + footer)
+    uint32_t isize;     // ISIZE from the footer
+    uint32_t crc;       // CRC32 from the footer
+    uint32_t status;    // InflateStatus
+    uint32_t produced;  // bytes actually inflated
+    uint32_t pad;
+};
+
+__global__ void k_dinit(uint32_t nb, const uint8_t *__restrict__ in, const uint64_t *__restrict__ offsets,
+                        const uint32_t *__restrict__ sizes, DBlock *__restrict__ blk) {
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nb) return;
+    const uint8_t *f = in + offsets[b] + sizes[b] - 8;  // get_footer_values, src/lib.rs:440-447
+    DBlock d;
+    d.in_off = offsets[b];
+    d.size = sizes[b];
+    d.crc = (uint32_t)f[0] | ((uint32_t)f[1] << 8) | ((uint32_t)f[2] << 16) | ((uint32_t)f[3] << 24);
+    d.isize = (uint32_t)f[4] | ((uint32_t)f[5] << 8) | ((uint32_t)f[6] << 16) | ((uint32_t)f[7] << 24);
+    d.status = kInfOk;
+    d.produced = 0;
+    d.pad = 0;
+    blk[b] = d;
+}
+
+__global__ __launch_bounds__(256) void k_dscan(uint32_t nb, const DBlock *__restrict__ blk,
+                                               uint64_t *__restrict__ out_off) {
+    __shared__ uint32_t wsum[4];
+    __shared__ uint64_t carry_s;
+    const uint32_t tid = threadIdx.x;
+    if (tid == 0) carry_s = 0;
+    __syncthreads();
+    for (uint32_t base = 0; base < nb; base += 256) {
+        const uint32_t i = base + tid;
+        const uint32_t v = i < nb ? blk[i].isize : 0;
+        uint32_t total;
+        const uint32_t ex = block_exclusive_scan256(v, wsum, &total);
+        const uint64_t carry = carry_s;
+        if (i < nb) out_off[i] = carry + ex;
+        __syncthreads();
+        if (tid == 0) carry_s = carry + total;
+        __syncthreads();
+    }
+    if (tid == 0) out_off[nb] = carry_s;
+}
+
+__global__ __launch_bounds__(64) void k_inflate(uint32_t hdr_len, const uint8_t *__restrict__ in_all,
+                                                DBlock *__restrict__ blk_all,
+                                                const uint64_t *__restrict__ out_off,
+                                                uint8_t *__restrict__ out_all, uint64_t out_cap) {
+    __shared__ InfLds h;
+    const uint32_t lane = threadIdx.x;
+    DBlock *blk = blk_all + blockIdx.x;
+    const uint32_t isize = blk->isize;
+    if (isize == 0) return;  // src/par/decompress.rs:163-171: nothing to decode
+    const uint64_t ooff = out_off[blockIdx.x];
+    if (ooff + isize > out_cap) {
+        if (lane == 0) blk->status = kInfInsufficientSpace;
+        return;
+    }
+    uint8_t *out = out_all + ooff;
+    const uint8_t *pay = in_all + blk->in_off + hdr_len;
+    const uint32_t pay_len = blk->size - hdr_len - 8;
+    const uint8_t *hwin = (const uint8_t *)h.win;
+
+    // ---- compressed bytes: a 512-byte register ring of aligned dwords, two per lane
+    const uint32_t pmis = (uint32_t)((uintptr_t)pay & 3u);
+    const uint32_t *pay32 = (const uint32_t *)(pay - pmis);
+    const uint32_t pay_words = (pmis + pay_len + 8 + 3) >> 2;  // the 8 footer bytes are readable too
+    uint32_t ring_base = 0;  // dword index of ring_a's lane 0
+    uint32_t ring_a = lane < pay_words ? pay32[lane] : 0u;
+    uint32_t ring_b = 64 + lane < pay_words ? pay32[64 + lane] : 0u;
+    auto ring_seek = [&](uint32_t byte_pos) {  // make the ring cover the dword of byte_pos (+ 8 bytes)
+        const uint32_t w = (byte_pos + pmis) >> 2;
+        while (w + 3 >= ring_base + 128) {
+            if (w >= ring_base + 192) {  // a jump (stored block): reload both halves
+                ring_base = w & ~63u;
+                ring_a = ring_base + lane < pay_words ? pay32[ring_base + lane] : 0u;
+                ring_b = ring_base + 64 + lane < pay_words ? pay32[ring_base + 64 + lane] : 0u;
+            } else {
+                ring_a = ring_b;
+                ring_base += 64;
+                ring_b = ring_base + 64 + lane < pay_words ? pay32[ring_base + 64 + lane] : 0u;
+            }
+        }
+    };
+    auto ring_word = [&](uint32_t w) -> uint32_t {  // aligned dword w (uniform)
+        const uint32_t i = w - ring_base;
+        const uint32_t va = __shfl(ring_a, (int)(i & 63u)), vb = __shfl(ring_b, (int)(i & 63u));
+        return i < 64 ? va : vb;
+    };
+    auto load32 = [&](uint32_t byte_pos) -> uint32_t {  // 4 payload bytes at byte_pos (uniform)
+        ring_seek(byte_pos);
+        const uint32_t a = byte_pos + pmis;
+        return __builtin_amdgcn_alignbyte(ring_word((a >> 2) + 1), ring_word(a >> 2), a & 3u);
+    };
+
+    // ---- bit reader (wave-uniform)
+    uint64_t bitbuf = 0;
+    uint32_t bitcnt = 0, in_pos = 0;  // in_pos: payload bytes already moved into bitbuf
+    auto refill = [&]() {
+        if (bitcnt <= 32) {
+            bitbuf |= (uint64_t)load32(in_pos) << bitcnt;
+            in_pos += 4;
+            bitcnt += 32;
+        }
+    };
+    auto take = [&](uint32_t nbits) -> uint32_t {
+        const uint32_t v = (uint32_t)bitbuf & ((nbits >= 32) ? 0xFFFFFFFFu : ((1u << nbits) - 1u));
+        bitbuf >>= nbits;
+        bitcnt -= nbits;
+        return v;
+    };
+
+    uint32_t o = 0;        // bytes produced
+    uint32_t flushed = 0;  // bytes already written to HBM
+    uint32_t status = kInfOk;
+    // write ring bytes [flushed, upto) to HBM: whole dwords where the destination is aligned
+    auto flush = [&](uint32_t upto) {
+        wave_sync();
+        uint32_t q = flushed;
+        while (q < upto && (((uintptr_t)(out + q)) & 3u)) {  // head bytes (uniform loop)
+            if (lane == 0) out[q] = hwin[q & 32767u];
+            q++;
+        }
+        const uint32_t nw = (upto - q) >> 2;
+        for (uint32_t k = lane; k < nw; k += 64) {
+            const uint32_t r = (q + 4 * k) & 32767u;
+            const uint32_t lo = h.win[r >> 2], hi = h.win[((r >> 2) + 1) & 8191u];
+            *(uint32_t *)(out + q + 4 * k) = __builtin_amdgcn_alignbyte(hi, lo, r & 3u);
+        }
+        q += 4 * nw;
+        if (q + lane < upto) out[q + lane] = hwin[(q + lane) & 32767u];
+        flushed = upto;
+        wave_sync();
+    };
+
+    bool final_block = false;
+    while (!final_block && status == kInfOk) {
+        refill();
+        final_block = take(1) != 0;
+        const uint32_t btype = take(2);
+        if (btype == 0) {
+            // stored: skip to a byte boundary, LEN, NLEN, raw bytes
+            take(bitcnt & 7u);
+            refill();
+            const uint32_t len = take(16), nlen = take(16);
+            if ((len ^ 0xFFFFu) != nlen) {
+                status = kInfBadData;
+                break;
+            }
+            const uint32_t src = in_pos - (bitcnt >> 3);  // next unread payload byte
+            if (src + len > pay_len) {
+                status = kInfBadData;
+                break;
+            }
+            if (o + len > isize) {
+                status = kInfInsufficientSpace;
+                break;
+            }
+            for (uint32_t done = 0; done < len; done += 16384u) {
+                const uint32_t piece = len - done < 16384u ? len - done : 16384u;
+                if (o + piece - flushed > 32768u - 16u) flush(o);
+                wave_sync();
+                for (uint32_t i = lane; i < piece; i += 64)
+                    ((uint8_t *)h.win)[(o + i) & 32767u] = pay[src + done + i];
+                o += piece;
+            }
+            bitbuf = 0;
+            bitcnt = 0;
+            in_pos = src + len;
+            continue;
+        }
+        if (btype == 3) {
+            status = kInfBadData;
+            break;
+        }
+        // ---- code lengths
+        uint32_t nlit, ndist;
+        if (btype == 1) {
+            nlit = 288;
+            ndist = 32;
+            for (uint32_t i = lane; i < 320; i += 64)
+                h.lens[i] = (uint8_t)(i < 144 ? 8 : i < 256 ? 9 : i < 280 ? 7 : i < 288 ? 8 : 5);
+            wave_sync();
+        } else {
+            refill();
+            nlit = take(5) + 257;
+            ndist = take(5) + 1;
+            const uint32_t nclen = take(4) + 4;
+            if (nlit > 286 + 2 || ndist > 32) {
+                status = kInfBadData;
+                break;
+            }
+            // the precode: 19 lengths of 3 bits in a fixed order, decoded with a 7-bit table that
+            // lives in ofast[0..127] until the real offset table is built
+            wave_sync();
+            if (lane < 19) h.lens[lane] = 0;
+            wave_sync();
+            for (uint32_t i = 0; i < nclen; i++) {
+                refill();
+                const uint32_t v = take(3);
+                const uint8_t order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+                if (lane == 0) h.lens[order[i]] = (uint8_t)v;
+            }
+            wave_sync();
+            if (!inflate_build(h.lens, 19, 7, h.ofast, h.osorted, h.ocount, h.ofirst, h.ooffs, lane)) {
+                status = kInfBadData;
+                break;
+            }
+            // litlen + offset lengths, run-length coded with the precode (sequential, uniform)
+            uint32_t i = 0;
+            const uint32_t total = nlit + ndist;
+            uint32_t prev = 0;
+            uint8_t *tmp = (uint8_t *)h.lfast;  // 2 KiB scratch, free until the litlen table is built
+            while (i < total) {
+                refill();
+                uint32_t l;
+                const uint32_t sym = inflate_sym((uint32_t)bitbuf, h.ofast, 7, h.osorted, h.ocount, h.ofirst,
+                                                 h.ooffs, l);
+                if (l == 0) {
+                    status = kInfBadData;
+                    break;
+                }
+                take(l);
+                uint32_t rep = 1, val = sym;
+                if (sym == 16) {
+                    if (i == 0) {
+                        status = kInfBadData;
+                        break;
+                    }
+                    rep = 3 + take(2);
+                    val = prev;
+                } else if (sym == 17) {
+                    rep = 3 + take(3);
+                    val = 0;
+                } else if (sym == 18) {
+                    rep = 11 + take(7);
+                    val = 0;
+                }
+                if (i + rep > total) {
+                    status = kInfBadData;
+                    break;
+                }
+                if (lane < rep) tmp[i + lane] = (uint8_t)val;  // rep <= 138: up to 3 rounds
+                if (lane + 64 < rep) tmp[i + lane + 64] = (uint8_t)val;
+                if (lane + 128 < rep) tmp[i + lane + 128] = (uint8_t)val;
+                prev = val;
+                i += rep;
+            }
+            if (status != kInfOk) break;
+            wave_sync();
+            // split into litlen [0,288) and offset [288,320)
+            uint8_t mine[5];
+            for (uint32_t k = 0; k < 5; k++) {
+                const uint32_t s = lane + 64 * k;
+                uint32_t v = 0;
+                if (s < 288) v = s < nlit ? tmp[s] : 0;
+                else if (s < 320) v = (s - 288) < ndist ? tmp[nlit + (s - 288)] : 0;
+                mine[k] = (uint8_t)v;
+            }
+            wave_sync();
+            for (uint32_t k = 0; k < 5; k++) h.lens[lane + 64 * k] = mine[k];
+            wave_sync();
+            if (h.lens[256] == 0) {  // no end-of-block code: the sub-block could never end
+                status = kInfBadData;
+                break;
+            }
+        }
+        if (!inflate_build(h.lens, 288, 10, h.lfast, h.lsorted, h.lcount, h.lfirst, h.loffs, lane) ||
+            !inflate_build(h.lens + 288, 32, 8, h.ofast, h.osorted, h.ocount, h.ofirst, h.ooffs, lane)) {
+            status = kInfBadData;
+            break;
+        }
+        // ---- symbols
+        for (;;) {
+            refill();
+            uint32_t l;
+            const uint32_t sym = inflate_sym((uint32_t)bitbuf, h.lfast, 10, h.lsorted, h.lcount, h.lfirst,
+                                             h.loffs, l);
+            if (l == 0) {
+                status = kInfBadData;
+                break;
+            }
+            take(l);
+            if (sym < 256) {
+                if (o >= isize) {
+                    status = kInfInsufficientSpace;
+                    break;
+                }
+                if (o - flushed >= 32768u - 320u) flush(o & ~3u);
+                if (lane == 0) ((uint8_t *)h.win)[o & 32767u] = (uint8_t)sym;
+                o++;
+                continue;
+            }
+            if (sym == 256) break;
+            if (sym > 285) {
+                status = kInfBadData;
+                break;
+            }
+            const uint32_t slot = sym - 257;
+            uint32_t len;
+            if (slot < 8) {
+                len = 3 + slot;
+            } else if (slot == 28) {
+                len = 258;
+            } else {
+                const uint32_t e = (slot - 4) >> 2;
+                len = 3 + ((4 + (slot & 3)) << e) + take(e);
+            }
+            refill();
+            uint32_t ol;
+            const uint32_t osym = inflate_sym((uint32_t)bitbuf, h.ofast, 8, h.osorted, h.ocount, h.ofirst,
+                                              h.ooffs, ol);
+            if (ol == 0 || osym > 29) {
+                status = kInfBadData;
+                break;
+            }
+            take(ol);
+            uint32_t dist;
+            if (osym < 4) {
+                dist = 1 + osym;
+            } else {
+                const uint32_t e = (osym - 2) >> 1;
+                dist = 1 + ((2 + (osym & 1)) << e) + take(e);
+            }
+            if (dist > o) {
+                status = kInfBadData;
+                break;
+            }
+            if (o + len > isize) {
+                status = kInfInsufficientSpace;
+                break;
+            }
+            if (o + len - flushed >= 32768u - 64u) flush(o & ~3u);
+            // out[o + i] = out[o - dist + (i mod dist)]: every source byte is older than o
+            wave_sync();
+            uint32_t v[5];
+            for (uint32_t k = 0; k < 5; k++) {
+                const uint32_t i = lane + 64 * k;
+                v[k] = i < len ? hwin[(o - dist + (i % dist)) & 32767u] : 0u;
+            }
+            wave_sync();
+            for (uint32_t k = 0; k < 5; k++) {
+                const uint32_t i = lane + 64 * k;
+                if (i < len) ((uint8_t *)h.win)[(o + i) & 32767u] = (uint8_t)v[k];
+            }
+            o += len;
+        }
+    }
+    if (status == kInfOk && o != isize) status = kInfShortOutput;
+    flush(o);
+    // libdeflater hands back a zero-initialised Vec of orig_size bytes: a short block stays zero
+    for (uint32_t i = o + lane; i < isize; i += 64) out[i] = 0;
+    if (lane == 0) {
+        blk->status = status;
+        blk->produced = o;
+    }
+}
+
+// CRC-32 of the inflated blocks (LibDeflateCrc over the whole orig_size buffer, src/check.rs:45-71):
+// the workgroup routine of k_crc32, blocks addressed through their output offsets.
+__global__ __launch_bounds__(256) void k_dcrc32(const uint8_t *__restrict__ out_all,
+                                                const uint64_t *__restrict__ out_off,
+                                                const DBlock *__restrict__ blk_all,
+                                                uint32_t *__restrict__ crc_found, CrcConsts cc) {
+    __shared__ CrcLds l;
+    const uint32_t b = blockIdx.x;
+    const uint32_t total = crc32_workgroup(l, out_all + out_off[b], blk_all[b].isize, cc, threadIdx.x);
+    if (threadIdx.x == 0) crc_found[b] = total;
+}
+
+// ------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------
 void launch_init_meta(const Config &cfg, uint64_t slab_len, uint32_t nb, int is_last,
@@ -2254,6 +2742,18 @@ void launch_emit(const Config &cfg, const uint8_t *slab, uint64_t, uint32_t nb, 
     hipLaunchKernelGGL(k_emit, dim3(nb), dim3(256), 0, stream, cfg, slab, (const BlockMeta *)s.meta,
                        (const SubMeta *)s.sub, (const uint32_t *)s.tok, (const uint32_t *)s.codes,
                        (const uint32_t *)s.hdr, (const uint64_t *)s.out_off, out, out_cap);
+}
+
+void launch_inflate(uint32_t hdr_len, const uint8_t *d_in, const uint64_t *d_offsets, const uint32_t *d_sizes,
+                    uint32_t nb, void *d_blk, uint64_t *d_out_off, uint8_t *d_out, uint64_t out_cap,
+                    uint32_t *d_crc_found, const CrcConsts &cc, hipStream_t stream) {
+    DBlock *blk = (DBlock *)d_blk;
+    hipLaunchKernelGGL(k_dinit, dim3((nb + 255) / 256), dim3(256), 0, stream, nb, d_in, d_offsets, d_sizes, blk);
+    hipLaunchKernelGGL(k_dscan, dim3(1), dim3(256), 0, stream, nb, (const DBlock *)blk, d_out_off);
+    hipLaunchKernelGGL(k_inflate, dim3(nb), dim3(64), 0, stream, hdr_len, d_in, blk,
+                       (const uint64_t *)d_out_off, d_out, out_cap);
+    hipLaunchKernelGGL(k_dcrc32, dim3(nb), dim3(256), 0, stream, (const uint8_t *)d_out,
+                       (const uint64_t *)d_out_off, (const DBlock *)blk, d_crc_found, cc);
 }
 
 }  // namespace gzpx

@@ -14,6 +14,9 @@ GzpError error_from_code(int code, size_t block) {
         case GZPX_ERR_BLOCK_SIZE_EXCEEDED:
             return GzpError(GzpErrorKind::BlockSizeExceeded, msg + " (block " + std::to_string(block) + ")");
         case GZPX_ERR_UNSUPPORTED: return GzpError(GzpErrorKind::Unsupported, msg);
+        case GZPX_ERR_INVALID_HEADER: return GzpError(GzpErrorKind::InvalidHeader, msg);
+        case GZPX_ERR_INVALID_CHECK: return GzpError(GzpErrorKind::InvalidCheck, msg);
+        case GZPX_ERR_BAD_DATA: return GzpError(GzpErrorKind::LibDeflaterDecompress, msg);
         default: return GzpError(GzpErrorKind::Device, msg);
     }
 }
@@ -209,6 +212,87 @@ void ParCompress::writer_main() {
     }
 }
 
+// ---------------------------------------------------------------- ParDecompress
+ParDecompress::ParDecompress(const ParDecompressConfig &cfg, ReadFn reader)
+    : cfg_(cfg), reader_(std::move(reader)) {
+    const int rc = gzpx_dctx_create(cfg_.device, cfg_.format, &ctx_);  // create_decompressor
+    if (rc != GZPX_OK) throw error_from_code(rc);
+}
+
+ParDecompress::~ParDecompress() {
+    if (ctx_) gzpx_dctx_destroy(ctx_);
+}
+
+bool ParDecompress::fill() {
+    const size_t hdr = cfg_.format == GZPX_FORMAT_BGZF ? 18 : 20;
+    for (;;) {
+        // top the slab up from the reader
+        while (!eof_ && in_.size() < cfg_.batch_bytes) {
+            const size_t old = in_.size();
+            const size_t want = cfg_.batch_bytes - old < (1u << 20) ? (1u << 20) : cfg_.batch_bytes - old;
+            in_.resize(old + want);
+            std::string err;
+            const long got = reader_(in_.data() + old, want, &err);
+            if (got < 0) {
+                in_.resize(old);
+                throw GzpError(GzpErrorKind::Io, err.empty() ? "read failed" : err);
+            }
+            in_.resize(old + (size_t)got);
+            if (got == 0) eof_ = true;
+        }
+        size_t nb = 0, used = 0;
+        int rc = gzpx_scan_blocks(cfg_.format, in_.data(), in_.size(), nullptr, nullptr, 0, &nb, &used);
+        if (rc != GZPX_OK) throw error_from_code(rc);
+        if (nb == 0) {
+            if (!eof_) {  // one block larger than the slab: keep reading
+                cfg_.batch_bytes *= 2;
+                continue;
+            }
+            // EOF: a failed header read ends the stream silently (src/par/decompress.rs:207-209);
+            // a header followed by a short body is read_exact's UnexpectedEof (:201-202)
+            if (in_.size() >= hdr) throw GzpError(GzpErrorKind::Io, "failed to fill whole buffer");
+            return false;
+        }
+        std::vector<uint64_t> offs(nb);
+        std::vector<uint32_t> sizes(nb);
+        rc = gzpx_scan_blocks(cfg_.format, in_.data(), in_.size(), offs.data(), sizes.data(), nb, &nb, &used);
+        if (rc != GZPX_OK) throw error_from_code(rc);
+        size_t total = 0;
+        for (size_t b = 0; b < nb; b++) {
+            const uint8_t *f = in_.data() + offs[b] + sizes[b] - 4;  // ISIZE
+            total += (size_t)f[0] | ((size_t)f[1] << 8) | ((size_t)f[2] << 16) | ((size_t)f[3] << 24);
+        }
+        out_.resize(total ? total : 1);
+        size_t got = 0;
+        gzpx_check_info info = {0, 0, 0};
+        rc = gzpx_decompress_blocks(ctx_, in_.data(), used, offs.data(), sizes.data(), nb, out_.data(), total,
+                                    &got, &info);
+        if (rc == GZPX_ERR_INVALID_CHECK)
+            throw GzpError(GzpErrorKind::InvalidCheck, "Invalid check value: found " + std::to_string(info.found) +
+                                                           ", expected " + std::to_string(info.expected));
+        if (rc != GZPX_OK) throw error_from_code(rc, info.block);
+        out_.resize(got);
+        out_pos_ = 0;
+        in_.erase(in_.begin(), in_.begin() + (ptrdiff_t)used);
+        if (got) return true;  // slabs of empty blocks only (e.g. the EOF marker): look further
+        if (eof_ && in_.empty()) return false;
+    }
+}
+
+size_t ParDecompress::read(uint8_t *buf, size_t n) {
+    if (out_pos_ == out_.size()) {
+        out_.clear();
+        out_pos_ = 0;
+        if (!fill()) return 0;
+    }
+    const size_t take = out_.size() - out_pos_ < n ? out_.size() - out_pos_ : n;
+    memcpy(buf, out_.data() + out_pos_, take);
+    out_pos_ += take;
+    return take;
+}
+
+void ParDecompress::finish() {}
+
 }  // namespace gzp
 
 // ---------------------------------------------------------------- C ABI of the twin
@@ -230,12 +314,34 @@ static int kind_to_code(gzp::GzpErrorKind k) {
         case K::ChannelSend:
         case K::ChannelReceive: return GZPX_ERR_CHANNEL;
         case K::Unsupported: return GZPX_ERR_UNSUPPORTED;
+        case K::InvalidHeader: return GZPX_ERR_INVALID_HEADER;
+        case K::InvalidCheck: return GZPX_ERR_INVALID_CHECK;
+        case K::LibDeflaterDecompress: return GZPX_ERR_BAD_DATA;
         default: return GZPX_ERR_DEVICE;
     }
 }
 
 template <class Fn>
 static int guarded(gzpx_par *p, Fn fn) {
+    try {
+        fn();
+        return GZPX_OK;
+    } catch (const gzp::GzpError &e) {
+        if (p) p->last_error = e.what();
+        return kind_to_code(e.kind);
+    } catch (const std::exception &e) {
+        if (p) p->last_error = e.what();
+        return GZPX_ERR_DEVICE;
+    }
+}
+
+struct gzpx_pard {
+    std::unique_ptr<gzp::ParDecompress> pd;
+    std::string last_error;
+};
+
+template <class Fn>
+static int guarded_d(gzpx_pard *p, Fn fn) {
     try {
         fn();
         return GZPX_OK;
@@ -301,5 +407,38 @@ void gzpx_par_destroy(gzpx_par *p) {
 }
 
 const char *gzpx_par_last_error(const gzpx_par *p) { return p ? p->last_error.c_str() : ""; }
+
+int gzpx_pard_create(int format, int device, size_t batch_bytes, gzpx_read_fn read_fn, void *user,
+                     gzpx_pard **out) {
+    if (!read_fn || !out) return GZPX_ERR_INVALID_ARG;
+    *out = nullptr;
+    auto *p = new gzpx_pard();
+    const int rc = guarded_d(p, [&] {
+        gzp::ParDecompressConfig c;
+        c.format = format;
+        c.device = device;
+        if (batch_bytes) c.batch_bytes = batch_bytes;
+        p->pd = std::make_unique<gzp::ParDecompress>(c, [read_fn, user](uint8_t *b, size_t cap, std::string *err) {
+            const long r = read_fn(user, b, cap);
+            if (r < 0 && err) *err = "reader callback returned " + std::to_string(r);
+            return r;
+        });
+    });
+    if (rc != GZPX_OK) {
+        delete p;
+        return rc;
+    }
+    *out = p;
+    return GZPX_OK;
+}
+
+int gzpx_pard_read(gzpx_pard *p, uint8_t *buf, size_t n, size_t *got) {
+    if (!p || (!buf && n) || !got) return GZPX_ERR_INVALID_ARG;
+    *got = 0;
+    return guarded_d(p, [&] { *got = p->pd->read(buf, n); });
+}
+
+void gzpx_pard_destroy(gzpx_pard *p) { delete p; }
+const char *gzpx_pard_last_error(const gzpx_pard *p) { return p ? p->last_error.c_str() : ""; }
 
 }  // extern "C"

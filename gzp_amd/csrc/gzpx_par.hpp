@@ -52,6 +52,9 @@ enum class GzpErrorKind {
     Io,                         // error returned by the wrapped writer
     ChannelSend,                // write()/finish() after the pipeline died
     ChannelReceive,
+    InvalidHeader,              // InvalidHeader(&str)
+    InvalidCheck,               // InvalidCheck { found, expected }
+    LibDeflaterDecompress,      // LibDelfaterDecompress(BadData | InsufficientSpace)
     Device,                     // HIP failure / no device (no CPU fallback exists)
     Unsupported,                // valid in gzp, not built yet
 };
@@ -193,6 +196,62 @@ class ParCompressBuilder {
 
   private:
     ParConfig cfg_;
+};
+
+// The wrapped `R: Read`: returns the number of bytes read into buf (0 = end of stream), -1 on error.
+using ReadFn = std::function<long(uint8_t *buf, size_t cap, std::string *err)>;
+
+struct ParDecompressConfig {
+    int format = GZPX_FORMAT_BGZF;
+    size_t num_threads = 0;  // accepted for API parity (src/par/decompress.rs:43-50)
+    int device = 0;
+    size_t batch_bytes = (size_t)64 << 20;  // compressed bytes handed to the GPU per slab
+};
+
+// ParDecompress (src/par/decompress.rs:112-352): `Read` over a block-compressed stream.  The
+// reader part (header walk: check_header + get_block_size, src/par/decompress.rs:195-209) runs on
+// the calling thread over a slab of input, the worker part (decode_block + per-block CRC check,
+// :162-186) is one GPU launch over every block of the slab; blocks come out in stream order.
+class ParDecompress {
+  public:
+    ParDecompress(const ParDecompressConfig &cfg, ReadFn reader);
+    ~ParDecompress();
+    ParDecompress(const ParDecompress &) = delete;
+    ParDecompress &operator=(const ParDecompress &) = delete;
+    size_t read(uint8_t *buf, size_t n);  // 0 = end of stream
+    void finish();                        // src/par/decompress.rs:222-238
+
+  private:
+    bool fill();
+    ParDecompressConfig cfg_;
+    ReadFn reader_;
+    gzpx_dctx *ctx_ = nullptr;
+    std::vector<uint8_t> in_;   // compressed bytes not yet decoded (may end in a partial block)
+    std::vector<uint8_t> out_;  // decoded bytes not yet handed out
+    size_t out_pos_ = 0;
+    bool eof_ = false;
+};
+
+// ParDecompressBuilder<F> (src/par/decompress.rs:17-109)
+template <class F>
+class ParDecompressBuilder {
+  public:
+    ParDecompressBuilder() { cfg_.format = F::FORMAT; }
+    ParDecompressBuilder &num_threads(size_t n) {
+        if (n == 0) throw GzpError(GzpErrorKind::NumThreads, "Invalid number of threads 0");
+        cfg_.num_threads = n;
+        return *this;
+    }
+    ParDecompressBuilder &device(int d) {
+        cfg_.device = d;
+        return *this;
+    }
+    std::unique_ptr<ParDecompress> from_reader(ReadFn r) const {
+        return std::make_unique<ParDecompress>(cfg_, std::move(r));
+    }
+
+  private:
+    ParDecompressConfig cfg_;
 };
 
 }  // namespace gzp

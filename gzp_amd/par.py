@@ -208,3 +208,100 @@ class ZBuilder:
     def from_writer(self, writer):
         self._b.num_threads(max(1, self._threads))
         return self._b.from_writer(writer)
+
+
+class ParDecompress:
+    """`Read` over a BGZF / Mgzip stream (src/par/decompress.rs:112-352)."""
+
+    def __init__(self, fmt, reader, device=0, batch_bytes=0, lib=None):
+        self._lib = lib or _native.load()
+        self._reader = reader
+        self._io_error = None
+
+        def _cb(user, buf, cap):
+            try:
+                data = self._reader.read(cap)
+                n = len(data)
+                ctypes.memmove(buf, data, n)
+                return n
+            except Exception as e:  # the wrapped reader failed: GzpError::Io
+                self._io_error = e
+                return -1
+
+        self._cb = _native.READ_FN(_cb)
+        h = ctypes.c_void_p()
+        self._lib.check(self._lib.L.gzpx_pard_create(fmt.FORMAT, device, batch_bytes, self._cb, None,
+                                                     ctypes.byref(h)))
+        self._h = h
+
+    def read(self, n=-1):
+        chunks = []
+        want = n
+        buf = np.empty(1 << 20 if n < 0 else max(n, 1), dtype=np.uint8)
+        while want != 0:
+            got = ctypes.c_size_t(0)
+            ask = buf.size if want < 0 else min(buf.size, want)
+            rc = self._lib.L.gzpx_pard_read(self._h, buf.ctypes.data, ask, ctypes.byref(got))
+            if rc != _native.OK:
+                msg = self._lib.L.gzpx_pard_last_error(self._h).decode() or self._lib.strerror(rc)
+                err = _native.GzpxError(rc, msg)
+                if self._io_error is not None:
+                    raise err from self._io_error
+                raise err
+            if got.value == 0:
+                break
+            chunks.append(buf[:got.value].tobytes())
+            if want > 0:
+                want -= got.value
+        return b"".join(chunks)
+
+    def finish(self):
+        return self._reader
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.L.gzpx_pard_destroy(self._h)
+            self._h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class ParDecompressBuilder:
+    """ParDecompressBuilder<F> (src/par/decompress.rs:17-109)."""
+
+    def __init__(self, fmt=Bgzf, lib=None):
+        self._fmt = fmt
+        self._lib = lib
+        self._device = 0
+        self._batch = 0
+        self._threads = os.cpu_count() or 1
+
+    def num_threads(self, n):
+        if n == 0:
+            raise _native.GzpxError(_native.ERR_NUM_THREADS, "Invalid number of threads 0")
+        self._threads = n
+        return self
+
+    def pin_threads(self, p):
+        return self
+
+    def device(self, d):
+        self._device = d
+        return self
+
+    def batch_bytes(self, b):
+        self._batch = b
+        return self
+
+    def from_reader(self, reader):
+        return ParDecompress(self._fmt, reader, self._device, self._batch, self._lib)

@@ -47,6 +47,9 @@ extern "C" {
 #define GZPX_ERR_NUM_THREADS 9         /* GzpError::NumThreads(0), src/par/compress.rs:84-90          */
 #define GZPX_ERR_IO 10                 /* GzpError::Io: the wrapped writer failed                     */
 #define GZPX_ERR_CHANNEL 11            /* GzpError::ChannelSend/Receive: pipeline already closed      */
+#define GZPX_ERR_INVALID_HEADER 12     /* GzpError::InvalidHeader (src/deflate.rs:555-565, 405-415)    */
+#define GZPX_ERR_INVALID_CHECK 13      /* GzpError::InvalidCheck{found, expected}                      */
+#define GZPX_ERR_BAD_DATA 14           /* GzpError::LibDelfaterDecompress(BadData)                     */
 
 /* how a slab is cut (the `mode` argument of gzpx_compress_slab*) */
 #define GZPX_SLAB_FULL_BLOCKS 0 /* write(): only whole buffer_size blocks, in_len a non-zero multiple   */
@@ -137,6 +140,49 @@ int gzpx_par_flush(gzpx_par *p);
 int gzpx_par_finish(gzpx_par *p);
 void gzpx_par_destroy(gzpx_par *p);
 const char *gzpx_par_last_error(const gzpx_par *p);
+
+/* ---- ParDecompress<Bgzf/Mgzip> (src/par/decompress.rs:132-337; BlockFormatSpec src/lib.rs:411-448) ----
+ *   gzpx_scan_blocks            the reader thread's header walk: check_header + get_block_size
+ *                               (src/deflate.rs:555-570 / 405-422) over a host buffer
+ *   gzpx_decompress_blocks*     the worker loop (src/par/decompress.rs:162-186) for every block of a
+ *                               slab: get_footer_values, decode_block = libdeflate_deflate_decompress
+ *                               into ISIZE bytes, LibDeflateCrc check (src/check.rs:38-82)
+ *   gzpx_*_decompressor         libdeflater::Decompressor (libdeflate.h: libdeflate_alloc_decompressor,
+ *                               libdeflate_deflate_decompress, libdeflate_free_decompressor)
+ */
+typedef struct gzpx_dctx gzpx_dctx;
+typedef struct gzpx_check_info {
+    size_t block;            /* index of the block that failed (any error)          */
+    uint32_t found, expected; /* InvalidCheck { found, expected }                    */
+} gzpx_check_info;
+int gzpx_dctx_create(int device, int format, gzpx_dctx **out);
+void gzpx_dctx_destroy(gzpx_dctx *ctx);
+/* Walks the block headers in in[0..in_len).  offsets[i] / sizes[i]: start and total size of block
+ * i; *consumed: bytes covered by complete blocks (a trailing partial block is left to the caller,
+ * as read_exact would block on it).  GZPX_ERR_INVALID_HEADER for a header that fails check_header. */
+int gzpx_scan_blocks(int format, const uint8_t *in, size_t in_len, uint64_t *offsets, uint32_t *sizes,
+                     size_t max_blocks, size_t *n_blocks, size_t *consumed);
+int gzpx_decompress_blocks(gzpx_dctx *ctx, const uint8_t *in, size_t in_len, const uint64_t *offsets,
+                           const uint32_t *sizes, size_t n_blocks, uint8_t *out, size_t out_cap,
+                           size_t *out_len, gzpx_check_info *info);
+/* d_in / d_out are device pointers; offsets / sizes stay host arrays */
+int gzpx_decompress_blocks_device(gzpx_dctx *ctx, const void *d_in, size_t in_len, const uint64_t *offsets,
+                                  const uint32_t *sizes, size_t n_blocks, void *d_out, size_t out_cap,
+                                  size_t *out_len, gzpx_check_info *info, void *hip_stream);
+typedef struct gzpx_decompressor gzpx_decompressor;
+gzpx_decompressor *gzpx_alloc_decompressor(void);
+/* 0 = ok (short output allowed, *actual = bytes produced), GZPX_ERR_BAD_DATA, GZPX_ERR_INSUFFICIENT_SPACE */
+int gzpx_deflate_decompress(gzpx_decompressor *d, const void *in, size_t n, void *out, size_t cap, size_t *actual);
+void gzpx_free_decompressor(gzpx_decompressor *d);
+
+/* ParDecompress twin: `Read` over a block stream (C++ class gzp::ParDecompress, gzpx_par.hpp) */
+typedef struct gzpx_pard gzpx_pard;
+typedef long (*gzpx_read_fn)(void *user, uint8_t *buf, size_t cap); /* bytes read, 0 = EOF, < 0 = error */
+int gzpx_pard_create(int format, int device, size_t batch_bytes, gzpx_read_fn read_fn, void *user,
+                     gzpx_pard **out);
+int gzpx_pard_read(gzpx_pard *p, uint8_t *buf, size_t n, size_t *got);
+void gzpx_pard_destroy(gzpx_pard *p);
+const char *gzpx_pard_last_error(const gzpx_pard *p);
 
 /* ---- measurement hooks (HIP events on the launching stream; bench.py roofline leg) ---- */
 #define GZPX_N_STAGES 9

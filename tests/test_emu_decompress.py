@@ -1,0 +1,117 @@
+"""ParDecompress<Bgzf/Mgzip> through the emulated kernels: our own streams, foreign (zlib-made)
+members, the reference's own round-trip test inputs, error classes.  No GPU."""
+import io
+import struct
+import zlib
+
+import numpy as np
+import pytest
+
+from gzp_amd import _native, par, synth
+
+
+def bgzf_member(chunk, level=6, strategy=zlib.Z_DEFAULT_STRATEGY):
+    co = zlib.compressobj(level, zlib.DEFLATED, -15, 9, strategy)
+    payload = co.compress(chunk) + co.flush()
+    hdr = struct.pack("<BBBBIBBHBBHH", 31, 139, 8, 4, 0, 0, 255, 6, ord("B"), ord("C"), 2, len(payload) + 25)
+    return hdr + payload + struct.pack("<II", zlib.crc32(chunk), len(chunk))
+
+
+@pytest.fixture(scope="module")
+def dctx(emu_lib):
+    c = _native.DContext(lib=emu_lib)
+    yield c
+    c.close()
+
+
+@pytest.mark.parametrize("cls", sorted(synth.CLASSES))
+def test_roundtrip_of_our_streams(dctx, oracle, cls):
+    for n, level in [(0, 1), (1, 1), (70000, 1), (2 * 65280 + 77, 3)]:
+        a = synth.make(cls, n, 60 + n % 13)
+        comp = oracle.compress_stream(a, oracle.FMT_BGZF, level, oracle.COMPAT_1_24, 65280)
+        assert dctx.decompress(comp) == a.tobytes(), (cls, n, level)
+
+
+def test_foreign_zlib_members(dctx):
+    for level in (1, 6, 9):
+        for cls in ("text", "dna", "mixed", "runs", "lowent", "random"):
+            a = synth.make(cls, 50000, 7 + level).tobytes()
+            stream = b"".join(bgzf_member(a[i:i + 25000], level) for i in range(0, len(a), 25000))
+            assert dctx.decompress(stream) == a, (level, cls)
+    tiny = b"hello hello hello"
+    assert dctx.decompress(bgzf_member(tiny, 9, zlib.Z_FIXED)) == tiny  # fixed Huffman block
+    far = synth.uniform_random(32768, 1).tobytes()
+    far = far + far[:5000]                                            # matches at distance 32768
+    assert dctx.decompress(bgzf_member(far, 9)) == far
+
+
+def test_reference_test_inputs_roundtrip(dctx, emu_lib, golden):
+    # src/deflate.rs:1024-1051 (test_simple_bgzf_etoe_decompress) and the 206-byte regression input
+    for e in golden["raw_deflate_literal_inputs"]:
+        data = bytes.fromhex(e["input_hex"])
+        with _native.Context(level=1, lib=emu_lib, max_slab_bytes=65280) as c:
+            comp = c.compress_slab(np.frombuffer(data, np.uint8), True)
+        assert dctx.decompress(comp) == data
+
+
+def test_mgzip_large_blocks(emu_lib, oracle):
+    a = synth.make("text", (1 << 20) + 999, 3)
+    comp = oracle.compress_stream(a, oracle.FMT_MGZIP, 3, oracle.COMPAT_1_24, 1 << 20)
+    with _native.DContext(format=_native.FORMAT_MGZIP, lib=emu_lib) as d:
+        assert d.decompress(comp) == a.tobytes()
+
+
+def test_error_classes(dctx, oracle):
+    a = synth.make("text", 70000, 2)
+    comp = bytearray(oracle.compress_stream(a, oracle.FMT_BGZF, 1, oracle.COMPAT_1_24, 65280))
+    bad = bytearray(comp)
+    bad[12] = ord("X")  # "Bad SID"
+    with pytest.raises(_native.GzpxError) as e:
+        dctx.decompress(bytes(bad))
+    assert e.value.code == _native.ERR_INVALID_HEADER
+    bad = bytearray(comp)
+    bad[3] = 0  # "Extra field flag not set"
+    with pytest.raises(_native.GzpxError) as e:
+        dctx.decompress(bytes(bad))
+    assert e.value.code == _native.ERR_INVALID_HEADER
+    offs, sizes, _ = dctx.scan_blocks(bytes(comp))
+    crc_pos = int(offs[0]) + int(sizes[0]) - 8
+    bad = bytearray(comp)
+    bad[crc_pos] ^= 0xFF  # InvalidCheck { found, expected }
+    with pytest.raises(_native.GzpxError) as e:
+        dctx.decompress(bytes(bad))
+    assert e.value.code == _native.ERR_INVALID_CHECK and e.value.block == 0
+    bad = bytearray(comp)
+    for k in range(200, 260):
+        bad[k] ^= 0x5A  # garbage inside the first payload: BadData, or a CRC mismatch
+    with pytest.raises(_native.GzpxError) as e:
+        dctx.decompress(bytes(bad))
+    assert e.value.code in (_native.ERR_BAD_DATA, _native.ERR_INVALID_CHECK, _native.ERR_INSUFFICIENT_SPACE)
+
+
+def test_libdeflate_shaped_decompressor(emu_lib, oracle):
+    d = _native.Decompressor(lib=emu_lib)
+    a = synth.make("fastq", 65280, 4)
+    raw = oracle.deflate_compress(a, 1)
+    assert d.deflate_decompress(raw, a.size) == a.tobytes()
+    assert d.deflate_decompress(raw, a.size + 100) == a.tobytes()  # short output is fine
+    with pytest.raises(_native.GzpxError) as e:
+        d.deflate_decompress(raw, a.size - 1)
+    assert e.value.code == _native.ERR_INSUFFICIENT_SPACE
+    d.close()
+
+
+def test_par_decompress_reader(emu_lib, oracle):
+    a = synth.make("mixed", 5 * 65280 + 321, 9)
+    comp = oracle.compress_stream(a, oracle.FMT_BGZF, 1, oracle.COMPAT_1_24, 65280)
+    r = par.ParDecompressBuilder(par.Bgzf, lib=emu_lib).batch_bytes(100000).from_reader(io.BytesIO(comp))
+    out = r.read(1000) + r.read()
+    assert out == a.tobytes()
+    assert r.read(10) == b""
+    r.close()
+    # a stream cut inside a block body: read_exact's UnexpectedEof (Io)
+    r = par.ParDecompressBuilder(par.Bgzf, lib=emu_lib).from_reader(io.BytesIO(comp[:len(comp) // 2]))
+    with pytest.raises(par.GzpError) as e:
+        r.read()
+    assert e.value.code == _native.ERR_IO
+    r.close()

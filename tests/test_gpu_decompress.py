@@ -1,0 +1,109 @@
+"""GPU ParDecompress<Bgzf/Mgzip> (BASELINE.json configs[5]): inflate kernels on the MI355X against
+the original input of the compressor, zlib-made foreign members, error classes.  Through the C ABI."""
+import io
+import struct
+import zlib
+
+import numpy as np
+import pytest
+
+from gzp_amd import _native, par, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def bgzf_member(chunk, level=6, strategy=zlib.Z_DEFAULT_STRATEGY):
+    co = zlib.compressobj(level, zlib.DEFLATED, -15, 9, strategy)
+    payload = co.compress(chunk) + co.flush()
+    hdr = struct.pack("<BBBBIBBHBBHH", 31, 139, 8, 4, 0, 0, 255, 6, ord("B"), ord("C"), 2, len(payload) + 25)
+    return hdr + payload + struct.pack("<II", zlib.crc32(chunk), len(chunk))
+
+
+@pytest.fixture(scope="module")
+def dctx(hip_lib):
+    c = _native.DContext(lib=hip_lib)
+    yield c
+    c.close()
+
+
+@pytest.mark.parametrize("level", [1, 3])
+def test_roundtrip_all_classes(dctx, hip_lib, level):
+    with _native.Context(level=level, lib=hip_lib) as c:
+        for cls in sorted(synth.CLASSES):
+            a = synth.make(cls, 40 * 65280 + 4321, 17)
+            comp = c.compress_slab(a, True)
+            assert dctx.decompress(comp) == a.tobytes(), cls
+
+
+def test_config5_shape_256mib(dctx, hip_lib):
+    # configs[5]: inflate the output of configs[2] (256 MiB here), verify per-block CRC on device
+    a = synth.text_slab(256 << 20, 5)
+    with _native.Context(level=1, lib=hip_lib) as c:
+        comp = c.compress_slab(a, True)
+    out = dctx.decompress(comp)
+    assert len(out) == a.size and zlib.crc32(out) == zlib.crc32(a.tobytes())
+    assert out == a.tobytes()
+
+
+def test_foreign_zlib_members(dctx):
+    for level in (1, 6, 9):
+        for cls in sorted(synth.CLASSES):
+            a = synth.make(cls, 300000, 7 + level).tobytes()
+            stream = b"".join(bgzf_member(a[i:i + 60000], level) for i in range(0, len(a), 60000))
+            assert dctx.decompress(stream) == a, (level, cls)
+    tiny = b"hello hello hello"
+    assert dctx.decompress(bgzf_member(tiny, 9, zlib.Z_FIXED)) == tiny
+    far = synth.uniform_random(32768, 1).tobytes()
+    far = far + far[:5000]
+    assert dctx.decompress(bgzf_member(far, 9)) == far
+
+
+def test_mgzip_large_blocks(hip_lib):
+    a = synth.make("mixed", (9 << 20) + 999, 3)
+    with _native.Context(format=_native.FORMAT_MGZIP, level=3, buffer_size=4 << 20, lib=hip_lib) as c:
+        comp = c.compress_slab(a, True)
+    with _native.DContext(format=_native.FORMAT_MGZIP, lib=hip_lib) as d:
+        assert d.decompress(comp) == a.tobytes()
+
+
+def test_error_classes(dctx, hip_lib):
+    a = synth.make("text", 5 * 65280, 2)
+    with _native.Context(level=1, lib=hip_lib) as c:
+        comp = c.compress_slab(a, True)
+    bad = bytearray(comp)
+    bad[12] = ord("X")
+    with pytest.raises(_native.GzpxError) as e:
+        dctx.decompress(bytes(bad))
+    assert e.value.code == _native.ERR_INVALID_HEADER
+    offs, sizes, _ = dctx.scan_blocks(comp)
+    bad = bytearray(comp)
+    bad[int(offs[2]) + int(sizes[2]) - 8] ^= 0xFF
+    with pytest.raises(_native.GzpxError) as e:
+        dctx.decompress(bytes(bad))
+    assert e.value.code == _native.ERR_INVALID_CHECK and e.value.block == 2
+    bad = bytearray(comp)
+    for k in range(int(offs[1]) + 200, int(offs[1]) + 260):
+        bad[k] ^= 0x5A
+    with pytest.raises(_native.GzpxError) as e:
+        dctx.decompress(bytes(bad))
+    assert e.value.code in (_native.ERR_BAD_DATA, _native.ERR_INVALID_CHECK, _native.ERR_INSUFFICIENT_SPACE)
+    assert e.value.block == 1
+    # the context stays usable after an error
+    assert dctx.decompress(comp) == a.tobytes()
+
+
+def test_par_decompress_reader(hip_lib):
+    a = synth.make("fastq", 200 * 65280 + 321, 9)
+    w = io.BytesIO()
+    pc = par.ParCompressBuilder(par.Bgzf, lib=hip_lib).from_writer(w)
+    pc.write(a.tobytes())
+    pc.finish()
+    comp = w.getvalue()
+    r = par.ParDecompressBuilder(par.Bgzf, lib=hip_lib).batch_bytes(1 << 20).from_reader(io.BytesIO(comp))
+    assert r.read(12345) + r.read() == a.tobytes()
+    r.close()
+    r = par.ParDecompressBuilder(par.Bgzf, lib=hip_lib).from_reader(io.BytesIO(comp[:len(comp) // 2]))
+    with pytest.raises(par.GzpError) as e:
+        r.read()
+    assert e.value.code == _native.ERR_IO
+    r.close()
