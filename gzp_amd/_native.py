@@ -168,6 +168,8 @@ class GzpxLib:
         L.gzpx_deflate_decompress.argtypes = [vp, vp, sz, vp, sz, psz]
         L.gzpx_free_decompressor.restype = None
         L.gzpx_free_decompressor.argtypes = [vp]
+        L.gzpx_debug_inflate.restype = i32
+        L.gzpx_debug_inflate.argtypes = [vp, i32, ctypes.POINTER(ctypes.c_uint64)]
         L.gzpx_pard_create.restype = i32
         L.gzpx_pard_create.argtypes = [i32, i32, sz, READ_FN, vp, ctypes.POINTER(vp)]
         L.gzpx_pard_read.restype = i32
@@ -435,6 +437,12 @@ class DContext:
         if rc != OK:
             self._raise(rc, info)
         return out[:out_len.value].tobytes()
+
+    def debug_inflate(self, enable):
+        """Switch the instrumented k_inflate on/off; returns the counters of the last launch."""
+        c = (ctypes.c_uint64 * 8)()
+        self.lib.check(self.lib.L.gzpx_debug_inflate(self.h, int(enable), c))
+        return list(c)
 
     def decompress_device(self, d_in_ptr, in_len, offsets, sizes, d_out_ptr, out_cap, stream=None):
         out_len = ctypes.c_size_t(0)

@@ -559,6 +559,8 @@ struct gzpx_dctx {
     uint64_t *h_total = nullptr;
     uint8_t *d_in = nullptr, *d_out = nullptr;
     size_t d_in_cap = 0, d_out_cap = 0;
+    bool debug = false;
+    size_t last_nb = 0;
     std::mutex mu;
 };
 
@@ -609,7 +611,8 @@ int decompress_device_locked(gzpx_dctx *c, const uint8_t *d_in, size_t in_len, c
     HIP_TRY(hipMemcpyAsync(c->d_offsets, offsets, nb * 8, hipMemcpyHostToDevice, stream));
     HIP_TRY(hipMemcpyAsync(c->d_sizes, sizes, nb * 4, hipMemcpyHostToDevice, stream));
     launch_inflate(hdr_len, d_in, c->d_offsets, c->d_sizes, (uint32_t)nb, c->d_blk, c->d_out_off, d_out, out_cap,
-                   c->d_crc, c->cc, stream);
+                   c->d_crc, c->cc, c->debug, stream);
+    c->last_nb = nb;
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(c->h_blk, c->d_blk, nb * sizeof(DBlockHost), hipMemcpyDeviceToHost, stream));
     HIP_TRY(hipMemcpyAsync(c->h_crc, c->d_crc, nb * 4, hipMemcpyDeviceToHost, stream));
@@ -849,6 +852,18 @@ int gzpx_debug_phase_cycles(const gzpx_ctx *ctx, uint64_t cycles[8]) {
     for (int k = 0; k < 8; k++) cycles[k] = 0;
     for (uint32_t b = 0; b < ctx->last_nb; b++)
         for (int k = 0; k < 8; k++) cycles[k] += ctx->h_meta[b].phase_cycles[k];
+    return GZPX_OK;
+}
+
+int gzpx_debug_inflate(gzpx_dctx *ctx, int enable, uint64_t sums[8]) {
+    if (!ctx) return GZPX_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> g(ctx->mu);
+    ctx->debug = enable != 0;
+    if (sums) {
+        for (int k = 0; k < 8; k++) sums[k] = 0;
+        for (size_t b = 0; b < ctx->last_nb; b++)
+            for (int k = 0; k < 8; k++) sums[k] += ctx->h_blk[b].cyc[k];
+    }
     return GZPX_OK;
 }
 

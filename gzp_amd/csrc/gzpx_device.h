@@ -127,9 +127,10 @@ void launch_emit(const Config &cfg, const uint8_t *slab, uint64_t slab_len, uint
 struct DBlockHost {
     uint64_t in_off;
     uint32_t size, isize, crc, status, produced, pad;
+    uint32_t cyc[8];  // debug launches: see DBlock in gzpx_kernels.hip
 };
 void launch_inflate(uint32_t hdr_len, const uint8_t *d_in, const uint64_t *d_offsets, const uint32_t *d_sizes,
                     uint32_t nb, void *d_blk, uint64_t *d_out_off, uint8_t *d_out, uint64_t out_cap,
-                    uint32_t *d_crc_found, const CrcConsts &cc, hipStream_t stream);
+                    uint32_t *d_crc_found, const CrcConsts &cc, bool debug, hipStream_t stream);
 
 }  // namespace gzpx

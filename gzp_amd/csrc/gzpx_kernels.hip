@@ -2186,19 +2186,22 @@ __global__ __launch_bounds__(256) void k_emit(Config cfg, const uint8_t *__restr
 // member, so a slab of blocks is inflated by one launch.
 //   k_dinit    footer (CRC32, ISIZE) of every block -> DBlock
 //   k_dscan    exclusive scan of ISIZE -> output offsets
-//   k_inflate  libdeflate_deflate_decompress for every block: one wave per block; the wave keeps
+//   k_inflate  libdeflate_deflate_decompress for every block: one wave per block.  The wave keeps
 //              the last 32 KiB of output in an LDS ring (the DEFLATE window) and streams finished
-//              output to HBM in coalesced 16 KiB pieces; the compressed bytes come through a
-//              512-byte register ring (two dwords per lane, refilled by cross-lane reads), Huffman
-//              decode tables (10-bit / 8-bit direct lookup + canonical fallback) are rebuilt in LDS
-//              for every dynamic sub-block by all 64 lanes.  The symbol loop itself is the
-//              sequential part: its state is wave-uniform.
+//              output to HBM in coalesced pieces; compressed dwords come through a 1 KiB LDS ring
+//              with one 256-byte piece prefetched in registers; Huffman decode tables (10-bit /
+//              8-bit direct lookup + canonical fallback) are rebuilt in LDS for every dynamic
+//              sub-block by all 64 lanes.  Symbols are decoded 128 bit positions per round: every
+//              lane decodes the symbol that would start at its two positions, a scalar walk picks
+//              the real ones, a prefix sum places them, and each output pass writes 64 bytes.
 //   k_crc32    (shared with the compressor) CRC-32 of the inflated bytes, checked against the footer
 // ------------------------------------------------------------------------------------------
 struct InfLds {
     uint32_t win[8192];     // 32 KiB ring of the most recent output bytes
-    uint16_t lfast[1024];   // litlen: sym | len << 9 for codes of <= 10 bits, 0 = longer code
-    uint16_t ofast[256];    // offset: sym | len << 9 for codes of <= 8 bits
+    uint32_t lfast[1024];   // litlen entries for codes of <= 10 bits, 0 = longer code
+    uint32_t ofast[256];    // offset entries for codes of <= 8 bits (and the 7-bit precode table)
+    uint32_t inr[256];      // ring of compressed dwords (absolute dword index & 255)
+    uint32_t own[64];       // output pass: which symbol starts at each output byte
     uint16_t lsorted[288];  // symbols in canonical order
     uint16_t osorted[32];
     uint8_t lens[320];      // code lengths: litlen then offset
@@ -2208,10 +2211,48 @@ struct InfLds {
 
 enum InflateStatus : uint32_t { kInfOk = 0, kInfBadData = 1, kInfInsufficientSpace = 2, kInfShortOutput = 3 };
 
-// Build the decode tables of one code from h.lens[base .. base + nsyms): counts, canonical first
-// codes, symbols in canonical order, and the direct-lookup table for codes of <= fast_bits bits.
-// All 64 lanes call it.  Returns false for an over-subscribed code.
-__device__ bool inflate_build(const uint8_t *lens, uint32_t nsyms, uint32_t fast_bits, uint16_t *fast,
+// Decode-table entries (32 bit).  bits 0-3: codeword length (0 = not in the fast table);
+//   litlen: bits 4-5 type (0 literal, 1 length, 2 end of block, 3 invalid symbol), bits 8-15 the
+//           literal byte or the number of extra bits, bits 16-24 the base match length;
+//   offset: bit 4 invalid symbol, bits 8-11 number of extra bits, bits 16-31 base distance;
+//   precode: bits 8-12 the symbol.
+enum InfKind { kInfLitlen = 0, kInfOffset = 1, kInfPrecode = 2 };
+
+template <int KIND>
+__device__ __forceinline__ uint32_t inflate_entry(uint32_t sym, uint32_t cl) {
+    if (KIND == kInfPrecode) return cl | (sym << 8);
+    if (KIND == kInfLitlen) {
+        if (sym < 256) return cl | (sym << 8);
+        if (sym == 256) return cl | (2u << 4);
+        if (sym > 285) return cl | (3u << 4);
+        const uint32_t slot = sym - 257;
+        uint32_t base, xb = 0;
+        if (slot < 8) {
+            base = 3 + slot;
+        } else if (slot == 28) {
+            base = 258;
+        } else {
+            xb = (slot - 4) >> 2;
+            base = 3 + ((4 + (slot & 3)) << xb);
+        }
+        return cl | (1u << 4) | (xb << 8) | (base << 16);
+    }
+    if (sym > 29) return cl | (1u << 4);
+    uint32_t base, xb = 0;
+    if (sym < 4) {
+        base = 1 + sym;
+    } else {
+        xb = (sym - 2) >> 1;
+        base = 1 + ((2 + (sym & 1)) << xb);
+    }
+    return cl | (xb << 8) | (base << 16);
+}
+
+// Build the decode tables of one code from lens[0 .. nsyms): counts, canonical first codes, symbols
+// in canonical order, and the direct-lookup table for codes of <= fast_bits bits.  All 64 lanes
+// call it.  Returns false for an over-subscribed code.
+template <int KIND>
+__device__ bool inflate_build(const uint8_t *lens, uint32_t nsyms, uint32_t fast_bits, uint32_t *fast,
                               uint16_t *sorted, uint32_t *count, uint32_t *first, uint32_t *offs,
                               uint32_t lane) {
     const uint64_t lane_below = (1ull << lane) - 1ull;
@@ -2256,7 +2297,7 @@ __device__ bool inflate_build(const uint8_t *lens, uint32_t nsyms, uint32_t fast
             sorted[off[myl] + rank] = (uint16_t)s;
             if (myl <= fast_bits) {
                 const uint32_t cw = __brev(fst[myl] + rank) >> (32 - myl);  // LSB-first codeword
-                const uint16_t e = (uint16_t)(s | (myl << 9));
+                const uint32_t e = inflate_entry<KIND>(s, myl);
                 for (uint32_t k = cw; k < (1u << fast_bits); k += 1u << myl) fast[k] = e;
             }
         }
@@ -2265,26 +2306,17 @@ __device__ bool inflate_build(const uint8_t *lens, uint32_t nsyms, uint32_t fast
     return true;
 }
 
-// One symbol of a canonical Huffman code from the low bits of `bits` (LSB first).  Returns the
-// symbol and its length, or len = 0 when no codeword matches (bad data).
-__device__ __forceinline__ uint32_t inflate_sym(uint32_t bits, const uint16_t *fast, uint32_t fast_bits,
-                                                const uint16_t *sorted, const uint32_t *count,
-                                                const uint32_t *first, const uint32_t *offs, uint32_t &len) {
-    const uint32_t e = fast[bits & ((1u << fast_bits) - 1u)];
-    if (e) {
-        len = e >> 9;
-        return e & 0x1FFu;
-    }
+// A codeword that is not in the fast table: canonical decode from the low bits of `bits` (LSB
+// first).  Wave-uniform.  Returns the entry, or 0 when no codeword matches (bad data).
+template <int KIND>
+__device__ uint32_t inflate_slow(uint32_t bits, const uint16_t *sorted, const uint32_t *count,
+                                 const uint32_t *first, const uint32_t *offs) {
     uint32_t code = 0;
     for (uint32_t l = 1; l <= 15; l++) {
         code = (code << 1) | ((bits >> (l - 1)) & 1u);
         const uint32_t c = count[l];
-        if (code - first[l] < c) {
-            len = l;
-            return sorted[offs[l] + code - first[l]];
-        }
+        if (code - first[l] < c) return inflate_entry<KIND>(sorted[offs[l] + code - first[l]], l);
     }
-    len = 0;
     return 0;
 }
 
@@ -2296,6 +2328,9 @@ struct DBlock {
     uint32_t status;    // InflateStatus
     uint32_t produced;  // bytes actually inflated
     uint32_t pad;
+    uint32_t cyc[8];    // debug launches only: shader-clock cycles [0] whole block, [1] headers + table
+                        // builds, [2] round set-up (input bits + table gathers), [3] literal stores +
+                        // match copies; counts [4] rounds, [5] literals, [6] matches, [7] window flushes
 };
 
 __global__ void k_dinit(uint32_t nb, const uint8_t *__restrict__ in, const uint64_t *__restrict__ offsets,
@@ -2311,6 +2346,7 @@ __global__ void k_dinit(uint32_t nb, const uint8_t *__restrict__ in, const uint6
     d.status = kInfOk;
     d.produced = 0;
     d.pad = 0;
+    for (uint32_t k = 0; k < 8; k++) d.cyc[k] = 0;
     blk[b] = d;
 }
 
@@ -2335,12 +2371,50 @@ __global__ __launch_bounds__(256) void k_dscan(uint32_t nb, const DBlock *__rest
     if (tid == 0) out_off[nb] = carry_s;
 }
 
+__device__ __forceinline__ uint32_t rdlane(uint32_t v, uint32_t l) {
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)l);
+}
+__device__ __forceinline__ uint32_t uniform(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+
+// wave-wide inclusive scans on the DPP network (row shifts, then the row broadcasts of gfx9)
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint32_t dpp_zero(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xf, false);
+}
+__device__ __forceinline__ uint32_t wave_incl_add(uint32_t v) {
+    v += dpp_zero<0x111, 0xf>(v);
+    v += dpp_zero<0x112, 0xf>(v);
+    v += dpp_zero<0x114, 0xf>(v);
+    v += dpp_zero<0x118, 0xf>(v);
+    v += dpp_zero<0x142, 0xa>(v);
+    v += dpp_zero<0x143, 0xc>(v);
+    return v;
+}
+__device__ __forceinline__ uint32_t umax32(uint32_t a, uint32_t b) { return a > b ? a : b; }
+__device__ __forceinline__ uint32_t wave_incl_max(uint32_t v) {
+    v = umax32(v, dpp_zero<0x111, 0xf>(v));
+    v = umax32(v, dpp_zero<0x112, 0xf>(v));
+    v = umax32(v, dpp_zero<0x114, 0xf>(v));
+    v = umax32(v, dpp_zero<0x118, 0xf>(v));
+    v = umax32(v, dpp_zero<0x142, 0xa>(v));
+    v = umax32(v, dpp_zero<0x143, 0xc>(v));
+    return v;
+}
+
+// The symbol loop works in rounds of 64 bit positions.  Lane i takes the 32 bits that start at bit
+// bp + i of the payload and looks them up in BOTH fast tables (two LDS gathers for the whole wave:
+// every lane decodes "as if a codeword started here").  The wave-uniform walk then hops from real
+// codeword to real codeword reading those per-lane results with v_readlane -- scalar ALU only, no
+// memory latency per symbol.  Literals of a round are stored together (one ds_write_b8, each marked
+// lane at o + its rank); a match first commits the literals before it, then copies with the wave.
+template <bool DBG>
 __global__ __launch_bounds__(64) void k_inflate(uint32_t hdr_len, const uint8_t *__restrict__ in_all,
                                                 DBlock *__restrict__ blk_all,
                                                 const uint64_t *__restrict__ out_off,
                                                 uint8_t *__restrict__ out_all, uint64_t out_cap) {
     __shared__ InfLds h;
     const uint32_t lane = threadIdx.x;
+    const uint64_t lane_below = (1ull << lane) - 1ull;
     DBlock *blk = blk_all + blockIdx.x;
     const uint32_t isize = blk->isize;
     if (isize == 0) return;  // src/par/decompress.rs:163-171: nothing to decode
@@ -2352,66 +2426,54 @@ __global__ __launch_bounds__(64) void k_inflate(uint32_t hdr_len, const uint8_t 
     uint8_t *out = out_all + ooff;
     const uint8_t *pay = in_all + blk->in_off + hdr_len;
     const uint32_t pay_len = blk->size - hdr_len - 8;
-    const uint8_t *hwin = (const uint8_t *)h.win;
+    uint8_t *win8 = (uint8_t *)h.win;
+    const long long t_begin = DBG ? clock64() : 0;
+    uint32_t dbg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 
-    // ---- compressed bytes: a 512-byte register ring of aligned dwords, two per lane
+    // ---- compressed bytes: aligned dwords through an LDS ring, one 256-byte piece prefetched in
+    // registers; bit positions count from the aligned dword that holds the first payload byte
     const uint32_t pmis = (uint32_t)((uintptr_t)pay & 3u);
     const uint32_t *pay32 = (const uint32_t *)(pay - pmis);
     const uint32_t pay_words = (pmis + pay_len + 8 + 3) >> 2;  // the 8 footer bytes are readable too
-    uint32_t ring_base = 0;  // dword index of ring_a's lane 0
-    uint32_t ring_a = lane < pay_words ? pay32[lane] : 0u;
-    uint32_t ring_b = 64 + lane < pay_words ? pay32[64 + lane] : 0u;
-    auto ring_seek = [&](uint32_t byte_pos) {  // make the ring cover the dword of byte_pos (+ 8 bytes)
-        const uint32_t w = (byte_pos + pmis) >> 2;
-        while (w + 3 >= ring_base + 128) {
-            if (w >= ring_base + 192) {  // a jump (stored block): reload both halves
-                ring_base = w & ~63u;
-                ring_a = ring_base + lane < pay_words ? pay32[ring_base + lane] : 0u;
-                ring_b = ring_base + 64 + lane < pay_words ? pay32[ring_base + 64 + lane] : 0u;
-            } else {
-                ring_a = ring_b;
-                ring_base += 64;
-                ring_b = ring_base + 64 + lane < pay_words ? pay32[ring_base + 64 + lane] : 0u;
-            }
+    const uint32_t bit0 = 8u * pmis, bit_end = bit0 + 8u * pay_len;
+    uint32_t hi_w = 0;  // dwords [.., hi_w) are in the ring; `pre` holds [hi_w, hi_w + 64)
+    auto fetch = [&](uint32_t w) -> uint32_t {  // clamped: bits past the footer are never used
+        return pay32[w < pay_words ? w : pay_words - 1];
+    };
+    uint32_t pre = fetch(lane);
+    auto ensure = [&](uint32_t bpos) {  // the ring covers dwords (bpos >> 5) .. (bpos >> 5) + 5
+        const uint32_t w = bpos >> 5;
+        if (w >= hi_w + 64) {  // a jump (after a stored block)
+            hi_w = w;
+            pre = fetch(hi_w + lane);
+        }
+        if (w + 6 > hi_w) {
+            wave_sync();
+            do {
+                h.inr[(hi_w + lane) & 255u] = pre;
+                hi_w += 64;
+                pre = fetch(hi_w + lane);
+            } while (w + 6 > hi_w);
+            wave_sync();
         }
     };
-    auto ring_word = [&](uint32_t w) -> uint32_t {  // aligned dword w (uniform)
-        const uint32_t i = w - ring_base;
-        const uint32_t va = __shfl(ring_a, (int)(i & 63u)), vb = __shfl(ring_b, (int)(i & 63u));
-        return i < 64 ? va : vb;
-    };
-    auto load32 = [&](uint32_t byte_pos) -> uint32_t {  // 4 payload bytes at byte_pos (uniform)
-        ring_seek(byte_pos);
-        const uint32_t a = byte_pos + pmis;
-        return __builtin_amdgcn_alignbyte(ring_word((a >> 2) + 1), ring_word(a >> 2), a & 3u);
+    auto bits_at = [&](uint32_t bpos) -> uint32_t {  // 32 payload bits from bit position bpos
+        const uint32_t w = bpos >> 5;
+        const uint32_t lo = h.inr[w & 255u], hi = h.inr[(w + 1) & 255u];
+        return (uint32_t)(((((uint64_t)hi) << 32) | lo) >> (bpos & 31u));
     };
 
-    // ---- bit reader (wave-uniform)
-    uint64_t bitbuf = 0;
-    uint32_t bitcnt = 0, in_pos = 0;  // in_pos: payload bytes already moved into bitbuf
-    auto refill = [&]() {
-        if (bitcnt <= 32) {
-            bitbuf |= (uint64_t)load32(in_pos) << bitcnt;
-            in_pos += 4;
-            bitcnt += 32;
-        }
-    };
-    auto take = [&](uint32_t nbits) -> uint32_t {
-        const uint32_t v = (uint32_t)bitbuf & ((nbits >= 32) ? 0xFFFFFFFFu : ((1u << nbits) - 1u));
-        bitbuf >>= nbits;
-        bitcnt -= nbits;
-        return v;
-    };
-
+    uint32_t bp = bit0;
     uint32_t o = 0;        // bytes produced
     uint32_t flushed = 0;  // bytes already written to HBM
     uint32_t status = kInfOk;
     // write ring bytes [flushed, upto) to HBM: whole dwords where the destination is aligned
     auto flush = [&](uint32_t upto) {
         wave_sync();
+        if (DBG) dbg[7]++;
         uint32_t q = flushed;
         while (q < upto && (((uintptr_t)(out + q)) & 3u)) {  // head bytes (uniform loop)
-            if (lane == 0) out[q] = hwin[q & 32767u];
+            if (lane == 0) out[q] = win8[q & 32767u];
             q++;
         }
         const uint32_t nw = (upto - q) >> 2;
@@ -2421,26 +2483,40 @@ __global__ __launch_bounds__(64) void k_inflate(uint32_t hdr_len, const uint8_t 
             *(uint32_t *)(out + q + 4 * k) = __builtin_amdgcn_alignbyte(hi, lo, r & 3u);
         }
         q += 4 * nw;
-        if (q + lane < upto) out[q + lane] = hwin[(q + lane) & 32767u];
+        if (q + lane < upto) out[q + lane] = win8[(q + lane) & 32767u];
         flushed = upto;
         wave_sync();
     };
 
     bool final_block = false;
     while (!final_block && status == kInfOk) {
-        refill();
-        final_block = take(1) != 0;
-        const uint32_t btype = take(2);
+        bp = uniform(bp);
+        o = uniform(o);
+        flushed = uniform(flushed);
+        hi_w = uniform(hi_w);
+        status = uniform(status);
+        if (bp > bit_end) {
+            status = kInfBadData;
+            break;
+        }
+        ensure(bp);
+        const long long t_hdr = DBG ? clock64() : 0;
+        const uint32_t hb = uniform(bits_at(bp));
+        final_block = (hb & 1u) != 0;
+        const uint32_t btype = (hb >> 1) & 3u;
+        bp += 3;
         if (btype == 0) {
             // stored: skip to a byte boundary, LEN, NLEN, raw bytes
-            take(bitcnt & 7u);
-            refill();
-            const uint32_t len = take(16), nlen = take(16);
+            bp = (bp + 7u) & ~7u;
+            ensure(bp);
+            const uint32_t x = uniform(bits_at(bp));
+            const uint32_t len = x & 0xFFFFu, nlen = x >> 16;
+            bp += 32;
             if ((len ^ 0xFFFFu) != nlen) {
                 status = kInfBadData;
                 break;
             }
-            const uint32_t src = in_pos - (bitcnt >> 3);  // next unread payload byte
+            const uint32_t src = (bp - bit0) >> 3;  // next unread payload byte
             if (src + len > pay_len) {
                 status = kInfBadData;
                 break;
@@ -2453,13 +2529,10 @@ __global__ __launch_bounds__(64) void k_inflate(uint32_t hdr_len, const uint8_t 
                 const uint32_t piece = len - done < 16384u ? len - done : 16384u;
                 if (o + piece - flushed > 32768u - 16u) flush(o);
                 wave_sync();
-                for (uint32_t i = lane; i < piece; i += 64)
-                    ((uint8_t *)h.win)[(o + i) & 32767u] = pay[src + done + i];
+                for (uint32_t i = lane; i < piece; i += 64) win8[(o + i) & 32767u] = pay[src + done + i];
                 o += piece;
             }
-            bitbuf = 0;
-            bitcnt = 0;
-            in_pos = src + len;
+            bp += 8u * len;
             continue;
         }
         if (btype == 3) {
@@ -2467,35 +2540,31 @@ __global__ __launch_bounds__(64) void k_inflate(uint32_t hdr_len, const uint8_t 
             break;
         }
         // ---- code lengths
-        uint32_t nlit, ndist;
         if (btype == 1) {
-            nlit = 288;
-            ndist = 32;
             for (uint32_t i = lane; i < 320; i += 64)
                 h.lens[i] = (uint8_t)(i < 144 ? 8 : i < 256 ? 9 : i < 280 ? 7 : i < 288 ? 8 : 5);
             wave_sync();
         } else {
-            refill();
-            nlit = take(5) + 257;
-            ndist = take(5) + 1;
-            const uint32_t nclen = take(4) + 4;
+            const uint32_t nlit = ((hb >> 3) & 31u) + 257, ndist = ((hb >> 8) & 31u) + 1;
+            const uint32_t nclen = ((hb >> 13) & 15u) + 4;
+            bp += 14;
             if (nlit > 286 + 2 || ndist > 32) {
                 status = kInfBadData;
                 break;
             }
-            // the precode: 19 lengths of 3 bits in a fixed order, decoded with a 7-bit table that
-            // lives in ofast[0..127] until the real offset table is built
+            // the precode: nclen lengths of 3 bits in a fixed order (one per lane), decoded with a
+            // 7-bit table that lives in ofast[0..127] until the real offset table is built
+            ensure(bp + 64);
             wave_sync();
-            if (lane < 19) h.lens[lane] = 0;
-            wave_sync();
-            for (uint32_t i = 0; i < nclen; i++) {
-                refill();
-                const uint32_t v = take(3);
+            {
                 const uint8_t order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
-                if (lane == 0) h.lens[order[i]] = (uint8_t)v;
+                const uint32_t v = bits_at(bp + 3u * (lane < 19 ? lane : 0)) & 7u;
+                if (lane < 19) h.lens[order[lane]] = (uint8_t)(lane < nclen ? v : 0u);
             }
+            bp += 3u * nclen;
             wave_sync();
-            if (!inflate_build(h.lens, 19, 7, h.ofast, h.osorted, h.ocount, h.ofirst, h.ooffs, lane)) {
+            if (!inflate_build<kInfPrecode>(h.lens, 19, 7, h.ofast, h.osorted, h.ocount, h.ofirst, h.ooffs,
+                                            lane)) {
                 status = kInfBadData;
                 break;
             }
@@ -2503,32 +2572,35 @@ __global__ __launch_bounds__(64) void k_inflate(uint32_t hdr_len, const uint8_t 
             uint32_t i = 0;
             const uint32_t total = nlit + ndist;
             uint32_t prev = 0;
-            uint8_t *tmp = (uint8_t *)h.lfast;  // 2 KiB scratch, free until the litlen table is built
+            uint8_t *tmp = (uint8_t *)h.lfast;  // scratch, free until the litlen table is built
             while (i < total) {
-                refill();
-                uint32_t l;
-                const uint32_t sym = inflate_sym((uint32_t)bitbuf, h.ofast, 7, h.osorted, h.ocount, h.ofirst,
-                                                 h.ooffs, l);
-                if (l == 0) {
+                ensure(bp);
+                const uint32_t b = uniform(bits_at(bp));
+                const uint32_t e = uniform(h.ofast[b & 127u]);
+                const uint32_t cl = e & 15u, sym = e >> 8;
+                if (cl == 0) {  // precode words are <= 7 bits: a miss is an unused codeword
                     status = kInfBadData;
                     break;
                 }
-                take(l);
-                uint32_t rep = 1, val = sym;
+                uint32_t rep = 1, val = sym, used = cl;
                 if (sym == 16) {
                     if (i == 0) {
                         status = kInfBadData;
                         break;
                     }
-                    rep = 3 + take(2);
+                    rep = 3 + ((b >> cl) & 3u);
+                    used += 2;
                     val = prev;
                 } else if (sym == 17) {
-                    rep = 3 + take(3);
+                    rep = 3 + ((b >> cl) & 7u);
+                    used += 3;
                     val = 0;
                 } else if (sym == 18) {
-                    rep = 11 + take(7);
+                    rep = 11 + ((b >> cl) & 127u);
+                    used += 7;
                     val = 0;
                 }
+                bp += used;
                 if (i + rep > total) {
                     status = kInfBadData;
                     break;
@@ -2558,63 +2630,216 @@ __global__ __launch_bounds__(64) void k_inflate(uint32_t hdr_len, const uint8_t 
                 break;
             }
         }
-        if (!inflate_build(h.lens, 288, 10, h.lfast, h.lsorted, h.lcount, h.lfirst, h.loffs, lane) ||
-            !inflate_build(h.lens + 288, 32, 8, h.ofast, h.osorted, h.ocount, h.ofirst, h.ooffs, lane)) {
+        if (!inflate_build<kInfLitlen>(h.lens, 288, 10, h.lfast, h.lsorted, h.lcount, h.lfirst, h.loffs, lane) ||
+            !inflate_build<kInfOffset>(h.lens + 288, 32, 8, h.ofast, h.osorted, h.ocount, h.ofirst, h.ooffs,
+                                       lane)) {
             status = kInfBadData;
             break;
         }
-        // ---- symbols
-        for (;;) {
-            refill();
-            uint32_t l;
-            const uint32_t sym = inflate_sym((uint32_t)bitbuf, h.lfast, 10, h.lsorted, h.lcount, h.lfirst,
-                                             h.loffs, l);
-            if (l == 0) {
+        if (DBG) dbg[1] += (uint32_t)(clock64() - t_hdr);
+        // ---- symbols, 64 bit positions per round
+        bool eob = false;
+        while (!eob && status == kInfOk) {
+            if (bp > bit_end) {
                 status = kInfBadData;
                 break;
             }
-            take(l);
-            if (sym < 256) {
+            const long long t_round = DBG ? clock64() : 0;
+            // (these are wave-uniform by construction; saying so keeps the loop on the scalar unit)
+            bp = uniform(bp);
+            o = uniform(o);
+            flushed = uniform(flushed);
+            hi_w = uniform(hi_w);
+            status = uniform(status);
+            ensure(bp + 64);
+            // (1) every lane decodes the symbols that would start at bits bp + lane and
+            // bp + 64 + lane, completely: litlen codeword, extra bits, offset codeword, extra bits
+            // (<= 48 of the 64 bits it reads from each position)
+            uint32_t le[2], pack2[2], adv[2], outlen[2];
+            bool is_match[2];
+            uint64_t stop_mask[2];
+#pragma unroll
+            for (uint32_t hf = 0; hf < 2; hf++) {
+                const uint32_t q = bp + 64 * hf + lane, qw = q >> 5;
+                const uint32_t d0 = h.inr[qw & 255u], d1 = h.inr[(qw + 1) & 255u], d2 = h.inr[(qw + 2) & 255u];
+                const uint32_t b_lo = __builtin_amdgcn_alignbit(d1, d0, q & 31u);
+                const uint32_t b_hi = __builtin_amdgcn_alignbit(d2, d1, q & 31u);
+                le[hf] = h.lfast[b_lo & 1023u];
+                const uint32_t cl = le[hf] & 15u, type = (le[hf] >> 4) & 3u, xb = (le[hf] >> 8) & 0xFFu;
+                const bool is_lit = cl != 0 && type == 0;
+                const bool is_len = cl != 0 && type == 1;
+                const uint32_t used1 = is_len ? cl + xb : 0u;  // <= 20
+                const uint32_t b2 = (uint32_t)(((((uint64_t)b_hi) << 32) | b_lo) >> used1);
+                uint32_t oe = 0;
+                if (is_len) oe = h.ofast[b2 & 255u];
+                const uint32_t dcl = oe & 15u, dxb = (oe >> 8) & 15u;
+                is_match[hf] = is_len && dcl != 0 && (oe & 16u) == 0;
+                const uint32_t mlen = (le[hf] >> 16) + ((b_lo >> cl) & ((1u << xb) - 1u));
+                const uint32_t mdist = (oe >> 16) + ((b2 >> dcl) & ((1u << dxb) - 1u));
+                pack2[hf] = mdist | (mlen << 16);
+                // anything else (end of block, codeword outside the fast tables, invalid symbol)
+                // stops the walk: that symbol goes through the one-symbol path below
+                adv[hf] = is_lit ? cl : is_match[hf] ? used1 + dcl + dxb : 128u;
+                outlen[hf] = is_lit ? 1u : is_match[hf] ? mlen : 0u;
+                stop_mask[hf] = __ballot(!is_lit && !is_match[hf]);
+            }
+            // (2) the walk: which positions hold real symbols (wave-uniform, scalar)
+            uint64_t started[2] = {0, 0};
+            uint32_t pos = 0, last = 0;
+            do {
+                last = pos;
+                pos += rdlane(adv[0], pos);
+                started[0] |= 1ull << last;
+            } while (pos < 64);
+            while (pos < 128) {
+                last = pos;
+                pos += rdlane(adv[1], pos - 64);
+                started[1] |= 1ull << (last - 64);
+            }
+            const bool hit_stop = ((stop_mask[last >> 6] >> (last & 63u)) & 1ull) != 0;
+            if (hit_stop) started[last >> 6] &= ~(1ull << (last & 63u));
+            if (DBG) {
+                dbg[2] += (uint32_t)(clock64() - t_round);
+                dbg[4]++;
+                dbg[5] += (uint32_t)(__popcll(started[0]) + __popcll(started[1]));
+            }
+            // (3) output of the started symbols: positions by a prefix sum of their lengths, then
+            // 64 output bytes per pass, every lane producing one byte
+            if (started[0] | started[1]) {
+                const long long t_out = DBG ? clock64() : 0;
+                bool mine[2];
+                uint32_t opos[2], pack1[2];
+                uint32_t tout = 0;
+                bool bad_dist = false;
+#pragma unroll
+                for (uint32_t hf = 0; hf < 2; hf++) {
+                    mine[hf] = ((started[hf] >> lane) & 1ull) != 0;
+                    const uint32_t mylen = mine[hf] ? outlen[hf] : 0u;
+                    const uint32_t incl = wave_incl_add(mylen) + tout;
+                    opos[hf] = incl - mylen;  // relative to o
+                    tout = rdlane(incl, 63);
+                    bad_dist = bad_dist || (mine[hf] && is_match[hf] && (pack2[hf] & 0xFFFFu) > o + opos[hf]);
+                    pack1[hf] = opos[hf] | ((le[hf] >> 8 & 0xFFu) << 16) | (is_match[hf] ? 1u << 24 : 0u);
+                }
+                if (__ballot(bad_dist)) {
+                    status = kInfBadData;
+                    break;
+                }
+                if (o + tout > isize) {
+                    status = kInfInsufficientSpace;
+                    break;
+                }
+                if (o + tout - flushed > 32768u) flush(o & ~3u);
+                uint32_t carry = 0;
+                for (uint32_t pass = 0; pass < tout; pass += 64) {
+                    // owner (position + 1) of every output byte of this pass: scatter the symbol
+                    // starts, then a running maximum
+                    wave_sync();
+                    h.own[lane] = 0;
+                    wave_sync();
+                    if (mine[0] && opos[0] - pass < 64u) h.own[opos[0] - pass] = lane + 1;
+                    if (mine[1] && opos[1] - pass < 64u) h.own[opos[1] - pass] = lane + 65;
+                    wave_sync();
+                    uint32_t own = h.own[lane];
+                    if (lane == 0 && own < carry) own = carry;
+                    own = wave_incl_max(own);
+                    carry = rdlane(own, 63);
+                    const int from = (int)(((own - 1) & 63u) << 2);
+                    const uint32_t p1a = (uint32_t)__builtin_amdgcn_ds_bpermute(from, (int)pack1[0]);
+                    const uint32_t p1b = (uint32_t)__builtin_amdgcn_ds_bpermute(from, (int)pack1[1]);
+                    const uint32_t p2a = (uint32_t)__builtin_amdgcn_ds_bpermute(from, (int)pack2[0]);
+                    const uint32_t p2b = (uint32_t)__builtin_amdgcn_ds_bpermute(from, (int)pack2[1]);
+                    const uint32_t p1 = own > 64 ? p1b : p1a, p2 = own > 64 ? p2b : p2a;
+                    const uint32_t prel = pass + lane;
+                    const bool active = prel < tout;
+                    const bool m = ((p1 >> 24) & 1u) != 0;
+                    const uint32_t sdist = p2 & 0xFFFFu, slen = p2 >> 16;
+                    uint32_t r = prel - (p1 & 0xFFFFu);
+                    if (m && sdist < slen) {  // overlapping copy: the source repeats with period dist
+                        uint32_t rr = r - (uint32_t)((float)r * (1.0f / (float)sdist)) * sdist;
+                        if ((int32_t)rr < 0) rr += sdist;
+                        if (rr >= sdist) rr -= sdist;
+                        r = rr;
+                    }
+                    const uint32_t srcrel = (p1 & 0xFFFFu) - sdist + r;  // relative to o; "negative" = older
+                    uint64_t done = __ballot(!active);
+                    bool pending = active;
+                    do {
+                        const bool in_pass = m && (int32_t)(srcrel - pass) >= 0;
+                        const bool ready = pending && (!in_pass || ((done >> ((srcrel - pass) & 63u)) & 1ull) != 0);
+                        uint32_t v = (p1 >> 16) & 0xFFu;
+                        if (ready && m) v = win8[(o + srcrel) & 32767u];
+                        wave_sync();
+                        if (ready) win8[(o + prel) & 32767u] = (uint8_t)v;
+                        wave_sync();
+                        done |= __ballot(ready);
+                        pending = pending && !ready;
+                        if (DBG) dbg[6]++;
+                    } while (__ballot(pending) != 0);
+                }
+                o += tout;
+                if (DBG) dbg[3] += (uint32_t)(clock64() - t_out);
+            }
+            if (!hit_stop) {
+                bp += pos;
+                continue;
+            }
+            // (4) one symbol the slow way: end of block, long codewords, errors
+            bp += last;
+            ensure(bp);
+            const uint32_t sw = bp >> 5;
+            const uint32_t s0 = h.inr[sw & 255u], s1 = h.inr[(sw + 1) & 255u], s2 = h.inr[(sw + 2) & 255u];
+            const uint32_t sb_lo = uniform(__builtin_amdgcn_alignbit(s1, s0, bp & 31u));
+            const uint32_t sb_hi = uniform(__builtin_amdgcn_alignbit(s2, s1, bp & 31u));
+            uint32_t e = uniform(h.lfast[sb_lo & 1023u]);
+            if ((e & 15u) == 0) {
+                e = uniform(inflate_slow<kInfLitlen>(sb_lo, h.lsorted, h.lcount, h.lfirst, h.loffs));
+                if (e == 0) {
+                    status = kInfBadData;
+                    break;
+                }
+            }
+            const uint32_t stype = (e >> 4) & 3u, scl = e & 15u;
+            if (stype == 2) {
+                bp += scl;
+                eob = true;
+                break;
+            }
+            if (stype == 3) {
+                status = kInfBadData;
+                break;
+            }
+            if (stype == 0) {
                 if (o >= isize) {
                     status = kInfInsufficientSpace;
                     break;
                 }
-                if (o - flushed >= 32768u - 320u) flush(o & ~3u);
-                if (lane == 0) ((uint8_t *)h.win)[o & 32767u] = (uint8_t)sym;
+                if (o + 1 - flushed > 32768u) flush(o & ~3u);
+                wave_sync();
+                if (lane == 0) win8[o & 32767u] = (uint8_t)(e >> 8);
+                wave_sync();
                 o++;
+                bp += scl;
                 continue;
             }
-            if (sym == 256) break;
-            if (sym > 285) {
+            const uint32_t sxb = (e >> 8) & 0xFFu;
+            const uint32_t len = (e >> 16) + ((sb_lo >> scl) & ((1u << sxb) - 1u));
+            const uint32_t sb2 = (uint32_t)(((((uint64_t)sb_hi) << 32) | sb_lo) >> (scl + sxb));
+            uint32_t d = uniform(h.ofast[sb2 & 255u]);
+            if ((d & 15u) == 0) {
+                d = uniform(inflate_slow<kInfOffset>(sb2, h.osorted, h.ocount, h.ofirst, h.ooffs));
+                if (d == 0) {
+                    status = kInfBadData;
+                    break;
+                }
+            }
+            if (d & 16u) {
                 status = kInfBadData;
                 break;
             }
-            const uint32_t slot = sym - 257;
-            uint32_t len;
-            if (slot < 8) {
-                len = 3 + slot;
-            } else if (slot == 28) {
-                len = 258;
-            } else {
-                const uint32_t e = (slot - 4) >> 2;
-                len = 3 + ((4 + (slot & 3)) << e) + take(e);
-            }
-            refill();
-            uint32_t ol;
-            const uint32_t osym = inflate_sym((uint32_t)bitbuf, h.ofast, 8, h.osorted, h.ocount, h.ofirst,
-                                              h.ooffs, ol);
-            if (ol == 0 || osym > 29) {
-                status = kInfBadData;
-                break;
-            }
-            take(ol);
-            uint32_t dist;
-            if (osym < 4) {
-                dist = 1 + osym;
-            } else {
-                const uint32_t e = (osym - 2) >> 1;
-                dist = 1 + ((2 + (osym & 1)) << e) + take(e);
-            }
+            const uint32_t sdcl = d & 15u, sdxb = (d >> 8) & 15u;
+            const uint32_t dist = (d >> 16) + ((sb2 >> sdcl) & ((1u << sdxb) - 1u));
+            bp += scl + sxb + sdcl + sdxb;
             if (dist > o) {
                 status = kInfBadData;
                 break;
@@ -2623,20 +2848,25 @@ __global__ __launch_bounds__(64) void k_inflate(uint32_t hdr_len, const uint8_t 
                 status = kInfInsufficientSpace;
                 break;
             }
-            if (o + len - flushed >= 32768u - 64u) flush(o & ~3u);
+            if (o + len - flushed > 32768u) flush(o & ~3u);
             // out[o + i] = out[o - dist + (i mod dist)]: every source byte is older than o
             wave_sync();
-            uint32_t v[5];
-            for (uint32_t k = 0; k < 5; k++) {
-                const uint32_t i = lane + 64 * k;
-                v[k] = i < len ? hwin[(o - dist + (i % dist)) & 32767u] : 0u;
-            }
-            wave_sync();
-            for (uint32_t k = 0; k < 5; k++) {
-                const uint32_t i = lane + 64 * k;
-                if (i < len) ((uint8_t *)h.win)[(o + i) & 32767u] = (uint8_t)v[k];
+            const uint32_t src0 = o - dist;
+            const float rcp = 1.0f / (float)dist;
+            for (uint32_t base = 0; base < len; base += 64) {
+                const uint32_t i = base + lane;
+                uint32_t r = i;
+                if (dist < len) {
+                    r = i - (uint32_t)((float)i * rcp) * dist;  // i mod dist (i < 320)
+                    if ((int32_t)r < 0) r += dist;
+                    if (r >= dist) r -= dist;
+                }
+                const uint32_t v = win8[(src0 + (i < len ? r : 0u)) & 32767u];
+                wave_sync();
+                if (i < len) win8[(o + i) & 32767u] = (uint8_t)v;
             }
             o += len;
+            wave_sync();
         }
     }
     if (status == kInfOk && o != isize) status = kInfShortOutput;
@@ -2646,6 +2876,10 @@ __global__ __launch_bounds__(64) void k_inflate(uint32_t hdr_len, const uint8_t 
     if (lane == 0) {
         blk->status = status;
         blk->produced = o;
+        if (DBG) {
+            dbg[0] = (uint32_t)(clock64() - t_begin);
+            for (uint32_t k = 0; k < 8; k++) blk->cyc[k] = dbg[k];
+        }
     }
 }
 
@@ -2746,12 +2980,16 @@ void launch_emit(const Config &cfg, const uint8_t *slab, uint64_t, uint32_t nb, 
 
 void launch_inflate(uint32_t hdr_len, const uint8_t *d_in, const uint64_t *d_offsets, const uint32_t *d_sizes,
                     uint32_t nb, void *d_blk, uint64_t *d_out_off, uint8_t *d_out, uint64_t out_cap,
-                    uint32_t *d_crc_found, const CrcConsts &cc, hipStream_t stream) {
+                    uint32_t *d_crc_found, const CrcConsts &cc, bool debug, hipStream_t stream) {
     DBlock *blk = (DBlock *)d_blk;
     hipLaunchKernelGGL(k_dinit, dim3((nb + 255) / 256), dim3(256), 0, stream, nb, d_in, d_offsets, d_sizes, blk);
     hipLaunchKernelGGL(k_dscan, dim3(1), dim3(256), 0, stream, nb, (const DBlock *)blk, d_out_off);
-    hipLaunchKernelGGL(k_inflate, dim3(nb), dim3(64), 0, stream, hdr_len, d_in, blk,
-                       (const uint64_t *)d_out_off, d_out, out_cap);
+    if (debug)
+        hipLaunchKernelGGL(k_inflate<true>, dim3(nb), dim3(64), 0, stream, hdr_len, d_in, blk,
+                           (const uint64_t *)d_out_off, d_out, out_cap);
+    else
+        hipLaunchKernelGGL(k_inflate<false>, dim3(nb), dim3(64), 0, stream, hdr_len, d_in, blk,
+                           (const uint64_t *)d_out_off, d_out, out_cap);
     hipLaunchKernelGGL(k_dcrc32, dim3(nb), dim3(256), 0, stream, (const uint8_t *)d_out,
                        (const uint64_t *)d_out_off, (const DBlock *)blk, d_crc_found, cc);
 }

@@ -203,6 +203,10 @@ int gzpx_debug_set_flags(gzpx_ctx *ctx, uint32_t flags);
  * [stage-in, match, parse rounds, mark walk, rank scan, token build, parse rounds count, -]. */
 int gzpx_debug_phase_cycles(const gzpx_ctx *ctx, uint64_t cycles[8]);
 /* k_candidates diagnostics: cycles [hash + first atomics, stage gather, file + store, total]. */
+/* inflate: switch the instrumented k_inflate on/off; sums[] = per-block counters of the last launch
+ * summed over its blocks ([0] cycles, [1] headers+tables, [2] round set-up, [3] stores+copies,
+ * [4] rounds, [5] literals, [6] matches, [7] window flushes) */
+int gzpx_debug_inflate(gzpx_dctx *ctx, int enable, uint64_t sums[8]);
 int gzpx_debug_cand_cycles(const gzpx_ctx *ctx, uint64_t cycles[4]);
 
 const char *gzpx_strerror(int code);

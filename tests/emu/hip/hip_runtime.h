@@ -148,6 +148,32 @@ static inline T __hip_atomic_load(const T *p, int, int) { return *(const volatil
 template <typename T, typename U>
 static inline void __hip_atomic_store(T *p, U v, int, int) { *(volatile T *)p = (T)v; }
 static inline unsigned __builtin_amdgcn_readfirstlane(unsigned v) { return __shfl(v, 0); }
+static inline int __builtin_amdgcn_readlane(int v, int lane) { return __shfl(v, lane); }
+static inline int __builtin_amdgcn_ds_bpermute(int addr, int v) { return __shfl(v, (addr >> 2) & 63); }
+// DPP controls used by the kernels: row_shr:n (0x110 + n), row_bcast15 (0x142), row_bcast31 (0x143);
+// lanes without a valid source, or in a row that row_mask disables, keep `old`
+static inline int __builtin_amdgcn_update_dpp(int old, int src, int ctrl, int row_mask, int bank_mask,
+                                              bool bound_ctrl) {
+    (void)bank_mask;
+    (void)bound_ctrl;
+    const int lane = (int)(emu::cur->flat & 63);
+    int from = lane;
+    bool valid = false;
+    if (ctrl > 0x110 && ctrl <= 0x11F) {
+        const int n = ctrl - 0x110;
+        valid = (lane & 15) >= n;
+        from = lane - n;
+    } else if (ctrl == 0x142) {
+        valid = lane >= 16;
+        from = (lane & ~15) - 1;
+    } else if (ctrl == 0x143) {
+        valid = lane >= 32;
+        from = 31;
+    }
+    if (!((row_mask >> (lane >> 4)) & 1)) valid = false;
+    const int got = __shfl(src, valid ? from : lane);
+    return valid ? got : old;
+}
 static inline unsigned min(unsigned a, unsigned b) { return a < b ? a : b; }
 static inline unsigned max(unsigned a, unsigned b) { return a > b ? a : b; }
 static inline int min(int a, int b) { return a < b ? a : b; }

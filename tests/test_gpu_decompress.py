@@ -37,7 +37,7 @@ def test_roundtrip_all_classes(dctx, hip_lib, level):
 
 def test_config5_shape_256mib(dctx, hip_lib):
     # configs[5]: inflate the output of configs[2] (256 MiB here), verify per-block CRC on device
-    a = synth.text_slab(256 << 20, 5)
+    a = synth.text_slab(256 << 20, seed=5)
     with _native.Context(level=1, lib=hip_lib) as c:
         comp = c.compress_slab(a, True)
     out = dctx.decompress(comp)

@@ -16,7 +16,7 @@ cls = sys.argv[2] if len(sys.argv) > 2 else "textslab"
 level = int(sys.argv[3]) if len(sys.argv) > 3 else 1
 reps = int(sys.argv[4]) if len(sys.argv) > 4 else 5
 n = mib << 20
-a = synth.text_slab(n, 5) if cls == "textslab" else synth.make(cls, n, 5)
+a = synth.text_slab(n, seed=5) if cls == "textslab" else synth.make(cls, n, 5)
 lib = _native.load()
 with _native.Context(level=level, lib=lib) as c:
     comp = np.frombuffer(c.compress_slab(a, True), dtype=np.uint8)
@@ -34,5 +34,11 @@ for r in range(reps + 1):
         print(f"{cls} L{level} {mib} MiB  blocks={offs.size} ratio={n/comp.size:.2f}  {dt*1e3:.2f} ms  "
               f"{n/dt/2**30:.2f} GiB/s out")
 assert got == n
+d.debug_inflate(True)
+d.decompress_device(d_in.data_ptr(), comp.size, offs, sizes, d_out.data_ptr(), n + 64)
+c = d.debug_inflate(False)
+nb = offs.size
+print("per block: cycles %.0f  hdr+tables %.0f  round-setup %.0f  stores+copies %.0f | rounds %.0f lits %.0f matches %.0f flushes %.1f"
+      % tuple(x / nb for x in c))
 assert bytes(d_out[:n].cpu().numpy().tobytes()) == a.tobytes()
 print("verified")
