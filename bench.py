@@ -29,42 +29,150 @@ BLOCK = 65280             # Bgzf::DEFAULT_BUFSIZE (src/deflate.rs:583)
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 
 
-def cpu_baseline(slab, wall_s=6.0):
-    """The CPU port (oracle/: C restatement of gzp's libdeflate level-1 BGZF path, one
-    ParCompress-style worker per hardware thread, each owning a contiguous run of blocks) timed on
-    this box's host cores over a bounded sample of the same slab -- a reported baseline, not a
-    target.  Every worker keeps compressing its blocks until `wall_s` has elapsed."""
+def available_cores():
+    """Hardware threads this process may actually use: the affinity mask, capped by the cgroup
+    CPU quota (cpu.max) of the container."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    note = ""
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            q = max(1, int(int(quota) / int(period)))
+            if q < n:
+                note = " (cgroup cpu.max caps this container at %d of the host's %d hardware threads)" % (q, n)
+                n = q
+    except Exception:
+        pass
+    return n, note
+
+
+def cpu_baseline(slab, wall_s=8.0):
+    """The CPU port (oracle/: C restatement of gzp's libdeflate level-1 BGZF path) run the way
+    ParCompress runs it -- one worker per hardware thread, each owning a contiguous run of the
+    slab's blocks -- natively timed (pthreads, oracle/cpu_bench.c) on this box's host cores for
+    `wall_s` seconds.  A reported baseline, not a target."""
     from oracle import oracle
     oracle.build()
-    cores = os.cpu_count() or 1
-    blocks_per_thread = max(1, min(8, slab.size // BLOCK // cores))
-    chunks = [slab[i * blocks_per_thread * BLOCK:(i + 1) * blocks_per_thread * BLOCK]
-              for i in range(cores)]
-    chunks = [c for c in chunks if c.size]
-    done = [0] * len(chunks)
-    t_start = time.perf_counter()
-    deadline = t_start + wall_s
-
-    def work(i, c):
-        while time.perf_counter() < deadline:
-            oracle.compress_stream(c, oracle.FMT_BGZF, 1, oracle.COMPAT_1_24, BLOCK)
-            done[i] += c.size
-
-    threads = [threading.Thread(target=work, args=(i, c)) for i, c in enumerate(chunks)]
-    for t in threads:
-        t.start()
-    for t in threads:
-        t.join()
-    dt = time.perf_counter() - t_start
-    total = sum(done)
+    cores, note = available_cores()
+    nbytes, dt, used = oracle.cpu_bench_compress(slab, oracle.FMT_BGZF, 1, oracle.COMPAT_1_24, BLOCK,
+                                                 threads=cores, wall_s=wall_s)
     return {
-        "value": round(total / dt / 2**20, 1),
+        "value": round(nbytes / dt / 2**20, 1),
         "unit": "MiB/s",
-        "cores": len(chunks),
+        "cores": used,
         "kind": "port",
-        "sample": "%d threads x %d BGZF blocks of the same slab, repeated for %.1f s wall "
-                  "(%.1f MiB compressed)" % (len(chunks), blocks_per_thread, dt, total / 2**20),
+        "sample": "%d native worker threads, each re-encoding its contiguous share of the same slab's "
+                  "BGZF blocks until %.0f s elapsed (%.1f MiB compressed in %.2f s)%s"
+                  % (used, wall_s, nbytes / 2**20, dt, note),
     }
+
+
+def cpu_baseline_inflate(comp, offs, sizes, wall_s=8.0):
+    """CPU side of the ParDecompress row: the image's libdeflate binary (the library gzp binds through
+    libdeflater: libdeflate_deflate_decompress + libdeflate_crc32 per block, src/bgzf.rs:103-121 /
+    src/par/decompress.rs:162-186), one native worker per hardware thread over its contiguous share
+    of the same blocks, for `wall_s` seconds (oracle/cpu_bench.c)."""
+    from oracle import oracle
+    oracle.build()
+    cores, note = available_cores()
+    r = oracle.cpu_bench_inflate(comp, offs, sizes, 18, threads=cores, wall_s=wall_s)
+    if r is None:
+        return {"value": None, "unit": "MiB/s", "cores": 0, "kind": "reference",
+                "sample": "no libdeflate.so on this box"}
+    nbytes, dt, used = r
+    return {
+        "value": round(nbytes / dt / 2**20, 1),
+        "unit": "MiB/s",
+        "cores": used,
+        "kind": "reference",
+        "sample": "%d native worker threads, each inflating + CRC-checking its contiguous share of the same "
+                  "stream's BGZF blocks with the image's libdeflate.so until %.0f s elapsed (%.1f MiB "
+                  "inflated in %.2f s)%s" % (used, wall_s, nbytes / 2**20, dt, note),
+    }
+
+
+def run_inflate(args, torch, dist, world, rank, local_rank, dev):
+    """--workload inflate: BASELINE.json configs[4] -- ParDecompress<Bgzf> over the output of the
+    compress workload.  One step = scan-free multi-block inflate + per-block CRC check of the whole
+    BGZF stream (already resident in HBM) into HBM."""
+    from gzp_amd import _native, synth
+    n = args.slab_bytes
+    slab = synth.text_slab(n, seed=20250927 + rank)
+    with _native.Context(format=_native.FORMAT_BGZF, level=1, buffer_size=BLOCK, compat=_native.COMPAT_1_24,
+                         device=local_rank, max_slab_bytes=n) as c:
+        comp = np.frombuffer(c.compress_slab(slab, True), dtype=np.uint8).copy()
+        device_name = c.device_name()
+    d = _native.DContext(format=_native.FORMAT_BGZF, device=local_rank)
+    offs, sizes, used = d.scan_blocks(comp)
+    d_in = torch.from_numpy(comp).to(dev)
+    d_out = torch.empty(n + 64, dtype=torch.uint8, device=dev)
+
+    def step():
+        return d.decompress_device(d_in.data_ptr(), comp.size, offs, sizes, d_out.data_ptr(), n + 64)
+
+    for _ in range(args.warmup):
+        step()
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    sync()
+    t0 = time.perf_counter()
+    kern_ms = 0.0
+    got = 0
+    for _ in range(args.steps):
+        got = step()
+        kern_ms += d.last_inflate_ms()
+    sync()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    if rank == 0:
+        ok = got == n and d_out[:n].cpu().numpy().tobytes() == slab.tobytes()
+        kern_ms /= args.steps
+        achieved = (comp.size + n) / (kern_ms * 1e-3) / 1e9  # reads the stream, writes the text
+        res = {
+            "metric": "BGZF decompress MiB/s (inflated bytes) of the level-1 550 MiB text stream",
+            "value": round(n * world / 2**20 / (dt / args.steps), 1),
+            "unit": "MiB/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 3),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u8",
+            "data": "synthetic",
+            "config": {
+                "workload": "ParDecompress<Bgzf>: GPU multi-block inflate of output from config 2, CRC "
+                            "check, MiB/s vs CPU path",
+                "compressed_bytes": int(comp.size),
+                "inflated_bytes": n,
+                "blocks": int(offs.size),
+                "parallelism": "block-shard x%d" % world,
+                "verified_round_trip": bool(ok),
+                "device": device_name,
+            },
+            "roofline": {
+                "bound": "hbm",
+                "kernel": "k_inflate",
+                "achieved": round(achieved, 2),
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 5),
+                "traffic": None,
+                "kernel_ms": round(kern_ms, 3),
+            },
+        }
+        if not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline_inflate(comp, offs, sizes)
+        print(json.dumps(res))
+    d.close()
 
 
 def verify(slab, out_bytes, block_sizes, tail=True):
@@ -94,6 +202,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--slab-bytes", type=int, default=SLAB_BYTES)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--workload", choices=["compress", "inflate"], default="compress",
+                    help="compress = the headline metric (default); inflate = the ParDecompress row")
     args = ap.parse_args()
 
     import torch
@@ -111,6 +221,12 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
+    if args.workload == "inflate":
+        run_inflate(args, torch, dist, world, rank, local_rank, dev)
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
 
     # One logical stream of world x 550 MiB, sharded at block boundaries (weak scaling: every
     # rank gets 550 MiB +- one block); only the rank that owns the final block emits the tail.

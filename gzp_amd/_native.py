@@ -168,6 +168,8 @@ class GzpxLib:
         L.gzpx_deflate_decompress.argtypes = [vp, vp, sz, vp, sz, psz]
         L.gzpx_free_decompressor.restype = None
         L.gzpx_free_decompressor.argtypes = [vp]
+        L.gzpx_dctx_last_inflate_ms.restype = i32
+        L.gzpx_dctx_last_inflate_ms.argtypes = [vp, ctypes.POINTER(ctypes.c_float)]
         L.gzpx_debug_inflate.restype = i32
         L.gzpx_debug_inflate.argtypes = [vp, i32, ctypes.POINTER(ctypes.c_uint64)]
         L.gzpx_pard_create.restype = i32
@@ -437,6 +439,11 @@ class DContext:
         if rc != OK:
             self._raise(rc, info)
         return out[:out_len.value].tobytes()
+
+    def last_inflate_ms(self):
+        ms = ctypes.c_float(0)
+        self.lib.check(self.lib.L.gzpx_dctx_last_inflate_ms(self.h, ctypes.byref(ms)))
+        return ms.value
 
     def debug_inflate(self, enable):
         """Switch the instrumented k_inflate on/off; returns the counters of the last launch."""

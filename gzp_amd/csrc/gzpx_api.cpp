@@ -561,6 +561,7 @@ struct gzpx_dctx {
     size_t d_in_cap = 0, d_out_cap = 0;
     bool debug = false;
     size_t last_nb = 0;
+    hipEvent_t ev[2] = {nullptr, nullptr};  // around k_inflate of the last launch
     std::mutex mu;
 };
 
@@ -611,7 +612,7 @@ int decompress_device_locked(gzpx_dctx *c, const uint8_t *d_in, size_t in_len, c
     HIP_TRY(hipMemcpyAsync(c->d_offsets, offsets, nb * 8, hipMemcpyHostToDevice, stream));
     HIP_TRY(hipMemcpyAsync(c->d_sizes, sizes, nb * 4, hipMemcpyHostToDevice, stream));
     launch_inflate(hdr_len, d_in, c->d_offsets, c->d_sizes, (uint32_t)nb, c->d_blk, c->d_out_off, d_out, out_cap,
-                   c->d_crc, c->cc, c->debug, stream);
+                   c->d_crc, c->cc, c->debug, c->ev[0], c->ev[1], stream);
     c->last_nb = nb;
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(c->h_blk, c->d_blk, nb * sizeof(DBlockHost), hipMemcpyDeviceToHost, stream));
@@ -655,6 +656,7 @@ int gzpx_dctx_create(int device, int format, gzpx_dctx **out) {
     for (unsigned l = 0; l < 8; l++) c->cc.pow256[l] = x2k(11 + l);
     c->cc.pow_tile = x2k(19);
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreate(&c->ev[0]) != hipSuccess || hipEventCreate(&c->ev[1]) != hipSuccess ||
         hipHostMalloc((void **)&c->h_total, 64, hipHostMallocDefault) != hipSuccess) {
         gzpx_dctx_destroy(c);
         return GZPX_ERR_DEVICE;
@@ -671,6 +673,8 @@ void gzpx_dctx_destroy(gzpx_dctx *c) {
     if (c->h_total) (void)hipHostFree(c->h_total);
     if (c->d_in) (void)hipFree(c->d_in);
     if (c->d_out) (void)hipFree(c->d_out);
+    if (c->ev[0]) (void)hipEventDestroy(c->ev[0]);
+    if (c->ev[1]) (void)hipEventDestroy(c->ev[1]);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -853,6 +857,14 @@ int gzpx_debug_phase_cycles(const gzpx_ctx *ctx, uint64_t cycles[8]) {
     for (uint32_t b = 0; b < ctx->last_nb; b++)
         for (int k = 0; k < 8; k++) cycles[k] += ctx->h_meta[b].phase_cycles[k];
     return GZPX_OK;
+}
+
+int gzpx_dctx_last_inflate_ms(gzpx_dctx *ctx, float *ms) {
+    if (!ctx || !ms) return GZPX_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> g(ctx->mu);
+    *ms = 0.0f;
+    if (!ctx->last_nb) return GZPX_OK;
+    return hipEventElapsedTime(ms, ctx->ev[0], ctx->ev[1]) == hipSuccess ? GZPX_OK : GZPX_ERR_DEVICE;
 }
 
 int gzpx_debug_inflate(gzpx_dctx *ctx, int enable, uint64_t sums[8]) {

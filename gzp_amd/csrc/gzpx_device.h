@@ -131,6 +131,7 @@ struct DBlockHost {
 };
 void launch_inflate(uint32_t hdr_len, const uint8_t *d_in, const uint64_t *d_offsets, const uint32_t *d_sizes,
                     uint32_t nb, void *d_blk, uint64_t *d_out_off, uint8_t *d_out, uint64_t out_cap,
-                    uint32_t *d_crc_found, const CrcConsts &cc, bool debug, hipStream_t stream);
+                    uint32_t *d_crc_found, const CrcConsts &cc, bool debug, hipEvent_t ev_begin,
+                    hipEvent_t ev_end, hipStream_t stream);
 
 }  // namespace gzpx

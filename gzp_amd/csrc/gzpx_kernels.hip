@@ -2980,16 +2980,19 @@ void launch_emit(const Config &cfg, const uint8_t *slab, uint64_t, uint32_t nb, 
 
 void launch_inflate(uint32_t hdr_len, const uint8_t *d_in, const uint64_t *d_offsets, const uint32_t *d_sizes,
                     uint32_t nb, void *d_blk, uint64_t *d_out_off, uint8_t *d_out, uint64_t out_cap,
-                    uint32_t *d_crc_found, const CrcConsts &cc, bool debug, hipStream_t stream) {
+                    uint32_t *d_crc_found, const CrcConsts &cc, bool debug, hipEvent_t ev_begin,
+                    hipEvent_t ev_end, hipStream_t stream) {
     DBlock *blk = (DBlock *)d_blk;
     hipLaunchKernelGGL(k_dinit, dim3((nb + 255) / 256), dim3(256), 0, stream, nb, d_in, d_offsets, d_sizes, blk);
     hipLaunchKernelGGL(k_dscan, dim3(1), dim3(256), 0, stream, nb, (const DBlock *)blk, d_out_off);
+    if (ev_begin) (void)hipEventRecord(ev_begin, stream);
     if (debug)
         hipLaunchKernelGGL(k_inflate<true>, dim3(nb), dim3(64), 0, stream, hdr_len, d_in, blk,
                            (const uint64_t *)d_out_off, d_out, out_cap);
     else
         hipLaunchKernelGGL(k_inflate<false>, dim3(nb), dim3(64), 0, stream, hdr_len, d_in, blk,
                            (const uint64_t *)d_out_off, d_out, out_cap);
+    if (ev_end) (void)hipEventRecord(ev_end, stream);
     hipLaunchKernelGGL(k_dcrc32, dim3(nb), dim3(256), 0, stream, (const uint8_t *)d_out,
                        (const uint64_t *)d_out_off, (const DBlock *)blk, d_crc_found, cc);
 }

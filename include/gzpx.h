@@ -203,6 +203,8 @@ int gzpx_debug_set_flags(gzpx_ctx *ctx, uint32_t flags);
  * [stage-in, match, parse rounds, mark walk, rank scan, token build, parse rounds count, -]. */
 int gzpx_debug_phase_cycles(const gzpx_ctx *ctx, uint64_t cycles[8]);
 /* k_candidates diagnostics: cycles [hash + first atomics, stage gather, file + store, total]. */
+/* HIP-event duration of k_inflate in the last decompress launch of this context */
+int gzpx_dctx_last_inflate_ms(gzpx_dctx *ctx, float *ms);
 /* inflate: switch the instrumented k_inflate on/off; sums[] = per-block counters of the last launch
  * summed over its blocks ([0] cycles, [1] headers+tables, [2] round set-up, [3] stores+copies,
  * [4] rounds, [5] literals, [6] matches, [7] window flushes) */

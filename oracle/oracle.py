@@ -21,10 +21,9 @@ _lib = None
 
 
 def build(force=False):
-    src = os.path.join(_HERE, "gzpx_oracle.c")
-    hdr = os.path.join(_HERE, "gzpx_oracle.h")
+    srcs = [os.path.join(_HERE, f) for f in ("gzpx_oracle.c", "gzpx_oracle.h", "cpu_bench.c", "Makefile")]
     if (not force and os.path.exists(_SO)
-            and os.path.getmtime(_SO) >= max(os.path.getmtime(src), os.path.getmtime(hdr))):
+            and os.path.getmtime(_SO) >= max(os.path.getmtime(f) for f in srcs)):
         return _SO
     subprocess.check_call(["make", "-C", _HERE, "-s", "-B", "libgzpx_oracle.so"])
     return _SO
@@ -60,8 +59,43 @@ def lib():
         L.gzpx_oracle_make_huffman_code.restype = None
         L.gzpx_oracle_make_huffman_code.argtypes = [ctypes.c_uint, ctypes.c_uint, ctypes.c_int, u8p,
                                                     u8p, u8p]
+        dp, u64p, ip = (ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_uint64),
+                        ctypes.POINTER(ctypes.c_int))
+        L.gzpx_cpu_bench_compress.restype = ctypes.c_int
+        L.gzpx_cpu_bench_compress.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_size_t, u8p,
+                                              ctypes.c_size_t, ctypes.c_int, ctypes.c_double, dp, u64p, ip]
+        L.gzpx_cpu_bench_inflate.restype = ctypes.c_int
+        L.gzpx_cpu_bench_inflate.argtypes = [u8p, u8p, u8p, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_int,
+                                             ctypes.c_double, dp, u64p, ip]
         _lib = L
     return _lib
+
+
+def cpu_bench_compress(slab, fmt=FMT_BGZF, level=1, compat=COMPAT_1_24, block=65280, threads=1, wall_s=6.0):
+    """Native (pthreads) ParCompress-style timing of the oracle: (bytes, seconds, threads)."""
+    a = _as_u8(slab)
+    el, nb, th = ctypes.c_double(0), ctypes.c_uint64(0), ctypes.c_int(0)
+    rc = lib().gzpx_cpu_bench_compress(fmt, level, compat, block, _ptr(a), a.size, threads, wall_s,
+                                       ctypes.byref(el), ctypes.byref(nb), ctypes.byref(th))
+    if rc != 0:
+        raise RuntimeError("gzpx_cpu_bench_compress failed (%d)" % rc)
+    return nb.value, el.value, th.value
+
+
+def cpu_bench_inflate(comp, offs, sizes, hdr_len=18, threads=1, wall_s=6.0):
+    """Native timing of the image's libdeflate inflate + CRC32 over the blocks of `comp`; returns
+    (bytes, seconds, threads) or None when the box has no libdeflate binary."""
+    a = _as_u8(comp)
+    o = np.ascontiguousarray(offs, dtype=np.uint64)
+    s = np.ascontiguousarray(sizes, dtype=np.uint32)
+    el, nb, th = ctypes.c_double(0), ctypes.c_uint64(0), ctypes.c_int(0)
+    rc = lib().gzpx_cpu_bench_inflate(_ptr(a), o.ctypes.data, s.ctypes.data, o.size, hdr_len, threads, wall_s,
+                                      ctypes.byref(el), ctypes.byref(nb), ctypes.byref(th))
+    if rc == -2:
+        return None
+    if rc != 0:
+        raise RuntimeError("gzpx_cpu_bench_inflate failed (%d)" % rc)
+    return nb.value, el.value, th.value
 
 
 def _as_u8(data):
