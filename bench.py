@@ -29,6 +29,15 @@ BLOCK = 65280             # Bgzf::DEFAULT_BUFSIZE (src/deflate.rs:583)
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 
 
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed PMC passes (profiles/), if any."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+            return json.load(f)["hbm_bytes_per_launch"].get(kernel)
+    except Exception:
+        return None
+
+
 def available_cores():
     """Hardware threads this process may actually use: the affinity mask, capped by the cgroup
     CPU quota (cpu.max) of the container."""
@@ -165,7 +174,7 @@ def run_inflate(args, torch, dist, world, rank, local_rank, dev):
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 5),
-                "traffic": None,
+                "traffic": pmc_traffic("k_inflate"),
                 "kernel_ms": round(kern_ms, 3),
             },
         }
@@ -285,12 +294,7 @@ def main():
         dom = max(stage_ms, key=stage_ms.get)
         alg_bytes = n + out_len  # 1 B read + r B written per input byte
         achieved = alg_bytes / (stage_ms[dom] * 1e-3) / 1e9
-        traffic = None  # HBM bytes per launch of `dom` from the committed PMC passes, if any
-        try:
-            with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
-                traffic = json.load(f)["hbm_bytes_per_launch"].get(dom)
-        except Exception:
-            pass
+        traffic = pmc_traffic(dom)
         res = {
             "metric": "BGZF compress MiB/s at level 1, 550 MiB text",
             "value": round(value, 1),

@@ -20,22 +20,47 @@ tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
 slab_bytes = 576_716_800
 
 os.makedirs(P, exist_ok=True)
-stats = os.path.join(G, "prof_%s" % tag, "%s_kernel_stats.csv" % tag)
-shutil.copy(stats, os.path.join(P, "%s_kernel_stats.csv" % tag))
+
+
+def find(dirname, suffix):
+    for base, _, files in os.walk(os.path.join(G, dirname)):
+        for f in files:
+            if f.endswith(suffix):
+                return os.path.join(base, f)
+    raise FileNotFoundError("%s/*%s" % (dirname, suffix))
+
+
+shutil.copy(find("prof_%s" % tag, "kernel_stats.csv"), os.path.join(P, "%s_kernel_stats.csv" % tag))
+try:
+    shutil.copy(find("prof_%s_inflate" % tag, "kernel_stats.csv"),
+                os.path.join(P, "%s_inflate_kernel_stats.csv" % tag))
+except FileNotFoundError:
+    pass
 
 
 def counters(path):
     acc = collections.defaultdict(list)
     for r in csv.DictReader(open(path)):
-        acc[r["Kernel_Name"].split("(")[0].replace("gzpx::", "")].append(float(r["Counter_Value"]))
+        name = r["Kernel_Name"].split("(")[0].replace("gzpx::", "").replace("void ", "").split("<")[0]
+        acc[name].append(float(r["Counter_Value"]))
     return {k: sum(v) / len(v) for k, v in acc.items() if k.startswith("k_")}
 
 
-fetch = counters(os.path.join(G, "pmc_fetch", "f_counter_collection.csv"))
-write = counters(os.path.join(G, "pmc_write", "w_counter_collection.csv"))
+fetch = counters(find("pmc_fetch", "counter_collection.csv"))
+write = counters(find("pmc_write", "counter_collection.csv"))
 cal = slab_bytes / (fetch["k_candidates"] * 1024.0)
+try:  # the ParDecompress workload: keep its own kernels only
+    fi = counters(find("pmc_fetch_inflate", "counter_collection.csv"))
+    wi = counters(find("pmc_write_inflate", "counter_collection.csv"))
+    for k in ("k_dinit", "k_dscan", "k_inflate", "k_dcrc32"):
+        if k in fi:
+            fetch[k] = fi[k]
+            write[k] = wi.get(k, 0.0)
+except FileNotFoundError:
+    pass
 doc = {
-    "source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), bench.py slab",
+    "source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), bench.py slab "
+              "(compress workload; k_d*/k_inflate from --workload inflate)",
     "units": "bytes per launch (counter KiB x 1024)",
     "fetch_calibration_factor": round(cal, 3),
     "fetch_calibration": "k_candidates reads the %d-byte slab exactly once" % slab_bytes,
