@@ -442,7 +442,7 @@ __global__ __launch_bounds__(kMpThreads, 8) void k_match(Config cfg, const uint8
 #pragma unroll
             for (uint32_t k = 0; k < 4; k++) {
                 const uint32_t p = p0 + k * kMpThreads;
-                const uint32_t r = d0s[k] ? cand[p - d0s[k]] : 0u;
+                const uint32_t r = (d0s[k] && !(cfg.debug & 4u)) ? cand[p - d0s[k]] : 0u;
                 d1s[k] = (r && d0s[k] + r <= 32767u) ? d0s[k] + r : 0u;
             }
 #pragma unroll
@@ -456,16 +456,46 @@ __global__ __launch_bounds__(kMpThreads, 8) void k_match(Config cfg, const uint8
                     const uint32_t max_len = rem < 258u ? rem : 258u;
                     const uint32_t nice_len = max_len < 32u ? max_len : 32u;
                     const uint32_t a = p - win_begin + mis;
-                    const uint32_t seq = lds_le32(in_w, a);
-                    if (lds_le32(in_w, a - d0) == seq) best = lds_extend(in_w, a, a - d0, max_len);
-                    if (d1 && best < nice_len && lds_le32(in_w, a - d1) == seq) {
-                        const uint32_t l1 = lds_extend(in_w, a, a - d1, max_len);
-                        if (l1 > best) {
-                            best = l1;
-                            const uint32_t r = p - tile_begin;
-                            atomicOr(&which_bits[r >> 5], 1u << (r & 31u));
-                            alt[p] = (uint16_t)d1;  // the match distance when the older candidate won
+                    // both candidates are extended by ONE loop, in lockstep (4 bytes per step from
+                    // the same own bytes): half the loop overhead and divergence of two loops.  Each
+                    // of the three byte streams slides a dword pair, so a step costs one new dword
+                    // per stream.  The older candidate only counts if the newer one stayed below
+                    // nice_len, which is applied to the finished lengths.
+                    const uint32_t c0 = a - d0, c1 = a - (d1 ? d1 : d0);
+                    const uint32_t *pa = in_w + (a >> 2), *p0 = in_w + (c0 >> 2), *p1 = in_w + (c1 >> 2);
+                    uint32_t lo_a = pa[0], hi_a = pa[1], lo_0 = p0[0], hi_0 = p0[1], lo_1 = p1[0], hi_1 = p1[1];
+                    const uint32_t seq = __builtin_amdgcn_alignbyte(hi_a, lo_a, a & 3u);
+                    bool act0 = __builtin_amdgcn_alignbyte(hi_0, lo_0, c0 & 3u) == seq;
+                    bool act1 = d1 != 0 && __builtin_amdgcn_alignbyte(hi_1, lo_1, c1 & 3u) == seq;
+                    uint32_t len0 = act0 ? max_len : 0u, len1 = act1 ? max_len : 0u;  // still matching => max_len
+                    for (uint32_t off = 4; (act0 || act1) && off < max_len; off += 4) {
+                        const uint32_t j = (off >> 2) + 1;
+                        lo_a = hi_a;
+                        hi_a = pa[j];
+                        lo_0 = hi_0;
+                        hi_0 = p0[j];
+                        lo_1 = hi_1;
+                        hi_1 = p1[j];
+                        const uint32_t own = __builtin_amdgcn_alignbyte(hi_a, lo_a, a & 3u);
+                        const uint32_t x0 = own ^ __builtin_amdgcn_alignbyte(hi_0, lo_0, c0 & 3u);
+                        const uint32_t x1 = own ^ __builtin_amdgcn_alignbyte(hi_1, lo_1, c1 & 3u);
+                        if (act0 && x0) {
+                            len0 = off + ((uint32_t)(__ffs((int)x0) - 1) >> 3);
+                            act0 = false;
                         }
+                        if (act1 && x1) {
+                            len1 = off + ((uint32_t)(__ffs((int)x1) - 1) >> 3);
+                            act1 = false;
+                        }
+                    }
+                    if (len0 > max_len) len0 = max_len;
+                    if (len1 > max_len) len1 = max_len;
+                    best = len0;
+                    if (best < nice_len && len1 > best) {
+                        best = len1;
+                        const uint32_t r = p - tile_begin;
+                        atomicOr(&which_bits[r >> 5], 1u << (r & 31u));
+                        alt[p] = (uint16_t)d1;  // the match distance when the older candidate won
                     }
                 }
                 len8[p] = (uint8_t)(best ? best - 3 : 0);

@@ -14,6 +14,8 @@ ctx = _native.Context(format=fmt, level=level, buffer_size=bs, max_slab_bytes=n)
 cap = ctx.slab_bound(n)
 d_out = torch.empty(cap, dtype=torch.uint8, device="cuda")
 ctx.set_profiling(True)
+if os.environ.get("GZPX_DEBUG_FLAGS"):
+    ctx.debug_set_flags(int(os.environ["GZPX_DEBUG_FLAGS"]))
 for i in range(3):
     out_len, nb = ctx.compress_slab_device(d_in.data_ptr(), n, d_out.data_ptr(), cap, True)
 ms = ctx.last_stage_ms()
