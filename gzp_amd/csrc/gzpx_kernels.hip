@@ -365,8 +365,8 @@ __global__ __launch_bounds__(64) void k_candidates_safe(Config cfg, const uint8_
 //   also holds the 32 KiB of history a match may reach back into.
 //   d0 = distance to the bucket predecessor (from k_candidates), d1 = d0 + the predecessor's own
 //   d0; 4-byte check + lz_extend run out of LDS with aligned dword reads + v_alignbyte.
-//   Output: len8[p] (0 = no match, else length - 3), which[p] (1 = the older candidate won) and,
-//   for those positions only, alt[p] = the winning distance d1.
+//   Output: len8[p] (0 = no match, else length - 3), val[p] (the winning distance, or the literal
+//   byte where there is no match) and one bit per position "a match starts here" (wave ballots).
 // ------------------------------------------------------------------------------------------
 constexpr uint32_t kSeg = 272;
 constexpr uint32_t kInWords = kTile / 4 + 132;  // 64 KiB window + max match + alignment slack
@@ -398,10 +398,9 @@ __global__ __launch_bounds__(kMpThreads, 8) void k_match(Config cfg, const uint8
                                                       BlockMeta *__restrict__ meta_all,
                                                       const uint16_t *__restrict__ cand_all,
                                                       uint8_t *__restrict__ len8_all,
-                                                      uint32_t *__restrict__ which_all,
-                                                      uint16_t *__restrict__ alt_all) {
-    __shared__ uint32_t in_w[kInWords];          // window bytes (+ lead misalignment, + pad)
-    __shared__ uint32_t which_bits[kTile / 32];  // 1 = the older candidate (c1) won (per tile)
+                                                      uint32_t *__restrict__ nz_all,
+                                                      uint16_t *__restrict__ val_all) {
+    __shared__ uint32_t in_w[kInWords];  // window bytes (+ lead misalignment, + pad)
     const uint32_t tid = threadIdx.x;
     const uint32_t b = blockIdx.x;
     BlockMeta *meta = meta_all + b;
@@ -410,8 +409,8 @@ __global__ __launch_bounds__(kMpThreads, 8) void k_match(Config cfg, const uint8
     const uint8_t *in = slab + (uint64_t)b * cfg.block_size;
     const uint16_t *cand = cand_all + (uint64_t)b * cfg.stride;
     uint8_t *len8 = len8_all + (uint64_t)b * cfg.stride;
-    uint32_t *which_out = which_all + (uint64_t)b * (cfg.stride / 32);
-    uint16_t *alt = alt_all + (uint64_t)b * cfg.stride;
+    unsigned long long *nz_out = (unsigned long long *)(nz_all + (uint64_t)b * (cfg.stride / 32));
+    uint16_t *val = val_all + (uint64_t)b * cfg.stride;
 
     const long long t_begin = clock64();
     const uint32_t tile_step = n <= kTile ? kTile : kTile / 2;
@@ -427,7 +426,6 @@ __global__ __launch_bounds__(kMpThreads, 8) void k_match(Config cfg, const uint8
             const uint32_t ndw = (mis + (win_end - win_begin) + 3) >> 2;
             for (uint32_t i = tid; i < ndw; i += kMpThreads) in_w[i] = src[i];
             for (uint32_t i = ndw + tid; i < ndw + 3 && i < kInWords; i += kMpThreads) in_w[i] = 0;
-            for (uint32_t i = tid; i < kTile / 32; i += kMpThreads) which_bits[i] = 0;
         }
         __syncthreads();
 
@@ -448,9 +446,10 @@ __global__ __launch_bounds__(kMpThreads, 8) void k_match(Config cfg, const uint8
 #pragma unroll
             for (uint32_t k = 0; k < 4; k++) {
                 const uint32_t p = p0 + k * kMpThreads;
-                if (p >= tile_end) break;
-                uint32_t best = 0;
+                // (no early exit: every lane takes part in the ballot below)
+                uint32_t best = 0, value = 0;
                 const uint32_t d0 = d0s[k], d1 = d1s[k];
+                if (p < tile_end) value = (lds_le32(in_w, p - win_begin + mis)) & 0xFFu;  // the literal
                 if (d0) {
                     const uint32_t rem = n - p;
                     const uint32_t max_len = rem < 258u ? rem : 258u;
@@ -491,20 +490,22 @@ __global__ __launch_bounds__(kMpThreads, 8) void k_match(Config cfg, const uint8
                     if (len0 > max_len) len0 = max_len;
                     if (len1 > max_len) len1 = max_len;
                     best = len0;
-                    if (best < nice_len && len1 > best) {
+                    if (best) value = d0;
+                    if (best < nice_len && len1 > best) {  // the older candidate won
                         best = len1;
-                        const uint32_t r = p - tile_begin;
-                        atomicOr(&which_bits[r >> 5], 1u << (r & 31u));
-                        alt[p] = (uint16_t)d1;  // the match distance when the older candidate won
+                        value = d1;
                     }
                 }
-                len8[p] = (uint8_t)(best ? best - 3 : 0);
+                // one 64-bit word of the "a match starts here" bitmap per wave step (the wave's 64
+                // positions are consecutive and 64-aligned)
+                const unsigned long long nzm = __ballot(best != 0);
+                if (p < tile_end) {
+                    len8[p] = (uint8_t)(best ? best - 3 : 0);
+                    val[p] = (uint16_t)value;  // match distance, or the literal byte
+                    if ((tid & 63u) == 0) nz_out[p >> 6] = nzm;
+                }
             }
         }
-        __syncthreads();
-        // tile_begin is a multiple of 32, so the tile's bit words are whole words of the block's
-        for (uint32_t i = tid; i < (tile_end - tile_begin + 31) / 32; i += kMpThreads)
-            which_out[tile_begin / 32 + i] = which_bits[i];
     }
     if (tid == 0) meta->phase_cycles[1] = (uint32_t)(clock64() - t_begin);
 }
@@ -513,18 +514,14 @@ __global__ __launch_bounds__(kMpThreads, 8) void k_match(Config cfg, const uint8
 // k_parse: deflate_compress_fastest's greedy parse + token stream + sub-block boundaries, per
 // block (1024 threads, < 80 KiB of LDS so two workgroups share a CU), in tiles of 64 KiB
 // positions whose len8 bytes are staged in LDS:
-//   phase 2  the parse as a segment-parallel pointer chase: 272-byte segments (>= max match
-//            length, so a token leaving segment s lands in segment s+1), each thread walks its
-//            segment from a speculated entry, entries are corrected round by round until none
-//            changes (greedy chains re-synchronise within a few tokens, so this is 2-3 rounds in
-//            practice, <= #segments always); every walk marks its token starts in an LDS bitmap
-//            and a re-walk first clears its segment's marks,
-//   phase 3  position-parallel token build: token / match ranks from wave ballots + one
-//            workgroup scan, coalesced reads and token stores; the same pass finds where the
-//            current DEFLATE sub-block ends (8192 matches, or the 65535-byte soft limit of
-//            choose_max_block_end).
+//   phase 2  the parse as a segment-parallel pointer chase over 64-position segments (one per
+//            thread, token marks = one 64-bit word per segment),
+//   phase 3  token build: per-group token / match counts from the bitmaps (tokens from the walk,
+//            "match here" from k_match) + one workgroup scan, then coalesced val reads and token
+//            stores; the same pass finds where the current DEFLATE sub-block ends (8192 matches,
+//            or the 65535-byte soft limit of choose_max_block_end).
 // ------------------------------------------------------------------------------------------
-// Walk one segment (tile-relative positions) from `pos`, marking every token start in tok_bits;
+// (k_parse_hc) Walk one segment (tile-relative positions) from `pos`, marking every token start in tok_bits;
 // returns the exit position.  A latency chain (LDS read -> add -> LDS read ...); the mark is a
 // fire-and-forget LDS atomic.
 __device__ __forceinline__ uint32_t walk_segment(const uint8_t *len8, uint32_t pos, uint32_t seg_end,
@@ -554,19 +551,22 @@ __device__ __forceinline__ uint32_t sub_limit_of(uint32_t start, uint32_t n) {
     return (n - start < kSoftMaxSub + kMinBlockLen) ? n : start + kSoftMaxSub;
 }
 
+constexpr uint32_t kPSeg = 64;  // positions per walk segment = one 64-bit word of the token bitmap
+
 __global__ __launch_bounds__(kMpThreads, 8) void k_parse(
     Config cfg, const uint8_t *__restrict__ slab, BlockMeta *__restrict__ meta_all,
-    SubMeta *__restrict__ sub_all, const uint16_t *__restrict__ cand_all,
-    const uint8_t *__restrict__ len8_all, const uint32_t *__restrict__ which_all,
-    const uint16_t *__restrict__ alt_all, uint32_t *__restrict__ tok_all) {
-    __shared__ uint32_t len8_w[kTile / 4];     // 0 = literal, else match length - 3 (bytes)
-    __shared__ uint32_t tok_bits[kTile / 32];  // 1 = a token starts here (tile-relative)
-    __shared__ uint32_t seg_exit[256];
-    __shared__ uint32_t rank_pre[kMpChunks * kMpWaves];  // (tokens | matches << 17) before (chunk, wave)
+    SubMeta *__restrict__ sub_all, const uint8_t *__restrict__ len8_all,
+    const uint32_t *__restrict__ nz_all, const uint16_t *__restrict__ val_all,
+    uint32_t *__restrict__ tok_all) {
+    __shared__ uint32_t len8_w[kTile / 4];                 // 0 = literal, else match length - 3 (bytes)
+    __shared__ unsigned long long tok_bits[kTile / 64];    // 1 = a token starts here (tile-relative)
+    __shared__ uint32_t rank_pre[kTile / 64];  // phase 2: exit of segment s; phase 3: (tokens |
+                                               // matches << 17) before 64-position group s
     __shared__ uint32_t wsum_t[kMpWaves], wsum_m[kMpWaves];
     __shared__ unsigned long long bnd;  // (position << 32 | token index) of the sub-block boundary
     __shared__ uint32_t bnd_mat;        // matches before that boundary
     const uint8_t *len8 = (const uint8_t *)len8_w;
+    uint32_t *seg_exit = rank_pre;
 
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint32_t b = blockIdx.x;
@@ -574,11 +574,10 @@ __global__ __launch_bounds__(kMpThreads, 8) void k_parse(
     SubMeta *sub = sub_all + (uint64_t)b * cfg.max_sub;
     const uint32_t n = meta->n;
     if (n <= cfg.passthrough) return;  // uniform for the workgroup
-    const uint8_t *in = slab + (uint64_t)b * cfg.block_size;
-    const uint16_t *cand = cand_all + (uint64_t)b * cfg.stride;
-    const uint32_t *which = which_all + (uint64_t)b * (cfg.stride / 32);
-    const uint16_t *alt = alt_all + (uint64_t)b * cfg.stride;
+    const unsigned long long *nz = (const unsigned long long *)(nz_all + (uint64_t)b * (cfg.stride / 32));
+    const uint16_t *val = val_all + (uint64_t)b * cfg.stride;
     uint32_t *tok = tok_all + (uint64_t)b * cfg.stride;
+    (void)slab;
 
     const long long t_begin = clock64();
     // state carried from tile to tile (uniform across the workgroup)
@@ -587,7 +586,6 @@ __global__ __launch_bounds__(kMpThreads, 8) void k_parse(
     uint32_t cur_sub = 0, sub_start = 0, sub_start_tok = 0, sub_start_mat = 0;
     uint32_t sub_limit = sub_limit_of(0, n);
     uint32_t rounds_total = 0;
-    const uint64_t lane_below = (1ull << lane) - 1ull;
 
     for (uint32_t tile_begin = 0; tile_begin < n; tile_begin += kTile) {
         const uint32_t tile_len = n - tile_begin < kTile ? n - tile_begin : kTile;
@@ -595,18 +593,33 @@ __global__ __launch_bounds__(kMpThreads, 8) void k_parse(
         {
             const uint32_t *src = (const uint32_t *)(len8_all + (uint64_t)b * cfg.stride + tile_begin);
             for (uint32_t i = tid; i < (tile_len + 3) / 4; i += kMpThreads) len8_w[i] = src[i];
-            for (uint32_t i = tid; i < kTile / 32; i += kMpThreads) tok_bits[i] = 0;
             if (tid == 0) bnd = ~0ull;
         }
         __syncthreads();
 
-        // ---- phase 2: greedy parse, speculative segment walk (threads 0..255 own segments)
-        const uint32_t seg_begin = tid * kSeg;  // tile-relative
-        const bool active = tid < 256 && seg_begin < tile_len;
-        const uint32_t seg_end = active ? (seg_begin + kSeg < tile_len ? seg_begin + kSeg : tile_len) : 0;
-        // the tile's true entry is known (thread 0); the others speculate "at my segment start"
+        // ---- phase 2: the greedy parse as a speculative segment walk.  Thread s owns the 64
+        // positions of segment s and walks them from an entry position: first guess "my segment
+        // start" (thread 0 knows the tile's true entry), then the exit of segment s-1, until no
+        // entry changes.  A segment whose entry lies beyond its end (a long match flew over it) has
+        // no tokens and hands the entry through.  Greedy walks re-synchronise within a few tokens,
+        // so a handful of rounds suffice; the token marks of a walk are one 64-bit word, rewritten
+        // by every re-walk.
+        const uint32_t seg_begin = tid * kPSeg;  // tile-relative; kTile / kPSeg == kMpThreads
+        const bool active = seg_begin < tile_len;
+        const uint32_t seg_end = active ? (seg_begin + kPSeg < tile_len ? seg_begin + kPSeg : tile_len) : 0;
+        auto walk = [&](uint32_t pos) -> uint32_t {
+            unsigned long long marks = 0;
+            while (pos < seg_end) {
+                const uint32_t l = len8[pos];
+                marks |= 1ull << (pos - seg_begin);
+                pos += l ? l + 3 : 1;
+            }
+            tok_bits[tid] = marks;
+            return pos;
+        };
         uint32_t entry = tid == 0 ? entry_carry - tile_begin : seg_begin;
-        if (active) seg_exit[tid] = walk_segment(len8, entry, seg_end, tok_bits);
+        if (active) seg_exit[tid] = walk(entry);
+        else tok_bits[tid] = 0;
         for (;;) {
             rounds_total++;
             __syncthreads();
@@ -618,33 +631,24 @@ __global__ __launch_bounds__(kMpThreads, 8) void k_parse(
             }
             __syncthreads();
             if (changed) {
-                clear_marks(seg_begin, seg_end, tok_bits);
                 entry = new_entry;
-                seg_exit[tid] = walk_segment(len8, entry, seg_end, tok_bits);
+                seg_exit[tid] = walk(entry);
             }
             if (!__syncthreads_or(changed)) break;
         }
         // where the parse leaves this tile (a match may overhang the tile end)
-        const uint32_t n_seg = (tile_len + kSeg - 1) / kSeg;
+        const uint32_t n_seg = (tile_len + kPSeg - 1) / kPSeg;
         const uint32_t exit_rel = seg_exit[n_seg - 1];
+        __syncthreads();  // seg_exit is rank_pre from here on
 
-        // ---- phase 3a: tokens / matches per (chunk, wave), then one workgroup-wide scan
-        const uint32_t nchunks = (tile_len + kMpThreads - 1) / kMpThreads;
-        for (uint32_t c = 0; c < nchunks; c++) {
-            const uint32_t r = c * kMpThreads + tid;
-            const bool is_tok = r < tile_len && ((tok_bits[r >> 5] >> (r & 31u)) & 1u);
-            const bool is_match = is_tok && len8[r] != 0;
-            const uint64_t mt = __ballot(is_tok), mm = __ballot(is_match);
-            if (lane == 0)
-                rank_pre[c * kMpWaves + wave] = (uint32_t)__popcll(mt) | ((uint32_t)__popcll(mm) << 17);
-        }
-        __syncthreads();
+        // ---- phase 3a: tokens / matches per 64-position group (one thread each, from the two
+        // bitmaps), then one workgroup-wide scan
+        const unsigned long long my_tok = tok_bits[tid];
+        const unsigned long long my_mat = my_tok & (active ? nz[(tile_begin >> 6) + tid] : 0ull);
         uint32_t tile_tok, tile_mat;
+        uint32_t my_pre;
         {
-            // entry e = chunk * 16 + wave is position order; thread e scans entry e
-            const bool have = tid < nchunks * kMpWaves;
-            const uint32_t v = have ? rank_pre[tid] : 0;
-            const uint32_t vt = v & 0x1FFFFu, vm = v >> 17;
+            const uint32_t vt = (uint32_t)__popcll(my_tok), vm = (uint32_t)__popcll(my_mat);
             const uint32_t it = wave_inclusive_scan(vt, lane), im = wave_inclusive_scan(vm, lane);
             if (lane == 63) {
                 wsum_t[wave] = it;
@@ -664,72 +668,56 @@ __global__ __launch_bounds__(kMpThreads, 8) void k_parse(
             tile_tok = tt;
             tile_mat = tm;
             // exclusive prefixes: tokens <= 65536 fit 17 bits, matches <= 16384 fit 15 bits
-            if (have) rank_pre[tid] = (bt + it - vt) | ((bm + im - vm) << 17);
+            my_pre = (bt + it - vt) | ((bm + im - vm) << 17);
+            rank_pre[tid] = my_pre;
         }
         __syncthreads();
 
-        // ---- phase 3b: build tokens in position order (global reads issued 4 chunks deep) and
-        // look for the end of the current sub-block.  A second boundary inside one tile needs
-        // another 8192 matches after the first, so the search is repeated only in that case.
+        // ---- phase 3b: build tokens in position order: lane l of a wave takes position l of a
+        // 64-position group (coalesced val reads and token stores), ranks from the group's prefix +
+        // popcounts below the lane.  The same pass looks for the end of the current sub-block.  A
+        // second boundary inside one tile needs another 8192 matches after the first, so the
+        // search is repeated only in that case.
+        const uint32_t ngroups = (tile_len + 63) / 64;
+        const unsigned long long lane_below = (1ull << lane) - 1ull;
         bool build = true;
         for (;;) {
-            for (uint32_t c0 = 0; c0 < nchunks; c0 += 4) {
-                uint32_t lens[4], tis[4], mis_[4], offs[4], alts[4], wbits[4], lits[4];
+            for (uint32_t g0 = wave; g0 < ngroups; g0 += 4 * kMpWaves) {
+                uint32_t vals[4];
 #pragma unroll
                 for (uint32_t k = 0; k < 4; k++) {
-                    const uint32_t c = c0 + k;
-                    const uint32_t r = c * kMpThreads + tid;
-                    const uint32_t p = tile_begin + r;
-                    const bool is_tok = c < nchunks && r < tile_len && ((tok_bits[r >> 5] >> (r & 31u)) & 1u);
-                    const uint32_t l = is_tok ? len8[r] : 0;
-                    const bool is_match = l != 0;
-                    const uint64_t mt = __ballot(is_tok), mm = __ballot(is_match);
-                    const uint32_t pre = rank_pre[(c < nchunks ? c : 0) * kMpWaves + wave];
-                    tis[k] = is_tok ? tok_carry + (pre & 0x1FFFFu) + (uint32_t)__popcll(mt & lane_below)
-                                    : 0xFFFFFFFFu;
-                    mis_[k] = mat_carry + (pre >> 17) + (uint32_t)__popcll(mm & lane_below);
-                    lens[k] = l;
-                    offs[k] = (build && is_match) ? cand[p] : 0u;
-                    alts[k] = (build && is_match) ? alt[p] : 0u;  // only meaningful where `which` is set
-                    wbits[k] = (build && is_match) ? which[p >> 5] : 0u;
-                    lits[k] = (build && is_tok && !is_match) ? in[p] : 0u;
+                    const uint32_t g = g0 + k * kMpWaves;
+                    const uint32_t r = g * 64 + lane;
+                    vals[k] = (build && g < ngroups && r < tile_len) ? val[tile_begin + r] : 0u;
                 }
 #pragma unroll
                 for (uint32_t k = 0; k < 4; k++) {
-                    const uint32_t p = tile_begin + (c0 + k) * kMpThreads + tid;
-                    if (tis[k] == 0xFFFFFFFFu) continue;
-                    const uint32_t ti = tis[k], mi = mis_[k];
+                    const uint32_t g = g0 + k * kMpWaves;
+                    if (g >= ngroups) break;  // wave-uniform
+                    const unsigned long long mt = tok_bits[g], mm = mt & nz[(tile_begin >> 6) + g];
+                    if (!((mt >> lane) & 1ull)) continue;
+                    const uint32_t r = g * 64 + lane, p = tile_begin + r;
+                    const uint32_t pre = rank_pre[g];
+                    const uint32_t ti = tok_carry + (pre & 0x1FFFFu) + (uint32_t)__popcll(mt & lane_below);
+                    const uint32_t mi = mat_carry + (pre >> 17) + (uint32_t)__popcll(mm & lane_below);
                     // sub-block boundary: this token would start past the soft limit, or 8192
                     // matches precede it in the current sub-block (src: deflate_compress_fastest)
                     if (p > sub_start && (p >= sub_limit || mi - sub_start_mat >= kSeqPerSub))
                         atomicMin(&bnd, ((unsigned long long)p << 32) | ti);
                     if (!build) continue;
-                    if (lens[k]) {
-                        const uint32_t len = lens[k] + 3;
-                        const uint32_t off = ((wbits[k] >> (p & 31u)) & 1u) ? alts[k] : offs[k];
-                        tok[ti] = kTokMatch | (off << 9) | len;
-                    } else {
-                        tok[ti] = lits[k];
-                    }
+                    const uint32_t l = len8[r];
+                    tok[ti] = l ? (kTokMatch | (vals[k] << 9) | (l + 3)) : vals[k];
                 }
             }
             __syncthreads();
             const unsigned long long bv = bnd;
             if (bv == ~0ull) break;  // the current sub-block runs past this tile
-            // the boundary token's match rank: recomputed by the wave that owns its position
+            // the boundary token's match rank, from its group's prefix and the bitmaps
             const uint32_t bp = (uint32_t)(bv >> 32), bti = (uint32_t)bv;
-            {
-                const uint32_t r = bp - tile_begin;
-                const uint32_t c = r / kMpThreads;
-                if (wave == (r % kMpThreads) / 64) {
-                    const uint32_t rr = c * kMpThreads + tid;
-                    const bool is_tok = rr < tile_len && ((tok_bits[rr >> 5] >> (rr & 31u)) & 1u);
-                    const bool is_match = is_tok && len8[rr] != 0;
-                    const uint64_t mm = __ballot(is_match);
-                    if (rr == r)
-                        bnd_mat = mat_carry + (rank_pre[c * kMpWaves + wave] >> 17) +
-                                  (uint32_t)__popcll(mm & lane_below);
-                }
+            if (tid == 0) {
+                const uint32_t r = bp - tile_begin, g = r >> 6;
+                const unsigned long long mm = tok_bits[g] & nz[(tile_begin >> 6) + g];
+                bnd_mat = mat_carry + (rank_pre[g] >> 17) + (uint32_t)__popcll(mm & ((1ull << (r & 63u)) - 1ull));
             }
             __syncthreads();
             const uint32_t bm = bnd_mat;
@@ -2966,8 +2954,7 @@ void launch_match(const Config &cfg, const uint8_t *slab, uint64_t, uint32_t nb,
 void launch_parse(const Config &cfg, const uint8_t *slab, uint64_t, uint32_t nb, const Scratch &s,
                   hipStream_t stream) {
     hipLaunchKernelGGL(k_parse, dim3(nb), dim3(kMpThreads), 0, stream, cfg, slab, s.meta, s.sub,
-                       (const uint16_t *)s.cand, (const uint8_t *)s.len8, (const uint32_t *)s.which,
-                       (const uint16_t *)s.alt, s.tok);
+                       (const uint8_t *)s.len8, (const uint32_t *)s.which, (const uint16_t *)s.alt, s.tok);
 }
 
 void launch_hc_round(const Config &cfg, const uint8_t *slab, uint32_t nb, const Scratch &s, int first,
