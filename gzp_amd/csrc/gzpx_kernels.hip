@@ -44,6 +44,13 @@ __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
 }
 
+// a value that is the same in every lane, moved to a scalar register (wave-uniform state that
+// comes out of LDS would otherwise occupy a VGPR in every lane)
+__device__ __forceinline__ uint32_t rdlane(uint32_t v, uint32_t l) {
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)l);
+}
+__device__ __forceinline__ uint32_t uniform(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+
 __device__ __forceinline__ uint32_t lz_hash15(uint32_t v) { return (v * 0x1E35A7BDu) >> 17; }
 
 // little-endian u32 at an arbitrary byte address of global memory via two aligned loads
@@ -591,8 +598,15 @@ __global__ __launch_bounds__(kMpThreads, 8) void k_parse(
         const uint32_t tile_len = n - tile_begin < kTile ? n - tile_begin : kTile;
         __syncthreads();  // previous tile fully consumed
         {
-            const uint32_t *src = (const uint32_t *)(len8_all + (uint64_t)b * cfg.stride + tile_begin);
-            for (uint32_t i = tid; i < (tile_len + 3) / 4; i += kMpThreads) len8_w[i] = src[i];
+            // 64 bytes per thread as four 16-byte loads, all in flight before the LDS stores (the
+            // per-block stride is a multiple of 1024 and padded, so whole uint4s are readable)
+            const uint4 *src = (const uint4 *)(len8_all + (uint64_t)b * cfg.stride + tile_begin);
+            uint4 *dst = (uint4 *)len8_w;
+            uint4 v[4];
+#pragma unroll
+            for (uint32_t k = 0; k < 4; k++) v[k] = src[tid + k * kMpThreads];
+#pragma unroll
+            for (uint32_t k = 0; k < 4; k++) dst[tid + k * kMpThreads] = v[k];
             if (tid == 0) bnd = ~0ull;
         }
         __syncthreads();
@@ -638,7 +652,7 @@ __global__ __launch_bounds__(kMpThreads, 8) void k_parse(
         }
         // where the parse leaves this tile (a match may overhang the tile end)
         const uint32_t n_seg = (tile_len + kPSeg - 1) / kPSeg;
-        const uint32_t exit_rel = seg_exit[n_seg - 1];
+        const uint32_t exit_rel = uniform(seg_exit[n_seg - 1]);
         __syncthreads();  // seg_exit is rank_pre from here on
 
         // ---- phase 3a: tokens / matches per 64-position group (one thread each, from the two
@@ -665,8 +679,8 @@ __global__ __launch_bounds__(kMpThreads, 8) void k_parse(
                 tt += st;
                 tm += sm;
             }
-            tile_tok = tt;
-            tile_mat = tm;
+            tile_tok = uniform(tt);
+            tile_mat = uniform(tm);
             // exclusive prefixes: tokens <= 65536 fit 17 bits, matches <= 16384 fit 15 bits
             my_pre = (bt + it - vt) | ((bm + im - vm) << 17);
             rank_pre[tid] = my_pre;
@@ -682,45 +696,65 @@ __global__ __launch_bounds__(kMpThreads, 8) void k_parse(
         const unsigned long long lane_below = (1ull << lane) - 1ull;
         bool build = true;
         for (;;) {
-            for (uint32_t g0 = wave; g0 < ngroups; g0 += 4 * kMpWaves) {
-                uint32_t vals[4];
+            // 8 groups of a wave per step: all val loads first, then every token word is formed
+            // (the last use of a loaded value), then the stores -- a loaded value consumed after a
+            // store had been issued would make the compiler drain the stores first (loads and
+            // stores share one counter on gfx9).  The match rank is only needed in the one group
+            // where the 8192-match rule can fire, which the group prefixes tell.
+            for (uint32_t g0 = wave; g0 < ngroups; g0 += 8 * kMpWaves) {
+                uint32_t vals[8], tis[8];
 #pragma unroll
-                for (uint32_t k = 0; k < 4; k++) {
+                for (uint32_t k = 0; k < 8; k++) {
                     const uint32_t g = g0 + k * kMpWaves;
                     const uint32_t r = g * 64 + lane;
                     vals[k] = (build && g < ngroups && r < tile_len) ? val[tile_begin + r] : 0u;
                 }
+                // every load has landed from here on, also on the paths that skip a group: without
+                // this the compiler must assume a pending load behind each later store's data
+                __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
 #pragma unroll
-                for (uint32_t k = 0; k < 4; k++) {
+                for (uint32_t k = 0; k < 8; k++) {
                     const uint32_t g = g0 + k * kMpWaves;
-                    if (g >= ngroups) break;  // wave-uniform
-                    const unsigned long long mt = tok_bits[g], mm = mt & nz[(tile_begin >> 6) + g];
-                    if (!((mt >> lane) & 1ull)) continue;
-                    const uint32_t r = g * 64 + lane, p = tile_begin + r;
+                    tis[k] = 0xFFFFFFFFu;
+                    if (g >= ngroups) continue;  // wave-uniform
+                    const unsigned long long mt = tok_bits[g];
                     const uint32_t pre = rank_pre[g];
+                    const uint32_t mat_after = mat_carry + (g + 1 < ngroups ? rank_pre[g + 1] >> 17 : tile_mat);
+                    const bool count_rule = mat_after - sub_start_mat >= kSeqPerSub;  // wave-uniform, rare
+                    const uint32_t r = g * 64 + lane, p = tile_begin + r;
+                    if (!((mt >> lane) & 1ull)) continue;
                     const uint32_t ti = tok_carry + (pre & 0x1FFFFu) + (uint32_t)__popcll(mt & lane_below);
-                    const uint32_t mi = mat_carry + (pre >> 17) + (uint32_t)__popcll(mm & lane_below);
                     // sub-block boundary: this token would start past the soft limit, or 8192
                     // matches precede it in the current sub-block (src: deflate_compress_fastest)
-                    if (p > sub_start && (p >= sub_limit || mi - sub_start_mat >= kSeqPerSub))
-                        atomicMin(&bnd, ((unsigned long long)p << 32) | ti);
-                    if (!build) continue;
+                    bool boundary = p >= sub_limit;
+                    if (count_rule) {
+                        const unsigned long long mm = mt & nz[(tile_begin >> 6) + g];
+                        const uint32_t mi = mat_carry + (pre >> 17) + (uint32_t)__popcll(mm & lane_below);
+                        boundary = boundary || mi - sub_start_mat >= kSeqPerSub;
+                    }
+                    if (p > sub_start && boundary) atomicMin(&bnd, ((unsigned long long)p << 32) | ti);
                     const uint32_t l = len8[r];
-                    tok[ti] = l ? (kTokMatch | (vals[k] << 9) | (l + 3)) : vals[k];
+                    vals[k] = l ? (kTokMatch | (vals[k] << 9) | (l + 3)) : vals[k];
+                    tis[k] = ti;
+                }
+                if (build) {
+#pragma unroll
+                    for (uint32_t k = 0; k < 8; k++)
+                        if (tis[k] != 0xFFFFFFFFu) tok[tis[k]] = vals[k];
                 }
             }
             __syncthreads();
             const unsigned long long bv = bnd;
             if (bv == ~0ull) break;  // the current sub-block runs past this tile
             // the boundary token's match rank, from its group's prefix and the bitmaps
-            const uint32_t bp = (uint32_t)(bv >> 32), bti = (uint32_t)bv;
+            const uint32_t bp = uniform((uint32_t)(bv >> 32)), bti = uniform((uint32_t)bv);
             if (tid == 0) {
                 const uint32_t r = bp - tile_begin, g = r >> 6;
                 const unsigned long long mm = tok_bits[g] & nz[(tile_begin >> 6) + g];
                 bnd_mat = mat_carry + (rank_pre[g] >> 17) + (uint32_t)__popcll(mm & ((1ull << (r & 63u)) - 1ull));
             }
             __syncthreads();
-            const uint32_t bm = bnd_mat;
+            const uint32_t bm = uniform(bnd_mat);
             if (tid == 0) {
                 sub[cur_sub].tok_begin = sub_start_tok;
                 sub[cur_sub].tok_end = bti;
@@ -2389,10 +2423,6 @@ __global__ __launch_bounds__(256) void k_dscan(uint32_t nb, const DBlock *__rest
     if (tid == 0) out_off[nb] = carry_s;
 }
 
-__device__ __forceinline__ uint32_t rdlane(uint32_t v, uint32_t l) {
-    return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)l);
-}
-__device__ __forceinline__ uint32_t uniform(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 
 // wave-wide inclusive scans on the DPP network (row shifts, then the row broadcasts of gfx9)
 template <int CTRL, int ROW_MASK>

@@ -141,6 +141,7 @@ static inline unsigned __builtin_amdgcn_alignbit(unsigned hi, unsigned lo, unsig
 static inline void __builtin_amdgcn_wave_barrier() { (void)emu::wave_ballot(0); }
 #define __builtin_amdgcn_fence(order, scope) ((void)0)
 static inline void __builtin_amdgcn_s_sleep(int) { emu::yield_now(); }
+#define __builtin_amdgcn_s_waitcnt(x) ((void)0)
 #define __HIP_MEMORY_SCOPE_WORKGROUP 2
 #define __HIP_MEMORY_SCOPE_AGENT 3
 template <typename T>
