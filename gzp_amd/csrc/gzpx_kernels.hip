@@ -436,18 +436,27 @@ __global__ __launch_bounds__(kMpThreads, 8) void k_match(Config cfg, const uint8
         }
         __syncthreads();
 
-        // candidate distances are read 4 positions deep (two dependent L2 reads per position)
+        // candidate distances, 4 positions per thread and step: d0 of the NEXT step is requested
+        // together with this step's dependent gather cand[p - d0], so a step waits for memory once
+        auto load_d0 = [&](uint32_t p) -> uint32_t { return (p < tile_end && p + 5 <= n) ? cand[p] : 0u; };
+        uint32_t d0n[4];
+#pragma unroll
+        for (uint32_t k = 0; k < 4; k++) d0n[k] = load_d0(tile_begin + tid + k * kMpThreads);
         for (uint32_t p0 = tile_begin + tid; p0 < tile_end; p0 += 4 * kMpThreads) {
             uint32_t d0s[4], d1s[4];
 #pragma unroll
-            for (uint32_t k = 0; k < 4; k++) {
-                const uint32_t p = p0 + k * kMpThreads;
-                d0s[k] = (p < tile_end && p + 5 <= n) ? cand[p] : 0u;
-            }
+            for (uint32_t k = 0; k < 4; k++) d0s[k] = d0n[k];
 #pragma unroll
             for (uint32_t k = 0; k < 4; k++) {
                 const uint32_t p = p0 + k * kMpThreads;
-                const uint32_t r = (d0s[k] && !(cfg.debug & 4u)) ? cand[p - d0s[k]] : 0u;
+                d1s[k] = d0s[k] ? cand[p - d0s[k]] : 0u;
+            }
+#pragma unroll
+            for (uint32_t k = 0; k < 4; k++) d0n[k] = load_d0(p0 + (4 + k) * kMpThreads);
+            __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): nothing below waits behind a store
+#pragma unroll
+            for (uint32_t k = 0; k < 4; k++) {
+                const uint32_t r = d1s[k];
                 d1s[k] = (r && d0s[k] + r <= 32767u) ? d0s[k] + r : 0u;
             }
 #pragma unroll
@@ -2151,17 +2160,34 @@ __global__ __launch_bounds__(256) void k_emit(Config cfg, const uint8_t *__restr
         __syncthreads();
         // 4 consecutive tokens per thread: one workgroup scan per 1024 tokens, and neighbouring
         // codewords are merged into <= 64-bit pieces before they are OR-ed into the staging buffer
+        // token words are fetched one step ahead, unconditionally (index clamped to the block's
+        // last token) so that the four loads of a step are in flight together
+        const uint32_t tok_last = meta->ntok - 1;
+        uint32_t tnext[4];
+#pragma unroll
+        for (uint32_t j = 0; j < 4; j++) {
+            const uint32_t i = sm.tok_begin + 4 * tid + j;
+            tnext[j] = tok[i < tok_last ? i : tok_last];
+        }
         for (uint32_t tb = sm.tok_begin; tb < sm.tok_end; tb += 1024) {
             ensure(1024u * 48u);
             const uint32_t t0 = tb + 4 * tid;
             uint64_t bits[4];
             uint32_t nbits[4], sum = 0;
+            uint32_t tcur[4];
+#pragma unroll
+            for (uint32_t j = 0; j < 4; j++) tcur[j] = tnext[j];
+#pragma unroll
+            for (uint32_t j = 0; j < 4; j++) {
+                const uint32_t i = t0 + 1024 + j;
+                tnext[j] = tok[i < tok_last ? i : tok_last];
+            }
 #pragma unroll
             for (uint32_t j = 0; j < 4; j++) {
                 bits[j] = 0;
                 nbits[j] = 0;
                 if (t0 + j < sm.tok_end) {
-                    const uint32_t t = tok[t0 + j];
+                    const uint32_t t = tcur[j];
                     if (t & kTokMatch) {
                         const uint32_t len = t & 0x1FFu, off = (t >> 9) & 0xFFFFu;
                         uint32_t ls, le, lv, os, oe, ov;
