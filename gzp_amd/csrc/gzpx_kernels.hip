@@ -73,6 +73,50 @@ __device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v, unsigned lan
     return v;
 }
 
+// wave-wide inclusive scans on the DPP network (row shifts, then the row broadcasts of gfx9)
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint32_t dpp_zero(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xf, false);
+}
+__device__ __forceinline__ uint32_t wave_incl_add(uint32_t v) {
+    v += dpp_zero<0x111, 0xf>(v);
+    v += dpp_zero<0x112, 0xf>(v);
+    v += dpp_zero<0x114, 0xf>(v);
+    v += dpp_zero<0x118, 0xf>(v);
+    v += dpp_zero<0x142, 0xa>(v);
+    v += dpp_zero<0x143, 0xc>(v);
+    return v;
+}
+__device__ __forceinline__ uint32_t umax32(uint32_t a, uint32_t b) { return a > b ? a : b; }
+__device__ __forceinline__ uint32_t wave_incl_max(uint32_t v) {
+    v = umax32(v, dpp_zero<0x111, 0xf>(v));
+    v = umax32(v, dpp_zero<0x112, 0xf>(v));
+    v = umax32(v, dpp_zero<0x114, 0xf>(v));
+    v = umax32(v, dpp_zero<0x118, 0xf>(v));
+    v = umax32(v, dpp_zero<0x142, 0xa>(v));
+    v = umax32(v, dpp_zero<0x143, 0xc>(v));
+    return v;
+}
+
+// Exclusive scan of one value per thread over a workgroup of NW waves; `wsum` is NW words of LDS.
+// Returns the exclusive prefix; *total receives the workgroup sum.  Two barriers.
+template <unsigned NW>
+__device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t *wsum, uint32_t *total) {
+    const unsigned tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t inc = wave_incl_add(v);
+    __syncthreads();  // protect wsum from the previous use
+    if (lane == 63) wsum[wave] = inc;
+    __syncthreads();
+    uint32_t base = 0, tot = 0;
+    for (unsigned w = 0; w < NW; w++) {
+        const uint32_t s = wsum[w];
+        if (w < wave) base += s;
+        tot += s;
+    }
+    *total = tot;
+    return base + inc - v;
+}
+
 // Exclusive scan of one value per thread over a 256-thread workgroup; `wsum` is 4 words of LDS.
 // Returns the exclusive prefix; *total receives the workgroup sum.  Two barriers.
 __device__ __forceinline__ uint32_t block_exclusive_scan256(uint32_t v, uint32_t *wsum,
@@ -2015,11 +2059,13 @@ __device__ __forceinline__ void stage_put_byte(uint32_t *stage, uint32_t byte_id
 // Write the window's bytes [win_base, upto) (coordinates: bytes from the 4-byte-aligned address
 // just below the block's first output byte) to global memory: whole dwords where every byte
 // belongs to this block, single bytes at the block's two edges.
+constexpr uint32_t kEmitThreads = 1024;
+
 __device__ __forceinline__ void stage_flush(const uint32_t *stage, uint8_t *dst_aligned,
                                             uint32_t win_base, uint32_t upto, uint32_t lead,
                                             uint32_t end_byte, uint32_t tid) {
     const uint32_t words = (upto - win_base + 3) >> 2;
-    for (uint32_t w = tid; w < words; w += 256) {
+    for (uint32_t w = tid; w < words; w += kEmitThreads) {
         const uint32_t v = stage[w];
         const uint32_t b0 = win_base + 4 * w;
         if (b0 >= lead && b0 + 4 <= end_byte && b0 + 4 <= upto) {
@@ -2032,7 +2078,7 @@ __device__ __forceinline__ void stage_flush(const uint32_t *stage, uint8_t *dst_
     }
 }
 
-__global__ __launch_bounds__(256) void k_emit(Config cfg, const uint8_t *__restrict__ slab,
+__global__ __launch_bounds__(kEmitThreads, 8) void k_emit(Config cfg, const uint8_t *__restrict__ slab,
                                               const BlockMeta *__restrict__ meta_all,
                                               const SubMeta *__restrict__ sub_all,
                                               const uint32_t *__restrict__ tok_all,
@@ -2042,7 +2088,7 @@ __global__ __launch_bounds__(256) void k_emit(Config cfg, const uint8_t *__restr
                                               uint8_t *__restrict__ out, uint64_t out_cap) {
     __shared__ uint32_t stage[kStageWords];
     __shared__ uint32_t codes[kCodeWords];
-    __shared__ uint32_t wsum[4];
+    __shared__ uint32_t wsum[kEmitThreads / 64];
     const uint32_t tid = threadIdx.x;
     const uint32_t b = blockIdx.x;
     const BlockMeta *meta = meta_all + b;
@@ -2061,7 +2107,7 @@ __global__ __launch_bounds__(256) void k_emit(Config cfg, const uint8_t *__restr
     const uint32_t end_byte = lead + framed;
     uint32_t win_base = 0;  // aligned coordinate of stage[0] (multiple of 4)
 
-    for (uint32_t i = tid; i < kStageWords; i += 256) stage[i] = 0;
+    for (uint32_t i = tid; i < kStageWords; i += kEmitThreads) stage[i] = 0;
     __syncthreads();
 
     // ---- gzip member header (src/bgzf.rs:274-303 / src/mgzip.rs:246-275)
@@ -2108,7 +2154,7 @@ __global__ __launch_bounds__(256) void k_emit(Config cfg, const uint8_t *__restr
         stage_flush(stage, dst_aligned, win_base, win_base + upto_rel, lead, end_byte, tid);
         const uint32_t keep = stage[upto_rel >> 2];
         __syncthreads();
-        for (uint32_t i = tid; i < kStageWords; i += 256) stage[i] = 0;
+        for (uint32_t i = tid; i < kStageWords; i += kEmitThreads) stage[i] = 0;
         __syncthreads();
         if (tid == 0) stage[0] = keep;
         win_base += upto_rel;
@@ -2138,7 +2184,7 @@ __global__ __launch_bounds__(256) void k_emit(Config cfg, const uint8_t *__restr
                     const uint32_t piece = chunk - done < 16384u ? chunk - done : 16384u;
                     ensure(8u * piece);
                     const uint32_t bytepos = bitpos >> 3;
-                    for (uint32_t i = tid; i < piece; i += 256)
+                    for (uint32_t i = tid; i < piece; i += kEmitThreads)
                         stage_put_byte(stage, bytepos + i, in[src + done + i]);
                     bitpos += 8u * piece;
                 }
@@ -2151,14 +2197,14 @@ __global__ __launch_bounds__(256) void k_emit(Config cfg, const uint8_t *__restr
         // ---- Huffman-coded sub-block: header bits, tokens, end-of-block
         __syncthreads();  // the previous sub-block is done with `codes`
         const uint32_t *cd = codes_all + ((uint64_t)b * cfg.max_sub + s) * kCodeWords;
-        for (uint32_t i = tid; i < kCodeWords; i += 256) codes[i] = cd[i];
+        for (uint32_t i = tid; i < kCodeWords; i += kEmitThreads) codes[i] = cd[i];
         const uint32_t *hw = hdr_all + ((uint64_t)b * cfg.max_sub + s) * kHdrWords;
         const uint32_t nhw = (sm.hdr_bits + 31) >> 5;
         ensure(32u * kHdrWords);
-        for (uint32_t i = tid; i < nhw; i += 256) stage_or_bits(stage, bitpos + 32 * i, hw[i]);
+        for (uint32_t i = tid; i < nhw; i += kEmitThreads) stage_or_bits(stage, bitpos + 32 * i, hw[i]);
         bitpos += sm.hdr_bits;
         __syncthreads();
-        // 4 consecutive tokens per thread: one workgroup scan per 1024 tokens, and neighbouring
+        // 4 consecutive tokens per thread: one workgroup scan per 4096 tokens, and neighbouring
         // codewords are merged into <= 64-bit pieces before they are OR-ed into the staging buffer
         // token words are fetched one step ahead, unconditionally (index clamped to the block's
         // last token) so that the four loads of a step are in flight together
@@ -2169,8 +2215,8 @@ __global__ __launch_bounds__(256) void k_emit(Config cfg, const uint8_t *__restr
             const uint32_t i = sm.tok_begin + 4 * tid + j;
             tnext[j] = tok[i < tok_last ? i : tok_last];
         }
-        for (uint32_t tb = sm.tok_begin; tb < sm.tok_end; tb += 1024) {
-            ensure(1024u * 48u);
+        for (uint32_t tb = sm.tok_begin; tb < sm.tok_end; tb += 4 * kEmitThreads) {
+            ensure(4u * kEmitThreads * 48u);
             const uint32_t t0 = tb + 4 * tid;
             uint64_t bits[4];
             uint32_t nbits[4], sum = 0;
@@ -2179,7 +2225,7 @@ __global__ __launch_bounds__(256) void k_emit(Config cfg, const uint8_t *__restr
             for (uint32_t j = 0; j < 4; j++) tcur[j] = tnext[j];
 #pragma unroll
             for (uint32_t j = 0; j < 4; j++) {
-                const uint32_t i = t0 + 1024 + j;
+                const uint32_t i = t0 + 4 * kEmitThreads + j;
                 tnext[j] = tok[i < tok_last ? i : tok_last];
             }
 #pragma unroll
@@ -2213,7 +2259,7 @@ __global__ __launch_bounds__(256) void k_emit(Config cfg, const uint8_t *__restr
                 }
             }
             uint32_t total;
-            const uint32_t ex = block_exclusive_scan256(sum, wsum, &total);
+            const uint32_t ex = block_exclusive_scan<kEmitThreads / 64>(sum, wsum, &total);
             uint32_t off_bits = bitpos + ex, accn = 0;
             uint64_t acc = 0;
 #pragma unroll
@@ -2450,30 +2496,6 @@ __global__ __launch_bounds__(256) void k_dscan(uint32_t nb, const DBlock *__rest
 }
 
 
-// wave-wide inclusive scans on the DPP network (row shifts, then the row broadcasts of gfx9)
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ uint32_t dpp_zero(uint32_t v) {
-    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xf, false);
-}
-__device__ __forceinline__ uint32_t wave_incl_add(uint32_t v) {
-    v += dpp_zero<0x111, 0xf>(v);
-    v += dpp_zero<0x112, 0xf>(v);
-    v += dpp_zero<0x114, 0xf>(v);
-    v += dpp_zero<0x118, 0xf>(v);
-    v += dpp_zero<0x142, 0xa>(v);
-    v += dpp_zero<0x143, 0xc>(v);
-    return v;
-}
-__device__ __forceinline__ uint32_t umax32(uint32_t a, uint32_t b) { return a > b ? a : b; }
-__device__ __forceinline__ uint32_t wave_incl_max(uint32_t v) {
-    v = umax32(v, dpp_zero<0x111, 0xf>(v));
-    v = umax32(v, dpp_zero<0x112, 0xf>(v));
-    v = umax32(v, dpp_zero<0x114, 0xf>(v));
-    v = umax32(v, dpp_zero<0x118, 0xf>(v));
-    v = umax32(v, dpp_zero<0x142, 0xa>(v));
-    v = umax32(v, dpp_zero<0x143, 0xc>(v));
-    return v;
-}
 
 // The symbol loop works in rounds of 64 bit positions.  Lane i takes the 32 bits that start at bit
 // bp + i of the payload and looks them up in BOTH fast tables (two LDS gathers for the whole wave:
@@ -3046,7 +3068,7 @@ void launch_scan(uint32_t nb, const Scratch &s, hipStream_t stream) {
 
 void launch_emit(const Config &cfg, const uint8_t *slab, uint64_t, uint32_t nb, const Scratch &s,
                  uint8_t *out, uint64_t out_cap, hipStream_t stream) {
-    hipLaunchKernelGGL(k_emit, dim3(nb), dim3(256), 0, stream, cfg, slab, (const BlockMeta *)s.meta,
+    hipLaunchKernelGGL(k_emit, dim3(nb), dim3(kEmitThreads), 0, stream, cfg, slab, (const BlockMeta *)s.meta,
                        (const SubMeta *)s.sub, (const uint32_t *)s.tok, (const uint32_t *)s.codes,
                        (const uint32_t *)s.hdr, (const uint64_t *)s.out_off, out, out_cap);
 }
