@@ -335,7 +335,7 @@ int gzpx_ctx_create(const gzpx_config *cfg, gzpx_ctx **out) {
     ctx->dcfg.xfl = cfg->level >= 9 ? 2u : cfg->level <= 1 ? 4u : 0u;  // src/bgzf.rs:278-284
     ctx->dcfg.debug = 0;
     // per-block strides: padding for k_candidates' last iteration / dword-wide tile loads
-    ctx->dcfg.stride = (uint32_t)((cfg->buffer_size + 1023) / 1024 * 1024 + 1024);
+    ctx->dcfg.stride = (uint32_t)((cfg->buffer_size + 2047) / 2048 * 2048 + 2048);
     // level 1 sub-blocks hold 8192 matches (>= 32768 bytes); the block splitter of levels 2-4 may
     // cut every MIN_BLOCK_LENGTH = 5000 bytes
     ctx->dcfg.max_sub = (uint32_t)(cfg->buffer_size / (cfg->level == 1 ? 32768 : 5000) + 2);

@@ -224,7 +224,7 @@ __global__ void k_init_meta(Config cfg, uint64_t slab_len, uint32_t nb, uint32_t
 // Output: cand[p] = d0 (u16, 0 = no live predecessor).
 // ------------------------------------------------------------------------------------------
 constexpr uint32_t kBuckets = 1u << 15;
-constexpr uint32_t kCandSteps = 8;  // steps per iteration; also the depth of the input prefetch
+constexpr uint32_t kCandSteps = 32;  // steps per iteration; also the depth of the input prefetch
 
 // aligned dword pair covering in[p .. p+3] (in32 = the block's bytes rounded down to a dword
 // boundary, mis = bytes skipped by that rounding).  Unconditional (index clamped to the block's
