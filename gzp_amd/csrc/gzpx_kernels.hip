@@ -425,6 +425,11 @@ constexpr uint32_t kMpThreads = 1024;
 constexpr uint32_t kMpWaves = kMpThreads / 64;
 constexpr uint32_t kMpChunks = kTile / kMpThreads;  // 64 position chunks of 1024
 
+// four dwords that are only dword-aligned in global memory (the hardware takes such 16-byte loads)
+struct __attribute__((aligned(4))) dword4 {
+    uint32_t x, y, z, w;
+};
+
 __device__ __forceinline__ uint32_t lds_le32(const uint32_t *in_w, uint32_t byte_addr) {
     const uint32_t w = byte_addr >> 2;
     return __builtin_amdgcn_alignbyte(in_w[w + 1], in_w[w], byte_addr & 3u);
@@ -475,7 +480,24 @@ __global__ __launch_bounds__(kMpThreads, 8) void k_match(Config cfg, const uint8
         {
             const uint32_t *src = (const uint32_t *)(in + win_begin - mis);
             const uint32_t ndw = (mis + (win_end - win_begin) + 3) >> 2;
-            for (uint32_t i = tid; i < ndw; i += kMpThreads) in_w[i] = src[i];
+            // 16 bytes per load, four loads per thread in flight before the LDS stores
+            const dword4 *src4 = (const dword4 *)src;
+            dword4 *dst4 = (dword4 *)in_w;
+            const uint32_t nq = ndw >> 2;
+            for (uint32_t q0 = 0; q0 < nq; q0 += 4 * kMpThreads) {
+                dword4 v[4];
+#pragma unroll
+                for (uint32_t k = 0; k < 4; k++) {
+                    const uint32_t q = q0 + tid + k * kMpThreads;
+                    v[k] = src4[q < nq ? q : nq - 1];
+                }
+#pragma unroll
+                for (uint32_t k = 0; k < 4; k++) {
+                    const uint32_t q = q0 + tid + k * kMpThreads;
+                    if (q < nq) dst4[q] = v[k];
+                }
+            }
+            for (uint32_t i = 4 * nq + tid; i < ndw; i += kMpThreads) in_w[i] = src[i];
             for (uint32_t i = ndw + tid; i < ndw + 3 && i < kInWords; i += kMpThreads) in_w[i] = 0;
         }
         __syncthreads();
