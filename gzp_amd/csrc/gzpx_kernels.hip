@@ -26,6 +26,7 @@
 //   k_emit         256 thr  / block : bit-exact bitstream assembly in LDS, coalesced write-out
 // Integer/byte work only: no MFMA; LDS and HBM coalescing are what matter.
 #include <hip/hip_runtime.h>
+#include <type_traits>
 
 #include "gzpx_device.h"
 
@@ -457,11 +458,13 @@ __global__ __launch_bounds__(kMpThreads, 8) void k_match(Config cfg, const uint8
                                                       uint32_t *__restrict__ nz_all,
                                                       uint16_t *__restrict__ val_all) {
     __shared__ uint32_t in_w[kInWords];  // window bytes (+ lead misalignment, + pad)
+    __shared__ uint32_t run_mode;        // sticky: some wave of this block has met a long run
     const uint32_t tid = threadIdx.x;
     const uint32_t b = blockIdx.x;
     BlockMeta *meta = meta_all + b;
     const uint32_t n = meta->n;
     if (n <= cfg.passthrough) return;  // uniform for the workgroup
+    if (tid == 0) run_mode = 0;
     const uint8_t *in = slab + (uint64_t)b * cfg.block_size;
     const uint16_t *cand = cand_all + (uint64_t)b * cfg.stride;
     uint8_t *len8 = len8_all + (uint64_t)b * cfg.stride;
@@ -508,7 +511,11 @@ __global__ __launch_bounds__(kMpThreads, 8) void k_match(Config cfg, const uint8
         uint32_t d0n[4];
 #pragma unroll
         for (uint32_t k = 0; k < 4; k++) d0n[k] = load_d0(tile_begin + tid + k * kMpThreads);
-        for (uint32_t p0 = tile_begin + tid; p0 < tile_end; p0 += 4 * kMpThreads) {
+        // One step = 4 positions per thread.  The step exists twice: the plain one, and one with
+        // the run-group logic compiled in, taken once the block has shown a long run (keeping the
+        // rarely needed code out of the plain step's registers and schedule).
+        auto step = [&](uint32_t p0, auto runs_tag) {
+            constexpr bool runs_on = decltype(runs_tag)::value;
             uint32_t d0s[4], d1s[4];
 #pragma unroll
             for (uint32_t k = 0; k < 4; k++) d0s[k] = d0n[k];
@@ -532,16 +539,59 @@ __global__ __launch_bounds__(kMpThreads, 8) void k_match(Config cfg, const uint8
                 uint32_t best = 0, value = 0;
                 const uint32_t d0 = d0s[k], d1 = d1s[k];
                 if (p < tile_end) value = (lds_le32(in_w, p - win_begin + mis)) & 0xFFu;  // the literal
+                const uint32_t rem = p < n ? n - p : 0u;
+                const uint32_t max_len = rem < 258u ? rem : 258u;
+                const uint32_t nice_len = max_len < 32u ? max_len : 32u;
+                const uint32_t a = p - win_begin + mis;
+                // Run groups (only once the block has shown a long run, see run_mode): consecutive
+                // lanes (= consecutive positions) whose newer candidate has the same distance compare
+                // the same two byte streams, shifted by one byte per lane.  For a group of > 32 lanes
+                // the wave measures the leader's common length L once, 256 bytes per step (every lane
+                // one dword), and lane j of the group takes L - j.  Long runs (zeros, periodic data)
+                // otherwise cost 64 loop steps for every wave.
+                uint32_t pre0 = 0xFFFFFFFFu;  // common length with the newer candidate, if derived
+                if constexpr (runs_on) {
+                    const uint32_t wl = tid & 63u;
+                    // d0 of the lane below (wave_shr:1 on the DPP network; lane 0 gets 0)
+                    const uint32_t dprev = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)d0, 0x138, 0xf, 0xf, false);
+                    const unsigned long long same_mask = __ballot(d0 != 0 && d0 == dprev);
+                    // leaders followed by >= 32 lanes of their group: such a match reaches nice_len,
+                    // so the older candidate of these lanes cannot count either
+                    unsigned long long run32 = same_mask & (same_mask >> 1);
+                    run32 &= run32 >> 2;
+                    run32 &= run32 >> 4;
+                    run32 &= run32 >> 8;
+                    run32 &= run32 >> 16;
+                    unsigned long long leaders = ~same_mask & (run32 >> 1);
+                    const uint32_t lds_end = win_end - win_begin + mis;  // LDS byte address of the window's end
+                    while (leaders) {
+                        const uint32_t sl = (uint32_t)__ffsll((long long)leaders) - 1;
+                        leaders &= leaders - 1;
+                        const unsigned long long rest = ~(same_mask >> (sl + 1));
+                        const uint32_t size = rest ? (uint32_t)__ffsll((long long)rest) - 1 : 63u - sl;  // followers
+                        const uint32_t a_s = rdlane(a, sl), c_s = a_s - rdlane(d0, sl);
+                        uint32_t cap = 258u + size;
+                        if (cap > lds_end - a_s) cap = lds_end - a_s;
+                        uint32_t L = cap;
+                        for (uint32_t base = 0; base < cap; base += 256) {
+                            const uint32_t o4 = base + 4 * wl;
+                            const uint32_t x = o4 < cap ? (lds_le32(in_w, a_s + o4) ^ lds_le32(in_w, c_s + o4)) : 0u;
+                            const unsigned long long mm = __ballot(x != 0);
+                            if (mm) {
+                                const uint32_t m = (uint32_t)__ffsll((long long)mm) - 1;
+                                L = base + 4 * m + ((uint32_t)(__ffs((int)rdlane(x, m)) - 1) >> 3);
+                                break;
+                            }
+                        }
+                        const bool exact = L < cap;  // a mismatch inside the compared range
+                        if (L > cap) L = cap;
+                        if (wl >= sl && wl <= sl + size) {
+                            const uint32_t lj = L > wl - sl ? L - (wl - sl) : 0u;
+                            if (exact || lj >= max_len) pre0 = lj;
+                        }
+                    }
+                }
                 if (d0) {
-                    const uint32_t rem = n - p;
-                    const uint32_t max_len = rem < 258u ? rem : 258u;
-                    const uint32_t nice_len = max_len < 32u ? max_len : 32u;
-                    const uint32_t a = p - win_begin + mis;
-                    // both candidates are extended by ONE loop, in lockstep (4 bytes per step from
-                    // the same own bytes): half the loop overhead and divergence of two loops.  Each
-                    // of the three byte streams slides a dword pair, so a step costs one new dword
-                    // per stream.  The older candidate only counts if the newer one stayed below
-                    // nice_len, which is applied to the finished lengths.
                     const uint32_t c0 = a - d0, c1 = a - (d1 ? d1 : d0);
                     const uint32_t *pa = in_w + (a >> 2), *p0 = in_w + (c0 >> 2), *p1 = in_w + (c1 >> 2);
                     uint32_t lo_a = pa[0], hi_a = pa[1], lo_0 = p0[0], hi_0 = p0[1], lo_1 = p1[0], hi_1 = p1[1];
@@ -549,6 +599,11 @@ __global__ __launch_bounds__(kMpThreads, 8) void k_match(Config cfg, const uint8
                     bool act0 = __builtin_amdgcn_alignbyte(hi_0, lo_0, c0 & 3u) == seq;
                     bool act1 = d1 != 0 && __builtin_amdgcn_alignbyte(hi_1, lo_1, c1 & 3u) == seq;
                     uint32_t len0 = act0 ? max_len : 0u, len1 = act1 ? max_len : 0u;  // still matching => max_len
+                    if (runs_on && pre0 != 0xFFFFFFFFu) {  // known from the run group (pre0 < 4 <=> the 4-byte check fails)
+                        len0 = pre0 >= 4 ? pre0 : 0u;
+                        act0 = false;
+                        if ((len0 < max_len ? len0 : max_len) >= nice_len) act1 = false;  // the older one cannot count
+                    }
                     for (uint32_t off = 4; (act0 || act1) && off < max_len; off += 4) {
                         const uint32_t j = (off >> 2) + 1;
                         lo_a = hi_a;
@@ -578,6 +633,8 @@ __global__ __launch_bounds__(kMpThreads, 8) void k_match(Config cfg, const uint8
                         value = d1;
                     }
                 }
+                // a match this long means the wave has met a long run: switch the block to run groups
+                if (!runs_on && __ballot(best >= 160) && (tid & 63u) == 0) run_mode = 1;
                 // one 64-bit word of the "a match starts here" bitmap per wave step (the wave's 64
                 // positions are consecutive and 64-aligned)
                 const unsigned long long nzm = __ballot(best != 0);
@@ -587,6 +644,12 @@ __global__ __launch_bounds__(kMpThreads, 8) void k_match(Config cfg, const uint8
                     if ((tid & 63u) == 0) nz_out[p >> 6] = nzm;
                 }
             }
+        };
+        for (uint32_t p0 = tile_begin + tid; p0 < tile_end; p0 += 4 * kMpThreads) {
+            if (uniform(__hip_atomic_load(&run_mode, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) != 0)
+                step(p0, std::true_type{});
+            else
+                step(p0, std::false_type{});
         }
     }
     if (tid == 0) meta->phase_cycles[1] = (uint32_t)(clock64() - t_begin);
@@ -634,6 +697,7 @@ __device__ __forceinline__ uint32_t sub_limit_of(uint32_t start, uint32_t n) {
 }
 
 constexpr uint32_t kPSeg = 64;  // positions per walk segment = one 64-bit word of the token bitmap
+constexpr uint32_t kRescueTokens = 512;
 
 __global__ __launch_bounds__(kMpThreads, 8) void k_parse(
     Config cfg, const uint8_t *__restrict__ slab, BlockMeta *__restrict__ meta_all,
@@ -647,6 +711,7 @@ __global__ __launch_bounds__(kMpThreads, 8) void k_parse(
     __shared__ uint32_t wsum_t[kMpWaves], wsum_m[kMpWaves];
     __shared__ unsigned long long bnd;  // (position << 32 | token index) of the sub-block boundary
     __shared__ uint32_t bnd_mat;        // matches before that boundary
+    __shared__ uint32_t rescue[2];      // first inconsistent segment / end of the rescued range
     const uint8_t *len8 = (const uint8_t *)len8_w;
     uint32_t *seg_exit = rank_pre;
 
@@ -709,7 +774,8 @@ __global__ __launch_bounds__(kMpThreads, 8) void k_parse(
         uint32_t entry = tid == 0 ? entry_carry - tile_begin : seg_begin;
         if (active) seg_exit[tid] = walk(entry);
         else tok_bits[tid] = 0;
-        for (;;) {
+        const uint32_t n_seg = (tile_len + kPSeg - 1) / kPSeg;
+        for (uint32_t round = 0;; round++) {
             rounds_total++;
             __syncthreads();
             bool changed = false;
@@ -717,6 +783,44 @@ __global__ __launch_bounds__(kMpThreads, 8) void k_parse(
             if (active && tid > 0) {
                 new_entry = seg_exit[tid - 1];
                 changed = new_entry != entry;
+            }
+            if (round >= 24) {
+                // Slow convergence (long runs: every 258-byte match shifts the phase of the
+                // segments behind it, one segment per round).  One thread then parses on from the
+                // first inconsistent segment for up to kRescueTokens tokens -- a chain of LDS
+                // reads, but each token of such data covers hundreds of bytes.
+                if (tid == 0) rescue[0] = 0xFFFFFFFFu;
+                __syncthreads();
+                if (changed) atomicMin(&rescue[0], tid);
+                __syncthreads();
+                const uint32_t s_first = rescue[0];
+                if (s_first == 0xFFFFFFFFu) break;  // nothing changed: converged
+                if (tid == 0) {
+                    uint32_t sg = s_first, pos = seg_exit[s_first - 1], budget = kRescueTokens;
+                    while (sg < n_seg && budget) {
+                        const uint32_t sb = sg * kPSeg, se = sb + kPSeg < tile_len ? sb + kPSeg : tile_len;
+                        unsigned long long marks = 0;
+                        while (pos < se) {
+                            const uint32_t l = len8[pos];
+                            marks |= 1ull << (pos - sb);
+                            pos += l ? l + 3 : 1;
+                            budget = budget ? budget - 1 : 0;
+                        }
+                        tok_bits[sg] = marks;
+                        seg_exit[sg] = pos;
+                        sg++;
+                    }
+                    rescue[1] = sg;  // segments [s_first, sg) are consistent with their entries now
+                }
+                __syncthreads();
+                const uint32_t s_end = rescue[1];
+                if (tid >= s_first && tid < s_end) {
+                    entry = seg_exit[tid - 1];
+                } else if (changed && tid > s_end) {  // the others keep correcting themselves in parallel
+                    entry = new_entry;
+                    seg_exit[tid] = walk(entry);
+                }
+                continue;
             }
             __syncthreads();
             if (changed) {
@@ -726,7 +830,6 @@ __global__ __launch_bounds__(kMpThreads, 8) void k_parse(
             if (!__syncthreads_or(changed)) break;
         }
         // where the parse leaves this tile (a match may overhang the tile end)
-        const uint32_t n_seg = (tile_len + kPSeg - 1) / kPSeg;
         const uint32_t exit_rel = uniform(seg_exit[n_seg - 1]);
         __syncthreads();  // seg_exit is rank_pre from here on
 

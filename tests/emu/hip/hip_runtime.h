@@ -164,6 +164,9 @@ static inline int __builtin_amdgcn_update_dpp(int old, int src, int ctrl, int ro
         const int n = ctrl - 0x110;
         valid = (lane & 15) >= n;
         from = lane - n;
+    } else if (ctrl == 0x138) {  // wave_shr:1
+        valid = lane >= 1;
+        from = lane - 1;
     } else if (ctrl == 0x142) {
         valid = lane >= 16;
         from = (lane & ~15) - 1;
