@@ -1597,25 +1597,47 @@ __global__ __launch_bounds__(256) void k_hist(Config cfg, const BlockMeta *__res
 //   across waves.
 // ------------------------------------------------------------------------------------------
 struct HuffLds {
-    uint32_t freq[kNumLitlen];    // input frequencies of the code being built
-    uint32_t key[kNumLitlen];     // (freq << 10) | sym, or ~0 for unused
-    uint32_t sfreq[kNumLitlen];   // sorted leaf frequencies
-    uint32_t nfreq[kNumLitlen];   // internal node frequencies
-    uint16_t ssym[kNumLitlen];    // sorted leaf symbols
-    uint16_t parent[kNumLitlen];  // internal node parents
+    // Arrays whose lifetimes do not overlap share storage, which brings the structure under
+    // 6.4 KiB: 25 blocks per CU instead of 16, so a slab's blocks take one round less.
+    //   region A: sort keys -> internal node frequencies (tree build) -> header bit string
+    //   region B: sorted leaf frequencies; from entry 32 on, the precode items (written when only
+    //             the 19-symbol precode is still to be built)
+    //   region C: input frequencies (read at the start of make_code); its upper half holds the
+    //             internal node parents, which are written later in the same call
+    union {
+        uint32_t key[kNumLitlen];    // (freq << 10) | sym, or ~0 for unused
+        uint32_t nfreq[kNumLitlen];  // internal node frequencies
+        uint32_t hdr[kHdrWords];     // dynamic block header bits
+    };
+    union {
+        uint32_t sfreq[kNumLitlen];  // sorted leaf frequencies
+        struct {
+            uint32_t sfreq_low[32];
+            uint16_t items[kNumLitlen + kNumOffset];  // precode items
+        };
+    };
+    union {
+        uint32_t freq[kNumLitlen];  // input frequencies of the code being built
+        struct {
+            uint32_t freq_low[kNumLitlen / 2];
+            uint16_t parent[kNumLitlen];  // internal node parents
+        };
+    };
+    uint32_t lcw[kNumLitlen];
+    uint16_t ssym[kNumLitlen];  // sorted leaf symbols
     uint8_t depth[kNumLitlen];
     uint8_t lens[kNumLitlen + kNumOffset];  // litlen lens, then (moved adjacent) offset lens
-    uint8_t olens[kNumOffset];
+    uint8_t olens[kNumOffset + 2];
     uint8_t plens[32];
-    uint32_t lcw[kNumLitlen];
     uint32_t ocw[kNumOffset];
     uint32_t pcw[32];
     uint32_t pfreq[32];
-    uint16_t items[kNumLitlen + kNumOffset];
     uint32_t len_counts[16];
-    uint32_t hdr[kHdrWords];
     uint32_t misc[8];
 };
+static_assert(sizeof(HuffLds) <= 6400, "HuffLds: 25 workgroups per CU");
+static_assert(kHdrWords <= kNumLitlen, "header bits fit region A");
+
 
 // Builds lens[] / cw[] for `num_syms` symbols from h.freq[].  All 64 lanes must call.
 __device__ void make_code(HuffLds &h, uint32_t num_syms, uint32_t max_len, uint32_t compat,
@@ -1684,23 +1706,72 @@ __device__ void make_code(HuffLds &h, uint32_t num_syms, uint32_t max_len, uint3
             }
             h.nfreq[e] = nf;
         } while (++e < last);
-        // compute_length_counts
-        for (uint32_t l = 0; l <= max_len; l++) h.len_counts[l] = 0;
-        h.len_counts[1] = 2;
-        const uint32_t root = last - 1;
-        h.depth[root] = 0;
-        for (int node = (int)root - 1; node >= 0; node--) {
-            const uint32_t d = (uint32_t)h.depth[h.parent[node]] + 1;
-            uint32_t l = d;
-            h.depth[node] = (uint8_t)d;
-            if (l >= max_len) {
-                l = max_len;
-                do {
-                    l--;
-                } while (h.len_counts[l] == 0);
+    }
+    wave_sync();
+    // compute_length_counts.  Depths of the internal nodes by fixed-point iteration over
+    // depth[node] = depth[parent[node]] + 1 (parents have higher indices; as many rounds as the
+    // tree is high); when no leaf would get deeper than max_len -- the normal case -- the counts
+    // follow from how many internal nodes sit at each depth, otherwise the sequential clamp runs.
+    {
+        const uint32_t last = used - 1, root = last - 1;
+        uint32_t par[5], dep[5];
+#pragma unroll
+        for (uint32_t k = 0; k < 5; k++) {
+            const uint32_t node = lane + 64 * k;
+            par[k] = node < root ? h.parent[node] : 0xFFFFu;
+            dep[k] = node == root ? 0u : 0xFFu;
+            if (node <= root) h.depth[node] = (uint8_t)dep[k];
+        }
+        wave_sync();
+        for (;;) {
+            bool changed = false;
+#pragma unroll
+            for (uint32_t k = 0; k < 5; k++) {
+                if (par[k] != 0xFFFFu && dep[k] == 0xFFu) {
+                    const uint32_t pd = h.depth[par[k]];
+                    if (pd != 0xFFu) {
+                        dep[k] = pd + 1 > 0xFEu ? 0xFEu : pd + 1;
+                        changed = true;
+                    }
+                }
             }
-            h.len_counts[l]--;
-            h.len_counts[l + 1] += 2;
+            wave_sync();
+#pragma unroll
+            for (uint32_t k = 0; k < 5; k++)
+                if (par[k] != 0xFFFFu && dep[k] != 0xFFu) h.depth[lane + 64 * k] = (uint8_t)dep[k];
+            wave_sync();
+            if (!__ballot(changed)) break;
+        }
+        uint32_t deepest = 0;
+#pragma unroll
+        for (uint32_t k = 0; k < 5; k++)
+            if (par[k] != 0xFFFFu && dep[k] > deepest) deepest = dep[k];
+        const bool clamp = __ballot(deepest >= max_len) != 0;  // an internal node at depth >= max_len
+        if (!clamp) {
+            // len_counts[l] = [l == 1] * 2 - (#nodes at depth l) + 2 * (#nodes at depth l - 1)
+            uint32_t prev = 0;
+            for (uint32_t l = 1; l <= max_len; l++) {
+                uint32_t c = 0;
+#pragma unroll
+                for (uint32_t k = 0; k < 5; k++) c += (uint32_t)__popcll(__ballot(par[k] != 0xFFFFu && dep[k] == l));
+                if (lane == 0) h.len_counts[l] = (l == 1 ? 2u : 0u) + 2u * prev - c;
+                prev = c;
+            }
+            if (lane == 0) h.len_counts[0] = 0;
+        } else if (lane == 0) {
+            for (uint32_t l = 0; l <= max_len; l++) h.len_counts[l] = 0;
+            h.len_counts[1] = 2;
+            for (int node = (int)root - 1; node >= 0; node--) {
+                uint32_t l = h.depth[node];
+                if (l >= max_len) {
+                    l = max_len;
+                    do {
+                        l--;
+                    } while (h.len_counts[l] == 0);
+                }
+                h.len_counts[l]--;
+                h.len_counts[l + 1] += 2;
+            }
         }
     }
     wave_sync();
@@ -1739,6 +1810,13 @@ __device__ void make_code(HuffLds &h, uint32_t num_syms, uint32_t max_len, uint3
     wave_sync();
 }
 
+// OR nbits (<= 25) bits of v into a zeroed bit string in LDS at bit position bitpos (any lane)
+__device__ __forceinline__ void hdr_or_bits(uint32_t *hdr, uint32_t bitpos, uint32_t v, uint32_t nbits) {
+    const uint32_t w = bitpos >> 5, sh = bitpos & 31u;
+    atomicOr(&hdr[w], v << sh);
+    if (sh + nbits > 32) atomicOr(&hdr[w + 1], v >> (32 - sh));
+}
+
 __device__ __forceinline__ void hdr_put(uint32_t *hdr, uint32_t &bitpos, uint32_t v, uint32_t nbits) {
     if (!nbits) return;
     const uint32_t w = bitpos >> 5, sh = bitpos & 31u;
@@ -1747,7 +1825,7 @@ __device__ __forceinline__ void hdr_put(uint32_t *hdr, uint32_t &bitpos, uint32_
     bitpos += nbits;
 }
 
-__global__ __launch_bounds__(64) void k_huffman(Config cfg, BlockMeta *__restrict__ meta_all,
+__global__ __launch_bounds__(64, 6) void k_huffman(Config cfg, BlockMeta *__restrict__ meta_all,
                                                 SubMeta *__restrict__ sub_all,
                                                 const uint32_t *__restrict__ hist_all,
                                                 uint32_t *__restrict__ codes_all,
@@ -1790,20 +1868,19 @@ __global__ __launch_bounds__(64) void k_huffman(Config cfg, BlockMeta *__restric
         const uint32_t is_final = sub[s].is_final;
 
         // ---- litlen code (EOB tallied once), offset code
-        for (uint32_t i = lane; i < kNumLitlen; i += 64) h.freq[i] = hist[i] + (i == 256 ? 1u : 0u);
-        wave_sync();
-        make_code(h, kNumLitlen, 14, cfg.compat, h.lens, h.lcw, lane);
-        // per-lane copies of the litlen frequencies for the cost sums (freq[] is reused)
+        // per-lane copies of the frequencies for the cost sums (make_code reuses freq[]'s storage)
         uint32_t lfreq[5];
         for (uint32_t k = 0; k < 5; k++) {
             const uint32_t i = lane + 64 * k;
-            lfreq[k] = i < kNumLitlen ? h.freq[i] : 0;
+            lfreq[k] = i < kNumLitlen ? hist[i] + (i == 256 ? 1u : 0u) : 0;
+            if (i < kNumLitlen) h.freq[i] = lfreq[k];
         }
         wave_sync();
-        if (lane < kNumOffset) h.freq[lane] = hist[kNumLitlen + lane];
+        make_code(h, kNumLitlen, 14, cfg.compat, h.lens, h.lcw, lane);
+        const uint32_t ofreq = lane < kNumOffset ? hist[kNumLitlen + lane] : 0;
+        if (lane < kNumOffset) h.freq[lane] = ofreq;
         wave_sync();
         make_code(h, kNumOffset, 15, cfg.compat, h.olens, h.ocw, lane);
-        const uint32_t ofreq = lane < kNumOffset ? h.freq[lane] : 0;
         wave_sync();
 
         // ---- deflate_precompute_huffman_header
@@ -1937,22 +2014,34 @@ __global__ __launch_bounds__(64) void k_huffman(Config cfg, BlockMeta *__restric
         for (uint32_t i = lane; i < kHdrWords; i += 64) h.hdr[i] = 0;
         wave_sync();
         if (type == kDynamic) {
-            if (lane == 0) {
+            {
+                // BFINAL, BTYPE, HLIT, HDIST, HCLEN (17 bits), the explicit precode lengths (3 bits
+                // each, one per lane), then the items: codeword + extra bits, placed by a running
+                // prefix sum of their bit counts and OR-ed into the header words
                 const uint32_t perm[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
-                uint32_t bp = 0;
-                hdr_put(h.hdr, bp, is_final, 1);
-                hdr_put(h.hdr, bp, 2, 2);
-                hdr_put(h.hdr, bp, num_litlen - 257, 5);
-                hdr_put(h.hdr, bp, num_offset - 1, 5);
-                hdr_put(h.hdr, bp, num_explicit - 4, 4);
-                for (uint32_t i = 0; i < num_explicit; i++) hdr_put(h.hdr, bp, h.plens[perm[i]], 3);
-                for (uint32_t i = 0; i < num_items; i++) {
-                    const uint32_t it = h.items[i];
-                    const uint32_t psym = it & 31u, extra = it >> 5;
-                    hdr_put(h.hdr, bp, h.pcw[psym], h.plens[psym]);
-                    if (psym >= 16) hdr_put(h.hdr, bp, extra, psym == 16 ? 2u : psym == 17 ? 3u : 7u);
+                if (lane == 0)
+                    atomicOr(&h.hdr[0], is_final | (2u << 1) | ((num_litlen - 257) << 3) | ((num_offset - 1) << 8) |
+                                            ((num_explicit - 4) << 13));
+                if (lane < num_explicit) hdr_or_bits(h.hdr, 17 + 3 * lane, h.plens[perm[lane < 19 ? lane : 0]], 3);
+                uint32_t bp = 17 + 3 * num_explicit;
+                for (uint32_t base = 0; base < num_items; base += 64) {
+                    const uint32_t i = base + lane;
+                    uint32_t v = 0, nb = 0;
+                    if (i < num_items) {
+                        const uint32_t it = h.items[i];
+                        const uint32_t psym = it & 31u, extra = it >> 5;
+                        nb = h.plens[psym];
+                        v = h.pcw[psym];
+                        if (psym >= 16) {
+                            v |= extra << nb;
+                            nb += psym == 16 ? 2u : psym == 17 ? 3u : 7u;
+                        }
+                    }
+                    const uint32_t incl = wave_incl_add(nb);
+                    if (nb) hdr_or_bits(h.hdr, bp + incl - nb, v, nb);
+                    bp += rdlane(incl, 63);
                 }
-                h.misc[1] = bp;
+                if (lane == 0) h.misc[1] = bp;
             }
             wave_sync();
             hdr_bits = h.misc[1];
