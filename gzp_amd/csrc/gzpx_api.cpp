@@ -345,7 +345,7 @@ int gzpx_ctx_create(const gzpx_config *cfg, gzpx_ctx **out) {
         ctx->dcfg.hc_depth = depth[cfg->level];
         ctx->dcfg.hc_nice = nice[cfg->level];
     }
-    for (unsigned l = 0; l < 8; l++) ctx->crc_consts.pow256[l] = x2k(11 + l);
+    for (unsigned l = 0; l < 10; l++) ctx->crc_consts.pow64[l] = x2k(9 + l);
     ctx->crc_consts.pow_tile = x2k(19);  // x^(8 * 65536) = x^(2^19)
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, cfg->device) == hipSuccess) {
@@ -653,7 +653,7 @@ int gzpx_dctx_create(int device, int format, gzpx_dctx **out) {
     if (!c) return GZPX_ERR_DEVICE;
     c->device = device;
     c->format = format;
-    for (unsigned l = 0; l < 8; l++) c->cc.pow256[l] = x2k(11 + l);
+    for (unsigned l = 0; l < 10; l++) c->cc.pow64[l] = x2k(9 + l);
     c->cc.pow_tile = x2k(19);
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreate(&c->ev[0]) != hipSuccess || hipEventCreate(&c->ev[1]) != hipSuccess ||

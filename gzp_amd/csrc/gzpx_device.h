@@ -68,7 +68,7 @@ struct HcState {
 };
 
 struct CrcConsts {
-    uint32_t pow256[8];  // x^(8*256*2^l) mod P (reflected), l = 0..7
+    uint32_t pow64[10];  // x^(8*64*2^l) mod P (reflected), l = 0..9
     uint32_t pow_tile;   // x^(8*65536) mod P: appends one full 64 KiB chunk
 };
 

@@ -2109,11 +2109,12 @@ __global__ __launch_bounds__(64, 6) void k_huffman(Config cfg, BlockMeta *__rest
 
 // ------------------------------------------------------------------------------------------
 // k_crc32: gzip CRC-32 of every block.  The block is staged in LDS with coalesced dword loads
-// (one HBM read of the input, no strided re-fetching).  Thread t owns the 256-byte segment that
-// ENDS at n - 256*(255 - t) (so only the first used segment is short), runs slice-by-4 over it
-// out of LDS (segments are laid out 65 dwords apart, so the 64 lanes of a wave hit 64 different
-// banks), and the 256 CRCs are merged by a log-tree of zlib-style crc32_combine steps:
-// crc(A||B) = crc(A) * x^(8|B|) mod P  xor  crc(B), with |B| = 256 * 2^level at every level.
+// (one HBM read of the input, no strided re-fetching).  1024 threads: thread t owns the 64-byte
+// segment that ENDS at n - 64*(1023 - t) (so only the first used segment is short), runs
+// slice-by-4 over it out of LDS (16 dependent steps; segments are laid out 17 dwords apart), and
+// the 1024 CRCs are merged by a log-tree of zlib-style crc32_combine steps:
+// crc(A||B) = crc(A) * x^(8|B|) mod P  xor  crc(B), with |B| = 64 * 2^level at every level.
+// Two workgroups (32 waves) share a CU.
 // ------------------------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t gf2_multmodp(uint32_t a, uint32_t bv) {
     uint32_t m = 1u << 31, p = 0;
@@ -2125,27 +2126,32 @@ __device__ __forceinline__ uint32_t gf2_multmodp(uint32_t a, uint32_t bv) {
     return p;
 }
 
-constexpr uint32_t kCrcDataWords = (kTile / 4 + 2) + (kTile / 4 + 2) / 64 + 2;
+constexpr uint32_t kCrcThreads = 1024;                     // one 64-byte segment per thread and chunk
+constexpr uint32_t kCrcSeg = kTile / kCrcThreads;          // 64 bytes
+constexpr uint32_t kCrcLevels = 10;                        // log2(kCrcThreads)
+constexpr uint32_t kCrcSegWords = kCrcSeg / 4;             // 16
+constexpr uint32_t kCrcDataWords = (kTile / 4 + 2) + (kTile / 4 + 2) / kCrcSegWords + 2;
 
-// dword index -> padded LDS index (one pad word after every 64)
-__device__ __forceinline__ uint32_t crc_pad(uint32_t w) { return w + (w >> 6); }
+// dword index -> padded LDS index (one pad word after every 16: segments lie 17 dwords apart, so
+// the 64 lanes of a wave, each in its own segment, spread evenly over the banks)
+__device__ __forceinline__ uint32_t crc_pad(uint32_t w) { return w + (w / kCrcSegWords); }
 
 struct CrcLds {
     uint32_t table[4][256];
     uint32_t data[kCrcDataWords];
-    uint32_t part[256];
+    uint32_t part[kCrcThreads];
 };
 
-// CRC-32 of in[0..n) by a 256-thread workgroup; the result is valid in every thread.
+// CRC-32 of in[0..n) by a 1024-thread workgroup; the result is valid in every thread.
 __device__ uint32_t crc32_workgroup(CrcLds &l, const uint8_t *__restrict__ in, uint32_t n,
                                     const CrcConsts &cc, uint32_t tid) {
-    {
+    if (tid < 256) {
         uint32_t c = tid;
         for (int k = 0; k < 8; k++) c = (c >> 1) ^ (0xEDB88320u & (0u - (c & 1u)));
         l.table[0][tid] = c;
     }
     __syncthreads();
-    {
+    if (tid < 256) {
         const uint32_t t0 = l.table[0][tid];
         const uint32_t t1 = (t0 >> 8) ^ l.table[0][t0 & 0xFFu];
         const uint32_t t2 = (t1 >> 8) ^ l.table[0][t1 & 0xFFu];
@@ -2166,16 +2172,16 @@ __device__ uint32_t crc32_workgroup(CrcLds &l, const uint8_t *__restrict__ in, u
         if (clen) {
             const uint32_t *src = (const uint32_t *)(cin - mis);
             const uint32_t ndw = (mis + clen + 3) >> 2;
-            for (uint32_t i = tid; i < ndw; i += 256) l.data[crc_pad(i)] = src[i];
+            for (uint32_t i = tid; i < ndw; i += kCrcThreads) l.data[crc_pad(i)] = src[i];
         }
         __syncthreads();
-        // segment of thread t in chunk bytes: [clen - 256*(256 - t), clen - 256*(255 - t)) clipped
+        // segment of thread t in chunk bytes: [clen - 64*(1024 - t), clen - 64*(1023 - t)) clipped
         // at 0; LDS byte address of chunk byte i is i + mis (before padding)
-        const int32_t seg_end_i = (int32_t)clen - 256 * (int32_t)(255 - tid);
+        const int32_t seg_end_i = (int32_t)clen - (int32_t)kCrcSeg * (int32_t)(kCrcThreads - 1 - tid);
         uint32_t crc = 0;
         if (seg_end_i > 0) {
             const uint32_t seg_end = (uint32_t)seg_end_i + mis;
-            uint32_t pos = (seg_end_i > 256 ? (uint32_t)(seg_end_i - 256) : 0u) + mis;
+            uint32_t pos = (seg_end_i > (int32_t)kCrcSeg ? (uint32_t)(seg_end_i - (int32_t)kCrcSeg) : 0u) + mis;
             uint32_t c = 0xFFFFFFFFu;
             while (pos < seg_end && (pos & 3u)) {  // head bytes up to a dword boundary
                 const uint32_t byte = (l.data[crc_pad(pos >> 2)] >> (8u * (pos & 3u))) & 0xFFu;
@@ -2197,13 +2203,16 @@ __device__ uint32_t crc32_workgroup(CrcLds &l, const uint8_t *__restrict__ in, u
         }
         l.part[tid] = crc;
         __syncthreads();
-        for (uint32_t level = 0; level < 8; level++) {
+        // the pairs of a level are handled by the LOWEST threads, so that a level keeps only as many
+        // waves busy as it has work for (8, 4, 2, 1, 1, ...)
+        for (uint32_t level = 0; level < kCrcLevels; level++) {
             const uint32_t stride = 1u << level;
+            const uint32_t left = 2 * stride * tid;  // index of the pair's left part
             uint32_t merged = 0;
-            const bool act = (tid & (2 * stride - 1)) == 0;
-            if (act) merged = gf2_multmodp(cc.pow256[level], l.part[tid]) ^ l.part[tid + stride];
+            const bool act = left < kCrcThreads;
+            if (act) merged = gf2_multmodp(cc.pow64[level], l.part[left]) ^ l.part[left + stride];
             __syncthreads();
-            if (act) l.part[tid] = merged;
+            if (act) l.part[left] = merged;
             __syncthreads();
         }
         // crc(A || chunk) = crc(A) * x^(8 * 65536) + crc(chunk); the first chunk has no A
@@ -2213,7 +2222,7 @@ __device__ uint32_t crc32_workgroup(CrcLds &l, const uint8_t *__restrict__ in, u
     return total;
 }
 
-__global__ __launch_bounds__(256) void k_crc32(Config cfg, const uint8_t *__restrict__ slab,
+__global__ __launch_bounds__(kCrcThreads, 8) void k_crc32(Config cfg, const uint8_t *__restrict__ slab,
                                                BlockMeta *__restrict__ meta_all, CrcConsts cc) {
     __shared__ CrcLds l;
     const uint32_t b = blockIdx.x;
@@ -3195,7 +3204,7 @@ __global__ __launch_bounds__(64) void k_inflate(uint32_t hdr_len, const uint8_t 
 
 // CRC-32 of the inflated blocks (LibDeflateCrc over the whole orig_size buffer, src/check.rs:45-71):
 // the workgroup routine of k_crc32, blocks addressed through their output offsets.
-__global__ __launch_bounds__(256) void k_dcrc32(const uint8_t *__restrict__ out_all,
+__global__ __launch_bounds__(kCrcThreads, 8) void k_dcrc32(const uint8_t *__restrict__ out_all,
                                                 const uint64_t *__restrict__ out_off,
                                                 const DBlock *__restrict__ blk_all,
                                                 uint32_t *__restrict__ crc_found, CrcConsts cc) {
@@ -3272,7 +3281,7 @@ void launch_huffman(const Config &cfg, uint32_t nb, const Scratch &s, hipStream_
 
 void launch_crc32(const Config &cfg, const uint8_t *slab, uint64_t, uint32_t nb, const Scratch &s,
                   const CrcConsts &cc, hipStream_t stream) {
-    hipLaunchKernelGGL(k_crc32, dim3(nb), dim3(256), 0, stream, cfg, slab, s.meta, cc);
+    hipLaunchKernelGGL(k_crc32, dim3(nb), dim3(kCrcThreads), 0, stream, cfg, slab, s.meta, cc);
 }
 
 void launch_scan(uint32_t nb, const Scratch &s, hipStream_t stream) {
@@ -3302,7 +3311,7 @@ void launch_inflate(uint32_t hdr_len, const uint8_t *d_in, const uint64_t *d_off
         hipLaunchKernelGGL(k_inflate<false>, dim3(nb), dim3(64), 0, stream, hdr_len, d_in, blk,
                            (const uint64_t *)d_out_off, d_out, out_cap);
     if (ev_end) (void)hipEventRecord(ev_end, stream);
-    hipLaunchKernelGGL(k_dcrc32, dim3(nb), dim3(256), 0, stream, (const uint8_t *)d_out,
+    hipLaunchKernelGGL(k_dcrc32, dim3(nb), dim3(kCrcThreads), 0, stream, (const uint8_t *)d_out,
                        (const uint64_t *)d_out_off, (const DBlock *)blk, d_crc_found, cc);
 }
 
