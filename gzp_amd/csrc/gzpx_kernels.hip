@@ -3003,18 +3003,21 @@ __global__ __launch_bounds__(64) void k_inflate(uint32_t hdr_len, const uint8_t 
                 stop_mask[hf] = __ballot(!is_lit && !is_match[hf]);
             }
             // (2) the walk: which positions hold real symbols (wave-uniform, scalar)
+            // (a lone wave gets roughly one dependent scalar instruction per ten cycles, so the hop
+            // is kept to the bare chain: mark, read the lane, add; the last hop is recovered from
+            // the marks afterwards)
             uint64_t started[2] = {0, 0};
-            uint32_t pos = 0, last = 0;
+            uint32_t pos = 0;
             do {
-                last = pos;
+                started[0] |= 1ull << pos;
                 pos += rdlane(adv[0], pos);
-                started[0] |= 1ull << last;
             } while (pos < 64);
             while (pos < 128) {
-                last = pos;
+                started[1] |= 1ull << (pos - 64);
                 pos += rdlane(adv[1], pos - 64);
-                started[1] |= 1ull << (last - 64);
             }
+            const uint32_t last = started[1] ? 127u - (uint32_t)__clzll((long long)started[1])
+                                             : 63u - (uint32_t)__clzll((long long)started[0]);
             const bool hit_stop = ((stop_mask[last >> 6] >> (last & 63u)) & 1ull) != 0;
             if (hit_stop) started[last >> 6] &= ~(1ull << (last & 63u));
             if (DBG) {
