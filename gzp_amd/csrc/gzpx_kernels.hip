@@ -52,6 +52,13 @@ __device__ __forceinline__ uint32_t rdlane(uint32_t v, uint32_t l) {
 }
 __device__ __forceinline__ uint32_t uniform(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 
+// keep a finished value in a VGPR here (stops the compiler from sinking its computation to the use)
+#if defined(__HIP_DEVICE_COMPILE__)
+#define GZPX_PIN_VGPR(x) asm volatile("" : "+v"(x))
+#else
+#define GZPX_PIN_VGPR(x) ((void)0)
+#endif
+
 __device__ __forceinline__ uint32_t lz_hash15(uint32_t v) { return (v * 0x1E35A7BDu) >> 17; }
 
 // little-endian u32 at an arbitrary byte address of global memory via two aligned loads
@@ -269,8 +276,8 @@ __global__ __launch_bounds__(64 * kCandWaves) void k_candidates(Config cfg,
                                                                  const uint8_t *__restrict__ slab,
                                                                  BlockMeta *__restrict__ meta,
                                                                  uint16_t *__restrict__ cand_all) {
-    __shared__ uint32_t tab[kBuckets];  // 128 KiB
-    __shared__ uint32_t turn;           // index of the iteration whose atomics may go next
+    __shared__ uint32_t tab[kBuckets + 1];  // 128 KiB + one word that lanes without a bucket hit
+    __shared__ uint32_t turn;               // index of the iteration whose atomics may go next
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint32_t b = blockIdx.x;
     const uint32_t n = meta[b].n;
@@ -281,7 +288,7 @@ __global__ __launch_bounds__(64 * kCandWaves) void k_candidates(Config cfg,
     const uint32_t wmax = (mis + n - 1) >> 2;  // last dword holding a byte of this block
     uint16_t *cand = cand_all + (uint64_t)b * cfg.stride;
 
-    for (uint32_t i = tid; i < kBuckets; i += 64 * kCandWaves) tab[i] = 0;
+    for (uint32_t i = tid; i <= kBuckets; i += 64 * kCandWaves) tab[i] = 0;
     if (tid == 0) turn = 0;
     __syncthreads();
 
@@ -300,13 +307,22 @@ __global__ __launch_bounds__(64 * kCandWaves) void k_candidates(Config cfg,
     const long long t_begin = clock64();
     for (uint32_t it = wave; it < n_iters; it += kCandWaves) {
         const uint32_t base0 = it * kIterPos;
-        uint32_t h[kCandSteps], old[kCandSteps];
+        // The serial phase must be nothing but the atomics: a lone wave issues about one dependent
+        // instruction per ten cycles, so every instruction inside the turn costs all four waves.
+        // LDS byte address and value of every step are therefore finished (and pinned in registers)
+        // before the wave asks for its turn; lanes without a bucket aim a zero at the spare word.
+        uint32_t addr[kCandSteps], val[kCandSteps], old[kCandSteps];
         bool mine[kCandSteps];  // this pass owns the position's bucket
 #pragma unroll
         for (uint32_t k = 0; k < kCandSteps; k++) {
             const uint32_t p = base0 + k * 64 + lane;
             const uint32_t v = __builtin_amdgcn_alignbyte(ring[k].y, ring[k].x, (p + mis) & 3u);
-            mine[k] = cand_bucket<MODE>(v, p, h[k]) && p + 5 <= n;
+            uint32_t hk;
+            mine[k] = cand_bucket<MODE>(v, p, hk) && p + 5 <= n;
+            addr[k] = 4u * (mine[k] ? hk : kBuckets);  // byte offset into the table
+            val[k] = mine[k] ? p + 1 : 0u;
+            GZPX_PIN_VGPR(addr[k]);
+            GZPX_PIN_VGPR(val[k]);
         }
 #pragma unroll
         for (uint32_t k = 0; k < kCandSteps; k++)  // this wave's next iteration
@@ -316,11 +332,8 @@ __global__ __launch_bounds__(64 * kCandWaves) void k_candidates(Config cfg,
             __builtin_amdgcn_s_sleep(1);
         // newest position per bucket; the return value is the predecessor
 #pragma unroll
-        for (uint32_t k = 0; k < kCandSteps; k++) {
-            const uint32_t p = base0 + k * 64 + lane;
-            old[k] = 0;
-            if (mine[k]) old[k] = atomicMax(&tab[h[k]], p + 1);
-        }
+        for (uint32_t k = 0; k < kCandSteps; k++)
+            old[k] = atomicMax((uint32_t *)((uint8_t *)tab + addr[k]), val[k]);
         // the returned values are in registers => every atomic of this iteration has been applied
         uint32_t seen = 0;
 #pragma unroll
