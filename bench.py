@@ -248,22 +248,38 @@ def main():
     ctx = _native.Context(format=_native.FORMAT_BGZF, level=1, buffer_size=BLOCK,
                           compat=_native.COMPAT_1_24, device=local_rank, max_slab_bytes=n)
     cap = ctx.slab_bound(n)
-    d_out = torch.empty(cap, dtype=torch.uint8, device=dev)
+    # two output buffers: with N > 1 the gather of one step's shard (RCCL, asynchronous) runs while
+    # the next step compresses into the other buffer, the way ParCompress's lanes overlap
+    d_outs = [torch.empty(cap, dtype=torch.uint8, device=dev) for _ in range(2 if world > 1 else 1)]
+    d_out = d_outs[0]
+    gathered = torch.empty(cap * world, dtype=torch.uint8, device=dev) if (world > 1 and rank == 0) else None
     nb = ctx.n_blocks(n)
     block_sizes = np.zeros(nb, dtype=np.uint32)
     ctx.set_profiling(True)
+    state = {"i": 0, "pending": None}
 
     def step():
-        out_len, _ = ctx.compress_slab_device(d_in.data_ptr(), n, d_out.data_ptr(), cap, mode,
+        buf = d_outs[state["i"] % len(d_outs)]
+        state["i"] += 1
+        out_len, _ = ctx.compress_slab_device(d_in.data_ptr(), n, buf.data_ptr(), cap, mode,
                                               None, block_sizes)
         if world > 1:
-            # in-order write-out: ordered variable-size gather of the shards to rank 0 (RCCL)
-            shard.ordered_gather(d_out[:out_len], dst=0)
+            # in-order write-out: ordered variable-size gather of the shards to rank 0 (RCCL),
+            # started now and completed while the next step compresses
+            if state["pending"] is not None:  # the previous shard has arrived (it travelled while
+                state["pending"].wait()       # this step compressed); `gathered` is free again
+            state["pending"] = shard.ordered_gather_start(buf[:out_len], dst=0, out=gathered)
         return out_len
+
+    def drain():
+        if state["pending"] is not None:
+            state["pending"].wait()
+            state["pending"] = None
 
     stage_acc = {}
     for _ in range(args.warmup):
         step()
+    drain()
 
     def sync():
         if world > 1:
@@ -277,6 +293,7 @@ def main():
         out_len = step()
         for k, v in ctx.last_stage_ms().items():
             stage_acc[k] = stage_acc.get(k, 0.0) + v
+    drain()  # the last gather belongs to the timed region
     sync()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -289,7 +306,8 @@ def main():
     value = total_mib / (dt / args.steps)
 
     if rank == 0:
-        ok = verify(slab, d_out[:out_len].cpu().numpy(), block_sizes, tail=(mode == _native.SLAB_LAST))
+        last_buf = d_outs[(state["i"] - 1) % len(d_outs)]
+        ok = verify(slab, last_buf[:out_len].cpu().numpy(), block_sizes, tail=(mode == _native.SLAB_LAST))
         stage_ms = {k: v / args.steps for k, v in stage_acc.items()}
         dom = max(stage_ms, key=stage_ms.get)
         alg_bytes = n + out_len  # 1 B read + r B written per input byte

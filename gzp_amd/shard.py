@@ -46,13 +46,31 @@ def slab_mode(rank, world, total_bytes, block_size):
     return _native.SLAB_LAST if first + nb == total_blocks else _native.SLAB_FULL_BLOCKS
 
 
-def ordered_gather(local, dst=0, group=None):
-    """Gather 1-D uint8 tensors of different lengths to `dst`, concatenated in rank order.
+class GatherHandle:
+    """An ordered gather in flight (ordered_gather_start): wait() completes it and returns the
+    stream on dst (a view of `out`), None elsewhere."""
+
+    def __init__(self, reqs, out, total):
+        self._reqs = reqs
+        self._out = out
+        self._total = total
+
+    def wait(self):
+        for q in self._reqs:
+            q.wait()
+        self._reqs = []
+        return None if self._out is None else self._out[:self._total]
+
+
+def ordered_gather_start(local, dst=0, group=None, out=None):
+    """Start gathering 1-D uint8 tensors of different lengths to `dst`, concatenated in rank order.
 
     Sizes travel with one all_gather (8 bytes per rank), payloads with point-to-point
     send/recv straight into their final offsets (RCCL has no gatherv; each peer has its own
-    xGMI link to the root, so the transfers run concurrently).  Returns the stream on dst,
-    None elsewhere."""
+    xGMI link to the root, so the transfers are posted as ONE batch and run concurrently).  The
+    transfers are asynchronous: the caller may compress the next slab into another buffer while
+    they run, and must keep `local` untouched until wait().  `out` (dst only, optional) is a
+    preallocated uint8 tensor large enough for the whole stream."""
     import torch
     import torch.distributed as dist
     world = dist.get_world_size(group)
@@ -61,18 +79,22 @@ def ordered_gather(local, dst=0, group=None):
     sizes = torch.zeros(world, dtype=torch.int64, device=local.device)
     dist.all_gather_into_tensor(sizes, n, group=group)
     if rank != dst:
+        reqs = []
         if local.numel():
-            dist.send(local, dst=dst, group=group)
-        return None
+            reqs = dist.batch_isend_irecv([dist.P2POp(dist.isend, local, dst, group)])
+        return GatherHandle(reqs, None, 0)
     sz = [int(x) for x in sizes.tolist()]
     offs = np.concatenate([[0], np.cumsum(sz)]).astype(np.int64)
-    out = torch.empty(int(offs[-1]), dtype=torch.uint8, device=local.device)
-    reqs = []
-    for r in range(world):
-        if r == dst or sz[r] == 0:
-            continue
-        reqs.append(dist.irecv(out[offs[r]:offs[r + 1]], src=r, group=group))
+    total = int(offs[-1])
+    if out is None or out.numel() < total:
+        out = torch.empty(total, dtype=torch.uint8, device=local.device)
+    ops = [dist.P2POp(dist.irecv, out[offs[r]:offs[r + 1]], r, group)
+           for r in range(world) if r != dst and sz[r]]
+    reqs = dist.batch_isend_irecv(ops) if ops else []
     out[offs[dst]:offs[dst + 1]].copy_(local)
-    for q in reqs:
-        q.wait()
-    return out
+    return GatherHandle(reqs, out, total)
+
+
+def ordered_gather(local, dst=0, group=None, out=None):
+    """Blocking form of ordered_gather_start: returns the stream on dst, None elsewhere."""
+    return ordered_gather_start(local, dst, group, out).wait()

@@ -29,9 +29,16 @@ WORKER = textwrap.dedent("""
         mine = ctx.compress_slab(stream[lo:lo + n], mode) if mode is not None else b""
     out = shard.ordered_gather(torch.frombuffer(bytearray(mine), dtype=torch.uint8) if mine
                                else torch.empty(0, dtype=torch.uint8), dst=0)
+    # the pipelined form bench.py uses: two gathers in flight, preallocated destination
+    mine_t = (torch.frombuffer(bytearray(mine), dtype=torch.uint8) if mine else torch.empty(0, dtype=torch.uint8))
+    pre = torch.empty(4 * 70000 * world + 64, dtype=torch.uint8) if rank == 0 else None
+    h1 = shard.ordered_gather_start(mine_t, dst=0, out=pre)
+    h2 = shard.ordered_gather_start(mine_t.clone(), dst=0)
+    out1, out2 = h1.wait(), h2.wait()
     if rank == 0:
         want = oracle.compress_stream(stream, oracle.FMT_BGZF, 1, oracle.COMPAT_1_10, 65280)
         assert out.numpy().tobytes() == want, "sharded stream differs from the single-process stream"
+        assert out1.numpy().tobytes() == want and out2.numpy().tobytes() == want
         print("GLOO_OK", total, len(want))
     dist.barrier()
     dist.destroy_process_group()
