@@ -2569,6 +2569,8 @@ struct InfLds {
     uint32_t ocount[16], ofirst[16], ooffs[16];
 };
 
+constexpr uint32_t kInfR = 2;  // groups of 64 bit positions decoded per round
+
 enum InflateStatus : uint32_t { kInfOk = 0, kInfBadData = 1, kInfInsufficientSpace = 2, kInfShortOutput = 3 };
 
 // Decode-table entries (32 bit).  bits 0-3: codeword length (0 = not in the fast table);
@@ -2969,7 +2971,7 @@ __global__ __launch_bounds__(64) void k_inflate(uint32_t hdr_len, const uint8_t 
             break;
         }
         if (DBG) dbg[1] += (uint32_t)(clock64() - t_hdr);
-        // ---- symbols, 64 bit positions per round
+        // ---- symbols, 64 * kInfR bit positions per round
         bool eob = false;
         while (!eob && status == kInfOk) {
             if (bp > bit_end) {
@@ -2983,15 +2985,15 @@ __global__ __launch_bounds__(64) void k_inflate(uint32_t hdr_len, const uint8_t 
             flushed = uniform(flushed);
             hi_w = uniform(hi_w);
             status = uniform(status);
-            ensure(bp + 64);
-            // (1) every lane decodes the symbols that would start at bits bp + lane and
-            // bp + 64 + lane, completely: litlen codeword, extra bits, offset codeword, extra bits
+            ensure(bp + 64 * kInfR - 64);
+            // (1) every lane decodes the symbols that would start at bits bp + 64 * g + lane
+            // (g < kInfR), completely: litlen codeword, extra bits, offset codeword, extra bits
             // (<= 48 of the 64 bits it reads from each position)
-            uint32_t le[2], pack2[2], adv[2], outlen[2];
-            bool is_match[2];
-            uint64_t stop_mask[2];
+            uint32_t le[kInfR], pack2[kInfR], adv[kInfR], outlen[kInfR];
+            bool is_match[kInfR];
+            uint64_t stop_mask[kInfR];
 #pragma unroll
-            for (uint32_t hf = 0; hf < 2; hf++) {
+            for (uint32_t hf = 0; hf < kInfR; hf++) {
                 const uint32_t q = bp + 64 * hf + lane, qw = q >> 5;
                 const uint32_t d0 = h.inr[qw & 255u], d1 = h.inr[(qw + 1) & 255u], d2 = h.inr[(qw + 2) & 255u];
                 const uint32_t b_lo = __builtin_amdgcn_alignbit(d1, d0, q & 31u);
@@ -3011,7 +3013,7 @@ __global__ __launch_bounds__(64) void k_inflate(uint32_t hdr_len, const uint8_t 
                 pack2[hf] = mdist | (mlen << 16);
                 // anything else (end of block, codeword outside the fast tables, invalid symbol)
                 // stops the walk: that symbol goes through the one-symbol path below
-                adv[hf] = is_lit ? cl : is_match[hf] ? used1 + dcl + dxb : 128u;
+                adv[hf] = is_lit ? cl : is_match[hf] ? used1 + dcl + dxb : 64u * kInfR;
                 outlen[hf] = is_lit ? 1u : is_match[hf] ? mlen : 0u;
                 stop_mask[hf] = __ballot(!is_lit && !is_match[hf]);
             }
@@ -3019,35 +3021,51 @@ __global__ __launch_bounds__(64) void k_inflate(uint32_t hdr_len, const uint8_t 
             // (a lone wave gets roughly one dependent scalar instruction per ten cycles, so the hop
             // is kept to the bare chain: mark, read the lane, add; the last hop is recovered from
             // the marks afterwards)
-            uint64_t started[2] = {0, 0};
+            uint64_t started[kInfR];
             uint32_t pos = 0;
-            do {
-                started[0] |= 1ull << pos;
-                pos += rdlane(adv[0], pos);
-            } while (pos < 64);
-            while (pos < 128) {
-                started[1] |= 1ull << (pos - 64);
-                pos += rdlane(adv[1], pos - 64);
+#pragma unroll
+            for (uint32_t g = 0; g < kInfR; g++) {
+                uint64_t marks = 0;
+                while (pos < 64 * (g + 1)) {
+                    marks |= 1ull << (pos - 64 * g);
+                    pos += rdlane(adv[g], pos - 64 * g);
+                }
+                started[g] = marks;
             }
-            const uint32_t last = started[1] ? 127u - (uint32_t)__clzll((long long)started[1])
-                                             : 63u - (uint32_t)__clzll((long long)started[0]);
-            const bool hit_stop = ((stop_mask[last >> 6] >> (last & 63u)) & 1ull) != 0;
-            if (hit_stop) started[last >> 6] &= ~(1ull << (last & 63u));
+            uint32_t last = 0;
+#pragma unroll
+            for (uint32_t g = 0; g < kInfR; g++)
+                if (started[g]) last = 64 * g + 63u - (uint32_t)__clzll((long long)started[g]);
+            bool hit_stop = false;
+#pragma unroll
+            for (uint32_t g = 0; g < kInfR; g++) {
+                if ((last >> 6) == g && ((stop_mask[g] >> (last & 63u)) & 1ull)) {
+                    hit_stop = true;
+                    started[g] &= ~(1ull << (last & 63u));
+                }
+            }
+            uint32_t nstarted = 0;
+            bool any_started = false;
+#pragma unroll
+            for (uint32_t g = 0; g < kInfR; g++) {
+                any_started = any_started || started[g] != 0;
+                if (DBG) nstarted += (uint32_t)__popcll(started[g]);
+            }
             if (DBG) {
                 dbg[2] += (uint32_t)(clock64() - t_round);
                 dbg[4]++;
-                dbg[5] += (uint32_t)(__popcll(started[0]) + __popcll(started[1]));
+                dbg[5] += nstarted;
             }
             // (3) output of the started symbols: positions by a prefix sum of their lengths, then
             // 64 output bytes per pass, every lane producing one byte
-            if (started[0] | started[1]) {
+            if (any_started) {
                 const long long t_out = DBG ? clock64() : 0;
-                bool mine[2];
-                uint32_t opos[2], pack1[2];
+                bool mine[kInfR];
+                uint32_t opos[kInfR], pack1[kInfR];
                 uint32_t tout = 0;
                 bool bad_dist = false;
 #pragma unroll
-                for (uint32_t hf = 0; hf < 2; hf++) {
+                for (uint32_t hf = 0; hf < kInfR; hf++) {
                     mine[hf] = ((started[hf] >> lane) & 1ull) != 0;
                     const uint32_t mylen = mine[hf] ? outlen[hf] : 0u;
                     const uint32_t incl = wave_incl_add(mylen) + tout;
@@ -3072,19 +3090,25 @@ __global__ __launch_bounds__(64) void k_inflate(uint32_t hdr_len, const uint8_t 
                     wave_sync();
                     h.own[lane] = 0;
                     wave_sync();
-                    if (mine[0] && opos[0] - pass < 64u) h.own[opos[0] - pass] = lane + 1;
-                    if (mine[1] && opos[1] - pass < 64u) h.own[opos[1] - pass] = lane + 65;
+#pragma unroll
+                    for (uint32_t g = 0; g < kInfR; g++)
+                        if (mine[g] && opos[g] - pass < 64u) h.own[opos[g] - pass] = 64 * g + lane + 1;
                     wave_sync();
                     uint32_t own = h.own[lane];
                     if (lane == 0 && own < carry) own = carry;
                     own = wave_incl_max(own);
                     carry = rdlane(own, 63);
                     const int from = (int)(((own - 1) & 63u) << 2);
-                    const uint32_t p1a = (uint32_t)__builtin_amdgcn_ds_bpermute(from, (int)pack1[0]);
-                    const uint32_t p1b = (uint32_t)__builtin_amdgcn_ds_bpermute(from, (int)pack1[1]);
-                    const uint32_t p2a = (uint32_t)__builtin_amdgcn_ds_bpermute(from, (int)pack2[0]);
-                    const uint32_t p2b = (uint32_t)__builtin_amdgcn_ds_bpermute(from, (int)pack2[1]);
-                    const uint32_t p1 = own > 64 ? p1b : p1a, p2 = own > 64 ? p2b : p2a;
+                    uint32_t p1 = 0, p2 = 0;
+#pragma unroll
+                    for (uint32_t g = 0; g < kInfR; g++) {
+                        const uint32_t a1 = (uint32_t)__builtin_amdgcn_ds_bpermute(from, (int)pack1[g]);
+                        const uint32_t a2 = (uint32_t)__builtin_amdgcn_ds_bpermute(from, (int)pack2[g]);
+                        if (((own - 1) >> 6) == g) {
+                            p1 = a1;
+                            p2 = a2;
+                        }
+                    }
                     const uint32_t prel = pass + lane;
                     const bool active = prel < tout;
                     const bool m = ((p1 >> 24) & 1u) != 0;
