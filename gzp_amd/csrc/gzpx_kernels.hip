@@ -1,30 +1,36 @@
-// gzpx_kernels.hip -- hand-written HIP kernels (gfx950 / CDNA4) for gzp's per-block encode:
-// libdeflate level-1 DEFLATE + CRC-32 + BGZF/Mgzip framing, thousands of blocks per launch.
+// gzpx_kernels.hip -- hand-written HIP kernels (gfx950 / CDNA4) for gzp's per-block encode and
+// decode: libdeflate DEFLATE (levels 1-4) + CRC-32 + BGZF/Mgzip framing, and inflate with the
+// per-block CRC check; thousands of blocks per launch.
 //
 // What this replaces (reference file:line, relative to the gzp tree):
 //   Bgzf::encode / Mgzip::encode                  src/deflate.rs:613-626, 463-472
 //   bgzf::compress / mgzip::compress              src/bgzf.rs:204-237 ; src/mgzip.rs:187-218
-//   libdeflater::Compressor::deflate_compress     call site src/bgzf.rs:214-216  (libdeflate, level 1)
+//   libdeflater::Compressor::deflate_compress     call site src/bgzf.rs:214-216
 //   libdeflater::Crc                              call site src/bgzf.rs:224-225
 //   header_inner / footer / BGZF_EOF              src/bgzf.rs:274-303, :233-234, :24-38
+//   bgzf::decompress + decode_block               src/bgzf.rs:103-121 ; src/par/decompress.rs:162-186
 //
 // MI355X design: libdeflate's level-1 matchfinder inserts EVERY position into a
 // 2-way hash bucket in order, so the two match candidates of a position are a pure function of
 // the input ("the two most recent earlier positions with the same 15-bit hash, within 32767
 // bytes") and do not depend on the parse.  That turns the sequential compressor into a pipeline
 // of data-parallel stages, each a kernel over all blocks of a slab:
-//   k_candidates   one wave / block : LDS-resident 128 KiB bucket table, atomicMax chain,
-//                                     512 positions in flight per iteration
-//   k_match        1024 thr / block : block input in LDS; lz_extend for every position
+//   k_candidates   4 waves  / block : LDS-resident 128 KiB bucket table, ordered atomicMax chain,
+//                                     2048 positions per ticket turn
+//   k_match        1024 thr / block : block input in LDS; both candidates of every position
+//                                     extended by one lockstep loop; run groups for long runs
 //   k_parse        1024 thr / block : per-position match lengths in LDS; the greedy parse as a
-//                                     segment-parallel pointer chase with speculative entries,
-//                                     then the position-parallel token build
+//                                     speculative walk over 64-position segments, then the
+//                                     position-parallel token build
+//   k_hist         256 thr  / block : symbol frequencies per DEFLATE sub-block
 //   k_huffman      one wave / block : libdeflate's length-limited Huffman construction, header
 //                                     RLE, exact cost comparison (dynamic / static / stored)
-//   k_crc32        256 thr  / block : per-segment CRC + GF(2) combine tree
+//   k_crc32        1024 thr / block : per-segment CRC + GF(2) combine tree
 //   k_scan         one workgroup    : exclusive scan of framed sizes -> output offsets
-//   k_emit         256 thr  / block : bit-exact bitstream assembly in LDS, coalesced write-out
-// Integer/byte work only: no MFMA; LDS and HBM coalescing are what matter.
+//   k_emit         1024 thr / block : bit-exact bitstream assembly in LDS, coalesced write-out
+// Levels 2-4 swap k_match / k_parse for k_match_hc / k_parse_hc (hc_matchfinder chains, block
+// splitting); ParDecompress is k_dinit / k_dscan / k_inflate / k_dcrc32.
+// Integer/byte work only: no MFMA; LDS, the texture path and instruction issue are what matter.
 #include <hip/hip_runtime.h>
 #include <type_traits>
 
