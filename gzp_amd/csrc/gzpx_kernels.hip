@@ -3005,7 +3005,7 @@ __global__ __launch_bounds__(64) void k_inflate(uint32_t hdr_len, const uint8_t 
                 const uint32_t b_lo = __builtin_amdgcn_alignbit(d1, d0, q & 31u);
                 const uint32_t b_hi = __builtin_amdgcn_alignbit(d2, d1, q & 31u);
                 le[hf] = h.lfast[b_lo & 1023u];
-                const uint32_t cl = le[hf] & 15u, type = (le[hf] >> 4) & 3u, xb = (le[hf] >> 8) & 0xFFu;
+                const uint32_t cl = le[hf] & 15u, type = (le[hf] >> 4) & 3u, xb = (le[hf] >> 8) & 7u;  // (a literal entry keeps its byte here: masked, unused)
                 const bool is_lit = cl != 0 && type == 0;
                 const bool is_len = cl != 0 && type == 1;
                 const uint32_t used1 = is_len ? cl + xb : 0u;  // <= 20
@@ -3187,7 +3187,7 @@ __global__ __launch_bounds__(64) void k_inflate(uint32_t hdr_len, const uint8_t 
                 bp += scl;
                 continue;
             }
-            const uint32_t sxb = (e >> 8) & 0xFFu;
+            const uint32_t sxb = (e >> 8) & 7u;
             const uint32_t len = (e >> 16) + ((sb_lo >> scl) & ((1u << sxb) - 1u));
             const uint32_t sb2 = (uint32_t)(((((uint64_t)sb_hi) << 32) | sb_lo) >> (scl + sxb));
             uint32_t d = uniform(h.ofast[sb2 & 255u]);
