@@ -184,7 +184,7 @@ int run_batch(gzpx_ctx *ctx, const uint8_t *d_in, size_t in_len, uint32_t nb, in
     if (prof) HIP_TRY(hipEventRecord(ev[++k], stream));
     launch_candidates(c, d_in, in_len, nb, s, stream);
     if (prof) HIP_TRY(hipEventRecord(ev[++k], stream));
-    if (c.level == 1) {
+    if (c.level <= 1) {  // (at level 0 every block is a passthrough block: both return at once)
         launch_match(c, d_in, in_len, nb, s, stream);
         if (prof) HIP_TRY(hipEventRecord(ev[++k], stream));
         launch_parse(c, d_in, in_len, nb, s, stream);
@@ -318,7 +318,7 @@ int gzpx_ctx_create(const gzpx_config *cfg, gzpx_ctx **out) {
     if (cfg->level < 0 || cfg->level > 12) return GZPX_ERR_COMPRESSION_LEVEL;
     if (cfg->compat != GZPX_COMPAT_LIBDEFLATE_1_24 && cfg->compat != GZPX_COMPAT_LIBDEFLATE_1_10)
         return GZPX_ERR_INVALID_ARG;
-    if (cfg->level < 1 || cfg->level > 4) return GZPX_ERR_UNSUPPORTED;  // 0, 5..12: not built yet
+    if (cfg->level > 4) return GZPX_ERR_UNSUPPORTED;  // 5..12 (lazy / near-optimal parsers): not built yet
     if (cfg->buffer_size > kMaxBlockSize) return GZPX_ERR_UNSUPPORTED;  // > 16 MiB blocks: not built
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return GZPX_ERR_NO_DEVICE;
@@ -339,7 +339,9 @@ int gzpx_ctx_create(const gzpx_config *cfg, gzpx_ctx **out) {
     // level 1 sub-blocks hold 8192 matches (>= 32768 bytes); the block splitter of levels 2-4 may
     // cut every MIN_BLOCK_LENGTH = 5000 bytes
     ctx->dcfg.max_sub = (uint32_t)(cfg->buffer_size / (cfg->level == 1 ? 32768 : 5000) + 2);
-    ctx->dcfg.passthrough = (uint32_t)(55 - 4 * cfg->level);
+    // deflate_compress: inputs up to 55 - 4*level bytes -- and everything at level 0 -- take
+    // deflate_compress_none
+    ctx->dcfg.passthrough = cfg->level == 0 ? 0xFFFFFFFFu : (uint32_t)(55 - 4 * cfg->level);
     {
         static const uint32_t depth[5] = {0, 0, 6, 12, 16}, nice[5] = {0, 0, 10, 14, 30};
         ctx->dcfg.hc_depth = depth[cfg->level];

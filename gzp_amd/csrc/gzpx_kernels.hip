@@ -1859,8 +1859,11 @@ __global__ __launch_bounds__(64, 6) void k_huffman(Config cfg, BlockMeta *__rest
     const uint32_t eof_len = (meta->is_last && cfg.format == 0) ? 28u : 0u;
 
     if (n <= cfg.passthrough) {
-        // deflate_compress_none: one final stored block
+        // deflate_compress_none (short inputs, and every input at level 0): stored blocks only, one
+        // per 65535 bytes (k_emit cuts them), the last one final
         if (lane == 0) {
+            const uint32_t chunks = n ? (n + 65534u) / 65535u : 1u;
+            const uint32_t c = 5u * chunks + n;
             meta->nsub = 1;
             meta->ntok = 0;
             sub[0].type = kStored;
@@ -1871,8 +1874,9 @@ __global__ __launch_bounds__(64, 6) void k_huffman(Config cfg, BlockMeta *__rest
             sub[0].bit_begin = 0;
             sub[0].hdr_bits = 0;
             sub[0].is_final = 1;
-            meta->payload_bytes = 5 + n;
-            meta->framed_bytes = hdr_len + 5 + n + 8 + eof_len;
+            meta->payload_bytes = c;
+            meta->framed_bytes = hdr_len + c + 8 + eof_len;
+            if (cfg.format == 0 && c >= 65536u) meta->status = kStatusBlockSizeExceeded;
         }
         return;
     }
@@ -3283,6 +3287,7 @@ static void launch_candidates_mode(const Config &cfg, const uint8_t *slab, uint3
 
 void launch_candidates(const Config &cfg, const uint8_t *slab, uint64_t, uint32_t nb, const Scratch &s,
                        hipStream_t stream) {
+    if (cfg.level == 0) return;  // stored blocks only: no matchfinding
     if (cfg.level == 1) {
         launch_candidates_mode<0>(cfg, slab, nb, s.meta, s.cand, stream);
     } else {  // hc_matchfinder: hash3 predecessor in cand, hash4 chain links in d4

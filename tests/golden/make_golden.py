@@ -172,8 +172,9 @@ def main():
         streams.append(e)
 
     # ---- levels 2-4 (greedy hc_matchfinder): gzp's DEFAULT level is 3 (src/par/compress.rs:54-62)
+    #      and level 0 (deflate_compress_none: stored blocks of at most 65535 bytes)
     hc_raw = []
-    for level in (2, 3, 4):
+    for level in (0, 2, 3, 4):
         for cls in synth.CLASSES:
             for n in (0, 43, 44, 47, 48, 300, 512, 4096, 5000, 32769, 65280):
                 seed = 2000 + n
@@ -182,7 +183,8 @@ def main():
                 e.update(entry(ld_deflate(a, level)))
                 hc_raw.append(e)
     for level, cls, n in [(3, "text", 1 << 20), (3, "ascii", 1 << 20), (3, "fastq", 1 << 20), (3, "mixed", 700000),
-                          (2, "text", 400000), (4, "repeats", 400000), (3, "dna", 305001), (3, "text", 304999)]:
+                          (2, "text", 400000), (4, "repeats", 400000), (3, "dna", 305001), (3, "text", 304999),
+                          (0, "mixed", 3 * 65535 + 1)]:
         a = synth.make(cls, n, 78)
         e = {"class": cls, "n": n, "seed": 78, "level": level}
         e.update(entry(ld_deflate(a, level)))
@@ -195,6 +197,8 @@ def main():
         ("bgzf", 65280, 4, [("repeats", 200000)]),
         ("mgzip", 1 << 20, 3, [("ascii", (1 << 20) + 7), ("text", 2 * (1 << 20))]),  # BASELINE config 3 shape
         ("mgzip", 131072, 3, [("mixed", 500000)]),
+        ("bgzf", 65280, 0, [("text", 0), ("mixed", 3 * 65280 + 1234)]),
+        ("mgzip", 200000, 0, [("random", 500001)]),  # stored blocks cut at 65535 bytes inside a block
     ]:
         for cls, n in cases:
             a = synth.make(cls, n, 4343)

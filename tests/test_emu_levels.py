@@ -22,7 +22,7 @@ def hetero(n, seed):
 
 
 def test_golden_raw_deflate_levels(emu_lib, golden_hc):
-    comps = {L: _native.Compressor(L, _native.COMPAT_1_10, lib=emu_lib) for L in (2, 3, 4)}
+    comps = {L: _native.Compressor(L, _native.COMPAT_1_10, lib=emu_lib) for L in (0, 2, 3, 4)}
     for e in golden_hc["raw_deflate"]:
         if e["n"] >= 400000 and (e["level"] != 3 or e["class"] != "text"):
             continue  # the big ones run on the GPU (tests/test_gpu_levels.py); one stays here
