@@ -761,9 +761,13 @@ __global__ __launch_bounds__(kMpThreads, 8) void k_parse(
             // per-block stride is a multiple of 1024 and padded, so whole uint4s are readable)
             const uint4 *src = (const uint4 *)(len8_all + (uint64_t)b * cfg.stride + tile_begin);
             uint4 *dst = (uint4 *)len8_w;
+            const uint32_t nq = (tile_len + 15) / 16;  // never past the block's own (padded) array
             uint4 v[4];
 #pragma unroll
-            for (uint32_t k = 0; k < 4; k++) v[k] = src[tid + k * kMpThreads];
+            for (uint32_t k = 0; k < 4; k++) {
+                const uint32_t q = tid + k * kMpThreads;
+                v[k] = src[q < nq ? q : nq - 1];
+            }
 #pragma unroll
             for (uint32_t k = 0; k < 4; k++) dst[tid + k * kMpThreads] = v[k];
             if (tid == 0) bnd = ~0ull;
@@ -966,8 +970,9 @@ __global__ __launch_bounds__(kMpThreads, 8) void k_parse(
             sub_start_mat = bm;
             sub_limit = sub_limit_of(bp, n);
             __syncthreads();
-            // another boundary in this tile is only possible through the match-count rule
-            if (mat_carry + tile_mat - bm < kSeqPerSub) break;
+            // another boundary in this tile needs 8192 more matches, or -- when this boundary sits
+            // on the tile's first positions -- the 65535-byte soft limit falling on its last ones
+            if (mat_carry + tile_mat - bm < kSeqPerSub && sub_limit >= tile_begin + tile_len) break;
             build = false;
         }
         tok_carry += tile_tok;

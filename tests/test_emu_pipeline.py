@@ -169,3 +169,14 @@ def test_large_mgzip_blocks_vs_oracle(emu_lib, oracle, cls):
                              lib=emu_lib, max_slab_bytes=a.size) as c:
             got = c.compress_slab(a, True)
         assert got == oracle.compress_stream(a, oracle.FMT_MGZIP, 1, oracle.COMPAT_1_10, bs), (cls, bs, n)
+
+
+def test_regression_soft_limit_boundary_on_a_tile_edge(emu_lib, oracle):
+    # found by tools/gpu_fuzz.py: a sub-block that starts on the first position of a 64 KiB parse
+    # tile ends (65535-byte soft limit) on the tile's last position -- a second boundary in one tile
+    # that is not caused by the 8192-match rule
+    a = synth.make("mixed", 256005, 514286759)
+    with _native.Context(format=_native.FORMAT_MGZIP, level=1, buffer_size=285614, lib=emu_lib,
+                         max_slab_bytes=a.size) as c:
+        got = c.compress_slab(a, True)
+    assert got == oracle.compress_stream(a, oracle.FMT_MGZIP, 1, oracle.COMPAT_1_24, 285614)
