@@ -40,6 +40,10 @@ typedef struct {
     int (*inflate)(void *, const void *, size_t, void *, size_t, size_t *);
     uint32_t (*crc32)(uint32_t, const void *, size_t);
     void (*free_d)(void *);
+    /* compress with the libdeflate binary */
+    void *(*alloc_c)(int);
+    size_t (*deflate)(void *, const void *, size_t, void *, size_t);
+    void (*free_c)(void *);
     /* both */
     double deadline;
     uint64_t bytes;
@@ -65,6 +69,33 @@ static void *compress_worker(void *arg) {
             w->bytes += n;
         }
     } while (now_s() < w->deadline);
+    free(out);
+    return NULL;
+}
+
+/* bgzf::compress with the real library: libdeflate_deflate_compress into buf[18..] + libdeflate_crc32
+ * (src/bgzf.rs:214-225); header and footer bytes are not worth timing */
+static void *compress_ref_worker(void *arg) {
+    worker_t *w = (worker_t *)arg;
+    const size_t cap = w->block + w->block / 8 + 4096;
+    uint8_t *out = (uint8_t *)malloc(cap);
+    void *c = w->alloc_c(w->level);
+    if (!out || !c) {
+        w->failed = 1;
+        return NULL;
+    }
+    uint32_t sink = 0;
+    do {
+        for (size_t b = 0; b < w->n_blocks; b++) {
+            const size_t off = (w->first_block + b) * w->block;
+            const size_t n = off + w->block <= w->slab_len ? w->block : w->slab_len - off;
+            if (w->deflate(c, w->slab + off, n, out + 18, cap - 26) == 0) w->failed = 1;
+            sink ^= w->crc32(0, w->slab + off, n);
+            w->bytes += n;
+        }
+    } while (now_s() < w->deadline);
+    out[0] = (uint8_t)sink;
+    w->free_c(c);
     free(out);
     return NULL;
 }
@@ -148,6 +179,41 @@ int gzpx_cpu_bench_compress(int fmt, int level, int compat, size_t block, const 
         ws[i].deadline = deadline;
     }
     const int rc = run(ws, threads, compress_worker, elapsed, bytes);
+    *threads_used = threads;
+    free(ws);
+    return rc;
+}
+
+/* The same with the libdeflate binary of the image doing the work (the library gzp calls).
+ * Returns 0 on success, -2 when no libdeflate binary can be loaded on this box. */
+int gzpx_cpu_bench_compress_ref(int level, size_t block, const uint8_t *slab, size_t slab_len, int threads,
+                                double wall_s, double *elapsed, uint64_t *bytes, int *threads_used) {
+    void *h = dlopen("libdeflate.so.0", RTLD_NOW);
+    if (!h) h = dlopen("/lib/x86_64-linux-gnu/libdeflate.so.0", RTLD_NOW);
+    if (!h) return -2;
+    worker_t proto;
+    memset(&proto, 0, sizeof(proto));
+    *(void **)(&proto.alloc_c) = dlsym(h, "libdeflate_alloc_compressor");
+    *(void **)(&proto.deflate) = dlsym(h, "libdeflate_deflate_compress");
+    *(void **)(&proto.crc32) = dlsym(h, "libdeflate_crc32");
+    *(void **)(&proto.free_c) = dlsym(h, "libdeflate_free_compressor");
+    const size_t nb = (slab_len + block - 1) / block;
+    if (!proto.alloc_c || !proto.deflate || !proto.crc32 || !proto.free_c || threads < 1 || nb == 0) return -2;
+    if ((size_t)threads > nb) threads = (int)nb;
+    worker_t *ws = (worker_t *)calloc((size_t)threads, sizeof(worker_t));
+    if (!ws) return -1;
+    const double deadline = now_s() + wall_s;
+    for (int i = 0; i < threads; i++) {
+        ws[i] = proto;
+        ws[i].slab = slab;
+        ws[i].slab_len = slab_len;
+        ws[i].block = block;
+        ws[i].first_block = nb * (size_t)i / (size_t)threads;
+        ws[i].n_blocks = nb * (size_t)(i + 1) / (size_t)threads - ws[i].first_block;
+        ws[i].level = level;
+        ws[i].deadline = deadline;
+    }
+    const int rc = run(ws, threads, compress_ref_worker, elapsed, bytes);
     *threads_used = threads;
     free(ws);
     return rc;

@@ -64,6 +64,9 @@ def lib():
         L.gzpx_cpu_bench_compress.restype = ctypes.c_int
         L.gzpx_cpu_bench_compress.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_size_t, u8p,
                                               ctypes.c_size_t, ctypes.c_int, ctypes.c_double, dp, u64p, ip]
+        L.gzpx_cpu_bench_compress_ref.restype = ctypes.c_int
+        L.gzpx_cpu_bench_compress_ref.argtypes = [ctypes.c_int, ctypes.c_size_t, u8p, ctypes.c_size_t, ctypes.c_int,
+                                                  ctypes.c_double, dp, u64p, ip]
         L.gzpx_cpu_bench_inflate.restype = ctypes.c_int
         L.gzpx_cpu_bench_inflate.argtypes = [u8p, u8p, u8p, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_int,
                                              ctypes.c_double, dp, u64p, ip]
@@ -79,6 +82,19 @@ def cpu_bench_compress(slab, fmt=FMT_BGZF, level=1, compat=COMPAT_1_24, block=65
                                        ctypes.byref(el), ctypes.byref(nb), ctypes.byref(th))
     if rc != 0:
         raise RuntimeError("gzpx_cpu_bench_compress failed (%d)" % rc)
+    return nb.value, el.value, th.value
+
+
+def cpu_bench_compress_ref(slab, level=1, block=65280, threads=1, wall_s=6.0):
+    """The same loop with the image's libdeflate binary doing the work; None if the box has none."""
+    a = _as_u8(slab)
+    el, nb, th = ctypes.c_double(0), ctypes.c_uint64(0), ctypes.c_int(0)
+    rc = lib().gzpx_cpu_bench_compress_ref(level, block, _ptr(a), a.size, threads, wall_s, ctypes.byref(el),
+                                           ctypes.byref(nb), ctypes.byref(th))
+    if rc == -2:
+        return None
+    if rc != 0:
+        raise RuntimeError("gzpx_cpu_bench_compress_ref failed (%d)" % rc)
     return nb.value, el.value, th.value
 
 
