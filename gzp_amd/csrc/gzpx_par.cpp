@@ -1,6 +1,8 @@
 // gzpx_par.cpp -- ParCompress twin (see gzpx_par.hpp) + its C ABI (gzpx_par_* in include/gzpx.h).
 #include "gzpx_par.hpp"
 
+#include <hip/hip_runtime.h>
+
 #include <cstring>
 
 namespace gzp {
@@ -59,6 +61,7 @@ ParCompress::~ParCompress() {
         }
     }
     for (gzpx_ctx *x : ctxs_) gzpx_ctx_destroy(x);
+    for (uint8_t *p : pinned_) (void)hipHostFree(p);  // (the threads have been joined by finish())
 }
 
 void ParCompress::raise_pipeline_error() {
@@ -71,14 +74,44 @@ void ParCompress::raise_pipeline_error() {
     throw GzpError(GzpErrorKind::ChannelSend, "compression pipeline is closed");
 }
 
-void ParCompress::dispatch(std::vector<uint8_t> &&input, int mode) {
+ParCompress::Pinned ParCompress::take_buffer(size_t cap) {
+    {
+        std::lock_guard<std::mutex> lk(pool_mu_);
+        for (size_t i = 0; i < pool_.size(); i++) {
+            if (pool_[i].cap >= cap) {
+                Pinned b = pool_[i];
+                pool_.erase(pool_.begin() + (ptrdiff_t)i);
+                b.len = 0;
+                return b;
+            }
+        }
+    }
+    Pinned b;
+    b.cap = cap < 4096 ? 4096 : cap;
+    if (hipHostMalloc((void **)&b.p, b.cap, hipHostMallocDefault) != hipSuccess)
+        throw GzpError(GzpErrorKind::Device, "hipHostMalloc failed");
+    {
+        std::lock_guard<std::mutex> lk(pool_mu_);
+        pinned_.push_back(b.p);
+    }
+    return b;
+}
+
+void ParCompress::give_buffer(Pinned b) {
+    if (!b.p) return;
+    std::lock_guard<std::mutex> lk(pool_mu_);
+    pool_.push_back(b);
+}
+
+void ParCompress::dispatch(Pinned input, int mode) {
     auto job = std::make_unique<Job>();
-    job->input = std::move(input);
+    job->input = input;
     job->mode = mode;
     std::unique_lock<std::mutex> lk(mu_);
     cv_space_.wait(lk, [&] { return failed_ || closed_ || (work_q_.size() < q_cap_ && order_q_.size() < q_cap_); });
     if (failed_ || closed_) {
         lk.unlock();
+        give_buffer(input);
         raise_pipeline_error();
     }
     order_q_.push_back(job->result.get_future());  // order token FIRST (src/par/compress.rs:424-440)
@@ -89,18 +122,27 @@ void ParCompress::dispatch(std::vector<uint8_t> &&input, int mode) {
 
 size_t ParCompress::write(const uint8_t *buf, size_t n) {
     if (finished_) throw GzpError(GzpErrorKind::ChannelSend, "write after finish");
-    buffer_.insert(buffer_.end(), buf, buf + n);
     // `while buffer.len() > buffer_size` (strict): full blocks leave only while at least one byte
     // stays behind.  Blocks are handed over batch_blocks at a time; the cut points are the same.
+    // Slabs are cut straight from the caller's bytes (behind whatever is still buffered), so a large
+    // write is copied once, not shuffled through the buffer.
     const size_t bs = cfg_.buffer_size;
-    while (buffer_.size() > batch_bytes_) {
-        size_t blocks = (buffer_.size() - 1) / bs;
+    size_t off = 0;  // bytes of buf already handed over or buffered
+    while (buffer_.size() + (n - off) > batch_bytes_) {
+        const size_t have = buffer_.size() + (n - off);
+        size_t blocks = (have - 1) / bs;
         if (blocks > cfg_.batch_blocks) blocks = cfg_.batch_blocks;
         const size_t take = blocks * bs;
-        std::vector<uint8_t> slab(buffer_.begin(), buffer_.begin() + (ptrdiff_t)take);
-        buffer_.erase(buffer_.begin(), buffer_.begin() + (ptrdiff_t)take);
-        dispatch(std::move(slab), GZPX_SLAB_FULL_BLOCKS);
+        Pinned slab = take_buffer(batch_bytes_);
+        const size_t from_buffer = buffer_.size() < take ? buffer_.size() : take;
+        memcpy(slab.p, buffer_.data(), from_buffer);
+        buffer_.erase(buffer_.begin(), buffer_.begin() + (ptrdiff_t)from_buffer);  // (at most one slab's worth)
+        memcpy(slab.p + from_buffer, buf + off, take - from_buffer);
+        off += take - from_buffer;
+        slab.len = take;
+        dispatch(slab, GZPX_SLAB_FULL_BLOCKS);
     }
+    buffer_.insert(buffer_.end(), buf + off, buf + n);
     return n;
 }
 
@@ -108,15 +150,20 @@ void ParCompress::flush_last(bool is_last) {
     // everything buffered goes out cut at buffer_size; the final piece may be short and -- if the
     // buffer is empty -- is an empty block (src/par/compress.rs:333-341 runs at least once)
     const size_t bs = cfg_.buffer_size;
-    while (buffer_.size() > batch_bytes_) {
+    size_t pos = 0;
+    while (buffer_.size() - pos > batch_bytes_) {
         const size_t take = cfg_.batch_blocks * bs;
-        std::vector<uint8_t> slab(buffer_.begin(), buffer_.begin() + (ptrdiff_t)take);
-        buffer_.erase(buffer_.begin(), buffer_.begin() + (ptrdiff_t)take);
-        dispatch(std::move(slab), GZPX_SLAB_FULL_BLOCKS);
+        Pinned slab = take_buffer(batch_bytes_);
+        memcpy(slab.p, buffer_.data() + pos, take);
+        slab.len = take;
+        pos += take;
+        dispatch(slab, GZPX_SLAB_FULL_BLOCKS);
     }
-    std::vector<uint8_t> rest;
-    rest.swap(buffer_);
-    dispatch(std::move(rest), is_last ? GZPX_SLAB_LAST : GZPX_SLAB_FLUSH);
+    Pinned rest = take_buffer(batch_bytes_);
+    rest.len = buffer_.size() - pos;
+    memcpy(rest.p, buffer_.data() + pos, rest.len);
+    buffer_.clear();
+    dispatch(rest, is_last ? GZPX_SLAB_LAST : GZPX_SLAB_FLUSH);
 }
 
 void ParCompress::flush() {
@@ -164,16 +211,22 @@ void ParCompress::worker_main(size_t lane) {
             cv_space_.notify_all();
         }
         try {
-            const size_t n = job->input.size();
+            const size_t n = job->input.len;
             const int mode = job->mode;
-            std::vector<uint8_t> out(gzpx_slab_bound(ctx, n));
+            Pinned out = take_buffer(gzpx_slab_bound(ctx, batch_bytes_));
             size_t out_len = 0, nb = 0;
-            const int rc = gzpx_compress_slab(ctx, job->input.data(), n, mode, out.data(), out.size(),
-                                              &out_len, nullptr, 0, &nb);
-            if (rc != GZPX_OK) throw error_from_code(rc, nb);
-            out.resize(out_len);
-            job->result.set_value(std::move(out));
+            const int rc = gzpx_compress_slab(ctx, job->input.p, n, mode, out.p, out.cap, &out_len, nullptr, 0, &nb);
+            give_buffer(job->input);
+            job->input = Pinned();
+            if (rc != GZPX_OK) {
+                give_buffer(out);
+                throw error_from_code(rc, nb);
+            }
+            out.len = out_len;
+            job->result.set_value(out);
         } catch (...) {
+            give_buffer(job->input);
+            job->input = Pinned();
             job->result.set_exception(std::current_exception());
         }
     }
@@ -181,7 +234,7 @@ void ParCompress::worker_main(size_t lane) {
 
 void ParCompress::writer_main() {
     for (;;) {
-        std::future<std::vector<uint8_t>> fut;
+        std::future<Pinned> fut;
         {
             std::unique_lock<std::mutex> lk(mu_);
             cv_order_.wait(lk, [&] { return !order_q_.empty() || closed_; });
@@ -191,15 +244,16 @@ void ParCompress::writer_main() {
             cv_space_.notify_all();
         }
         try {
-            std::vector<uint8_t> chunk = fut.get();  // blocks until THAT slab is done -> in order
+            Pinned chunk = fut.get();  // blocks until THAT slab is done -> in order
             std::string err;
             bool ok;
             {
                 std::lock_guard<std::mutex> lk(mu_);
                 ok = !failed_;
             }
-            if (ok && !writer_(chunk.data(), chunk.size(), &err))
-                throw GzpError(GzpErrorKind::Io, err.empty() ? "write failed" : err);
+            const bool wrote = !ok || writer_(chunk.p, chunk.len, &err);
+            give_buffer(chunk);
+            if (!wrote) throw GzpError(GzpErrorKind::Io, err.empty() ? "write failed" : err);
         } catch (...) {
             std::lock_guard<std::mutex> lk(mu_);
             if (!failed_) {

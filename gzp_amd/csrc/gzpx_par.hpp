@@ -116,13 +116,22 @@ class ParCompress {
     void finish();  // src/par/compress.rs:377-388 -> flush_last(true), join
 
   private:
-    struct Job {
-        std::vector<uint8_t> input;  // whole blocks (or the final short piece)
-        int mode = GZPX_SLAB_FULL_BLOCKS;
-        std::promise<std::vector<uint8_t>> result;
+    // Slabs travel in page-locked host memory (a small pool, reused), so that the copies to and
+    // from the device are DMA transfers that overlap with the other lane's kernels.
+    struct Pinned {
+        uint8_t *p = nullptr;
+        size_t cap = 0;
+        size_t len = 0;
     };
+    struct Job {
+        Pinned input;  // whole blocks (or the final short piece)
+        int mode = GZPX_SLAB_FULL_BLOCKS;
+        std::promise<Pinned> result;
+    };
+    Pinned take_buffer(size_t cap);
+    void give_buffer(Pinned b);
     void flush_last(bool is_last);
-    void dispatch(std::vector<uint8_t> &&input, int mode);
+    void dispatch(Pinned input, int mode);
     void worker_main(size_t lane);
     void writer_main();
     void raise_pipeline_error();
@@ -137,7 +146,10 @@ class ParCompress {
     std::mutex mu_;
     std::condition_variable cv_work_, cv_order_, cv_space_;
     std::deque<std::unique_ptr<Job>> work_q_;
-    std::deque<std::future<std::vector<uint8_t>>> order_q_;
+    std::deque<std::future<Pinned>> order_q_;
+    std::mutex pool_mu_;
+    std::vector<Pinned> pool_;         // free buffers
+    std::vector<uint8_t *> pinned_;    // every buffer ever allocated (freed by the destructor)
     size_t q_cap_;
     bool closed_ = false;
     bool failed_ = false;
