@@ -427,9 +427,11 @@ class DContext:
         if used != a.size:
             raise GzpxError(ERR_INVALID_ARG, "trailing partial block (%d bytes)" % (a.size - used))
         isz = 0
-        for o, s_ in zip(offs, sizes):
-            e = int(o) + int(s_)
-            isz += int.from_bytes(a[e - 4:e].tobytes(), "little")
+        if offs.size:  # ISIZE fields of all blocks (little-endian u32 at the end of every member)
+            ends = offs.astype(np.int64) + sizes.astype(np.int64)
+            fields = a[(ends[:, None] - 4) + np.arange(4)].astype(np.uint64)
+            isz = int((fields[:, 0] | (fields[:, 1] << np.uint64(8)) | (fields[:, 2] << np.uint64(16)) |
+                       (fields[:, 3] << np.uint64(24))).sum())
         out = np.empty(max(isz, 1), dtype=np.uint8)
         out_len = ctypes.c_size_t(0)
         info = GzpxCheckInfo()

@@ -275,27 +275,37 @@ ParDecompress::ParDecompress(const ParDecompressConfig &cfg, ReadFn reader)
 
 ParDecompress::~ParDecompress() {
     if (ctx_) gzpx_dctx_destroy(ctx_);
+    if (in_.p) (void)hipHostFree(in_.p);
+    if (out_.p) (void)hipHostFree(out_.p);
+}
+
+void ParDecompress::reserve(Staging &s, size_t cap) {
+    if (cap <= s.cap) return;
+    cap += cap / 4;
+    uint8_t *np = nullptr;
+    if (hipHostMalloc((void **)&np, cap, hipHostMallocDefault) != hipSuccess)
+        throw GzpError(GzpErrorKind::Device, "hipHostMalloc failed");
+    if (s.len) memcpy(np, s.p, s.len);
+    if (s.p) (void)hipHostFree(s.p);
+    s.p = np;
+    s.cap = cap;
 }
 
 bool ParDecompress::fill() {
     const size_t hdr = cfg_.format == GZPX_FORMAT_BGZF ? 18 : 20;
     for (;;) {
         // top the slab up from the reader
-        while (!eof_ && in_.size() < cfg_.batch_bytes) {
-            const size_t old = in_.size();
-            const size_t want = cfg_.batch_bytes - old < (1u << 20) ? (1u << 20) : cfg_.batch_bytes - old;
-            in_.resize(old + want);
+        reserve(in_, cfg_.batch_bytes + (1u << 20));
+        while (!eof_ && in_.len < cfg_.batch_bytes) {
+            const size_t want = in_.cap - in_.len;
             std::string err;
-            const long got = reader_(in_.data() + old, want, &err);
-            if (got < 0) {
-                in_.resize(old);
-                throw GzpError(GzpErrorKind::Io, err.empty() ? "read failed" : err);
-            }
-            in_.resize(old + (size_t)got);
+            const long got = reader_(in_.p + in_.len, want, &err);
+            if (got < 0) throw GzpError(GzpErrorKind::Io, err.empty() ? "read failed" : err);
+            in_.len += (size_t)got;
             if (got == 0) eof_ = true;
         }
         size_t nb = 0, used = 0;
-        int rc = gzpx_scan_blocks(cfg_.format, in_.data(), in_.size(), nullptr, nullptr, 0, &nb, &used);
+        int rc = gzpx_scan_blocks(cfg_.format, in_.p, in_.len, nullptr, nullptr, 0, &nb, &used);
         if (rc != GZPX_OK) throw error_from_code(rc);
         if (nb == 0) {
             if (!eof_) {  // one block larger than the slab: keep reading
@@ -304,43 +314,44 @@ bool ParDecompress::fill() {
             }
             // EOF: a failed header read ends the stream silently (src/par/decompress.rs:207-209);
             // a header followed by a short body is read_exact's UnexpectedEof (:201-202)
-            if (in_.size() >= hdr) throw GzpError(GzpErrorKind::Io, "failed to fill whole buffer");
+            if (in_.len >= hdr) throw GzpError(GzpErrorKind::Io, "failed to fill whole buffer");
             return false;
         }
         std::vector<uint64_t> offs(nb);
         std::vector<uint32_t> sizes(nb);
-        rc = gzpx_scan_blocks(cfg_.format, in_.data(), in_.size(), offs.data(), sizes.data(), nb, &nb, &used);
+        rc = gzpx_scan_blocks(cfg_.format, in_.p, in_.len, offs.data(), sizes.data(), nb, &nb, &used);
         if (rc != GZPX_OK) throw error_from_code(rc);
         size_t total = 0;
         for (size_t b = 0; b < nb; b++) {
-            const uint8_t *f = in_.data() + offs[b] + sizes[b] - 4;  // ISIZE
+            const uint8_t *f = in_.p + offs[b] + sizes[b] - 4;  // ISIZE
             total += (size_t)f[0] | ((size_t)f[1] << 8) | ((size_t)f[2] << 16) | ((size_t)f[3] << 24);
         }
-        out_.resize(total ? total : 1);
+        out_.len = 0;
+        reserve(out_, total ? total : 1);
         size_t got = 0;
         gzpx_check_info info = {0, 0, 0};
-        rc = gzpx_decompress_blocks(ctx_, in_.data(), used, offs.data(), sizes.data(), nb, out_.data(), total,
-                                    &got, &info);
+        rc = gzpx_decompress_blocks(ctx_, in_.p, used, offs.data(), sizes.data(), nb, out_.p, total, &got, &info);
         if (rc == GZPX_ERR_INVALID_CHECK)
             throw GzpError(GzpErrorKind::InvalidCheck, "Invalid check value: found " + std::to_string(info.found) +
                                                            ", expected " + std::to_string(info.expected));
         if (rc != GZPX_OK) throw error_from_code(rc, info.block);
-        out_.resize(got);
+        out_.len = got;
         out_pos_ = 0;
-        in_.erase(in_.begin(), in_.begin() + (ptrdiff_t)used);
+        memmove(in_.p, in_.p + used, in_.len - used);  // the partial block at the end, if any
+        in_.len -= used;
         if (got) return true;  // slabs of empty blocks only (e.g. the EOF marker): look further
-        if (eof_ && in_.empty()) return false;
+        if (eof_ && in_.len == 0) return false;
     }
 }
 
 size_t ParDecompress::read(uint8_t *buf, size_t n) {
-    if (out_pos_ == out_.size()) {
-        out_.clear();
+    if (out_pos_ == out_.len) {
+        out_.len = 0;
         out_pos_ = 0;
         if (!fill()) return 0;
     }
-    const size_t take = out_.size() - out_pos_ < n ? out_.size() - out_pos_ : n;
-    memcpy(buf, out_.data() + out_pos_, take);
+    const size_t take = out_.len - out_pos_ < n ? out_.len - out_pos_ : n;
+    memcpy(buf, out_.p + out_pos_, take);
     out_pos_ += take;
     return take;
 }

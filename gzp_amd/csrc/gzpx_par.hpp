@@ -238,8 +238,14 @@ class ParDecompress {
     ParDecompressConfig cfg_;
     ReadFn reader_;
     gzpx_dctx *ctx_ = nullptr;
-    std::vector<uint8_t> in_;   // compressed bytes not yet decoded (may end in a partial block)
-    std::vector<uint8_t> out_;  // decoded bytes not yet handed out
+    // page-locked staging (grown on demand, never value-initialised): compressed bytes not yet
+    // decoded (may end in a partial block) and decoded bytes not yet handed out
+    struct Staging {
+        uint8_t *p = nullptr;
+        size_t cap = 0, len = 0;
+    };
+    void reserve(Staging &s, size_t cap);
+    Staging in_, out_;
     size_t out_pos_ = 0;
     bool eof_ = false;
 };

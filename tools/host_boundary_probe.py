@@ -45,3 +45,25 @@ for _ in range(2):
     dt = time.perf_counter() - t1
 print("ParCompress twin (two lanes): builder %.1f ms; write_all + finish %.1f ms = %.2f GiB/s (%d bytes out)"
       % ((t1 - t0) * 1e3, dt * 1e3, n / dt / 2**30, s.n))
+
+comp = out if isinstance(out, (bytes, bytearray)) else bytes(out)
+for _ in range(2):
+    t0 = time.perf_counter()
+    r = par.ParDecompressBuilder(par.Bgzf, lib=lib).from_reader(io.BytesIO(comp))
+    t1 = time.perf_counter()
+    total = 0
+    while True:
+        chunk = r.read(64 << 20)
+        if not chunk:
+            break
+        total += len(chunk)
+    dt = time.perf_counter() - t1
+    r.close()
+print("ParDecompress twin: builder %.1f ms; read to end %.1f ms = %.2f GiB/s (%d bytes)"
+      % ((t1 - t0) * 1e3, dt * 1e3, total / dt / 2**30, total))
+with _native.DContext(lib=lib) as d:
+    for _ in range(2):
+        t0 = time.perf_counter()
+        back = d.decompress(comp)
+        dt = time.perf_counter() - t0
+    print("gzpx_decompress_blocks (pageable host in/out, incl. header walk): %.1f ms = %.2f GiB/s" % (dt * 1e3, len(back) / dt / 2**30))
