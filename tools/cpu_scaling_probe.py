@@ -1,5 +1,7 @@
+"""Host-side probe: how many hardware threads the container may really use (cgroup cpu.max) and how
+the oracle port scales with worker threads.  Used to size bench.py's cpu_baseline."""
 import os, sys
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import numpy as np
 print("cpu_count", os.cpu_count(), "affinity", len(os.sched_getaffinity(0)))
 for f in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "/sys/fs/cgroup/cpu/cpu.cfs_period_us"):
