@@ -443,7 +443,6 @@ constexpr uint32_t kSeg = 272;
 constexpr uint32_t kInWords = kTile / 4 + 132;  // 64 KiB window + max match + alignment slack
 constexpr uint32_t kMpThreads = 1024;
 constexpr uint32_t kMpWaves = kMpThreads / 64;
-constexpr uint32_t kMpChunks = kTile / kMpThreads;  // 64 position chunks of 1024
 
 // four dwords that are only dword-aligned in global memory (the hardware takes such 16-byte loads)
 struct __attribute__((aligned(4))) dword4 {
@@ -2763,7 +2762,6 @@ __global__ __launch_bounds__(64) void k_inflate(uint32_t hdr_len, const uint8_t 
                                                 uint8_t *__restrict__ out_all, uint64_t out_cap) {
     __shared__ InfLds h;
     const uint32_t lane = threadIdx.x;
-    const uint64_t lane_below = (1ull << lane) - 1ull;
     DBlock *blk = blk_all + blockIdx.x;
     const uint32_t isize = blk->isize;
     if (isize == 0) return;  // src/par/decompress.rs:163-171: nothing to decode
