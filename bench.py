@@ -185,7 +185,7 @@ def run_inflate(args, torch, dist, world, rank, local_rank, dev):
                 "kernel_ms": round(kern_ms, 3),
             },
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:
             res["cpu_baseline"] = cpu_baseline_inflate(comp, offs, sizes)
         print(json.dumps(res))
     d.close()
@@ -358,7 +358,7 @@ def main():
                 "stage_ms": {k: round(v, 3) for k, v in stage_ms.items()},
             },
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # the CPU leg is timed at N = 1 only
             res["cpu_baseline"] = cpu_baseline(slab)
         print(json.dumps(res))
     ctx.close()
