@@ -168,6 +168,10 @@ class GzpxLib:
         L.gzpx_deflate_decompress.argtypes = [vp, vp, sz, vp, sz, psz]
         L.gzpx_free_decompressor.restype = None
         L.gzpx_free_decompressor.argtypes = [vp]
+        L.gzpx_host_alloc.restype = vp
+        L.gzpx_host_alloc.argtypes = [sz]
+        L.gzpx_host_free.restype = None
+        L.gzpx_host_free.argtypes = [vp]
         L.gzpx_dctx_last_inflate_ms.restype = i32
         L.gzpx_dctx_last_inflate_ms.argtypes = [vp, ctypes.POINTER(ctypes.c_float)]
         L.gzpx_debug_inflate.restype = i32

@@ -861,6 +861,16 @@ int gzpx_debug_phase_cycles(const gzpx_ctx *ctx, uint64_t cycles[8]) {
     return GZPX_OK;
 }
 
+void *gzpx_host_alloc(size_t bytes) {
+    void *p = nullptr;
+    if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) return nullptr;
+    return p;
+}
+
+void gzpx_host_free(void *p) {
+    if (p) (void)hipHostFree(p);
+}
+
 int gzpx_dctx_last_inflate_ms(gzpx_dctx *ctx, float *ms) {
     if (!ctx || !ms) return GZPX_ERR_INVALID_ARG;
     std::lock_guard<std::mutex> g(ctx->mu);
