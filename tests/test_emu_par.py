@@ -133,3 +133,39 @@ def test_zbuilder(emu_lib, oracle):
     w.finish()
     w.close()
     assert sink.getvalue() == oracle.compress_stream(a, oracle.FMT_BGZF, 1, oracle.COMPAT_1_10, 65280)
+
+
+def test_random_write_sizes_and_flushes_match_the_oracle(emu_lib, oracle):
+    # seeded soak of the twin's buffering (slabs cut straight from the caller's bytes into pooled
+    # staging buffers): any chunking of the writes gives the same stream; a flush closes the pending
+    # short block (no EOF marker); ParDecompress gives the bytes back
+    import io
+    rng = np.random.default_rng(20250927)
+    classes = sorted(synth.CLASSES)
+    for case in range(16):
+        fmt_cls, fmt, bs = (par.Bgzf, oracle.FMT_BGZF, 65280) if case % 3 else (par.Mgzip, oracle.FMT_MGZIP, 70000)
+        level = int(rng.integers(0, 5))
+        n = int(rng.integers(0, 4 * bs))
+        data = synth.make(classes[rng.integers(len(classes))], n, int(rng.integers(1, 1 << 30))).tobytes()
+        sink = io.BytesIO()
+        w = (par.ParCompressBuilder(fmt_cls, lib=emu_lib).compression_level(par.Compression(level)).buffer_size(bs)
+             .batch_blocks(int(rng.choice([1, 2, 5]))).from_writer(sink))
+        pos, start, pieces = 0, 0, []
+        while pos < n:
+            step = int(rng.integers(1, 3 * bs)) if rng.random() < 0.7 else int(rng.integers(1, 300))
+            w.write(data[pos:pos + step])
+            pos = min(n, pos + step)
+            if rng.random() < 0.15:
+                w.flush()
+                pieces.append((start, pos))
+                start = pos
+        w.finish()
+        want = b""
+        for a, b in pieces:
+            s = oracle.compress_stream(np.frombuffer(data[a:b], dtype=np.uint8), fmt, level, oracle.COMPAT_1_24, bs)
+            want += s[:-28] if fmt == oracle.FMT_BGZF else s
+        want += oracle.compress_stream(np.frombuffer(data[start:], dtype=np.uint8), fmt, level, oracle.COMPAT_1_24, bs)
+        assert sink.getvalue() == want, (case, n, level, bs, len(pieces))
+        r = par.ParDecompressBuilder(fmt_cls, lib=emu_lib).batch_bytes(1 << 16).from_reader(io.BytesIO(want))
+        assert r.read() == data, case
+        r.close()
