@@ -26,6 +26,7 @@ ERR_CHANNEL = 11
 ERR_INVALID_HEADER = 12
 ERR_INVALID_CHECK = 13
 ERR_BAD_DATA = 14
+ERR_BUSY = 15
 
 SLAB_FULL_BLOCKS = 0
 SLAB_LAST = 1
@@ -43,7 +44,16 @@ EXPORTS = [
     "gzpx_alloc_compressor", "gzpx_deflate_compress", "gzpx_deflate_compress_bound",
     "gzpx_free_compressor", "gzpx_compressor_set_compat", "gzpx_crc32",
     "gzpx_ctx_set_profiling", "gzpx_ctx_last_stage_ms", "gzpx_stage_name", "gzpx_debug_tokens",
-    "gzpx_debug_phase_cycles", "gzpx_debug_cand_cycles", "gzpx_debug_set_flags", "gzpx_strerror", "gzpx_device_name", "gzpx_version",
+    "gzpx_debug_set_flags", "gzpx_strerror", "gzpx_device_name", "gzpx_version",
+    "gzpx_compress_slab_submit", "gzpx_compress_slab_submit_device", "gzpx_compress_slab_wait",
+    "gzpx_compress_slab_event", "gzpx_crc32_checked", "gzpx_last_status",
+    "gzpx_par_create", "gzpx_par_write", "gzpx_par_flush", "gzpx_par_finish", "gzpx_par_destroy",
+    "gzpx_par_last_error", "gzpx_dctx_create", "gzpx_dctx_destroy", "gzpx_scan_blocks",
+    "gzpx_decompress_blocks", "gzpx_decompress_blocks_device", "gzpx_decompress_blocks_submit",
+    "gzpx_decompress_blocks_wait", "gzpx_alloc_decompressor", "gzpx_deflate_decompress",
+    "gzpx_free_decompressor", "gzpx_pard_create", "gzpx_pard_read", "gzpx_pard_destroy",
+    "gzpx_pard_last_error", "gzpx_host_alloc", "gzpx_host_free", "gzpx_dctx_last_inflate_ms",
+    "gzpx_debug_inflate",
 ]
 
 
@@ -127,12 +137,21 @@ class GzpxLib:
         L.gzpx_stage_name.argtypes = [i32]
         L.gzpx_debug_tokens.restype = i32
         L.gzpx_debug_tokens.argtypes = [vp, sz, vp, sz, psz, vp, psz]
-        L.gzpx_debug_cand_cycles.restype = i32
-        L.gzpx_debug_cand_cycles.argtypes = [vp, ctypes.POINTER(ctypes.c_uint64)]
         L.gzpx_debug_set_flags.restype = i32
         L.gzpx_debug_set_flags.argtypes = [vp, u32]
-        L.gzpx_debug_phase_cycles.restype = i32
-        L.gzpx_debug_phase_cycles.argtypes = [vp, ctypes.POINTER(ctypes.c_uint64)]
+        pu64 = ctypes.POINTER(ctypes.c_uint64)
+        L.gzpx_compress_slab_submit.restype = i32
+        L.gzpx_compress_slab_submit.argtypes = [vp, vp, sz, i32, vp, sz, pu64]
+        L.gzpx_compress_slab_submit_device.restype = i32
+        L.gzpx_compress_slab_submit_device.argtypes = [vp, vp, sz, i32, vp, sz, vp, pu64]
+        L.gzpx_compress_slab_wait.restype = i32
+        L.gzpx_compress_slab_wait.argtypes = [vp, ctypes.c_uint64, psz, vp, sz, psz]
+        L.gzpx_compress_slab_event.restype = i32
+        L.gzpx_compress_slab_event.argtypes = [vp, ctypes.c_uint64, ctypes.POINTER(vp)]
+        L.gzpx_crc32_checked.restype = i32
+        L.gzpx_crc32_checked.argtypes = [u32, vp, sz, ctypes.POINTER(u32)]
+        L.gzpx_last_status.restype = i32
+        L.gzpx_last_status.argtypes = []
         L.gzpx_strerror.restype = ctypes.c_char_p
         L.gzpx_strerror.argtypes = [i32]
         L.gzpx_device_name.restype = ctypes.c_char_p
@@ -160,6 +179,10 @@ class GzpxLib:
         L.gzpx_scan_blocks.argtypes = [i32, vp, sz, vp, vp, sz, psz, psz]
         L.gzpx_decompress_blocks.restype = i32
         L.gzpx_decompress_blocks.argtypes = [vp, vp, sz, vp, vp, sz, vp, sz, psz, pinfo]
+        L.gzpx_decompress_blocks_submit.restype = i32
+        L.gzpx_decompress_blocks_submit.argtypes = [vp, vp, sz, vp, vp, sz, vp, sz, ctypes.POINTER(ctypes.c_uint64)]
+        L.gzpx_decompress_blocks_wait.restype = i32
+        L.gzpx_decompress_blocks_wait.argtypes = [vp, ctypes.c_uint64, psz, pinfo]
         L.gzpx_decompress_blocks_device.restype = i32
         L.gzpx_decompress_blocks_device.argtypes = [vp, vp, sz, vp, vp, sz, vp, sz, psz, pinfo, vp]
         L.gzpx_alloc_decompressor.restype = vp
@@ -315,11 +338,6 @@ class Context:
         self.lib.check(self.lib.L.gzpx_ctx_last_stage_ms(self.h, ms))
         return {self.lib.L.gzpx_stage_name(i).decode(): float(ms[i]) for i in range(N_STAGES)}
 
-    def debug_cand_cycles(self):
-        c = (ctypes.c_uint64 * 4)()
-        self.lib.check(self.lib.L.gzpx_debug_cand_cycles(self.h, c))
-        return [int(x) for x in c]
-
     def debug_set_flags(self, flags):
         self.lib.check(self.lib.L.gzpx_debug_set_flags(self.h, flags))
 
@@ -374,7 +392,9 @@ class Compressor:
 def crc32(data, crc=0, lib=None):
     lib = lib or load()
     a = _u8(data)
-    return int(lib.L.gzpx_crc32(crc, a.ctypes.data, a.size))
+    out = ctypes.c_uint32(0)
+    lib.check(lib.L.gzpx_crc32_checked(crc, a.ctypes.data, a.size, ctypes.byref(out)))
+    return int(out.value)
 
 
 class DContext:

@@ -7,6 +7,7 @@
 // a HIP device every entry point fails with GZPX_ERR_NO_DEVICE.
 #include <hip/hip_runtime.h>
 
+#include <condition_variable>
 #include <mutex>
 #include <new>
 #include <string.h>
@@ -65,29 +66,55 @@ struct StageEvents {
     bool created = false;
 };
 
+constexpr int kSlots = 3;  // slabs of one context that may be in flight (copy in / kernels / copy out)
+
+// One slab in flight.  Host-buffer jobs own a pair of device staging buffers per slot, so the H2D
+// copy of slab k+1 and the D2H copy of slab k-1 run (on their own streams) while the kernels of
+// slab k occupy the compute stream.
+struct Slot {
+    int state = 0;  // 0 free, 1 submitted, 2 a thread is inside wait()
+    uint64_t gen = 0;
+    uint8_t *d_in = nullptr, *d_out = nullptr;  // staging of host-buffer jobs (grown on demand)
+    size_t d_in_cap = 0, d_out_cap = 0;
+    hipEvent_t ev_h2d = nullptr, ev_kernels = nullptr, ev_d2h = nullptr;
+    SlabResult *d_results = nullptr, *h_results = nullptr;  // one per batch of the slab (h_: pinned)
+    size_t results_cap = 0;
+    uint32_t *h_sizes = nullptr;  // pinned: framed size of every block of the slab
+    size_t sizes_cap = 0;
+    // the job
+    uint8_t *job_d_out = nullptr;  // where the kernels wrote
+    size_t job_out_cap = 0;
+    uint8_t *host_out = nullptr;  // null: device job (output stays in HBM)
+    size_t host_out_cap = 0;
+    uint64_t total_nb = 0;
+    uint32_t n_batches = 0;
+};
+
 }  // namespace
 
 struct gzpx_ctx {
     gzpx_config cfg;
     Config dcfg;
     CrcConsts crc_consts;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;  // compute: every kernel of this context, in submission order
+    hipStream_t s_h2d = nullptr, s_d2h = nullptr;
+    hipEvent_t ev_dep = nullptr;  // "the caller's stream got this far" (device jobs)
+    hipEvent_t ev_round[2] = {nullptr, nullptr};  // levels 2-4: end of a match/parse round
     uint32_t batch_blocks = 0;
     Scratch scratch = {};
-    uint8_t *d_in = nullptr;
-    size_t d_in_cap = 0;
-    uint8_t *d_out = nullptr;
-    size_t d_out_cap = 0;
-    BlockMeta *h_meta = nullptr;  // pinned, batch_blocks entries
-    SubMeta *h_sub = nullptr;     // pinned, batch_blocks * max_sub entries (debug hooks)
-    uint64_t *h_total = nullptr;  // pinned
+    Slot slots[kSlots];
+    uint64_t next_gen = 1;
+    BlockMeta *h_meta = nullptr;  // pinned; CRC-only contexts and the debug hooks
+    SubMeta *h_sub = nullptr;     // pinned, max_sub entries (debug hooks)
+    uint32_t *h_pending = nullptr;  // pinned
     StageEvents events;
     bool profiling = false;
+    bool crc_only = false;
     float stage_ms[GZPX_N_STAGES] = {0};
-    // last call bookkeeping for the debug hooks
     uint32_t last_nb = 0;
     char devname[256] = {0};
     std::mutex mu;
+    std::condition_variable cv_slot;
 };
 
 namespace {
@@ -97,6 +124,8 @@ namespace {
         hipError_t _e = (expr);                \
         if (_e != hipSuccess) return GZPX_ERR_DEVICE; \
     } while (0)
+
+thread_local int t_last_status = GZPX_OK;  // libdeflate-shaped calls have no status channel
 
 size_t extra_amount(size_t n) {  // src/bgzf.rs:45,50-52
     size_t e = (size_t)((double)n * 0.1);
@@ -117,7 +146,7 @@ uint64_t blocks_of(const gzpx_ctx *ctx, size_t in_len) {
 size_t scratch_bytes_per_block(const Config &c) {
     return (size_t)c.stride * (2 + 1 + 2 + 4 + (c.level >= 2 ? 2 : 0)) + c.stride / 8 +
            (size_t)c.max_sub * (sizeof(SubMeta) + (kHistStride + kCodeWords + kHdrWords) * 4) +
-           sizeof(BlockMeta) + 8;
+           sizeof(BlockMeta) + 8 + 4;
 }
 
 int alloc_scratch(gzpx_ctx *ctx) {
@@ -125,6 +154,12 @@ int alloc_scratch(gzpx_ctx *ctx) {
     const Config &c = ctx->dcfg;
     Scratch &s = ctx->scratch;
     HIP_TRY(hipMalloc((void **)&s.meta, nb * sizeof(BlockMeta)));
+    HIP_TRY(hipHostMalloc((void **)&ctx->h_pending, 64, hipHostMallocDefault));
+    if (ctx->crc_only) {  // gzpx_crc32's private context: k_init_meta + k_crc32 only
+        HIP_TRY(hipHostMalloc((void **)&ctx->h_meta, nb * sizeof(BlockMeta), hipHostMallocDefault));
+        return GZPX_OK;
+    }
+    HIP_TRY(hipHostMalloc((void **)&ctx->h_meta, sizeof(BlockMeta), hipHostMallocDefault));
     HIP_TRY(hipMalloc((void **)&s.sub, nb * (size_t)c.max_sub * sizeof(SubMeta)));
     HIP_TRY(hipMalloc((void **)&s.cand, nb * (size_t)c.stride * sizeof(uint16_t)));
     HIP_TRY(hipMalloc((void **)&s.len8, nb * (size_t)c.stride));
@@ -140,10 +175,21 @@ int alloc_scratch(gzpx_ctx *ctx) {
     HIP_TRY(hipMalloc((void **)&s.codes, nb * (size_t)c.max_sub * kCodeWords * 4));
     HIP_TRY(hipMalloc((void **)&s.hdr, nb * (size_t)c.max_sub * kHdrWords * 4));
     HIP_TRY(hipMalloc((void **)&s.out_off, (nb + 1) * sizeof(uint64_t)));
-    HIP_TRY(hipHostMalloc((void **)&ctx->h_meta, nb * sizeof(BlockMeta), hipHostMallocDefault));
-    HIP_TRY(hipHostMalloc((void **)&ctx->h_sub, nb * (size_t)c.max_sub * sizeof(SubMeta), hipHostMallocDefault));
-    HIP_TRY(hipHostMalloc((void **)&ctx->h_total, 64, hipHostMallocDefault));
+    HIP_TRY(hipMalloc((void **)&s.sizes, nb * sizeof(uint32_t)));
+    HIP_TRY(hipHostMalloc((void **)&ctx->h_sub, (size_t)c.max_sub * sizeof(SubMeta), hipHostMallocDefault));
     return GZPX_OK;
+}
+
+void free_slot(Slot &sl) {
+    if (sl.d_in) (void)hipFree(sl.d_in);
+    if (sl.d_out) (void)hipFree(sl.d_out);
+    if (sl.d_results) (void)hipFree(sl.d_results);
+    if (sl.h_results) (void)hipHostFree(sl.h_results);
+    if (sl.h_sizes) (void)hipHostFree(sl.h_sizes);
+    if (sl.ev_h2d) (void)hipEventDestroy(sl.ev_h2d);
+    if (sl.ev_kernels) (void)hipEventDestroy(sl.ev_kernels);
+    if (sl.ev_d2h) (void)hipEventDestroy(sl.ev_d2h);
+    sl = Slot();
 }
 
 void free_scratch(gzpx_ctx *ctx) {
@@ -163,17 +209,20 @@ void free_scratch(gzpx_ctx *ctx) {
     if (s.codes) (void)hipFree(s.codes);
     if (s.hdr) (void)hipFree(s.hdr);
     if (s.out_off) (void)hipFree(s.out_off);
+    if (s.sizes) (void)hipFree(s.sizes);
     if (ctx->h_meta) (void)hipHostFree(ctx->h_meta);
-    if (ctx->h_total) (void)hipHostFree(ctx->h_total);
-    if (ctx->d_in) (void)hipFree(ctx->d_in);
-    if (ctx->d_out) (void)hipFree(ctx->d_out);
+    if (ctx->h_pending) (void)hipHostFree(ctx->h_pending);
+    for (Slot &sl : ctx->slots) free_slot(sl);
     s = Scratch{};
 }
 
-// One batch of blocks through the pipeline.  d_in/d_out are device pointers for this batch.
-int run_batch(gzpx_ctx *ctx, const uint8_t *d_in, size_t in_len, uint32_t nb, int is_last,
-              uint8_t *d_out, size_t out_cap, hipStream_t stream, size_t *produced,
-              uint32_t *block_sizes, size_t *fail_block) {
+// One batch of blocks through the pipeline, enqueued on `stream`.  Nothing here waits for the
+// device at level 0/1; the match/parse rounds of levels 2-4 read one word back per round.
+// `prev` / `result`: the batch before this one of the same slab (device, may be null) and this
+// batch's own record; output offsets continue from prev->total.
+int enqueue_batch(gzpx_ctx *ctx, const uint8_t *d_in, size_t in_len, uint32_t nb, int is_last,
+                  uint8_t *d_out, size_t out_cap, hipStream_t stream, const SlabResult *prev,
+                  SlabResult *result) {
     const Config &c = ctx->dcfg;
     const Scratch &s = ctx->scratch;
     const bool prof = ctx->profiling;
@@ -191,13 +240,18 @@ int run_batch(gzpx_ctx *ctx, const uint8_t *d_in, size_t in_len, uint32_t nb, in
         if (prof) HIP_TRY(hipEventRecord(ev[++k], stream));
     } else {
         // levels 2-4: match + parse rounds until no block needs its tail redone with another
-        // min_len (one round unless should_end_block splits a block into unlike halves)
+        // min_len (one round unless should_end_block splits a block into unlike halves).  Round
+        // r + 1 is enqueued before round r's "blocks left" word is looked at, so the device never
+        // idles while the host decides; a round with nothing left costs two empty launches.
+        uint32_t *pend = ctx->h_pending;  // [round & 1]
         for (uint32_t round = 0;; round++) {
             launch_hc_round(c, d_in, nb, s, round == 0, stream);
-            HIP_TRY(hipMemcpyAsync(ctx->h_total, s.pending, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
-            HIP_TRY(hipStreamSynchronize(stream));
-            if (*(const uint32_t *)ctx->h_total == 0) break;
-            if (round > c.max_sub + 2) return GZPX_ERR_DEVICE;  // cannot happen: one sub-block per round
+            HIP_TRY(hipMemcpyAsync(&pend[round & 1], s.pending, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+            HIP_TRY(hipEventRecord(ctx->ev_round[round & 1], stream));
+            if (round == 0) continue;
+            HIP_TRY(hipEventSynchronize(ctx->ev_round[(round - 1) & 1]));
+            if (pend[(round - 1) & 1] == 0) break;  // (the round just enqueued finds every block done)
+            if (round > c.max_sub + 3) return GZPX_ERR_DEVICE;  // cannot happen: one sub-block per round
         }
         if (prof) HIP_TRY(hipEventRecord(ev[++k], stream));
         if (prof) HIP_TRY(hipEventRecord(ev[++k], stream));
@@ -208,17 +262,13 @@ int run_batch(gzpx_ctx *ctx, const uint8_t *d_in, size_t in_len, uint32_t nb, in
     if (prof) HIP_TRY(hipEventRecord(ev[++k], stream));
     launch_crc32(c, d_in, in_len, nb, s, ctx->crc_consts, stream);
     if (prof) HIP_TRY(hipEventRecord(ev[++k], stream));
-    launch_scan(nb, s, stream);
+    launch_scan(nb, s, prev, result, stream);
     if (prof) HIP_TRY(hipEventRecord(ev[++k], stream));
     launch_emit(c, d_in, in_len, nb, s, d_out, out_cap, stream);
     if (prof) HIP_TRY(hipEventRecord(ev[++k], stream));
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpyAsync(ctx->h_total, s.out_off + nb, sizeof(uint64_t), hipMemcpyDeviceToHost,
-                           stream));
-    HIP_TRY(hipMemcpyAsync(ctx->h_meta, s.meta, nb * sizeof(BlockMeta), hipMemcpyDeviceToHost,
-                           stream));
-    HIP_TRY(hipStreamSynchronize(stream));
-    if (prof) {
+    if (prof) {  // measurement mode: one host wait per batch
+        HIP_TRY(hipStreamSynchronize(stream));
         for (int i = 0; i < GZPX_N_STAGES; i++) {
             float ms = 0;
             HIP_TRY(hipEventElapsedTime(&ms, ev[i], ev[i + 1]));
@@ -226,73 +276,187 @@ int run_batch(gzpx_ctx *ctx, const uint8_t *d_in, size_t in_len, uint32_t nb, in
         }
     }
     ctx->last_nb = nb;
-    for (uint32_t b = 0; b < nb; b++) {
-        if (ctx->h_meta[b].status == kStatusBlockSizeExceeded) {
-            *fail_block = b;
-            return GZPX_ERR_BLOCK_SIZE_EXCEEDED;
-        }
-        if (block_sizes) block_sizes[b] = ctx->h_meta[b].framed_bytes;
-    }
-    *produced = (size_t)*ctx->h_total;
-    if (*produced > out_cap) return GZPX_ERR_INSUFFICIENT_SPACE;
     return GZPX_OK;
 }
 
-int compress_device_locked(gzpx_ctx *ctx, const uint8_t *d_in, size_t in_len, int mode,
-                           uint8_t *d_out, size_t out_cap, size_t *out_len, uint32_t *block_sizes,
-                           size_t max_blocks, size_t *n_blocks, hipStream_t stream) {
+int slot_reserve(Slot &sl, size_t n_batches, size_t n_blocks) {
+    if (n_batches > sl.results_cap) {
+        if (sl.d_results) (void)hipFree(sl.d_results);
+        if (sl.h_results) (void)hipHostFree(sl.h_results);
+        sl.d_results = sl.h_results = nullptr;
+        sl.results_cap = 0;
+        const size_t cap = n_batches + 8;
+        HIP_TRY(hipMalloc((void **)&sl.d_results, cap * sizeof(SlabResult)));
+        HIP_TRY(hipHostMalloc((void **)&sl.h_results, cap * sizeof(SlabResult), hipHostMallocDefault));
+        sl.results_cap = cap;
+    }
+    if (n_blocks > sl.sizes_cap) {
+        if (sl.h_sizes) (void)hipHostFree(sl.h_sizes);
+        sl.h_sizes = nullptr;
+        sl.sizes_cap = 0;
+        const size_t cap = n_blocks + n_blocks / 4 + 64;
+        HIP_TRY(hipHostMalloc((void **)&sl.h_sizes, cap * sizeof(uint32_t), hipHostMallocDefault));
+        sl.sizes_cap = cap;
+    }
+    return GZPX_OK;
+}
+
+int slot_staging(Slot &sl, size_t in_len, size_t out_need) {
+    if (in_len + 16 > sl.d_in_cap) {
+        if (sl.d_in) (void)hipFree(sl.d_in);
+        sl.d_in = nullptr;
+        sl.d_in_cap = 0;
+        const size_t cap = in_len + in_len / 8 + 4096;
+        HIP_TRY(hipMalloc((void **)&sl.d_in, cap));
+        sl.d_in_cap = cap;
+    }
+    if (out_need > sl.d_out_cap) {
+        if (sl.d_out) (void)hipFree(sl.d_out);
+        sl.d_out = nullptr;
+        sl.d_out_cap = 0;
+        const size_t cap = out_need + out_need / 8 + 4096;
+        HIP_TRY(hipMalloc((void **)&sl.d_out, cap));
+        sl.d_out_cap = cap;
+    }
+    return GZPX_OK;
+}
+
+int check_slab_args(const gzpx_ctx *ctx, const void *in, size_t in_len, int mode, const void *out) {
     const size_t bs = ctx->cfg.buffer_size;
     if (mode != GZPX_SLAB_FULL_BLOCKS && mode != GZPX_SLAB_LAST && mode != GZPX_SLAB_FLUSH)
         return GZPX_ERR_INVALID_ARG;
     if (mode == GZPX_SLAB_FULL_BLOCKS && (in_len == 0 || in_len % bs != 0)) return GZPX_ERR_INVALID_ARG;
-    const int is_last = mode == GZPX_SLAB_LAST;
-    if ((in_len && !d_in) || !d_out || !out_len) return GZPX_ERR_INVALID_ARG;
+    if ((in_len && !in) || !out) return GZPX_ERR_INVALID_ARG;
+    return GZPX_OK;
+}
+
+// Enqueue one slab (ctx->mu held).  host_in / host_out non-null: a host-buffer job that goes
+// through the slot's staging buffers; otherwise d_in / d_out are the caller's device buffers.
+int submit_locked(gzpx_ctx *ctx, const uint8_t *host_in, const uint8_t *d_in, size_t in_len, int mode,
+                  uint8_t *host_out, uint8_t *d_out, size_t out_cap, hipStream_t after, bool block_for_slot,
+                  std::unique_lock<std::mutex> &lk, uint64_t *ticket) {
+    if (ctx->crc_only) return GZPX_ERR_INVALID_ARG;
+    int si = -1;
+    for (;;) {
+        for (int i = 0; i < kSlots; i++)
+            if (ctx->slots[i].state == 0) {
+                si = i;
+                break;
+            }
+        if (si >= 0) break;
+        if (!block_for_slot) return GZPX_ERR_BUSY;
+        ctx->cv_slot.wait(lk);
+    }
+    Slot &sl = ctx->slots[si];
+    if (!sl.ev_kernels) {
+        HIP_TRY(hipEventCreateWithFlags(&sl.ev_h2d, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&sl.ev_kernels, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&sl.ev_d2h, hipEventDisableTiming));
+    }
+    const size_t bs = ctx->cfg.buffer_size;
     const uint64_t total_nb = blocks_of(ctx, in_len);
-    if (block_sizes && max_blocks < total_nb) return GZPX_ERR_INVALID_ARG;
-    if (!stream) stream = ctx->stream;
+    const uint64_t n_batches = (total_nb + ctx->batch_blocks - 1) / ctx->batch_blocks;
+    int rc = slot_reserve(sl, (size_t)n_batches, (size_t)total_nb);
+    if (rc != GZPX_OK) return rc;
+    hipStream_t stream = ctx->stream;
+    if (host_out) {
+        rc = slot_staging(sl, in_len, gzpx_slab_bound(ctx, in_len));
+        if (rc != GZPX_OK) return rc;
+        if (in_len) {
+            HIP_TRY(hipMemcpyAsync(sl.d_in, host_in, in_len, hipMemcpyHostToDevice, ctx->s_h2d));
+            HIP_TRY(hipEventRecord(sl.ev_h2d, ctx->s_h2d));
+            HIP_TRY(hipStreamWaitEvent(stream, sl.ev_h2d, 0));
+        }
+        d_in = sl.d_in;
+        d_out = sl.d_out;
+        out_cap = sl.d_out_cap;
+    } else if (after && after != stream) {  // the slab is ready once `after` has reached this point
+        HIP_TRY(hipEventRecord(ctx->ev_dep, after));
+        HIP_TRY(hipStreamWaitEvent(stream, ctx->ev_dep, 0));
+    }
     memset(ctx->stage_ms, 0, sizeof(ctx->stage_ms));
-    size_t produced_total = 0;
-    for (uint64_t b0 = 0; b0 < total_nb; b0 += ctx->batch_blocks) {
-        const uint32_t nb = (uint32_t)((total_nb - b0 < ctx->batch_blocks) ? total_nb - b0
-                                                                          : ctx->batch_blocks);
+    const int is_last = mode == GZPX_SLAB_LAST;
+    for (uint64_t bi = 0; bi < n_batches; bi++) {
+        const uint64_t b0 = bi * ctx->batch_blocks;
+        const uint32_t nb = (uint32_t)((total_nb - b0 < ctx->batch_blocks) ? total_nb - b0 : ctx->batch_blocks);
         const size_t in_begin = (size_t)b0 * bs;
         size_t in_batch = in_len > in_begin ? in_len - in_begin : 0;
         if (in_batch > (size_t)nb * bs) in_batch = (size_t)nb * bs;
         const int last_batch = (b0 + nb == total_nb) ? is_last : 0;
-        size_t produced = 0, fail = 0;
-        int rc = run_batch(ctx, d_in + in_begin, in_batch, nb, last_batch, d_out + produced_total,
-                           out_cap - produced_total, stream, &produced,
-                           block_sizes ? block_sizes + b0 : nullptr, &fail);
+        rc = enqueue_batch(ctx, d_in + in_begin, in_batch, nb, last_batch, d_out, out_cap, stream,
+                           bi ? sl.d_results + (bi - 1) : nullptr, sl.d_results + bi);
         if (rc != GZPX_OK) {
-            if (n_blocks) *n_blocks = (size_t)(b0 + fail);
+            (void)hipStreamSynchronize(stream);
             return rc;
         }
-        produced_total += produced;
+        // the per-block sizes of this batch, before the next batch reuses the scratch
+        HIP_TRY(hipMemcpyAsync(sl.h_sizes + b0, ctx->scratch.sizes, nb * sizeof(uint32_t), hipMemcpyDeviceToHost,
+                               stream));
     }
-    *out_len = produced_total;
-    if (n_blocks) *n_blocks = (size_t)total_nb;
+    HIP_TRY(hipMemcpyAsync(sl.h_results, sl.d_results, (size_t)n_batches * sizeof(SlabResult),
+                           hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipEventRecord(sl.ev_kernels, stream));
+    sl.job_d_out = d_out;
+    sl.job_out_cap = out_cap;
+    sl.host_out = host_out;
+    sl.host_out_cap = host_out ? out_cap : 0;
+    sl.total_nb = total_nb;
+    sl.n_batches = (uint32_t)n_batches;
+    sl.state = 1;
+    sl.gen = ctx->next_gen++;
+    *ticket = (sl.gen << 8) | (uint64_t)si;
     return GZPX_OK;
 }
 
-int ensure_buffers(gzpx_ctx *ctx, size_t in_len, size_t out_need) {
-    if (in_len + 16 > ctx->d_in_cap) {
-        if (ctx->d_in) (void)hipFree(ctx->d_in);
-        ctx->d_in = nullptr;
-        ctx->d_in_cap = 0;
-        const size_t cap = in_len + in_len / 8 + 4096;
-        HIP_TRY(hipMalloc((void **)&ctx->d_in, cap));
-        ctx->d_in_cap = cap;
+// Complete a ticket: wait for its kernels, copy the stream out (host jobs), report.
+int wait_ticket(gzpx_ctx *ctx, uint64_t ticket, size_t host_out_cap, size_t *out_len, uint32_t *block_sizes,
+                size_t max_blocks, size_t *n_blocks) {
+    const int si = (int)(ticket & 0xFF);
+    if (si >= kSlots) return GZPX_ERR_INVALID_ARG;
+    Slot &sl = ctx->slots[si];
+    {
+        std::lock_guard<std::mutex> lk(ctx->mu);
+        if (sl.state != 1 || sl.gen != (ticket >> 8)) return GZPX_ERR_INVALID_ARG;
+        sl.state = 2;
     }
-    if (out_need > ctx->d_out_cap) {
-        if (ctx->d_out) (void)hipFree(ctx->d_out);
-        ctx->d_out = nullptr;
-        ctx->d_out_cap = 0;
-        const size_t cap = out_need + out_need / 8 + 4096;
-        HIP_TRY(hipMalloc((void **)&ctx->d_out, cap));
-        ctx->d_out_cap = cap;
+    int rc = GZPX_OK;
+    size_t produced = 0, blocks_done = (size_t)sl.total_nb;
+    if (hipSetDevice(ctx->cfg.device) != hipSuccess || hipEventSynchronize(sl.ev_kernels) != hipSuccess) {
+        rc = GZPX_ERR_DEVICE;
+    } else {
+        for (uint32_t bi = 0; bi < sl.n_batches && rc == GZPX_OK; bi++) {
+            const SlabResult &r = sl.h_results[bi];
+            if (r.fail_block != 0xFFFFFFFFu) {
+                blocks_done = (size_t)bi * ctx->batch_blocks + r.fail_block;
+                rc = r.fail_status == kStatusBlockSizeExceeded ? GZPX_ERR_BLOCK_SIZE_EXCEEDED : GZPX_ERR_DEVICE;
+            }
+        }
+        if (rc == GZPX_OK) {
+            produced = (size_t)sl.h_results[sl.n_batches - 1].total;
+            if (produced > sl.job_out_cap || (sl.host_out && produced > host_out_cap)) rc = GZPX_ERR_INSUFFICIENT_SPACE;
+        }
+        if (rc == GZPX_OK && block_sizes) {
+            if (max_blocks < sl.total_nb) rc = GZPX_ERR_INVALID_ARG;
+            else memcpy(block_sizes, sl.h_sizes, (size_t)sl.total_nb * sizeof(uint32_t));
+        }
+        if (rc == GZPX_OK && sl.host_out && produced) {
+            // the kernels are done (the host has seen their event): the copy needs no stream dependency
+            if (hipMemcpyAsync(sl.host_out, sl.job_d_out, produced, hipMemcpyDeviceToHost, ctx->s_d2h) != hipSuccess ||
+                hipEventRecord(sl.ev_d2h, ctx->s_d2h) != hipSuccess || hipEventSynchronize(sl.ev_d2h) != hipSuccess)
+                rc = GZPX_ERR_DEVICE;
+        }
     }
-    return GZPX_OK;
+    if (out_len) *out_len = rc == GZPX_OK ? produced : 0;
+    if (n_blocks) *n_blocks = blocks_done;
+    {
+        std::lock_guard<std::mutex> lk(ctx->mu);
+        sl.state = 0;
+    }
+    ctx->cv_slot.notify_all();
+    return rc;
 }
+
+int ctx_create(const gzpx_config *cfg, bool crc_only, gzpx_ctx **out);
 
 }  // namespace
 
@@ -310,7 +474,13 @@ void gzpx_config_default(gzpx_config *cfg, int format) {
     cfg->max_slab_bytes = (size_t)1 << 30;
 }
 
-int gzpx_ctx_create(const gzpx_config *cfg, gzpx_ctx **out) {
+int gzpx_ctx_create(const gzpx_config *cfg, gzpx_ctx **out) { return ctx_create(cfg, false, out); }
+
+}  // extern "C"
+
+namespace {
+
+int ctx_create(const gzpx_config *cfg, bool crc_only, gzpx_ctx **out) {
     if (!cfg || !out) return GZPX_ERR_INVALID_ARG;
     *out = nullptr;
     if (cfg->format != GZPX_FORMAT_BGZF && cfg->format != GZPX_FORMAT_MGZIP) return GZPX_ERR_INVALID_ARG;
@@ -328,6 +498,7 @@ int gzpx_ctx_create(const gzpx_config *cfg, gzpx_ctx **out) {
     gzpx_ctx *ctx = new (std::nothrow) gzpx_ctx();
     if (!ctx) return GZPX_ERR_DEVICE;
     ctx->cfg = *cfg;
+    ctx->crc_only = crc_only;
     ctx->dcfg.format = (uint32_t)cfg->format;
     ctx->dcfg.level = (uint32_t)cfg->level;
     ctx->dcfg.compat = (uint32_t)cfg->compat;
@@ -356,13 +527,19 @@ int gzpx_ctx_create(const gzpx_config *cfg, gzpx_ctx **out) {
     }
     const uint64_t want = blocks_of(ctx, cfg->max_slab_bytes ? cfg->max_slab_bytes : 1);
     ctx->batch_blocks = (uint32_t)(want < kMaxBatchBlocks ? want : kMaxBatchBlocks);
-    {
+    if (!crc_only) {
         const size_t fit = kMaxScratchBytes / scratch_bytes_per_block(ctx->dcfg);
         if (ctx->batch_blocks > fit) ctx->batch_blocks = (uint32_t)fit;
     }
     if (ctx->batch_blocks == 0) ctx->batch_blocks = 1;
     int rc = GZPX_OK;
-    if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) rc = GZPX_ERR_DEVICE;
+    if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&ctx->s_h2d, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&ctx->s_d2h, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->ev_dep, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->ev_round[0], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->ev_round[1], hipEventDisableTiming) != hipSuccess)
+        rc = GZPX_ERR_DEVICE;
     if (rc == GZPX_OK) rc = alloc_scratch(ctx);
     if (rc == GZPX_OK) {
         for (int i = 0; i <= GZPX_N_STAGES; i++)
@@ -377,14 +554,25 @@ int gzpx_ctx_create(const gzpx_config *cfg, gzpx_ctx **out) {
     return GZPX_OK;
 }
 
+}  // namespace
+
+extern "C" {
+
 void gzpx_ctx_destroy(gzpx_ctx *ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->cfg.device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->s_h2d) (void)hipStreamSynchronize(ctx->s_h2d);
+    if (ctx->s_d2h) (void)hipStreamSynchronize(ctx->s_d2h);
     free_scratch(ctx);
     if (ctx->events.created)
         for (int i = 0; i <= GZPX_N_STAGES; i++) (void)hipEventDestroy(ctx->events.ev[i]);
+    if (ctx->ev_dep) (void)hipEventDestroy(ctx->ev_dep);
+    for (hipEvent_t e : ctx->ev_round)
+        if (e) (void)hipEventDestroy(e);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    if (ctx->s_h2d) (void)hipStreamDestroy(ctx->s_h2d);
+    if (ctx->s_d2h) (void)hipStreamDestroy(ctx->s_d2h);
     delete ctx;
 }
 
@@ -393,36 +581,79 @@ size_t gzpx_slab_bound(const gzpx_ctx *ctx, size_t in_len) {
     return (size_t)blocks_of(ctx, in_len) * framed_bound_per_block(ctx) + 28 + 64;
 }
 
+int gzpx_compress_slab_submit(gzpx_ctx *ctx, const uint8_t *in, size_t in_len, int mode, uint8_t *out,
+                              size_t out_cap, uint64_t *ticket) {
+    if (!ctx || !ticket) return GZPX_ERR_INVALID_ARG;
+    int rc = check_slab_args(ctx, in, in_len, mode, out);
+    if (rc != GZPX_OK) return rc;
+    std::unique_lock<std::mutex> lk(ctx->mu);
+    if (hipSetDevice(ctx->cfg.device) != hipSuccess) return GZPX_ERR_DEVICE;
+    return submit_locked(ctx, in, nullptr, in_len, mode, out, nullptr, out_cap, nullptr, false, lk, ticket);
+}
+
+int gzpx_compress_slab_submit_device(gzpx_ctx *ctx, const void *d_in, size_t in_len, int mode, void *d_out,
+                                     size_t out_cap, void *after_stream, uint64_t *ticket) {
+    if (!ctx || !ticket) return GZPX_ERR_INVALID_ARG;
+    int rc = check_slab_args(ctx, d_in, in_len, mode, d_out);
+    if (rc != GZPX_OK) return rc;
+    std::unique_lock<std::mutex> lk(ctx->mu);
+    if (hipSetDevice(ctx->cfg.device) != hipSuccess) return GZPX_ERR_DEVICE;
+    return submit_locked(ctx, nullptr, (const uint8_t *)d_in, in_len, mode, nullptr, (uint8_t *)d_out, out_cap,
+                         (hipStream_t)after_stream, false, lk, ticket);
+}
+
+int gzpx_compress_slab_wait(gzpx_ctx *ctx, uint64_t ticket, size_t *out_len, uint32_t *block_sizes,
+                            size_t max_blocks, size_t *n_blocks) {
+    if (!ctx) return GZPX_ERR_INVALID_ARG;
+    const int si = (int)(ticket & 0xFF);
+    if (si >= kSlots) return GZPX_ERR_INVALID_ARG;
+    return wait_ticket(ctx, ticket, ctx->slots[si].host_out_cap, out_len, block_sizes, max_blocks, n_blocks);
+}
+
+int gzpx_compress_slab_event(gzpx_ctx *ctx, uint64_t ticket, void **hip_event) {
+    if (!ctx || !hip_event) return GZPX_ERR_INVALID_ARG;
+    const int si = (int)(ticket & 0xFF);
+    if (si >= kSlots) return GZPX_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    Slot &sl = ctx->slots[si];
+    if (sl.state != 1 || sl.gen != (ticket >> 8)) return GZPX_ERR_INVALID_ARG;
+    *hip_event = (void *)sl.ev_kernels;
+    return GZPX_OK;
+}
+
 int gzpx_compress_slab_device(gzpx_ctx *ctx, const void *d_in, size_t in_len, int mode,
                               void *d_out, size_t out_cap, size_t *out_len, uint32_t *block_sizes,
                               size_t max_blocks, size_t *n_blocks, void *hip_stream) {
-    if (!ctx) return GZPX_ERR_INVALID_ARG;
-    std::lock_guard<std::mutex> lock(ctx->mu);
-    if (hipSetDevice(ctx->cfg.device) != hipSuccess) return GZPX_ERR_DEVICE;
-    return compress_device_locked(ctx, (const uint8_t *)d_in, in_len, mode, (uint8_t *)d_out,
-                                  out_cap, out_len, block_sizes, max_blocks, n_blocks,
-                                  (hipStream_t)hip_stream);
+    if (!ctx || !out_len) return GZPX_ERR_INVALID_ARG;
+    int rc = check_slab_args(ctx, d_in, in_len, mode, d_out);
+    if (rc != GZPX_OK) return rc;
+    if (block_sizes && max_blocks < blocks_of(ctx, in_len)) return GZPX_ERR_INVALID_ARG;
+    uint64_t ticket = 0;
+    {
+        std::unique_lock<std::mutex> lk(ctx->mu);
+        if (hipSetDevice(ctx->cfg.device) != hipSuccess) return GZPX_ERR_DEVICE;
+        rc = submit_locked(ctx, nullptr, (const uint8_t *)d_in, in_len, mode, nullptr, (uint8_t *)d_out, out_cap,
+                           (hipStream_t)hip_stream, true, lk, &ticket);
+    }
+    if (rc != GZPX_OK) return rc;
+    return wait_ticket(ctx, ticket, 0, out_len, block_sizes, max_blocks, n_blocks);
 }
 
 int gzpx_compress_slab(gzpx_ctx *ctx, const uint8_t *in, size_t in_len, int mode, uint8_t *out,
                        size_t out_cap, size_t *out_len, uint32_t *block_sizes, size_t max_blocks,
                        size_t *n_blocks) {
-    if (!ctx || (in_len && !in) || !out || !out_len) return GZPX_ERR_INVALID_ARG;
-    std::lock_guard<std::mutex> lock(ctx->mu);
-    if (hipSetDevice(ctx->cfg.device) != hipSuccess) return GZPX_ERR_DEVICE;
-    const size_t need = gzpx_slab_bound(ctx, in_len);
-    int rc = ensure_buffers(ctx, in_len, need);
+    if (!ctx || !out_len) return GZPX_ERR_INVALID_ARG;
+    int rc = check_slab_args(ctx, in, in_len, mode, out);
     if (rc != GZPX_OK) return rc;
-    if (in_len) HIP_TRY(hipMemcpyAsync(ctx->d_in, in, in_len, hipMemcpyHostToDevice, ctx->stream));
-    size_t produced = 0;
-    rc = compress_device_locked(ctx, ctx->d_in, in_len, mode, ctx->d_out, ctx->d_out_cap, &produced,
-                                block_sizes, max_blocks, n_blocks, ctx->stream);
+    if (block_sizes && max_blocks < blocks_of(ctx, in_len)) return GZPX_ERR_INVALID_ARG;
+    uint64_t ticket = 0;
+    {
+        std::unique_lock<std::mutex> lk(ctx->mu);
+        if (hipSetDevice(ctx->cfg.device) != hipSuccess) return GZPX_ERR_DEVICE;
+        rc = submit_locked(ctx, in, nullptr, in_len, mode, out, nullptr, out_cap, nullptr, true, lk, &ticket);
+    }
     if (rc != GZPX_OK) return rc;
-    if (produced > out_cap) return GZPX_ERR_INSUFFICIENT_SPACE;
-    HIP_TRY(hipMemcpyAsync(out, ctx->d_out, produced, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
-    *out_len = produced;
-    return GZPX_OK;
+    return wait_ticket(ctx, ticket, out_cap, out_len, block_sizes, max_blocks, n_blocks);
 }
 
 int gzpx_encode_block(gzpx_ctx *ctx, const uint8_t *in, size_t n, int is_last, uint8_t *out,
@@ -496,11 +727,14 @@ size_t gzpx_deflate_compress(gzpx_compressor *c, const void *in, size_t n, void 
     return payload;
 }
 
-size_t gzpx_deflate_compress_bound(gzpx_compressor *, size_t n) {
-    // libdeflate_deflate_compress_bound: stored blocks of >= 10000 bytes, 5 bytes each, + slack
-    size_t max_blocks = (n + 9999) / 10000;
+size_t gzpx_deflate_compress_bound(gzpx_compressor *c, size_t n) {
+    // libdeflate_deflate_compress_bound: worst case = stored blocks of MIN_BLOCK_LENGTH (5000)
+    // bytes, 5 bytes of header each.  v1.10 (probed on the image's binary) adds 1 + 8 bytes of
+    // slack (OUTPUT_END_PADDING); the pinned v1.24 does not.
+    size_t max_blocks = (n + 4999) / 5000;
     if (max_blocks < 1) max_blocks = 1;
-    return 5 * max_blocks + n + 1 + 8;
+    const size_t slack = (c && c->compat == GZPX_COMPAT_LIBDEFLATE_1_10) ? 9 : 0;
+    return 5 * max_blocks + n + slack;
 }
 
 void gzpx_free_compressor(gzpx_compressor *c) {
@@ -509,10 +743,11 @@ void gzpx_free_compressor(gzpx_compressor *c) {
     delete c;
 }
 
-uint32_t gzpx_crc32(uint32_t crc, const void *buf, size_t n) {
+int gzpx_crc32_checked(uint32_t crc, const void *buf, size_t n, uint32_t *out) {
     // libdeflate_crc32 semantics: crc32(crc, buf) = combine(crc, crc32(0, buf), n)
     static std::mutex mu;
     static gzpx_ctx *ctx = nullptr;
+    if (!out || (!buf && n)) return GZPX_ERR_INVALID_ARG;
     std::lock_guard<std::mutex> lock(mu);
     if (!ctx) {
         gzpx_config cfg;
@@ -520,124 +755,259 @@ uint32_t gzpx_crc32(uint32_t crc, const void *buf, size_t n) {
         cfg.level = 1;
         cfg.buffer_size = kTile;
         cfg.max_slab_bytes = (size_t)64 << 20;
-        if (gzpx_ctx_create(&cfg, &ctx) != GZPX_OK) return 0;
+        const int rc = ctx_create(&cfg, true, &ctx);  // k_init_meta + k_crc32 only: no compressor scratch
+        if (rc != GZPX_OK) return rc;
     }
-    if (n == 0) return crc;
+    *out = crc;
+    if (n == 0) return GZPX_OK;
     std::lock_guard<std::mutex> lock2(ctx->mu);
-    if (hipSetDevice(ctx->cfg.device) != hipSuccess) return 0;
+    if (hipSetDevice(ctx->cfg.device) != hipSuccess) return GZPX_ERR_DEVICE;
+    Slot &sl = ctx->slots[0];  // staging only
     const uint8_t *p = (const uint8_t *)buf;
     const size_t slab_max = (size_t)ctx->batch_blocks * kTile;
     while (n) {
         const size_t take = n < slab_max ? n : slab_max;
-        if (ensure_buffers(ctx, take, 64) != GZPX_OK) return 0;
+        int rc = slot_staging(sl, take, 0);
+        if (rc != GZPX_OK) return rc;
         const uint32_t nb = (uint32_t)((take + kTile - 1) / kTile);
-        if (hipMemcpyAsync(ctx->d_in, p, take, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) return 0;
+        HIP_TRY(hipMemcpyAsync(sl.d_in, p, take, hipMemcpyHostToDevice, ctx->stream));
         launch_init_meta(ctx->dcfg, take, nb, 0, ctx->scratch, ctx->stream);
-        launch_crc32(ctx->dcfg, ctx->d_in, take, nb, ctx->scratch, ctx->crc_consts, ctx->stream);
-        if (hipMemcpyAsync(ctx->h_meta, ctx->scratch.meta, nb * sizeof(BlockMeta), hipMemcpyDeviceToHost,
-                           ctx->stream) != hipSuccess)
-            return 0;
-        if (hipStreamSynchronize(ctx->stream) != hipSuccess) return 0;
-        for (uint32_t b = 0; b < nb; b++)
-            crc = crc32_combine(crc, ctx->h_meta[b].crc, ctx->h_meta[b].n);
+        launch_crc32(ctx->dcfg, sl.d_in, take, nb, ctx->scratch, ctx->crc_consts, ctx->stream);
+        HIP_TRY(hipMemcpyAsync(ctx->h_meta, ctx->scratch.meta, nb * sizeof(BlockMeta), hipMemcpyDeviceToHost,
+                               ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        for (uint32_t b = 0; b < nb; b++) crc = crc32_combine(crc, ctx->h_meta[b].crc, ctx->h_meta[b].n);
         p += take;
         n -= take;
     }
-    return crc;
+    *out = crc;
+    return GZPX_OK;
 }
 
+uint32_t gzpx_crc32(uint32_t crc, const void *buf, size_t n) {
+    // libdeflate_crc32's signature has no error channel: a device failure leaves `crc` unchanged
+    // and is reported through gzpx_last_status() (thread-local); gzpx_crc32_checked returns it.
+    uint32_t out = crc;
+    t_last_status = gzpx_crc32_checked(crc, buf, n, &out);
+    return t_last_status == GZPX_OK ? out : crc;
+}
+
+int gzpx_last_status(void) { return t_last_status; }
+
 // ---------------------------------------------------------------- ParDecompress side
-struct gzpx_dctx {
-    int device = 0;
-    int format = 0;
-    CrcConsts cc;
-    hipStream_t stream = nullptr;
+namespace {
+
+// One slab of blocks being inflated.  Everything a slab needs lives in its slot (block tables,
+// staging), so up to kSlots slabs are in flight: copy-in of one, kernels of another, copy-out of
+// a third, each on its own stream.
+struct DSlot {
+    int state = 0;  // 0 free, 1 submitted, 2 a thread is inside wait()
+    uint64_t gen = 0;
     size_t cap_blocks = 0;
     uint64_t *d_offsets = nullptr, *d_out_off = nullptr;
     uint32_t *d_sizes = nullptr, *d_crc = nullptr;
     DBlockHost *d_blk = nullptr;
-    DBlockHost *h_blk = nullptr;
-    uint32_t *h_crc = nullptr;
-    uint64_t *h_total = nullptr;
+    DBlockHost *h_blk = nullptr;  // pinned
+    uint32_t *h_crc = nullptr;    // pinned
+    uint64_t *h_offsets = nullptr;  // pinned copies of the caller's arrays (the caller's may be pageable
+    uint32_t *h_sizes = nullptr;    //  and must not be referenced after submit returns)
+    uint64_t *h_total = nullptr;  // pinned
     uint8_t *d_in = nullptr, *d_out = nullptr;
     size_t d_in_cap = 0, d_out_cap = 0;
+    hipEvent_t ev_h2d = nullptr, ev_kernels = nullptr, ev_done = nullptr;
+    hipEvent_t ev_t0 = nullptr, ev_t1 = nullptr;  // around k_inflate (timing enabled)
+    size_t nb = 0;
+};
+
+void dslot_free_tables(DSlot &c) {
+    if (c.d_offsets) (void)hipFree(c.d_offsets);
+    if (c.d_out_off) (void)hipFree(c.d_out_off);
+    if (c.d_sizes) (void)hipFree(c.d_sizes);
+    if (c.d_crc) (void)hipFree(c.d_crc);
+    if (c.d_blk) (void)hipFree(c.d_blk);
+    if (c.h_blk) (void)hipHostFree(c.h_blk);
+    if (c.h_crc) (void)hipHostFree(c.h_crc);
+    if (c.h_offsets) (void)hipHostFree(c.h_offsets);
+    if (c.h_sizes) (void)hipHostFree(c.h_sizes);
+    c.d_offsets = c.d_out_off = nullptr;
+    c.d_sizes = c.d_crc = nullptr;
+    c.d_blk = c.h_blk = nullptr;
+    c.h_crc = c.h_sizes = nullptr;
+    c.h_offsets = nullptr;
+    c.cap_blocks = 0;
+}
+
+int dslot_reserve(DSlot &c, size_t nb) {
+    if (!c.ev_kernels) {
+        HIP_TRY(hipEventCreateWithFlags(&c.ev_h2d, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&c.ev_kernels, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&c.ev_done, hipEventDisableTiming));
+        HIP_TRY(hipEventCreate(&c.ev_t0));
+        HIP_TRY(hipEventCreate(&c.ev_t1));
+        HIP_TRY(hipHostMalloc((void **)&c.h_total, 64, hipHostMallocDefault));
+    }
+    if (nb <= c.cap_blocks) return GZPX_OK;
+    dslot_free_tables(c);
+    const size_t cap = nb + nb / 4 + 64;
+    HIP_TRY(hipMalloc((void **)&c.d_offsets, cap * 8));
+    HIP_TRY(hipMalloc((void **)&c.d_out_off, (cap + 1) * 8));
+    HIP_TRY(hipMalloc((void **)&c.d_sizes, cap * 4));
+    HIP_TRY(hipMalloc((void **)&c.d_crc, cap * 4));
+    HIP_TRY(hipMalloc((void **)&c.d_blk, cap * sizeof(DBlockHost)));
+    HIP_TRY(hipHostMalloc((void **)&c.h_blk, cap * sizeof(DBlockHost), hipHostMallocDefault));
+    HIP_TRY(hipHostMalloc((void **)&c.h_crc, cap * 4, hipHostMallocDefault));
+    HIP_TRY(hipHostMalloc((void **)&c.h_offsets, cap * 8, hipHostMallocDefault));
+    HIP_TRY(hipHostMalloc((void **)&c.h_sizes, cap * 4, hipHostMallocDefault));
+    c.cap_blocks = cap;
+    return GZPX_OK;
+}
+
+}  // namespace
+
+struct gzpx_dctx {
+    int device = 0;
+    int format = 0;
+    CrcConsts cc;
+    hipStream_t stream = nullptr, s_h2d = nullptr, s_d2h = nullptr;
+    hipEvent_t ev_dep = nullptr;
+    DSlot slots[kSlots];
+    uint64_t next_gen = 1;
     bool debug = false;
+    int last_slot = -1;  // the slot of the last completed launch (timing / debug counters)
     size_t last_nb = 0;
-    hipEvent_t ev[2] = {nullptr, nullptr};  // around k_inflate of the last launch
     std::mutex mu;
+    std::condition_variable cv_slot;
 };
 
 namespace {
 
-void dctx_free_tables(gzpx_dctx *c) {
-    if (c->d_offsets) (void)hipFree(c->d_offsets);
-    if (c->d_out_off) (void)hipFree(c->d_out_off);
-    if (c->d_sizes) (void)hipFree(c->d_sizes);
-    if (c->d_crc) (void)hipFree(c->d_crc);
-    if (c->d_blk) (void)hipFree(c->d_blk);
-    if (c->h_blk) (void)hipHostFree(c->h_blk);
-    if (c->h_crc) (void)hipHostFree(c->h_crc);
-    c->d_offsets = c->d_out_off = nullptr;
-    c->d_sizes = c->d_crc = nullptr;
-    c->d_blk = c->h_blk = nullptr;
-    c->h_crc = nullptr;
-    c->cap_blocks = 0;
-}
-
-int dctx_reserve(gzpx_dctx *c, size_t nb) {
-    if (nb <= c->cap_blocks) return GZPX_OK;
-    dctx_free_tables(c);
-    const size_t cap = nb + nb / 4 + 64;
-    HIP_TRY(hipMalloc((void **)&c->d_offsets, cap * 8));
-    HIP_TRY(hipMalloc((void **)&c->d_out_off, (cap + 1) * 8));
-    HIP_TRY(hipMalloc((void **)&c->d_sizes, cap * 4));
-    HIP_TRY(hipMalloc((void **)&c->d_crc, cap * 4));
-    HIP_TRY(hipMalloc((void **)&c->d_blk, cap * sizeof(DBlockHost)));
-    HIP_TRY(hipHostMalloc((void **)&c->h_blk, cap * sizeof(DBlockHost), hipHostMallocDefault));
-    HIP_TRY(hipHostMalloc((void **)&c->h_crc, cap * 4, hipHostMallocDefault));
-    c->cap_blocks = cap;
-    return GZPX_OK;
-}
-
-int decompress_device_locked(gzpx_dctx *c, const uint8_t *d_in, size_t in_len, const uint64_t *offsets,
-                             const uint32_t *sizes, size_t nb, uint8_t *d_out, size_t out_cap,
-                             size_t *out_len, gzpx_check_info *info, hipStream_t stream) {
-    if (!out_len || (nb && (!offsets || !sizes || !d_in))) return GZPX_ERR_INVALID_ARG;
-    *out_len = 0;
-    if (nb == 0) return GZPX_OK;
+int dsubmit_locked(gzpx_dctx *c, const uint8_t *host_in, const uint8_t *d_in, size_t in_len,
+                   const uint64_t *offsets, const uint32_t *sizes, size_t nb, uint8_t *host_out, uint8_t *d_out,
+                   size_t out_cap, hipStream_t after, bool block_for_slot, std::unique_lock<std::mutex> &lk,
+                   uint64_t *ticket) {
+    if (nb && (!offsets || !sizes || (!host_in && !d_in))) return GZPX_ERR_INVALID_ARG;
+    if (nb > 0xFFFFFFFFull) return GZPX_ERR_INVALID_ARG;
     const uint32_t hdr_len = c->format == GZPX_FORMAT_BGZF ? 18 : 20;
     for (size_t b = 0; b < nb; b++)
-        if (sizes[b] < hdr_len + 8 || offsets[b] + sizes[b] > in_len) return GZPX_ERR_INVALID_ARG;
-    int rc = dctx_reserve(c, nb);
-    if (rc != GZPX_OK) return rc;
-    if (!stream) stream = c->stream;
-    HIP_TRY(hipMemcpyAsync(c->d_offsets, offsets, nb * 8, hipMemcpyHostToDevice, stream));
-    HIP_TRY(hipMemcpyAsync(c->d_sizes, sizes, nb * 4, hipMemcpyHostToDevice, stream));
-    launch_inflate(hdr_len, d_in, c->d_offsets, c->d_sizes, (uint32_t)nb, c->d_blk, c->d_out_off, d_out, out_cap,
-                   c->d_crc, c->cc, c->debug, c->ev[0], c->ev[1], stream);
-    c->last_nb = nb;
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpyAsync(c->h_blk, c->d_blk, nb * sizeof(DBlockHost), hipMemcpyDeviceToHost, stream));
-    HIP_TRY(hipMemcpyAsync(c->h_crc, c->d_crc, nb * 4, hipMemcpyDeviceToHost, stream));
-    HIP_TRY(hipMemcpyAsync(c->h_total, c->d_out_off + nb, 8, hipMemcpyDeviceToHost, stream));
-    HIP_TRY(hipStreamSynchronize(stream));
-    for (size_t b = 0; b < nb; b++) {  // first failing block, in stream order (src/par/decompress.rs:162-186)
-        const DBlockHost &d = c->h_blk[b];
-        int err = GZPX_OK;
-        if (d.status == 1) err = GZPX_ERR_BAD_DATA;
-        else if (d.status == 2) err = GZPX_ERR_INSUFFICIENT_SPACE;
-        else if (c->h_crc[b] != d.crc) err = GZPX_ERR_INVALID_CHECK;
-        if (err != GZPX_OK) {
-            if (info) {
-                info->block = b;
-                info->found = c->h_crc[b];
-                info->expected = d.crc;
+        if (sizes[b] < hdr_len + 8 || offsets[b] > in_len || sizes[b] > in_len - offsets[b]) return GZPX_ERR_INVALID_ARG;
+    int si = -1;
+    for (;;) {
+        for (int i = 0; i < kSlots; i++)
+            if (c->slots[i].state == 0) {
+                si = i;
+                break;
             }
-            return err;
+        if (si >= 0) break;
+        if (!block_for_slot) return GZPX_ERR_BUSY;
+        c->cv_slot.wait(lk);
+    }
+    DSlot &sl = c->slots[si];
+    int rc = dslot_reserve(sl, nb ? nb : 1);
+    if (rc != GZPX_OK) return rc;
+    sl.nb = nb;
+    hipStream_t stream = c->stream;
+    if (nb) {
+        if (host_in) {  // staging
+            if (in_len + 16 > sl.d_in_cap) {
+                if (sl.d_in) (void)hipFree(sl.d_in);
+                sl.d_in = nullptr;
+                sl.d_in_cap = 0;
+                HIP_TRY(hipMalloc((void **)&sl.d_in, in_len + in_len / 8 + 4096));
+                sl.d_in_cap = in_len + in_len / 8 + 4096;
+            }
+            if (out_cap + 16 > sl.d_out_cap) {
+                if (sl.d_out) (void)hipFree(sl.d_out);
+                sl.d_out = nullptr;
+                sl.d_out_cap = 0;
+                HIP_TRY(hipMalloc((void **)&sl.d_out, out_cap + out_cap / 8 + 4096));
+                sl.d_out_cap = out_cap + out_cap / 8 + 4096;
+            }
+            HIP_TRY(hipMemcpyAsync(sl.d_in, host_in, in_len, hipMemcpyHostToDevice, c->s_h2d));
+            d_in = sl.d_in;
+            d_out = sl.d_out;
+        } else if (after && after != stream) {
+            HIP_TRY(hipEventRecord(c->ev_dep, after));
+            HIP_TRY(hipStreamWaitEvent(stream, c->ev_dep, 0));
+        }
+        memcpy(sl.h_offsets, offsets, nb * 8);
+        memcpy(sl.h_sizes, sizes, nb * 4);
+        HIP_TRY(hipMemcpyAsync(sl.d_offsets, sl.h_offsets, nb * 8, hipMemcpyHostToDevice, c->s_h2d));
+        HIP_TRY(hipMemcpyAsync(sl.d_sizes, sl.h_sizes, nb * 4, hipMemcpyHostToDevice, c->s_h2d));
+        HIP_TRY(hipEventRecord(sl.ev_h2d, c->s_h2d));
+        HIP_TRY(hipStreamWaitEvent(stream, sl.ev_h2d, 0));
+        launch_inflate(hdr_len, d_in, sl.d_offsets, sl.d_sizes, (uint32_t)nb, sl.d_blk, sl.d_out_off, d_out, out_cap,
+                       sl.d_crc, c->cc, c->debug, sl.ev_t0, sl.ev_t1, stream);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(sl.h_blk, sl.d_blk, nb * sizeof(DBlockHost), hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipMemcpyAsync(sl.h_crc, sl.d_crc, nb * 4, hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipMemcpyAsync(sl.h_total, sl.d_out_off + nb, 8, hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipEventRecord(sl.ev_kernels, stream));
+        if (host_out) {
+            // Blocks land back to back from offset 0 and their sizes are the footers' ISIZE fields,
+            // so the bytes to bring back are known now: the copy-out is enqueued behind the kernels
+            // and needs no host round trip.
+            uint64_t total = 0;
+            for (size_t b = 0; b < nb; b++) {
+                const uint8_t *f = host_in + offsets[b] + sizes[b] - 4;
+                total += (uint64_t)f[0] | ((uint64_t)f[1] << 8) | ((uint64_t)f[2] << 16) | ((uint64_t)f[3] << 24);
+            }
+            if (total > out_cap) total = out_cap;  // (the kernels flag the blocks that do not fit)
+            HIP_TRY(hipStreamWaitEvent(c->s_d2h, sl.ev_kernels, 0));
+            if (total) HIP_TRY(hipMemcpyAsync(host_out, sl.d_out, (size_t)total, hipMemcpyDeviceToHost, c->s_d2h));
+            HIP_TRY(hipEventRecord(sl.ev_done, c->s_d2h));
+        } else {
+            HIP_TRY(hipEventRecord(sl.ev_done, stream));
         }
     }
-    *out_len = (size_t)*c->h_total;
+    sl.state = 1;
+    sl.gen = c->next_gen++;
+    *ticket = (sl.gen << 8) | (uint64_t)si;
     return GZPX_OK;
+}
+
+int dwait_ticket(gzpx_dctx *c, uint64_t ticket, size_t *out_len, gzpx_check_info *info) {
+    const int si = (int)(ticket & 0xFF);
+    if (si >= kSlots) return GZPX_ERR_INVALID_ARG;
+    DSlot &sl = c->slots[si];
+    {
+        std::lock_guard<std::mutex> lk(c->mu);
+        if (sl.state != 1 || sl.gen != (ticket >> 8)) return GZPX_ERR_INVALID_ARG;
+        sl.state = 2;
+    }
+    int rc = GZPX_OK;
+    size_t produced = 0;
+    if (sl.nb) {
+        if (hipSetDevice(c->device) != hipSuccess || hipEventSynchronize(sl.ev_done) != hipSuccess) {
+            rc = GZPX_ERR_DEVICE;
+        } else {
+            for (size_t b = 0; b < sl.nb; b++) {  // first failing block, in stream order (src/par/decompress.rs:162-186)
+                const DBlockHost &d = sl.h_blk[b];
+                int err = GZPX_OK;
+                if (d.status == 1) err = GZPX_ERR_BAD_DATA;
+                else if (d.status == 2) err = GZPX_ERR_INSUFFICIENT_SPACE;
+                else if (sl.h_crc[b] != d.crc) err = GZPX_ERR_INVALID_CHECK;
+                if (err != GZPX_OK) {
+                    if (info) {
+                        info->block = b;
+                        info->found = sl.h_crc[b];
+                        info->expected = d.crc;
+                    }
+                    rc = err;
+                    break;
+                }
+            }
+            if (rc == GZPX_OK) produced = (size_t)*sl.h_total;
+        }
+    }
+    if (out_len) *out_len = produced;
+    {
+        std::lock_guard<std::mutex> lk(c->mu);
+        sl.state = 0;
+        c->last_slot = si;
+        c->last_nb = sl.nb;
+    }
+    c->cv_slot.notify_all();
+    return rc;
 }
 
 }  // namespace
@@ -658,8 +1028,9 @@ int gzpx_dctx_create(int device, int format, gzpx_dctx **out) {
     for (unsigned l = 0; l < 10; l++) c->cc.pow64[l] = x2k(9 + l);
     c->cc.pow_tile = x2k(19);
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
-        hipEventCreate(&c->ev[0]) != hipSuccess || hipEventCreate(&c->ev[1]) != hipSuccess ||
-        hipHostMalloc((void **)&c->h_total, 64, hipHostMallocDefault) != hipSuccess) {
+        hipStreamCreateWithFlags(&c->s_h2d, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&c->s_d2h, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_dep, hipEventDisableTiming) != hipSuccess) {
         gzpx_dctx_destroy(c);
         return GZPX_ERR_DEVICE;
     }
@@ -671,13 +1042,20 @@ void gzpx_dctx_destroy(gzpx_dctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    dctx_free_tables(c);
-    if (c->h_total) (void)hipHostFree(c->h_total);
-    if (c->d_in) (void)hipFree(c->d_in);
-    if (c->d_out) (void)hipFree(c->d_out);
-    if (c->ev[0]) (void)hipEventDestroy(c->ev[0]);
-    if (c->ev[1]) (void)hipEventDestroy(c->ev[1]);
+    if (c->s_h2d) (void)hipStreamSynchronize(c->s_h2d);
+    if (c->s_d2h) (void)hipStreamSynchronize(c->s_d2h);
+    for (DSlot &sl : c->slots) {
+        dslot_free_tables(sl);
+        if (sl.h_total) (void)hipHostFree(sl.h_total);
+        if (sl.d_in) (void)hipFree(sl.d_in);
+        if (sl.d_out) (void)hipFree(sl.d_out);
+        for (hipEvent_t e : {sl.ev_h2d, sl.ev_kernels, sl.ev_done, sl.ev_t0, sl.ev_t1})
+            if (e) (void)hipEventDestroy(e);
+    }
+    if (c->ev_dep) (void)hipEventDestroy(c->ev_dep);
     if (c->stream) (void)hipStreamDestroy(c->stream);
+    if (c->s_h2d) (void)hipStreamDestroy(c->s_h2d);
+    if (c->s_d2h) (void)hipStreamDestroy(c->s_d2h);
     delete c;
 }
 
@@ -711,45 +1089,56 @@ int gzpx_scan_blocks(int format, const uint8_t *in, size_t in_len, uint64_t *off
     return GZPX_OK;
 }
 
+int gzpx_decompress_blocks_submit(gzpx_dctx *c, const uint8_t *in, size_t in_len, const uint64_t *offsets,
+                                  const uint32_t *sizes, size_t n_blocks, uint8_t *out, size_t out_cap,
+                                  uint64_t *ticket) {
+    if (!c || (!in && in_len) || (!out && out_cap) || !ticket) return GZPX_ERR_INVALID_ARG;
+    std::unique_lock<std::mutex> lk(c->mu);
+    if (hipSetDevice(c->device) != hipSuccess) return GZPX_ERR_DEVICE;
+    return dsubmit_locked(c, in, nullptr, in_len, offsets, sizes, n_blocks, out, nullptr, out_cap, nullptr, false,
+                          lk, ticket);
+}
+
+int gzpx_decompress_blocks_wait(gzpx_dctx *c, uint64_t ticket, size_t *out_len, gzpx_check_info *info) {
+    if (!c) return GZPX_ERR_INVALID_ARG;
+    return dwait_ticket(c, ticket, out_len, info);
+}
+
 int gzpx_decompress_blocks_device(gzpx_dctx *c, const void *d_in, size_t in_len, const uint64_t *offsets,
                                   const uint32_t *sizes, size_t n_blocks, void *d_out, size_t out_cap,
                                   size_t *out_len, gzpx_check_info *info, void *hip_stream) {
-    if (!c) return GZPX_ERR_INVALID_ARG;
-    std::lock_guard<std::mutex> lock(c->mu);
-    if (hipSetDevice(c->device) != hipSuccess) return GZPX_ERR_DEVICE;
-    return decompress_device_locked(c, (const uint8_t *)d_in, in_len, offsets, sizes, n_blocks, (uint8_t *)d_out,
-                                    out_cap, out_len, info, (hipStream_t)hip_stream);
+    if (!c || !out_len) return GZPX_ERR_INVALID_ARG;
+    *out_len = 0;
+    if (n_blocks == 0) return GZPX_OK;
+    uint64_t ticket = 0;
+    int rc;
+    {
+        std::unique_lock<std::mutex> lk(c->mu);
+        if (hipSetDevice(c->device) != hipSuccess) return GZPX_ERR_DEVICE;
+        rc = dsubmit_locked(c, nullptr, (const uint8_t *)d_in, in_len, offsets, sizes, n_blocks, nullptr,
+                            (uint8_t *)d_out, out_cap, (hipStream_t)hip_stream, true, lk, &ticket);
+    }
+    if (rc != GZPX_OK) return rc;
+    return dwait_ticket(c, ticket, out_len, info);
 }
 
 int gzpx_decompress_blocks(gzpx_dctx *c, const uint8_t *in, size_t in_len, const uint64_t *offsets,
                            const uint32_t *sizes, size_t n_blocks, uint8_t *out, size_t out_cap,
                            size_t *out_len, gzpx_check_info *info) {
     if (!c || (!in && in_len) || (!out && out_cap) || !out_len) return GZPX_ERR_INVALID_ARG;
-    std::lock_guard<std::mutex> lock(c->mu);
-    if (hipSetDevice(c->device) != hipSuccess) return GZPX_ERR_DEVICE;
-    if (in_len + 16 > c->d_in_cap) {
-        if (c->d_in) (void)hipFree(c->d_in);
-        c->d_in = nullptr;
-        c->d_in_cap = 0;
-        HIP_TRY(hipMalloc((void **)&c->d_in, in_len + in_len / 8 + 4096));
-        c->d_in_cap = in_len + in_len / 8 + 4096;
+    *out_len = 0;
+    if (n_blocks == 0) return GZPX_OK;
+    uint64_t ticket = 0;
+    int rc;
+    {
+        std::unique_lock<std::mutex> lk(c->mu);
+        if (hipSetDevice(c->device) != hipSuccess) return GZPX_ERR_DEVICE;
+        uint8_t dummy = 0;
+        rc = dsubmit_locked(c, in, nullptr, in_len, offsets, sizes, n_blocks, out ? out : &dummy, nullptr, out_cap,
+                            nullptr, true, lk, &ticket);
     }
-    if (out_cap + 16 > c->d_out_cap) {
-        if (c->d_out) (void)hipFree(c->d_out);
-        c->d_out = nullptr;
-        c->d_out_cap = 0;
-        HIP_TRY(hipMalloc((void **)&c->d_out, out_cap + out_cap / 8 + 4096));
-        c->d_out_cap = out_cap + out_cap / 8 + 4096;
-    }
-    if (in_len) HIP_TRY(hipMemcpyAsync(c->d_in, in, in_len, hipMemcpyHostToDevice, c->stream));
-    size_t produced = 0;
-    const int rc = decompress_device_locked(c, c->d_in, in_len, offsets, sizes, n_blocks, c->d_out, out_cap,
-                                            &produced, info, c->stream);
     if (rc != GZPX_OK) return rc;
-    if (produced) HIP_TRY(hipMemcpyAsync(out, c->d_out, produced, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    *out_len = produced;
-    return GZPX_OK;
+    return dwait_ticket(c, ticket, out_len, info);
 }
 
 struct gzpx_decompressor {
@@ -765,36 +1154,49 @@ gzpx_decompressor *gzpx_alloc_decompressor(void) {
 
 int gzpx_deflate_decompress(gzpx_decompressor *d, const void *in, size_t n, void *out, size_t cap, size_t *actual) {
     if (!d || (!in && n) || (!out && cap)) return GZPX_ERR_INVALID_ARG;
+    if (cap > 0xFFFFFFFFull || n > 0xFFFFFFFFull - 64) return GZPX_ERR_UNSUPPORTED;  // one member: 32-bit sizes
     if (!d->ctx) {
         const int rc = gzpx_dctx_create(0, GZPX_FORMAT_MGZIP, &d->ctx);
         if (rc != GZPX_OK) return rc;
     }
     // the kernels work on framed members: wrap the raw stream with a header and a footer whose
-    // ISIZE is the caller's capacity (libdeflate semantics: at most `cap` bytes may come out)
+    // ISIZE is the caller's capacity (libdeflate semantics: at most `cap` bytes may come out).  With
+    // cap == 0 one byte of room is offered, so that a stream with output is told apart from an
+    // empty one (libdeflate: INSUFFICIENT_SPACE).
+    const size_t room = cap ? cap : 1;
     d->framed.assign(20 + n + 8, 0);
     memcpy(d->framed.data() + 20, in, n);
     uint8_t *f = d->framed.data() + 20 + n;
-    const uint32_t isz = (uint32_t)cap;
+    const uint32_t isz = (uint32_t)room;
     f[4] = (uint8_t)isz;
     f[5] = (uint8_t)(isz >> 8);
     f[6] = (uint8_t)(isz >> 16);
     f[7] = (uint8_t)(isz >> 24);
     const uint64_t off = 0;
     const uint32_t size = (uint32_t)d->framed.size();
-    std::vector<uint8_t> tmp(cap ? cap : 1);
-    size_t produced = 0;
-    gzpx_check_info info = {0, 0, 0};
+    std::vector<uint8_t> tmp(room);
     gzpx_dctx *c = d->ctx;
-    int rc = gzpx_decompress_blocks(c, d->framed.data(), d->framed.size(), &off, &size, 1, tmp.data(), cap,
-                                    &produced, &info);
+    uint64_t ticket = 0;
+    int rc;
+    size_t got = 0;
+    {
+        std::unique_lock<std::mutex> lk(c->mu);
+        if (hipSetDevice(c->device) != hipSuccess) return GZPX_ERR_DEVICE;
+        rc = dsubmit_locked(c, d->framed.data(), nullptr, d->framed.size(), &off, &size, 1, tmp.data(), nullptr, room,
+                            nullptr, true, lk, &ticket);
+    }
+    if (rc != GZPX_OK) return rc;
+    const DSlot &sl = c->slots[ticket & 0xFF];
+    gzpx_check_info info = {0, 0, 0};
+    rc = dwait_ticket(c, ticket, nullptr, &info);
     if (rc == GZPX_ERR_INVALID_CHECK) rc = GZPX_OK;  // a raw stream carries no checksum
     if (rc != GZPX_OK) return rc;
-    const size_t got = cap ? c->h_blk[0].produced : 0;
-    if (cap) {
-        // on the InvalidCheck path nothing was copied back: fetch the bytes now
-        if (hipMemcpy(tmp.data(), c->d_out, got, hipMemcpyDeviceToHost) != hipSuccess) return GZPX_ERR_DEVICE;
-        memcpy(out, tmp.data(), got);
+    {
+        std::lock_guard<std::mutex> lk(c->mu);  // (this handle is single-threaded like libdeflate's: the
+        got = sl.h_blk[0].produced;             //  slot has not been reused since the wait)
     }
+    if (got > cap) return GZPX_ERR_INSUFFICIENT_SPACE;  // cap == 0 and the stream has output
+    if (got) memcpy(out, tmp.data(), got);
     if (actual) *actual = got;
     return GZPX_OK;
 }
@@ -828,16 +1230,18 @@ const char *gzpx_stage_name(int stage) {
 
 int gzpx_debug_tokens(gzpx_ctx *ctx, size_t block, uint32_t *tokens, size_t max_tokens,
                       size_t *n_tokens, uint32_t *sub_first_token, size_t *n_sub) {
-    if (!ctx || !n_tokens || block >= ctx->last_nb) return GZPX_ERR_INVALID_ARG;
+    if (!ctx || !n_tokens || block >= ctx->last_nb || ctx->crc_only) return GZPX_ERR_INVALID_ARG;
     std::lock_guard<std::mutex> lock(ctx->mu);
     if (hipSetDevice(ctx->cfg.device) != hipSuccess) return GZPX_ERR_DEVICE;
-    const BlockMeta &m = ctx->h_meta[block];
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    HIP_TRY(hipMemcpy(ctx->h_meta, ctx->scratch.meta + block, sizeof(BlockMeta), hipMemcpyDeviceToHost));
+    const BlockMeta m = ctx->h_meta[0];
     const uint32_t max_sub = ctx->dcfg.max_sub;
     *n_tokens = m.ntok;
     if (n_sub) *n_sub = m.nsub;
     if (sub_first_token && m.nsub) {
         HIP_TRY(hipMemcpy(ctx->h_sub, ctx->scratch.sub + block * (size_t)max_sub,
-                          (size_t)m.nsub * sizeof(SubMeta), hipMemcpyDeviceToHost));
+                          (size_t)(m.nsub < max_sub ? m.nsub : max_sub) * sizeof(SubMeta), hipMemcpyDeviceToHost));
         for (uint32_t s = 0; s < m.nsub && s < max_sub; s++) sub_first_token[s] = ctx->h_sub[s].tok_begin;
     }
     const size_t ncopy = m.ntok < max_tokens ? m.ntok : max_tokens;
@@ -850,14 +1254,6 @@ int gzpx_debug_tokens(gzpx_ctx *ctx, size_t block, uint32_t *tokens, size_t max_
 int gzpx_debug_set_flags(gzpx_ctx *ctx, uint32_t flags) {
     if (!ctx) return GZPX_ERR_INVALID_ARG;
     ctx->dcfg.debug = flags;
-    return GZPX_OK;
-}
-
-int gzpx_debug_phase_cycles(const gzpx_ctx *ctx, uint64_t cycles[8]) {
-    if (!ctx || !cycles) return GZPX_ERR_INVALID_ARG;
-    for (int k = 0; k < 8; k++) cycles[k] = 0;
-    for (uint32_t b = 0; b < ctx->last_nb; b++)
-        for (int k = 0; k < 8; k++) cycles[k] += ctx->h_meta[b].phase_cycles[k];
     return GZPX_OK;
 }
 
@@ -875,8 +1271,9 @@ int gzpx_dctx_last_inflate_ms(gzpx_dctx *ctx, float *ms) {
     if (!ctx || !ms) return GZPX_ERR_INVALID_ARG;
     std::lock_guard<std::mutex> g(ctx->mu);
     *ms = 0.0f;
-    if (!ctx->last_nb) return GZPX_OK;
-    return hipEventElapsedTime(ms, ctx->ev[0], ctx->ev[1]) == hipSuccess ? GZPX_OK : GZPX_ERR_DEVICE;
+    if (!ctx->last_nb || ctx->last_slot < 0) return GZPX_OK;
+    const DSlot &sl = ctx->slots[ctx->last_slot];
+    return hipEventElapsedTime(ms, sl.ev_t0, sl.ev_t1) == hipSuccess ? GZPX_OK : GZPX_ERR_DEVICE;
 }
 
 int gzpx_debug_inflate(gzpx_dctx *ctx, int enable, uint64_t sums[8]) {
@@ -885,17 +1282,10 @@ int gzpx_debug_inflate(gzpx_dctx *ctx, int enable, uint64_t sums[8]) {
     ctx->debug = enable != 0;
     if (sums) {
         for (int k = 0; k < 8; k++) sums[k] = 0;
-        for (size_t b = 0; b < ctx->last_nb; b++)
-            for (int k = 0; k < 8; k++) sums[k] += ctx->h_blk[b].cyc[k];
+        if (ctx->last_slot >= 0)
+            for (size_t b = 0; b < ctx->last_nb; b++)
+                for (int k = 0; k < 8; k++) sums[k] += ctx->slots[ctx->last_slot].h_blk[b].cyc[k];
     }
-    return GZPX_OK;
-}
-
-int gzpx_debug_cand_cycles(const gzpx_ctx *ctx, uint64_t cycles[4]) {
-    if (!ctx || !cycles) return GZPX_ERR_INVALID_ARG;
-    for (int k = 0; k < 4; k++) cycles[k] = 0;
-    for (uint32_t b = 0; b < ctx->last_nb; b++)
-        for (int k = 0; k < 4; k++) cycles[k] += ctx->h_meta[b].cand_cycles[k];
     return GZPX_OK;
 }
 
@@ -916,6 +1306,7 @@ const char *gzpx_strerror(int code) {
         case GZPX_ERR_INVALID_HEADER: return "invalid block header (GzpError::InvalidHeader)";
         case GZPX_ERR_INVALID_CHECK: return "checksum mismatch (GzpError::InvalidCheck)";
         case GZPX_ERR_BAD_DATA: return "invalid DEFLATE stream (GzpError::LibDelfaterDecompress(BadData))";
+        case GZPX_ERR_BUSY: return "every slab slot of the context is in flight: wait for one first";
         default: return "unknown error";
     }
 }

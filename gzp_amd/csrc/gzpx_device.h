@@ -49,9 +49,14 @@ struct BlockMeta {
     uint32_t framed_bytes;   // header + c + footer (+ EOF)
     uint32_t crc;
     uint32_t status;
-    uint32_t phase_cycles[8];  // k_match [0,1] / k_parse [2..5]: shader-clock cycles per phase, [6] parse rounds
     uint32_t cand_redo;        // k_candidates' LDS-order check failed: redo with k_candidates_safe
-    uint32_t cand_cycles[4];   // k_candidates: shader-clock cycles [-, -, -, main loop total]
+};
+
+// What the host needs back from one batch (written by k_scan): 16 bytes instead of every BlockMeta.
+struct SlabResult {
+    uint64_t total;        // framed bytes of the slab up to and including this batch
+    uint32_t fail_block;   // first block whose status is not kStatusOk, 0xFFFFFFFF = none
+    uint32_t fail_status;  // that block's BlockStatus
 };
 
 // Levels 2-4: per-block parse state carried between tiles and between match/parse rounds (a
@@ -102,6 +107,7 @@ struct Scratch {
     uint32_t *codes;      // [nb][max_sub][kCodeWords]
     uint32_t *hdr;        // [nb][max_sub][kHdrWords]
     uint64_t *out_off;    // [nb + 1] byte offset of each framed block in the output
+    uint32_t *sizes;      // [nb]     framed size of each block (compact copy for the host / the index)
 };
 
 // Host-side launchers (gzpx_kernels.hip).  All asynchronous on `stream`.
@@ -119,7 +125,7 @@ void launch_hist(const Config &cfg, uint32_t nb, const Scratch &s, hipStream_t s
 void launch_huffman(const Config &cfg, uint32_t nb, const Scratch &s, hipStream_t stream);
 void launch_crc32(const Config &cfg, const uint8_t *slab, uint64_t slab_len, uint32_t nb,
                   const Scratch &s, const CrcConsts &cc, hipStream_t stream);
-void launch_scan(uint32_t nb, const Scratch &s, hipStream_t stream);
+void launch_scan(uint32_t nb, const Scratch &s, const SlabResult *prev, SlabResult *result, hipStream_t stream);
 void launch_emit(const Config &cfg, const uint8_t *slab, uint64_t slab_len, uint32_t nb,
                  const Scratch &s, uint8_t *out, uint64_t out_cap, hipStream_t stream);
 

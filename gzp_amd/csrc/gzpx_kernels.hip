@@ -131,18 +131,22 @@ __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t *w
     return base + inc - v;
 }
 
-// Exclusive scan of one value per thread over a 256-thread workgroup; `wsum` is 4 words of LDS.
-// Returns the exclusive prefix; *total receives the workgroup sum.  Two barriers.
-__device__ __forceinline__ uint32_t block_exclusive_scan256(uint32_t v, uint32_t *wsum,
-                                                            uint32_t *total) {
+// Exclusive scan of one 64-bit value per thread over a 256-thread workgroup; `wsum` is 4 words of
+// LDS.  Returns the exclusive prefix; *total receives the workgroup sum.  Two barriers.  (64-bit:
+// 256 Mgzip blocks of 16 MiB, or foreign ISIZE fields, sum to 2^32 and more.)
+__device__ __forceinline__ uint64_t block_exclusive_scan256(uint64_t v, uint64_t *wsum, uint64_t *total) {
     const unsigned tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    uint32_t inc = wave_inclusive_scan(v, lane);
+    uint64_t inc = v;
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint64_t t = __shfl_up(inc, d);
+        if (lane >= (unsigned)d) inc += t;
+    }
     __syncthreads();  // protect wsum from the previous use
     if (lane == 63) wsum[wave] = inc;
     __syncthreads();
-    uint32_t base = 0, tot = 0;
+    uint64_t base = 0, tot = 0;
     for (unsigned w = 0; w < 4; w++) {
-        uint32_t s = wsum[w];
+        const uint64_t s = wsum[w];
         if (w < wave) base += s;
         tot += s;
     }
@@ -208,9 +212,7 @@ __global__ void k_init_meta(Config cfg, uint64_t slab_len, uint32_t nb, uint32_t
     m.framed_bytes = 0;
     m.crc = 0;
     m.status = kStatusOk;
-    for (unsigned k = 0; k < 8; k++) m.phase_cycles[k] = 0;
     m.cand_redo = 0;
-    for (unsigned k = 0; k < 4; k++) m.cand_cycles[k] = 0;
     meta[b] = m;
 }
 
@@ -310,7 +312,6 @@ __global__ __launch_bounds__(64 * kCandWaves) void k_candidates(Config cfg,
         ring[k] = cand_fetch(in32, mis, wave * kIterPos + k * 64 + lane, wmax);
 
     bool bad = false;
-    const long long t_begin = clock64();
     for (uint32_t it = wave; it < n_iters; it += kCandWaves) {
         const uint32_t base0 = it * kIterPos;
         // The serial phase must be nothing but the atomics: a lone wave issues about one dependent
@@ -358,7 +359,6 @@ __global__ __launch_bounds__(64 * kCandWaves) void k_candidates(Config cfg,
             if (MODE < 2 || mine[k] || (MODE == 2 && p + 5 > n)) cand[p] = (uint16_t)d0;
         }
     }
-    if (tid == 0 && MODE == 0) meta[b].cand_cycles[3] = (uint32_t)(clock64() - t_begin);
     if (__ballot(bad) && lane == 0) atomicOr(&meta[b].cand_redo, 1u << MODE);
 }
 
@@ -489,7 +489,6 @@ __global__ __launch_bounds__(kMpThreads, 8) void k_match(Config cfg, const uint8
     unsigned long long *nz_out = (unsigned long long *)(nz_all + (uint64_t)b * (cfg.stride / 32));
     uint16_t *val = val_all + (uint64_t)b * cfg.stride;
 
-    const long long t_begin = clock64();
     const uint32_t tile_step = n <= kTile ? kTile : kTile / 2;
     for (uint32_t tile_begin = 0; tile_begin < n; tile_begin += tile_step) {
         const uint32_t tile_end = tile_begin + tile_step < n ? tile_begin + tile_step : n;
@@ -670,7 +669,6 @@ __global__ __launch_bounds__(kMpThreads, 8) void k_match(Config cfg, const uint8
                 step(p0, std::false_type{});
         }
     }
-    if (tid == 0) meta->phase_cycles[1] = (uint32_t)(clock64() - t_begin);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -744,13 +742,11 @@ __global__ __launch_bounds__(kMpThreads, 8) void k_parse(
     uint32_t *tok = tok_all + (uint64_t)b * cfg.stride;
     (void)slab;
 
-    const long long t_begin = clock64();
     // state carried from tile to tile (uniform across the workgroup)
     uint32_t entry_carry = 0;            // where the parse enters the next tile
     uint32_t tok_carry = 0, mat_carry = 0;
     uint32_t cur_sub = 0, sub_start = 0, sub_start_tok = 0, sub_start_mat = 0;
     uint32_t sub_limit = sub_limit_of(0, n);
-    uint32_t rounds_total = 0;
 
     for (uint32_t tile_begin = 0; tile_begin < n; tile_begin += kTile) {
         const uint32_t tile_len = n - tile_begin < kTile ? n - tile_begin : kTile;
@@ -798,7 +794,6 @@ __global__ __launch_bounds__(kMpThreads, 8) void k_parse(
         else tok_bits[tid] = 0;
         const uint32_t n_seg = (tile_len + kPSeg - 1) / kPSeg;
         for (uint32_t round = 0;; round++) {
-            rounds_total++;
             __syncthreads();
             bool changed = false;
             uint32_t new_entry = entry;
@@ -986,8 +981,6 @@ __global__ __launch_bounds__(kMpThreads, 8) void k_parse(
         sub[cur_sub].is_final = 1;
         meta->ntok = tok_carry;
         meta->nsub = cur_sub + 1;
-        meta->phase_cycles[2] = (uint32_t)(clock64() - t_begin);
-        meta->phase_cycles[6] = rounds_total;
     }
 }
 
@@ -2262,24 +2255,39 @@ __global__ __launch_bounds__(kCrcThreads, 8) void k_crc32(Config cfg, const uint
 // stream (the in-order property of the reference's writer loop, src/par/compress.rs:305-310).
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_scan(uint32_t nb, const BlockMeta *__restrict__ meta,
-                                              uint64_t *__restrict__ out_off) {
-    __shared__ uint32_t wsum[4];
+                                              uint64_t *__restrict__ out_off, uint32_t *__restrict__ sizes,
+                                              const SlabResult *__restrict__ prev,
+                                              SlabResult *__restrict__ result) {
+    __shared__ uint64_t wsum[4];
     __shared__ uint64_t carry_s;
+    __shared__ uint32_t fail_s;
     const uint32_t tid = threadIdx.x;
-    if (tid == 0) carry_s = 0;
+    if (tid == 0) {
+        carry_s = prev ? prev->total : 0;  // a slab of several batches: offsets run on
+        fail_s = 0xFFFFFFFFu;
+    }
     __syncthreads();
     for (uint32_t base = 0; base < nb; base += 256) {
         const uint32_t i = base + tid;
         const uint32_t v = i < nb ? meta[i].framed_bytes : 0;
-        uint32_t total;
-        const uint32_t ex = block_exclusive_scan256(v, wsum, &total);
+        if (i < nb) {
+            sizes[i] = v;
+            if (meta[i].status != kStatusOk) atomicMin(&fail_s, i);
+        }
+        uint64_t total;
+        const uint64_t ex = block_exclusive_scan256((uint64_t)v, wsum, &total);
         const uint64_t carry = carry_s;
         if (i < nb) out_off[i] = carry + ex;
         __syncthreads();
         if (tid == 0) carry_s = carry + total;
         __syncthreads();
     }
-    if (tid == 0) out_off[nb] = carry_s;
+    if (tid == 0) {
+        out_off[nb] = carry_s;
+        result->total = carry_s;
+        result->fail_block = fail_s;
+        result->fail_status = fail_s != 0xFFFFFFFFu ? meta[fail_s].status : kStatusOk;
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -2728,16 +2736,16 @@ __global__ void k_dinit(uint32_t nb, const uint8_t *__restrict__ in, const uint6
 
 __global__ __launch_bounds__(256) void k_dscan(uint32_t nb, const DBlock *__restrict__ blk,
                                                uint64_t *__restrict__ out_off) {
-    __shared__ uint32_t wsum[4];
+    __shared__ uint64_t wsum[4];
     __shared__ uint64_t carry_s;
     const uint32_t tid = threadIdx.x;
     if (tid == 0) carry_s = 0;
     __syncthreads();
     for (uint32_t base = 0; base < nb; base += 256) {
         const uint32_t i = base + tid;
-        const uint32_t v = i < nb ? blk[i].isize : 0;
-        uint32_t total;
-        const uint32_t ex = block_exclusive_scan256(v, wsum, &total);
+        const uint64_t v = i < nb ? blk[i].isize : 0;  // untrusted footers: sums need 64 bits
+        uint64_t total;
+        const uint64_t ex = block_exclusive_scan256(v, wsum, &total);
         const uint64_t carry = carry_s;
         if (i < nb) out_off[i] = carry + ex;
         __syncthreads();
@@ -3241,6 +3249,9 @@ __global__ __launch_bounds__(64) void k_inflate(uint32_t hdr_len, const uint8_t 
             wave_sync();
         }
     }
+    // a payload that ends before its final end-of-block symbol has been decoded out of the footer
+    // bytes: libdeflate reports BadData for it (the reads themselves are in bounds by construction)
+    if (bp > bit_end && status != kInfBadData) status = kInfBadData;
     if (status == kInfOk && o != isize) status = kInfShortOutput;
     flush(o);
     // libdeflater hands back a zero-initialised Vec of orig_size bytes: a short block stays zero
@@ -3338,9 +3349,9 @@ void launch_crc32(const Config &cfg, const uint8_t *slab, uint64_t, uint32_t nb,
     hipLaunchKernelGGL(k_crc32, dim3(nb), dim3(kCrcThreads), 0, stream, cfg, slab, s.meta, cc);
 }
 
-void launch_scan(uint32_t nb, const Scratch &s, hipStream_t stream) {
+void launch_scan(uint32_t nb, const Scratch &s, const SlabResult *prev, SlabResult *result, hipStream_t stream) {
     hipLaunchKernelGGL(k_scan, dim3(1), dim3(256), 0, stream, nb, (const BlockMeta *)s.meta,
-                       s.out_off);
+                       s.out_off, s.sizes, prev, result);
 }
 
 void launch_emit(const Config &cfg, const uint8_t *slab, uint64_t, uint32_t nb, const Scratch &s,

@@ -50,6 +50,7 @@ extern "C" {
 #define GZPX_ERR_INVALID_HEADER 12     /* GzpError::InvalidHeader (src/deflate.rs:555-565, 405-415)    */
 #define GZPX_ERR_INVALID_CHECK 13      /* GzpError::InvalidCheck{found, expected}                      */
 #define GZPX_ERR_BAD_DATA 14           /* GzpError::LibDelfaterDecompress(BadData)                     */
+#define GZPX_ERR_BUSY 15               /* submit: every slab slot of the context is in flight          */
 
 /* how a slab is cut (the `mode` argument of gzpx_compress_slab*) */
 #define GZPX_SLAB_FULL_BLOCKS 0 /* write(): only whole buffer_size blocks, in_len a non-zero multiple   */
@@ -101,11 +102,39 @@ int gzpx_compress_slab(gzpx_ctx *ctx, const uint8_t *in, size_t in_len, int mode
                        size_t *n_blocks);
 
 /* Same, with the slab and the output already resident in DEVICE memory (d_in, d_out are device
- * pointers; hip_stream is a hipStream_t or NULL for the context's own stream).  Synchronous
- * with respect to the host on return. */
+ * pointers).  hip_stream (a hipStream_t, may be NULL): the slab is read only after everything
+ * enqueued on that stream so far has completed.  Synchronous with respect to the host on return. */
 int gzpx_compress_slab_device(gzpx_ctx *ctx, const void *d_in, size_t in_len, int mode,
                               void *d_out, size_t out_cap, size_t *out_len, uint32_t *block_sizes,
                               size_t max_blocks, size_t *n_blocks, void *hip_stream);
+
+/*
+ * Asynchronous form ("async variant with stream/event handles for H2D || kernel || D2H
+ * overlap").  A context owns a copy-in stream, a compute stream and a copy-out stream and up to
+ * GZPX_SLOTS slabs in flight, each with its own device staging buffers:
+ *
+ *   gzpx_compress_slab_submit   enqueues the copy-in of `in` (page-locked memory makes it a DMA
+ *                               transfer: gzpx_host_alloc) and every kernel of the slab, and returns
+ *                               without waiting for the device at levels 0/1 (the match/parse rounds
+ *                               of levels 2-4 read one word back per round).  GZPX_ERR_BUSY when all
+ *                               slots are taken.  `in` and `out` must stay valid until the wait.
+ *   gzpx_compress_slab_wait     blocks until that slab's kernels are done, copies exactly the
+ *                               produced bytes to `out`, reports like gzpx_compress_slab, frees the slot.
+ *
+ * Submitting slab k+1 before waiting for slab k overlaps k+1's copy-in with k's kernels and k's
+ * copy-out with k+1's kernels; results come back in submission order if waited for in that order.
+ * The _device form works on device pointers (no copies); `after_stream` as above.
+ * gzpx_compress_slab_event hands out the hipEvent_t that fires when the slab's kernels and result
+ * records are complete, for callers that chain their own streams (valid until the wait).
+ */
+#define GZPX_SLOTS 3
+int gzpx_compress_slab_submit(gzpx_ctx *ctx, const uint8_t *in, size_t in_len, int mode, uint8_t *out,
+                              size_t out_cap, uint64_t *ticket);
+int gzpx_compress_slab_submit_device(gzpx_ctx *ctx, const void *d_in, size_t in_len, int mode, void *d_out,
+                                     size_t out_cap, void *after_stream, uint64_t *ticket);
+int gzpx_compress_slab_wait(gzpx_ctx *ctx, uint64_t ticket, size_t *out_len, uint32_t *block_sizes,
+                            size_t max_blocks, size_t *n_blocks);
+int gzpx_compress_slab_event(gzpx_ctx *ctx, uint64_t ticket, void **hip_event);
 
 /* FormatSpec::encode: one framed block (is_last => BGZF_EOF appended for BGZF). */
 int gzpx_encode_block(gzpx_ctx *ctx, const uint8_t *in, size_t n, int is_last, uint8_t *out,
@@ -120,6 +149,10 @@ void gzpx_free_compressor(gzpx_compressor *c);
 /* compat / device knobs for the handle above (before first use) */
 int gzpx_compressor_set_compat(gzpx_compressor *c, int compat);
 uint32_t gzpx_crc32(uint32_t crc, const void *buf, size_t n);
+/* libdeflate_crc32's signature cannot report a failure: on a device error gzpx_crc32 returns `crc`
+ * unchanged and records the status for the calling thread; gzpx_crc32_checked returns it directly. */
+int gzpx_crc32_checked(uint32_t crc, const void *buf, size_t n, uint32_t *out);
+int gzpx_last_status(void);
 
 /* ---- ParCompress<Bgzf/Mgzip> twin: Write + ZWriter::finish over device lanes (C++ class
  * gzp::ParCompress in gzp_amd/csrc/gzpx_par.hpp; src/par/compress.rs:33-469) ---- */
@@ -165,6 +198,14 @@ int gzpx_scan_blocks(int format, const uint8_t *in, size_t in_len, uint64_t *off
 int gzpx_decompress_blocks(gzpx_dctx *ctx, const uint8_t *in, size_t in_len, const uint64_t *offsets,
                            const uint32_t *sizes, size_t n_blocks, uint8_t *out, size_t out_cap,
                            size_t *out_len, gzpx_check_info *info);
+/* asynchronous form (same slots / streams scheme as gzpx_compress_slab_submit): the copy-in, the
+ * kernels and the copy-out of the inflated bytes (their count is the sum of the footers' ISIZE fields,
+ * known at submit time) are all enqueued by submit; wait blocks for them and reports the first
+ * failing block in stream order.  offsets / sizes are copied by submit. */
+int gzpx_decompress_blocks_submit(gzpx_dctx *ctx, const uint8_t *in, size_t in_len, const uint64_t *offsets,
+                                  const uint32_t *sizes, size_t n_blocks, uint8_t *out, size_t out_cap,
+                                  uint64_t *ticket);
+int gzpx_decompress_blocks_wait(gzpx_dctx *ctx, uint64_t ticket, size_t *out_len, gzpx_check_info *info);
 /* d_in / d_out are device pointers; offsets / sizes stay host arrays */
 int gzpx_decompress_blocks_device(gzpx_dctx *ctx, const void *d_in, size_t in_len, const uint64_t *offsets,
                                   const uint32_t *sizes, size_t n_blocks, void *d_out, size_t out_cap,
@@ -205,17 +246,12 @@ int gzpx_debug_tokens(gzpx_ctx *ctx, size_t block, uint32_t *tokens, size_t max_
  * (k_candidates_safe) on every block instead of the atomic-chain kernel. */
 int gzpx_debug_set_flags(gzpx_ctx *ctx, uint32_t flags);
 
-/* k_match / k_parse diagnostics of the last batch: shader-clock cycles per phase summed over blocks
- * [stage-in, match, parse rounds, mark walk, rank scan, token build, parse rounds count, -]. */
-int gzpx_debug_phase_cycles(const gzpx_ctx *ctx, uint64_t cycles[8]);
-/* k_candidates diagnostics: cycles [hash + first atomics, stage gather, file + store, total]. */
 /* HIP-event duration of k_inflate in the last decompress launch of this context */
 int gzpx_dctx_last_inflate_ms(gzpx_dctx *ctx, float *ms);
 /* inflate: switch the instrumented k_inflate on/off; sums[] = per-block counters of the last launch
  * summed over its blocks ([0] cycles, [1] headers+tables, [2] round set-up, [3] stores+copies,
  * [4] rounds, [5] literals, [6] matches, [7] window flushes) */
 int gzpx_debug_inflate(gzpx_dctx *ctx, int enable, uint64_t sums[8]);
-int gzpx_debug_cand_cycles(const gzpx_ctx *ctx, uint64_t cycles[4]);
 
 const char *gzpx_strerror(int code);
 const char *gzpx_device_name(const gzpx_ctx *ctx);

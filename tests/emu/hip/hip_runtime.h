@@ -238,6 +238,7 @@ enum hipMemcpyKind { hipMemcpyHostToHost, hipMemcpyHostToDevice, hipMemcpyDevice
 #define hipStreamNonBlocking 1
 #define hipHostMallocDefault 0
 #define hipEventDefault 0
+#define hipEventDisableTiming 2
 
 struct hipDeviceProp_t {
     char name[256];
