@@ -48,7 +48,8 @@ EXPORTS = [
     "gzpx_compress_slab_submit", "gzpx_compress_slab_submit_device", "gzpx_compress_slab_wait",
     "gzpx_compress_slab_event", "gzpx_crc32_checked", "gzpx_last_status",
     "gzpx_par_create", "gzpx_par_write", "gzpx_par_flush", "gzpx_par_finish", "gzpx_par_destroy",
-    "gzpx_par_last_error", "gzpx_dctx_create", "gzpx_dctx_destroy", "gzpx_scan_blocks",
+    "gzpx_par_last_error", "gzpx_par_reserve", "gzpx_par_commit", "gzpx_par_index", "gzpx_gzi_size",
+    "gzpx_gzi_write", "gzpx_dctx_create", "gzpx_dctx_destroy", "gzpx_scan_blocks",
     "gzpx_decompress_blocks", "gzpx_decompress_blocks_device", "gzpx_decompress_blocks_submit",
     "gzpx_decompress_blocks_wait", "gzpx_alloc_decompressor", "gzpx_deflate_decompress",
     "gzpx_free_decompressor", "gzpx_pard_create", "gzpx_pard_read", "gzpx_pard_destroy",
@@ -162,6 +163,16 @@ class GzpxLib:
         L.gzpx_par_create.argtypes = [ctypes.POINTER(GzpxParConfig), WRITE_FN, vp, ctypes.POINTER(vp)]
         L.gzpx_par_write.restype = i32
         L.gzpx_par_write.argtypes = [vp, vp, sz]
+        L.gzpx_par_reserve.restype = i32
+        L.gzpx_par_reserve.argtypes = [vp, ctypes.POINTER(vp), psz]
+        L.gzpx_par_commit.restype = i32
+        L.gzpx_par_commit.argtypes = [vp, sz]
+        L.gzpx_par_index.restype = i32
+        L.gzpx_par_index.argtypes = [vp, vp, sz, psz]
+        L.gzpx_gzi_size.restype = sz
+        L.gzpx_gzi_size.argtypes = [sz]
+        L.gzpx_gzi_write.restype = i32
+        L.gzpx_gzi_write.argtypes = [vp, sz, vp, sz, psz]
         L.gzpx_par_flush.restype = i32
         L.gzpx_par_flush.argtypes = [vp]
         L.gzpx_par_finish.restype = i32
@@ -341,10 +352,37 @@ class Context:
     def debug_set_flags(self, flags):
         self.lib.check(self.lib.L.gzpx_debug_set_flags(self.h, flags))
 
-    def debug_phase_cycles(self):
-        c = (ctypes.c_uint64 * 8)()
-        self.lib.check(self.lib.L.gzpx_debug_phase_cycles(self.h, c))
-        return [int(x) for x in c]
+    def submit(self, in_ptr, in_len, out_ptr, out_cap, mode=SLAB_LAST):
+        """gzpx_compress_slab_submit on raw host pointers (page-locked for DMA overlap); returns the
+        ticket, or None when every slot is in flight."""
+        t = ctypes.c_uint64(0)
+        rc = self.lib.L.gzpx_compress_slab_submit(self.h, in_ptr, in_len, int(mode), out_ptr, out_cap,
+                                                  ctypes.byref(t))
+        if rc == ERR_BUSY:
+            return None
+        self.lib.check(rc)
+        return t.value
+
+    def submit_device(self, d_in_ptr, in_len, d_out_ptr, out_cap, mode=SLAB_LAST, after_stream=None):
+        t = ctypes.c_uint64(0)
+        rc = self.lib.L.gzpx_compress_slab_submit_device(self.h, d_in_ptr, in_len, int(mode), d_out_ptr,
+                                                         out_cap, after_stream, ctypes.byref(t))
+        if rc == ERR_BUSY:
+            return None
+        self.lib.check(rc)
+        return t.value
+
+    def wait(self, ticket, block_sizes=None):
+        """gzpx_compress_slab_wait: (out_len, n_blocks)."""
+        out_len = ctypes.c_size_t(0)
+        nb = ctypes.c_size_t(0)
+        bs_ptr, bs_n = (None, 0)
+        if block_sizes is not None:
+            bs_ptr, bs_n = block_sizes.ctypes.data, block_sizes.size
+        rc = self.lib.L.gzpx_compress_slab_wait(self.h, ticket, ctypes.byref(out_len), bs_ptr, bs_n,
+                                                ctypes.byref(nb))
+        self.lib.check(rc, nb.value if rc == ERR_BLOCK_SIZE_EXCEEDED else None)
+        return out_len.value, nb.value
 
     def debug_tokens(self, block):
         toks = np.empty(max(65536, int(self.buffer_size)), dtype=np.uint32)

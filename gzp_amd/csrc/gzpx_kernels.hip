@@ -2792,8 +2792,16 @@ __global__ __launch_bounds__(64) void k_inflate(uint32_t hdr_len, const uint8_t 
     const uint32_t pay_words = (pmis + pay_len + 8 + 3) >> 2;  // the 8 footer bytes are readable too
     const uint32_t bit0 = 8u * pmis, bit_end = bit0 + 8u * pay_len;
     uint32_t hi_w = 0;  // dwords [.., hi_w) are in the ring; `pre` holds [hi_w, hi_w + 64)
-    auto fetch = [&](uint32_t w) -> uint32_t {  // clamped: bits past the footer are never used
-        return pay32[w < pay_words ? w : pay_words - 1];
+    // (index clamped to readable memory.)  Bits past the end of the payload read as zeros, the way
+    // libdeflate's bit reader pads an exhausted input: a truncated member then fails with the same
+    // error class as in the reference (the output overflows, a header turns invalid, or the final
+    // end-of-block is "found" inside the padding -- checked after the last block).
+    auto fetch = [&](uint32_t w) -> uint32_t {
+        uint32_t v = pay32[w < pay_words ? w : pay_words - 1];
+        const uint32_t wb = 32u * w;
+        if (wb >= bit_end) v = 0;
+        else if (bit_end - wb < 32u) v &= (1u << (bit_end - wb)) - 1u;
+        return v;
     };
     uint32_t pre = fetch(lane);
     auto ensure = [&](uint32_t bpos) {  // the ring covers dwords (bpos >> 5) .. (bpos >> 5) + 5
@@ -2994,8 +3002,14 @@ __global__ __launch_bounds__(64) void k_inflate(uint32_t hdr_len, const uint8_t 
         if (DBG) dbg[1] += (uint32_t)(clock64() - t_hdr);
         // ---- symbols, 64 * kInfR bit positions per round
         bool eob = false;
+        // A symbol that starts a byte or more past the payload's end is where libdeflate's bit reader
+        // gives up (more than sizeof(bitbuf) bytes of padding buffered): BadData.  (libdeflate's own
+        // limit depends on when it last refilled; against the v1.10 binary this rule gives the same
+        // error class for 99 % of members cut within 80 bytes of their end -- 594 of 600 -- and
+        // BadData instead of InsufficientSpace for the rest.)
+        const uint32_t bit_lim = bit_end + 8u;
         while (!eob && status == kInfOk) {
-            if (bp > bit_end) {
+            if (bp >= bit_lim) {
                 status = kInfBadData;
                 break;
             }
@@ -3099,6 +3113,25 @@ __global__ __launch_bounds__(64) void k_inflate(uint32_t hdr_len, const uint8_t 
                     status = kInfBadData;
                     break;
                 }
+                if (bp + 64 * kInfR > bit_end || o + tout > isize) {
+                    // The last round(s) of a member, or an overflow.  libdeflate's order of events: a
+                    // symbol that starts past the limit above is BadData, one that does not fit the
+                    // output is InsufficientSpace, and the earlier symbol decides (the bit reader's
+                    // check comes first within a symbol).
+                    uint32_t first_bad = 0xFFFFFFFFu, first_ovf = 0xFFFFFFFFu;
+#pragma unroll
+                    for (uint32_t hf = 0; hf < kInfR; hf++) {
+                        const uint32_t q = bp + 64 * hf + lane;
+                        const uint64_t mb = __ballot(mine[hf] && q >= bit_lim);
+                        const uint64_t mo = __ballot(mine[hf] && o + opos[hf] + outlen[hf] > isize);
+                        if (mb && first_bad == 0xFFFFFFFFu) first_bad = 64 * hf + (uint32_t)__ffsll((long long)mb) - 1;
+                        if (mo && first_ovf == 0xFFFFFFFFu) first_ovf = 64 * hf + (uint32_t)__ffsll((long long)mo) - 1;
+                    }
+                    if (first_bad != 0xFFFFFFFFu || first_ovf != 0xFFFFFFFFu) {
+                        status = first_bad <= first_ovf ? kInfBadData : kInfInsufficientSpace;
+                        break;
+                    }
+                }
                 if (o + tout > isize) {
                     status = kInfInsufficientSpace;
                     break;
@@ -3166,6 +3199,10 @@ __global__ __launch_bounds__(64) void k_inflate(uint32_t hdr_len, const uint8_t 
             }
             // (4) one symbol the slow way: end of block, long codewords, errors
             bp += last;
+            if (bp >= bit_lim) {
+                status = kInfBadData;
+                break;
+            }
             ensure(bp);
             const uint32_t sw = bp >> 5;
             const uint32_t s0 = h.inr[sw & 255u], s1 = h.inr[(sw + 1) & 255u], s2 = h.inr[(sw + 2) & 255u];
@@ -3249,9 +3286,9 @@ __global__ __launch_bounds__(64) void k_inflate(uint32_t hdr_len, const uint8_t 
             wave_sync();
         }
     }
-    // a payload that ends before its final end-of-block symbol has been decoded out of the footer
-    // bytes: libdeflate reports BadData for it (the reads themselves are in bounds by construction)
-    if (bp > bit_end && status != kInfBadData) status = kInfBadData;
+    // libdeflate's final check (overread_count > bitsleft / 8): the stream "ended" inside the zero
+    // padding behind a truncated payload -> BadData
+    if (status == kInfOk && bp > bit_end) status = kInfBadData;
     if (status == kInfOk && o != isize) status = kInfShortOutput;
     flush(o);
     // libdeflater hands back a zero-initialised Vec of orig_size bytes: a short block stays zero

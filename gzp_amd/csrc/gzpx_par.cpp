@@ -1,4 +1,5 @@
-// gzpx_par.cpp -- ParCompress twin (see gzpx_par.hpp) + its C ABI (gzpx_par_* in include/gzpx.h).
+// gzpx_par.cpp -- ParCompress / ParDecompress twins (see gzpx_par.hpp) + their C ABI (gzpx_par_* /
+// gzpx_pard_* in include/gzpx.h).
 #include "gzpx_par.hpp"
 
 #include <hip/hip_runtime.h>
@@ -23,32 +24,91 @@ GzpError error_from_code(int code, size_t block) {
     }
 }
 
+// ---------------------------------------------------------------- CopyPool
+CopyPool::CopyPool(size_t helpers) {
+    for (size_t i = 0; i < helpers; i++) threads_.emplace_back([this] { main(); });
+}
+
+CopyPool::~CopyPool() {
+    {
+        std::lock_guard<std::mutex> lk(mu_);
+        stop_ = true;
+    }
+    cv_task_.notify_all();
+    for (auto &t : threads_) t.join();
+}
+
+void CopyPool::main() {
+    for (;;) {
+        Task t;
+        {
+            std::unique_lock<std::mutex> lk(mu_);
+            cv_task_.wait(lk, [&] { return stop_ || !tasks_.empty(); });
+            if (tasks_.empty()) return;
+            t = tasks_.front();
+            tasks_.pop_front();
+        }
+        memcpy(t.dst, t.src, t.n);
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            pending_--;
+        }
+        cv_done_.notify_all();
+    }
+}
+
+void CopyPool::copy(uint8_t *dst, const uint8_t *src, size_t n) {
+    const size_t parts = threads_.size() + 1;
+    if (n < ((size_t)1 << 20) || parts == 1) {
+        memcpy(dst, src, n);
+        return;
+    }
+    const size_t piece = ((n / parts) + 4095) & ~(size_t)4095;
+    size_t off = piece < n ? piece : n;  // the caller's own share is the first piece
+    {
+        std::lock_guard<std::mutex> lk(mu_);
+        for (size_t o = off; o < n; o += piece) {
+            tasks_.push_back(Task{dst + o, src + o, n - o < piece ? n - o : piece});
+            pending_++;
+        }
+    }
+    cv_task_.notify_all();
+    memcpy(dst, src, off);
+    std::unique_lock<std::mutex> lk(mu_);
+    cv_done_.wait(lk, [&] { return pending_ == 0; });
+}
+
+// ---------------------------------------------------------------- ParCompress
 ParCompress::ParCompress(const ParConfig &cfg, WriteFn writer) : cfg_(cfg), writer_(std::move(writer)) {
     if (cfg_.buffer_size < DICT_SIZE) throw error_from_code(GZPX_ERR_BUFFER_SIZE);
     if (cfg_.num_threads == 0) cfg_.num_threads = 1;
-    const size_t lanes = cfg_.num_threads < 2 ? 1 : 2;  // device lanes: one copies while one computes
-    if (cfg_.batch_blocks == 0) cfg_.batch_blocks = 1;
-    batch_bytes_ = cfg_.batch_blocks * cfg_.buffer_size;
-    q_cap_ = 2 * lanes;  // bounded(num_threads * 2), src/par/compress.rs:111-112
-    for (size_t i = 0; i < lanes; i++) {
-        gzpx_config c;
-        gzpx_config_default(&c, cfg_.format);
-        c.device = cfg_.device;
-        c.level = cfg_.compression_level.level();
-        c.compat = cfg_.compat;
-        c.buffer_size = cfg_.buffer_size;
-        c.max_slab_bytes = batch_bytes_;
-        gzpx_ctx *ctx = nullptr;
-        const int rc = gzpx_ctx_create(&c, &ctx);  // Bgzf::create_compressor, once per worker
-        if (rc != GZPX_OK) {
-            for (gzpx_ctx *x : ctxs_) gzpx_ctx_destroy(x);
-            ctxs_.clear();
-            throw error_from_code(rc);
-        }
-        ctxs_.push_back(ctx);
+    // a slab is batch_blocks blocks, but never more than kMaxSlabBytes of page-locked memory (1 MiB
+    // or 16 MiB Mgzip blocks would otherwise ask for gigabytes per slab) and never less than one block
+    const size_t by_budget = kMaxSlabBytes / cfg_.buffer_size;
+    batch_blocks_ = cfg_.batch_blocks ? cfg_.batch_blocks : 1;
+    if (batch_blocks_ > by_budget) batch_blocks_ = by_budget;
+    if (batch_blocks_ == 0) batch_blocks_ = 1;
+    batch_bytes_ = batch_blocks_ * cfg_.buffer_size;
+    q_cap_ = 4;  // bounded(num_threads * 2) in the reference (src/par/compress.rs:111-112)
+    gzpx_config c;
+    gzpx_config_default(&c, cfg_.format);
+    c.device = cfg_.device;
+    c.level = cfg_.compression_level.level();
+    c.compat = cfg_.compat;
+    c.buffer_size = cfg_.buffer_size;
+    c.max_slab_bytes = batch_bytes_;
+    const int rc = gzpx_ctx_create(&c, &ctx_);  // Bgzf::create_compressor
+    if (rc != GZPX_OK) throw error_from_code(rc);
+    (void)hipSetDevice(cfg_.device);
+    try {
+        fill_ = take_buffer(batch_bytes_ + cfg_.buffer_size);
+    } catch (...) {
+        gzpx_ctx_destroy(ctx_);
+        throw;
     }
-    buffer_.reserve(batch_bytes_ + cfg_.buffer_size);
-    for (size_t i = 0; i < lanes; i++) workers_.emplace_back([this, i] { worker_main(i); });
+    const size_t helpers = cfg_.num_threads > 1 ? (cfg_.num_threads - 1 < 3 ? cfg_.num_threads - 1 : 3) : 0;
+    copier_ = std::make_unique<CopyPool>(helpers);
+    device_thread_ = std::thread([this] { device_main(); });
     writer_thread_ = std::thread([this] { writer_main(); });
 }
 
@@ -60,7 +120,8 @@ ParCompress::~ParCompress() {
             // Drop cannot report; the reference unwraps here (src/par/compress.rs:398)
         }
     }
-    for (gzpx_ctx *x : ctxs_) gzpx_ctx_destroy(x);
+    copier_.reset();
+    if (ctx_) gzpx_ctx_destroy(ctx_);
     for (uint8_t *p : pinned_) (void)hipHostFree(p);  // (the threads have been joined by finish())
 }
 
@@ -120,49 +181,54 @@ void ParCompress::dispatch(Pinned input, int mode) {
     cv_work_.notify_one();
 }
 
+// `while buffer.len() > buffer_size` (strict, src/par/compress.rs:415): full blocks leave only while
+// at least one byte stays behind.  Blocks are handed over batch_blocks at a time -- the cut points
+// are the same multiples of buffer_size -- and what stays behind (at most one block) moves to the
+// front of the next slab.
+void ParCompress::after_append() {
+    while (fill_.len > batch_bytes_) {
+        Pinned next = take_buffer(batch_bytes_ + cfg_.buffer_size);
+        next.len = fill_.len - batch_bytes_;
+        memcpy(next.p, fill_.p + batch_bytes_, next.len);
+        Pinned full = fill_;
+        full.len = batch_bytes_;
+        fill_ = next;
+        dispatch(full, GZPX_SLAB_FULL_BLOCKS);
+    }
+}
+
 size_t ParCompress::write(const uint8_t *buf, size_t n) {
     if (finished_) throw GzpError(GzpErrorKind::ChannelSend, "write after finish");
-    // `while buffer.len() > buffer_size` (strict): full blocks leave only while at least one byte
-    // stays behind.  Blocks are handed over batch_blocks at a time; the cut points are the same.
-    // Slabs are cut straight from the caller's bytes (behind whatever is still buffered), so a large
-    // write is copied once, not shuffled through the buffer.
-    const size_t bs = cfg_.buffer_size;
-    size_t off = 0;  // bytes of buf already handed over or buffered
-    while (buffer_.size() + (n - off) > batch_bytes_) {
-        const size_t have = buffer_.size() + (n - off);
-        size_t blocks = (have - 1) / bs;
-        if (blocks > cfg_.batch_blocks) blocks = cfg_.batch_blocks;
-        const size_t take = blocks * bs;
-        Pinned slab = take_buffer(batch_bytes_);
-        const size_t from_buffer = buffer_.size() < take ? buffer_.size() : take;
-        memcpy(slab.p, buffer_.data(), from_buffer);
-        buffer_.erase(buffer_.begin(), buffer_.begin() + (ptrdiff_t)from_buffer);  // (at most one slab's worth)
-        memcpy(slab.p + from_buffer, buf + off, take - from_buffer);
-        off += take - from_buffer;
-        slab.len = take;
-        dispatch(slab, GZPX_SLAB_FULL_BLOCKS);
+    size_t off = 0;
+    while (off < n) {
+        const size_t room = fill_.cap - fill_.len;  // >= buffer_size: after_append keeps len <= batch_bytes_
+        const size_t take = n - off < room ? n - off : room;
+        copier_->copy(fill_.p + fill_.len, buf + off, take);
+        fill_.len += take;
+        off += take;
+        after_append();
     }
-    buffer_.insert(buffer_.end(), buf + off, buf + n);
     return n;
+}
+
+std::pair<uint8_t *, size_t> ParCompress::reserve() {
+    if (finished_) throw GzpError(GzpErrorKind::ChannelSend, "reserve after finish");
+    return {fill_.p + fill_.len, fill_.cap - fill_.len};
+}
+
+void ParCompress::commit(size_t n) {
+    if (finished_) throw GzpError(GzpErrorKind::ChannelSend, "commit after finish");
+    if (n > fill_.cap - fill_.len) throw GzpError(GzpErrorKind::LibDeflaterCompress, "commit past the reserved room");
+    fill_.len += n;
+    after_append();
 }
 
 void ParCompress::flush_last(bool is_last) {
     // everything buffered goes out cut at buffer_size; the final piece may be short and -- if the
     // buffer is empty -- is an empty block (src/par/compress.rs:333-341 runs at least once)
-    const size_t bs = cfg_.buffer_size;
-    size_t pos = 0;
-    while (buffer_.size() - pos > batch_bytes_) {
-        const size_t take = cfg_.batch_blocks * bs;
-        Pinned slab = take_buffer(batch_bytes_);
-        memcpy(slab.p, buffer_.data() + pos, take);
-        slab.len = take;
-        pos += take;
-        dispatch(slab, GZPX_SLAB_FULL_BLOCKS);
-    }
-    Pinned rest = take_buffer(batch_bytes_);
-    rest.len = buffer_.size() - pos;
-    memcpy(rest.p, buffer_.data() + pos, rest.len);
-    buffer_.clear();
+    Pinned rest = fill_;
+    fill_ = Pinned();
+    if (!is_last) fill_ = take_buffer(batch_bytes_ + cfg_.buffer_size);
     dispatch(rest, is_last ? GZPX_SLAB_LAST : GZPX_SLAB_FLUSH);
 }
 
@@ -187,7 +253,7 @@ void ParCompress::finish() {
     cv_work_.notify_all();
     cv_order_.notify_all();
     cv_space_.notify_all();
-    for (auto &t : workers_) t.join();
+    if (device_thread_.joinable()) device_thread_.join();
     if (writer_thread_.joinable()) writer_thread_.join();
     std::exception_ptr e;
     {
@@ -198,32 +264,68 @@ void ParCompress::finish() {
     if (first) std::rethrow_exception(first);
 }
 
-void ParCompress::worker_main(size_t lane) {
-    gzpx_ctx *ctx = ctxs_[lane];
+void ParCompress::complete(InFlight &f) {
+    const size_t n = f.job->input.len, bs = cfg_.buffer_size;
+    const size_t nb = n == 0 ? 1 : (n + bs - 1) / bs;
+    try {
+        Done d;
+        d.block_sizes.resize(nb);
+        d.in_len = n;
+        size_t out_len = 0, blk = 0;
+        const int rc = gzpx_compress_slab_wait(ctx_, f.ticket, &out_len, d.block_sizes.data(), nb, &blk);
+        give_buffer(f.job->input);
+        f.job->input = Pinned();
+        if (rc != GZPX_OK) {
+            give_buffer(f.out);
+            throw error_from_code(rc, blk);
+        }
+        f.out.len = out_len;
+        d.out = f.out;
+        f.job->result.set_value(std::move(d));
+    } catch (...) {
+        f.job->result.set_exception(std::current_exception());
+    }
+}
+
+// The device thread: the N compressor threads of the reference (src/par/compress.rs:267-296) folded
+// into one submitter that keeps up to GZPX_SLOTS slabs in flight.  With nothing queued it completes
+// the oldest slab instead of idling, so a slow producer still sees its blocks written promptly.
+void ParCompress::device_main() {
+    (void)hipSetDevice(cfg_.device);
+    std::deque<InFlight> fl;
     for (;;) {
         std::unique_ptr<Job> job;
         {
             std::unique_lock<std::mutex> lk(mu_);
-            cv_work_.wait(lk, [&] { return !work_q_.empty() || closed_ || failed_; });
-            if (work_q_.empty()) return;
-            job = std::move(work_q_.front());
-            work_q_.pop_front();
-            cv_space_.notify_all();
-        }
-        try {
-            const size_t n = job->input.len;
-            const int mode = job->mode;
-            Pinned out = take_buffer(gzpx_slab_bound(ctx, batch_bytes_));
-            size_t out_len = 0, nb = 0;
-            const int rc = gzpx_compress_slab(ctx, job->input.p, n, mode, out.p, out.cap, &out_len, nullptr, 0, &nb);
-            give_buffer(job->input);
-            job->input = Pinned();
-            if (rc != GZPX_OK) {
-                give_buffer(out);
-                throw error_from_code(rc, nb);
+            if (fl.empty()) cv_work_.wait(lk, [&] { return !work_q_.empty() || closed_ || failed_; });
+            if (!work_q_.empty()) {
+                job = std::move(work_q_.front());
+                work_q_.pop_front();
+                cv_space_.notify_all();
+            } else if (fl.empty()) {
+                return;  // closed (or failed) and drained
             }
-            out.len = out_len;
-            job->result.set_value(out);
+        }
+        if (!job) {
+            complete(fl.front());
+            fl.pop_front();
+            continue;
+        }
+        if (fl.size() == GZPX_SLOTS) {
+            complete(fl.front());
+            fl.pop_front();
+        }
+        InFlight f;
+        try {
+            f.out = take_buffer(gzpx_slab_bound(ctx_, batch_bytes_));
+            const int rc = gzpx_compress_slab_submit(ctx_, job->input.p, job->input.len, job->mode, f.out.p,
+                                                     f.out.cap, &f.ticket);
+            if (rc != GZPX_OK) {
+                give_buffer(f.out);
+                throw error_from_code(rc);
+            }
+            f.job = std::move(job);
+            fl.push_back(std::move(f));
         } catch (...) {
             give_buffer(job->input);
             job->input = Pinned();
@@ -234,7 +336,7 @@ void ParCompress::worker_main(size_t lane) {
 
 void ParCompress::writer_main() {
     for (;;) {
-        std::future<Pinned> fut;
+        std::future<Done> fut;
         {
             std::unique_lock<std::mutex> lk(mu_);
             cv_order_.wait(lk, [&] { return !order_q_.empty() || closed_; });
@@ -244,16 +346,25 @@ void ParCompress::writer_main() {
             cv_space_.notify_all();
         }
         try {
-            Pinned chunk = fut.get();  // blocks until THAT slab is done -> in order
+            Done d = fut.get();  // blocks until THAT slab is done -> in order
             std::string err;
             bool ok;
             {
                 std::lock_guard<std::mutex> lk(mu_);
                 ok = !failed_;
             }
-            const bool wrote = !ok || writer_(chunk.p, chunk.len, &err);
-            give_buffer(chunk);
+            const bool wrote = !ok || writer_(d.out.p, d.out.len, &err);
+            give_buffer(d.out);
             if (!wrote) throw GzpError(GzpErrorKind::Io, err.empty() ? "write failed" : err);
+            if (ok) {  // the index side-product: where every block of the slab starts
+                std::lock_guard<std::mutex> lk(index_mu_);
+                const size_t nb = d.block_sizes.size(), bs = cfg_.buffer_size;
+                for (size_t i = 0; i < nb; i++) {
+                    index_.push_back(IndexEntry{coff_, uoff_});
+                    coff_ += d.block_sizes[i];
+                    uoff_ += i + 1 < nb ? bs : d.in_len - (nb - 1) * bs;
+                }
+            }
         } catch (...) {
             std::lock_guard<std::mutex> lk(mu_);
             if (!failed_) {
@@ -266,101 +377,250 @@ void ParCompress::writer_main() {
     }
 }
 
+std::vector<IndexEntry> ParCompress::index() const {
+    std::lock_guard<std::mutex> lk(index_mu_);
+    return index_;
+}
+
 // ---------------------------------------------------------------- ParDecompress
 ParDecompress::ParDecompress(const ParDecompressConfig &cfg, ReadFn reader)
     : cfg_(cfg), reader_(std::move(reader)) {
     const int rc = gzpx_dctx_create(cfg_.device, cfg_.format, &ctx_);  // create_decompressor
     if (rc != GZPX_OK) throw error_from_code(rc);
+    reader_thread_ = std::thread([this] { reader_main(); });
+    device_thread_ = std::thread([this] { device_main(); });
+}
+
+void ParDecompress::stop_threads() {
+    {
+        std::lock_guard<std::mutex> lk(mu_);
+        stop_ = true;
+    }
+    cv_in_.notify_all();
+    cv_out_.notify_all();
+    cv_space_.notify_all();
+    if (reader_thread_.joinable()) reader_thread_.join();
+    if (device_thread_.joinable()) device_thread_.join();
 }
 
 ParDecompress::~ParDecompress() {
+    stop_threads();
     if (ctx_) gzpx_dctx_destroy(ctx_);
-    if (in_.p) (void)hipHostFree(in_.p);
-    if (out_.p) (void)hipHostFree(out_.p);
+    for (uint8_t *p : pinned_) (void)hipHostFree(p);
 }
 
-void ParDecompress::reserve(Staging &s, size_t cap) {
+void ParDecompress::finish() { stop_threads(); }
+
+// grow a page-locked staging buffer, keeping its first `keep` bytes
+void ParDecompress::reserve(Staging &s, size_t cap, size_t keep) {
     if (cap <= s.cap) return;
     cap += cap / 4;
     uint8_t *np = nullptr;
     if (hipHostMalloc((void **)&np, cap, hipHostMallocDefault) != hipSuccess)
         throw GzpError(GzpErrorKind::Device, "hipHostMalloc failed");
-    if (s.len) memcpy(np, s.p, s.len);
-    if (s.p) (void)hipHostFree(s.p);
+    if (keep) memcpy(np, s.p, keep);
+    {
+        std::lock_guard<std::mutex> lk(mu_);
+        if (s.p) {
+            for (auto &q : pinned_)
+                if (q == s.p) q = np;
+            (void)hipHostFree(s.p);
+        } else {
+            pinned_.push_back(np);
+        }
+    }
     s.p = np;
     s.cap = cap;
 }
 
-bool ParDecompress::fill() {
+bool ParDecompress::push(std::deque<SlabPtr> &q, SlabPtr s, std::condition_variable &cv) {
+    std::unique_lock<std::mutex> lk(mu_);
+    cv_space_.wait(lk, [&] { return stop_ || q.size() < q_cap_; });
+    if (stop_) return false;
+    q.push_back(std::move(s));
+    cv.notify_all();
+    return true;
+}
+
+ParDecompress::SlabPtr ParDecompress::pop(std::deque<SlabPtr> &q, std::condition_variable &cv, bool wait) {
+    std::unique_lock<std::mutex> lk(mu_);
+    if (wait) cv.wait(lk, [&] { return stop_ || !q.empty(); });
+    if (q.empty()) return nullptr;
+    SlabPtr s = std::move(q.front());
+    q.pop_front();
+    cv_space_.notify_all();
+    return s;
+}
+
+ParDecompress::SlabPtr ParDecompress::recycle() {
+    {
+        std::lock_guard<std::mutex> lk(mu_);
+        if (!free_.empty()) {
+            SlabPtr s = std::move(free_.front());
+            free_.pop_front();
+            s->in.len = s->out.len = 0;
+            s->used = s->total = 0;
+            s->error = nullptr;
+            s->end = false;
+            return s;
+        }
+    }
+    return std::make_unique<Slab>();
+}
+
+// The reader thread of ParDecompress::run (src/par/decompress.rs:188-219): read ahead, walk the block
+// headers, hand whole blocks on.
+void ParDecompress::reader_main() {
+    (void)hipSetDevice(cfg_.device);
     const size_t hdr = cfg_.format == GZPX_FORMAT_BGZF ? 18 : 20;
+    std::vector<uint8_t> carry;  // the partial block at the end of the previous slab
+    bool eof = false;
     for (;;) {
-        // top the slab up from the reader
-        reserve(in_, cfg_.batch_bytes + (1u << 20));
-        while (!eof_ && in_.len < cfg_.batch_bytes) {
-            const size_t want = in_.cap - in_.len;
-            std::string err;
-            const long got = reader_(in_.p + in_.len, want, &err);
-            if (got < 0) throw GzpError(GzpErrorKind::Io, err.empty() ? "read failed" : err);
-            in_.len += (size_t)got;
-            if (got == 0) eof_ = true;
-        }
-        size_t nb = 0, used = 0;
-        int rc = gzpx_scan_blocks(cfg_.format, in_.p, in_.len, nullptr, nullptr, 0, &nb, &used);
-        if (rc != GZPX_OK) throw error_from_code(rc);
-        if (nb == 0) {
-            if (!eof_) {  // one block larger than the slab: keep reading
-                cfg_.batch_bytes *= 2;
-                continue;
+        SlabPtr s = recycle();
+        try {
+            reserve(s->in, cfg_.batch_bytes + ((size_t)1 << 20) + carry.size(), 0);
+            memcpy(s->in.p, carry.data(), carry.size());
+            s->in.len = carry.size();
+            carry.clear();
+            size_t nb = 0, used = 0;
+            for (;;) {
+                while (!eof && s->in.len < cfg_.batch_bytes) {  // top the slab up from the reader
+                    {
+                        std::lock_guard<std::mutex> lk(mu_);
+                        if (stop_) return;
+                    }
+                    std::string err;
+                    const long got = reader_(s->in.p + s->in.len, s->in.cap - s->in.len, &err);
+                    if (got < 0) throw GzpError(GzpErrorKind::Io, err.empty() ? "read failed" : err);
+                    s->in.len += (size_t)got;
+                    if (got == 0) eof = true;
+                }
+                const int rc = gzpx_scan_blocks(cfg_.format, s->in.p, s->in.len, nullptr, nullptr, 0, &nb, &used);
+                if (rc != GZPX_OK) throw error_from_code(rc);
+                if (nb || eof) break;
+                cfg_.batch_bytes *= 2;  // one block larger than the slab: keep reading
+                reserve(s->in, cfg_.batch_bytes + ((size_t)1 << 20), s->in.len);
             }
-            // EOF: a failed header read ends the stream silently (src/par/decompress.rs:207-209);
-            // a header followed by a short body is read_exact's UnexpectedEof (:201-202)
-            if (in_.len >= hdr) throw GzpError(GzpErrorKind::Io, "failed to fill whole buffer");
-            return false;
+            if (nb == 0) {
+                // EOF: a failed header read ends the stream silently (src/par/decompress.rs:207-209);
+                // a header followed by a short body is read_exact's UnexpectedEof (:201-202)
+                if (s->in.len >= hdr) throw GzpError(GzpErrorKind::Io, "failed to fill whole buffer");
+                s->end = true;
+                (void)push(in_q_, std::move(s), cv_in_);
+                return;
+            }
+            s->offs.resize(nb);
+            s->sizes.resize(nb);
+            const int rc = gzpx_scan_blocks(cfg_.format, s->in.p, s->in.len, s->offs.data(), s->sizes.data(), nb, &nb,
+                                            &used);
+            if (rc != GZPX_OK) throw error_from_code(rc);
+            size_t total = 0;
+            for (size_t b = 0; b < nb; b++) {
+                const uint8_t *f = s->in.p + s->offs[b] + s->sizes[b] - 4;  // ISIZE (get_footer_values)
+                total += (size_t)f[0] | ((size_t)f[1] << 8) | ((size_t)f[2] << 16) | ((size_t)f[3] << 24);
+            }
+            s->used = used;
+            s->total = total;
+            carry.assign(s->in.p + used, s->in.p + s->in.len);
+            if (!push(in_q_, std::move(s), cv_in_)) return;
+        } catch (...) {
+            s->error = std::current_exception();
+            (void)push(in_q_, std::move(s), cv_in_);
+            return;
         }
-        std::vector<uint64_t> offs(nb);
-        std::vector<uint32_t> sizes(nb);
-        rc = gzpx_scan_blocks(cfg_.format, in_.p, in_.len, offs.data(), sizes.data(), nb, &nb, &used);
-        if (rc != GZPX_OK) throw error_from_code(rc);
-        size_t total = 0;
-        for (size_t b = 0; b < nb; b++) {
-            const uint8_t *f = in_.p + offs[b] + sizes[b] - 4;  // ISIZE
-            total += (size_t)f[0] | ((size_t)f[1] << 8) | ((size_t)f[2] << 16) | ((size_t)f[3] << 24);
-        }
-        out_.len = 0;
-        reserve(out_, total ? total : 1);
+    }
+}
+
+// The inflate workers (src/par/decompress.rs:162-186) as one device thread with GZPX_SLOTS slabs in
+// flight; results leave in submission order.
+void ParDecompress::device_main() {
+    (void)hipSetDevice(cfg_.device);
+    std::deque<SlabPtr> fl;
+    auto complete_oldest = [&]() -> bool {  // false: the stream ends here (error or shutdown)
+        SlabPtr s = std::move(fl.front());
+        fl.pop_front();
         size_t got = 0;
         gzpx_check_info info = {0, 0, 0};
-        rc = gzpx_decompress_blocks(ctx_, in_.p, used, offs.data(), sizes.data(), nb, out_.p, total, &got, &info);
+        const int rc = gzpx_decompress_blocks_wait(ctx_, s->ticket, &got, &info);
         if (rc == GZPX_ERR_INVALID_CHECK)
-            throw GzpError(GzpErrorKind::InvalidCheck, "Invalid check value: found " + std::to_string(info.found) +
-                                                           ", expected " + std::to_string(info.expected));
-        if (rc != GZPX_OK) throw error_from_code(rc, info.block);
-        out_.len = got;
-        out_pos_ = 0;
-        memmove(in_.p, in_.p + used, in_.len - used);  // the partial block at the end, if any
-        in_.len -= used;
-        if (got) return true;  // slabs of empty blocks only (e.g. the EOF marker): look further
-        if (eof_ && in_.len == 0) return false;
+            s->error = std::make_exception_ptr(
+                GzpError(GzpErrorKind::InvalidCheck, "Invalid check value: found " + std::to_string(info.found) +
+                                                         ", expected " + std::to_string(info.expected)));
+        else if (rc != GZPX_OK)
+            s->error = std::make_exception_ptr(error_from_code(rc, info.block));
+        s->out.len = got;
+        const bool bad = (bool)s->error;
+        if (!push(out_q_, std::move(s), cv_out_)) return false;
+        return !bad;
+    };
+    for (;;) {
+        SlabPtr s = pop(in_q_, cv_in_, fl.empty());
+        if (!s) {
+            if (fl.empty()) return;  // shutdown
+            if (!complete_oldest()) break;
+            continue;
+        }
+        if (s->error || s->end) {  // everything before it first, then the marker itself
+            bool ok = true;
+            while (ok && !fl.empty()) ok = complete_oldest();
+            if (ok) (void)push(out_q_, std::move(s), cv_out_);
+            break;
+        }
+        if (fl.size() == GZPX_SLOTS && !complete_oldest()) break;
+        try {
+            reserve(s->out, s->total ? s->total : 1, 0);
+            const int rc = gzpx_decompress_blocks_submit(ctx_, s->in.p, s->used, s->offs.data(), s->sizes.data(),
+                                                         s->offs.size(), s->out.p, s->total, &s->ticket);
+            if (rc != GZPX_OK) throw error_from_code(rc);
+            fl.push_back(std::move(s));
+        } catch (...) {
+            s->error = std::current_exception();
+            bool ok = true;
+            while (ok && !fl.empty()) ok = complete_oldest();
+            if (ok) (void)push(out_q_, std::move(s), cv_out_);
+            break;
+        }
+    }
+    // slabs still in flight hold device work that references their buffers: wait for it
+    while (!fl.empty()) {
+        size_t got = 0;
+        (void)gzpx_decompress_blocks_wait(ctx_, fl.front()->ticket, &got, nullptr);
+        fl.pop_front();
     }
 }
 
 size_t ParDecompress::read(uint8_t *buf, size_t n) {
-    if (out_pos_ == out_.len) {
-        out_.len = 0;
+    if (sticky_) std::rethrow_exception(sticky_);
+    while (!cur_ || out_pos_ == cur_->out.len) {
+        if (cur_) {
+            std::lock_guard<std::mutex> lk(mu_);
+            free_.push_back(std::move(cur_));
+            cur_ = nullptr;
+        }
+        if (done_) return 0;
+        SlabPtr s = pop(out_q_, cv_out_, true);
+        if (!s || s->end) {
+            done_ = true;
+            return 0;
+        }
+        if (s->error) {
+            sticky_ = s->error;
+            done_ = true;
+            stop_threads();
+            std::rethrow_exception(sticky_);
+        }
+        cur_ = std::move(s);  // (a slab of empty blocks only -- e.g. the EOF marker -- is skipped by the loop)
         out_pos_ = 0;
-        if (!fill()) return 0;
     }
-    const size_t take = out_.len - out_pos_ < n ? out_.len - out_pos_ : n;
-    memcpy(buf, out_.p + out_pos_, take);
+    const size_t take = cur_->out.len - out_pos_ < n ? cur_->out.len - out_pos_ : n;
+    memcpy(buf, cur_->out.p + out_pos_, take);
     out_pos_ += take;
     return take;
 }
 
-void ParDecompress::finish() {}
-
 }  // namespace gzp
 
-// ---------------------------------------------------------------- C ABI of the twin
+// ---------------------------------------------------------------- C ABI of the twins
 struct gzpx_par {
     std::unique_ptr<gzp::ParCompress> pc;
     std::string last_error;
@@ -455,6 +715,20 @@ int gzpx_par_write(gzpx_par *p, const uint8_t *buf, size_t n) {
     return guarded(p, [&] { p->pc->write(buf, n); });
 }
 
+int gzpx_par_reserve(gzpx_par *p, uint8_t **ptr, size_t *cap) {
+    if (!p || !ptr || !cap) return GZPX_ERR_INVALID_ARG;
+    return guarded(p, [&] {
+        const auto r = p->pc->reserve();
+        *ptr = r.first;
+        *cap = r.second;
+    });
+}
+
+int gzpx_par_commit(gzpx_par *p, size_t n) {
+    if (!p) return GZPX_ERR_INVALID_ARG;
+    return guarded(p, [&] { p->pc->commit(n); });
+}
+
 int gzpx_par_flush(gzpx_par *p) {
     if (!p) return GZPX_ERR_INVALID_ARG;
     return guarded(p, [&] { p->pc->flush(); });
@@ -465,6 +739,17 @@ int gzpx_par_finish(gzpx_par *p) {
     return guarded(p, [&] { p->pc->finish(); });
 }
 
+int gzpx_par_index(gzpx_par *p, gzpx_index_entry *entries, size_t max_entries, size_t *n_entries) {
+    if (!p || !n_entries) return GZPX_ERR_INVALID_ARG;
+    return guarded(p, [&] {
+        const std::vector<gzp::IndexEntry> idx = p->pc->index();
+        *n_entries = idx.size();
+        if (entries)
+            for (size_t i = 0; i < idx.size() && i < max_entries; i++)
+                entries[i] = gzpx_index_entry{idx[i].compressed_offset, idx[i].uncompressed_offset};
+    });
+}
+
 void gzpx_par_destroy(gzpx_par *p) {
     if (!p) return;
     p->pc.reset();  // Drop: finishes if needed
@@ -472,6 +757,25 @@ void gzpx_par_destroy(gzpx_par *p) {
 }
 
 const char *gzpx_par_last_error(const gzpx_par *p) { return p ? p->last_error.c_str() : ""; }
+
+size_t gzpx_gzi_size(size_t n_entries) { return 8 + 16 * (n_entries ? n_entries - 1 : 0); }
+
+int gzpx_gzi_write(const gzpx_index_entry *entries, size_t n_entries, uint8_t *out, size_t out_cap,
+                   size_t *out_len) {
+    if ((!entries && n_entries) || !out || !out_len) return GZPX_ERR_INVALID_ARG;
+    const size_t need = gzpx_gzi_size(n_entries);
+    if (need > out_cap) return GZPX_ERR_INSUFFICIENT_SPACE;
+    auto put64 = [](uint8_t *q, uint64_t v) {
+        for (int k = 0; k < 8; k++) q[k] = (uint8_t)(v >> (8 * k));
+    };
+    put64(out, n_entries ? n_entries - 1 : 0);  // the first block (0, 0) is implicit
+    for (size_t i = 1; i < n_entries; i++) {
+        put64(out + 8 + 16 * (i - 1), entries[i].compressed_offset);
+        put64(out + 16 + 16 * (i - 1), entries[i].uncompressed_offset);
+    }
+    *out_len = need;
+    return GZPX_OK;
+}
 
 int gzpx_pard_create(int format, int device, size_t batch_bytes, gzpx_read_fn read_fn, void *user,
                      gzpx_pard **out) {

@@ -97,6 +97,37 @@ class ParCompress:
 
     write_all = write
 
+    def reserve(self):
+        """Room inside the page-locked slab being filled, as a writable numpy view (gzpx_par_reserve);
+        fill a prefix of it and commit(n)."""
+        ptr = ctypes.c_void_p()
+        cap = ctypes.c_size_t(0)
+        self._check(self._lib.L.gzpx_par_reserve(self._h, ctypes.byref(ptr), ctypes.byref(cap)))
+        buf = (ctypes.c_uint8 * cap.value).from_address(ptr.value)
+        return np.frombuffer(buf, dtype=np.uint8)
+
+    def commit(self, n):
+        self._check(self._lib.L.gzpx_par_commit(self._h, int(n)))
+
+    def index(self):
+        """(compressed_offset, uncompressed_offset) of every block written so far, as an (n, 2) uint64
+        array in stream order (README.md:161); complete after finish()."""
+        n = ctypes.c_size_t(0)
+        self._check(self._lib.L.gzpx_par_index(self._h, None, 0, ctypes.byref(n)))
+        out = np.zeros((n.value, 2), dtype=np.uint64)
+        self._check(self._lib.L.gzpx_par_index(self._h, out.ctypes.data, n.value, ctypes.byref(n)))
+        return out[:n.value]
+
+    def gzi(self):
+        """The index in htslib's .gzi layout (bytes)."""
+        idx = np.ascontiguousarray(self.index())
+        cap = int(self._lib.L.gzpx_gzi_size(idx.shape[0]))
+        out = np.zeros(cap, dtype=np.uint8)
+        got = ctypes.c_size_t(0)
+        self._lib.check(self._lib.L.gzpx_gzi_write(idx.ctypes.data, idx.shape[0], out.ctypes.data, cap,
+                                                   ctypes.byref(got)))
+        return out[:got.value].tobytes()
+
     def flush(self):
         self._check(self._lib.L.gzpx_par_flush(self._h))
 
@@ -179,6 +210,11 @@ class ParCompressBuilder:
         cfg = _native.GzpxParConfig(self._fmt.FORMAT, self._level.level(), self._compat, self._device,
                                     self._buffer_size, self._num_threads, self._batch_blocks)
         return ParCompress(cfg, writer, self._lib)
+
+    # from_borrowed_writer (src/par/compress.rs:162-194): the caller keeps the writer; in Python
+    # (and through the C ABI's callback + user pointer) every writer is borrowed, so this is the
+    # same constructor -- finish() before the writer goes away, as the reference demands.
+    from_borrowed_writer = from_writer
 
 
 class ZBuilder:

@@ -164,15 +164,35 @@ typedef struct gzpx_par_config {
     int compat;          /* GZPX_COMPAT_*                                               */
     int device;          /* HIP device                                                  */
     size_t buffer_size;  /* ParCompressBuilder::buffer_size (>= 32768)                  */
-    size_t num_threads;  /* ParCompressBuilder::num_threads (> 0); >= 2 -> two lanes    */
-    size_t batch_blocks; /* blocks per slab handed to a device lane (0 = default 1024)  */
+    size_t num_threads;  /* ParCompressBuilder::num_threads (> 0); > 1 adds copy helpers */
+    size_t batch_blocks; /* blocks per slab handed to the device (0 = default 1024; a slab is capped at 128 MiB) */
 } gzpx_par_config;
 int gzpx_par_create(const gzpx_par_config *cfg, gzpx_write_fn write_fn, void *user, gzpx_par **out);
 int gzpx_par_write(gzpx_par *p, const uint8_t *buf, size_t n);
+/* In-place form of write() for producers that can fill memory they are handed (read(2) into the
+ * slab, a decoder's output): reserve returns room (>= buffer_size bytes) inside the page-locked slab
+ * that is being filled, commit appends the first n bytes of it to the stream.  Same cut rule as
+ * write(), no copy on the way to the device. */
+int gzpx_par_reserve(gzpx_par *p, uint8_t **ptr, size_t *cap);
+int gzpx_par_commit(gzpx_par *p, size_t n);
 int gzpx_par_flush(gzpx_par *p);
 int gzpx_par_finish(gzpx_par *p);
 void gzpx_par_destroy(gzpx_par *p);
 const char *gzpx_par_last_error(const gzpx_par *p);
+
+/* ---- block index side-product (README.md:161 "Return an auto-generated index for BGZF / Mgzip
+ * formats"): where every block written so far starts in the compressed and in the uncompressed
+ * stream, in stream order; complete after gzpx_par_finish.  gzpx_gzi_write serialises it in
+ * htslib's .gzi layout (u64 count, then (compressed, uncompressed) u64 pairs of every block but
+ * the first, little-endian). */
+typedef struct gzpx_index_entry {
+    uint64_t compressed_offset;
+    uint64_t uncompressed_offset;
+} gzpx_index_entry;
+int gzpx_par_index(gzpx_par *p, gzpx_index_entry *entries, size_t max_entries, size_t *n_entries);
+size_t gzpx_gzi_size(size_t n_entries);
+int gzpx_gzi_write(const gzpx_index_entry *entries, size_t n_entries, uint8_t *out, size_t out_cap,
+                   size_t *out_len);
 
 /* ---- ParDecompress<Bgzf/Mgzip> (src/par/decompress.rs:132-337; BlockFormatSpec src/lib.rs:411-448) ----
  *   gzpx_scan_blocks            the reader thread's header walk: check_header + get_block_size
