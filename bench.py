@@ -8,14 +8,23 @@ complete BGZF stream in HBM.  With N > 1 ranks every rank compresses its own sla
 blocks, no data-path collective: weak scaling) and the compressed shards are gathered in rank
 order to rank 0 over RCCL inside the timed step (the in-order write-out exchange).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
-    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+    python bench.py [--gpus N] [--steps K] [--warmup W]        (N > 1 launches itself under
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...   torch.distributed.run)
+
+The same JSON line carries, measured in the same run after the headline region (N = 1):
+    "e2e"      host-to-host rates: pinned submit/wait pipeline, and the Write API (ParCompress twin)
+    "inflate"  the ParDecompress row (BASELINE configs[4]) over the stream just produced
+Other workloads: --workload inflate (configs[4] alone), --workload fastq (configs[3]: a 32 GiB
+synthetic FASTQ stream generated in HBM, sharded over the ranks).
 """
 import argparse
+import ctypes
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
-import threading
 import time
 
 import numpy as np
@@ -27,6 +36,8 @@ if ROOT not in sys.path:
 SLAB_BYTES = 576_716_800  # 550 MiB = shakespeare.txt x 100 shape (README.md:166-167)
 BLOCK = 65280             # Bgzf::DEFAULT_BUFSIZE (src/deflate.rs:583)
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+FASTQ_STREAM = 32 << 30   # BASELINE configs[3]
+FASTQ_SEED = 20250927
 
 
 def pmc_traffic(kernel):
@@ -107,58 +118,104 @@ def cpu_baseline_inflate(comp, offs, sizes, wall_s=8.0):
     }
 
 
-def run_inflate(args, torch, dist, world, rank, local_rank, dev):
-    """--workload inflate: BASELINE.json configs[4] -- ParDecompress<Bgzf> over the output of the
-    compress workload.  One step = scan-free multi-block inflate + per-block CRC check of the whole
-    BGZF stream (already resident in HBM) into HBM."""
-    from gzp_amd import _native, synth
+class Env:
+    """Where the bench runs: ranks, device, library.  --emulate (tests only) swaps the HIP library for
+    the CPU-emulated build and RCCL for gloo, so that the N > 1 control flow can be exercised
+    without GPUs; such a run measures nothing."""
+
+    def __init__(self, args):
+        import torch
+        import torch.distributed as dist
+        from gzp_amd import _native
+        self.torch, self.dist, self.native = torch, dist, _native
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        self.emulate = args.emulate
+        if self.emulate:
+            sys.path.insert(0, os.path.join(ROOT, "tests", "emu"))
+            import build_emu
+            self.lib = _native.GzpxLib(build_emu.build())
+            self.dev = torch.device("cpu")
+            self.device_index = 0
+        else:
+            self.lib = _native.load()
+            torch.cuda.set_device(self.local_rank)
+            self.dev = torch.device("cuda", self.local_rank)
+            self.device_index = self.local_rank
+        if self.world > 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            if self.emulate:
+                dist.init_process_group("gloo")
+            else:
+                dist.init_process_group("nccl", device_id=self.dev)
+
+    def sync(self):
+        if self.world > 1:
+            self.dist.barrier()
+        if not self.emulate:
+            self.torch.cuda.synchronize()
+
+    def max_over_ranks(self, dt):
+        if self.world > 1:
+            t = self.torch.tensor([dt], dtype=self.torch.float64, device=self.dev)
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt
+
+    def close(self):
+        if self.world > 1:
+            self.dist.barrier()
+            self.dist.destroy_process_group()
+
+
+def run_inflate(args, env, emit=True, d_stream=None, comp_host=None, slab=None, steps=None):
+    """BASELINE.json configs[4] -- ParDecompress<Bgzf> over the output of the compress workload.  One
+    step = multi-block inflate + per-block CRC check of the whole BGZF stream (already resident in
+    HBM) into HBM.  Also the "inflate" leg of the default line (d_stream / comp_host given)."""
+    torch, _native = env.torch, env.native
     n = args.slab_bytes
-    slab = synth.text_slab(n, seed=20250927 + rank)
-    with _native.Context(format=_native.FORMAT_BGZF, level=1, buffer_size=BLOCK, compat=_native.COMPAT_1_24,
-                         device=local_rank, max_slab_bytes=n) as c:
-        comp = np.frombuffer(c.compress_slab(slab, True), dtype=np.uint8).copy()
-        device_name = c.device_name()
-    d = _native.DContext(format=_native.FORMAT_BGZF, device=local_rank)
-    offs, sizes, used = d.scan_blocks(comp)
-    d_in = torch.from_numpy(comp).to(dev)
-    d_out = torch.empty(n + 64, dtype=torch.uint8, device=dev)
+    steps = steps or args.steps
+    device_name = ""
+    if comp_host is None:
+        from gzp_amd import synth
+        slab = synth.text_slab(n, seed=20250927 + env.rank)
+        with _native.Context(format=_native.FORMAT_BGZF, level=1, buffer_size=BLOCK, compat=_native.COMPAT_1_24,
+                             device=env.device_index, max_slab_bytes=n, lib=env.lib) as c:
+            comp_host = np.frombuffer(c.compress_slab(slab, True), dtype=np.uint8).copy()
+            device_name = c.device_name()
+        d_stream = torch.from_numpy(comp_host).to(env.dev)
+    d = _native.DContext(format=_native.FORMAT_BGZF, device=env.device_index, lib=env.lib)
+    offs, sizes, used = d.scan_blocks(comp_host)
+    d_out = torch.empty(n + 64, dtype=torch.uint8, device=env.dev)
 
     def step():
-        return d.decompress_device(d_in.data_ptr(), comp.size, offs, sizes, d_out.data_ptr(), n + 64)
+        return d.decompress_device(d_stream.data_ptr(), comp_host.size, offs, sizes, d_out.data_ptr(), n + 64)
 
-    for _ in range(args.warmup):
+    for _ in range(min(args.warmup, 2) if not emit else args.warmup):
         step()
-
-    def sync():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    sync()
+    env.sync()
     t0 = time.perf_counter()
     kern_ms = 0.0
     got = 0
-    for _ in range(args.steps):
+    for _ in range(steps):
         got = step()
         kern_ms += d.last_inflate_ms()
-    sync()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    if rank == 0:
-        ok = got == n and d_out[:n].cpu().numpy().tobytes() == slab.tobytes()
-        kern_ms /= args.steps
-        achieved = (comp.size + n) / (kern_ms * 1e-3) / 1e9  # reads the stream, writes the text
+    env.sync()
+    dt = env.max_over_ranks(time.perf_counter() - t0)
+    res = None
+    if env.rank == 0:
+        ok = got == n and bool((d_out[:n].cpu() == torch.from_numpy(slab)).all())
+        kern_ms /= steps
+        achieved = (comp_host.size + n) / (max(kern_ms, 1e-9) * 1e-3) / 1e9  # reads the stream, writes the text
         res = {
             "metric": "BGZF decompress MiB/s (inflated bytes) of the level-1 550 MiB text stream",
-            "value": round(n * world / 2**20 / (dt / args.steps), 1),
+            "value": round(n * env.world / 2**20 / (dt / steps), 1),
             "unit": "MiB/s",
-            "n_gpus": world,
-            "steps": args.steps,
+            "n_gpus": env.world,
+            "steps": steps,
             "warmup": args.warmup,
-            "ms_per_step": round(dt / args.steps * 1e3, 3),
+            "ms_per_step": round(dt / steps * 1e3, 3),
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
@@ -167,10 +224,10 @@ def run_inflate(args, torch, dist, world, rank, local_rank, dev):
             "config": {
                 "workload": "ParDecompress<Bgzf>: GPU multi-block inflate of output from config 2, CRC "
                             "check, MiB/s vs CPU path",
-                "compressed_bytes": int(comp.size),
+                "compressed_bytes": int(comp_host.size),
                 "inflated_bytes": n,
                 "blocks": int(offs.size),
-                "parallelism": "block-shard x%d" % world,
+                "parallelism": "block-shard x%d" % env.world,
                 "verified_round_trip": bool(ok),
                 "device": device_name,
             },
@@ -185,10 +242,12 @@ def run_inflate(args, torch, dist, world, rank, local_rank, dev):
                 "kernel_ms": round(kern_ms, 3),
             },
         }
-        if not args.no_cpu_baseline and world == 1:
-            res["cpu_baseline"] = cpu_baseline_inflate(comp, offs, sizes)
-        print(json.dumps(res))
+        if not args.no_cpu_baseline and env.world == 1:
+            res["cpu_baseline"] = cpu_baseline_inflate(comp_host, offs, sizes, wall_s=8.0 if emit else 4.0)
+        if emit:
+            print(json.dumps(res))
     d.close()
+    return res
 
 
 def verify(slab, out_bytes, block_sizes, tail=True):
@@ -211,37 +270,257 @@ def verify(slab, out_bytes, block_sizes, tail=True):
     return True
 
 
+def e2e_legs(env, slab, want_sha):
+    """Host-to-host rates of the same slab, measured after the headline region (SURVEY 8(d) timings
+    ii and iii):
+      device_pinned  page-locked host buffers through gzpx_compress_slab_submit / _wait, 8 slabs,
+                     up to three in flight: copy-in, kernels and copy-out overlap on three streams
+      api_write      the Write API: ParCompress twin (C ABI gzpx_par_*), ordinary pageable input,
+                     one write_all of the whole slab + finish(), the writer callback is a sink
+      api_write_64k  the same through 64 KiB write() calls, the shape of benches/bench.rs:36-45
+    Every output is checked against the device-resident result (SHA-256)."""
+    _native = env.native
+    L = env.lib.L
+    n = slab.size
+    out = {}
+    nb_total = -(-n // BLOCK)
+    per = -(-nb_total // 8)
+    cuts = [min(n, i * per * BLOCK) for i in range(9)]
+    pieces = [(cuts[i], cuts[i + 1]) for i in range(8) if cuts[i + 1] > cuts[i]]
+    ctx = _native.Context(format=_native.FORMAT_BGZF, level=1, buffer_size=BLOCK, compat=_native.COMPAT_1_24,
+                          device=env.device_index, max_slab_bytes=per * BLOCK, lib=env.lib)
+    cap = ctx.slab_bound(n) + 8 * 4096
+    p_in = L.gzpx_host_alloc(n)
+    p_out = L.gzpx_host_alloc(cap)
+    if not p_in or not p_out:
+        return {"error": "gzpx_host_alloc failed"}
+    ctypes.memmove(p_in, slab.ctypes.data, n)
+    best = None
+    digest = None
+    for rep in range(3):  # first repetition warms the staging buffers
+        t0 = time.perf_counter()
+        tickets, pos, total = [], 0, 0
+        sizes = []
+        for i, (lo, hi) in enumerate(pieces):
+            mode = _native.SLAB_LAST if i == len(pieces) - 1 else _native.SLAB_FULL_BLOCKS
+            bound = ctx.slab_bound(hi - lo)
+            if len(tickets) == 3:
+                t, o = tickets.pop(0)
+                sizes.append((o, ctx.wait(t)[0]))
+            tk = ctx.submit(p_in + lo, hi - lo, p_out + pos, bound, mode)
+            tickets.append((tk, pos))
+            pos += bound
+        for t, o in tickets:
+            sizes.append((o, ctx.wait(t)[0]))
+        dt = time.perf_counter() - t0
+        if rep and (best is None or dt < best):
+            best = dt
+        if rep == 2:
+            h = hashlib.sha256()
+            buf = (ctypes.c_uint8 * cap).from_address(p_out)
+            view = np.frombuffer(buf, dtype=np.uint8)
+            for o, s in sizes:
+                h.update(view[o:o + s])
+            digest = h.hexdigest()
+    out["device_pinned_MiBps"] = round(n / 2**20 / best, 1)
+    out["device_pinned_ok"] = digest == want_sha
+    ctx.close()
+    L.gzpx_host_free(p_in)
+    L.gzpx_host_free(p_out)
+
+    # the Write API
+    state = {"h": None, "n": 0}
+
+    def sink(user, data, nbytes):
+        state["n"] += nbytes
+        if state["h"] is not None:
+            state["h"].update(ctypes.string_at(data, nbytes))
+        return 0
+
+    cb = _native.WRITE_FN(sink)
+    for name, chunk in (("api_write_MiBps", n), ("api_write_64k_MiBps", 65536)):
+        best = None
+        for rep in range(3):
+            state["h"] = hashlib.sha256() if rep == 2 else None
+            state["n"] = 0
+            cfg = _native.GzpxParConfig(_native.FORMAT_BGZF, 1, _native.COMPAT_1_24, env.device_index, BLOCK, 8, 1024)
+            h = ctypes.c_void_p()
+            env.lib.check(L.gzpx_par_create(ctypes.byref(cfg), cb, None, ctypes.byref(h)))
+            base = slab.ctypes.data
+            t0 = time.perf_counter()
+            for lo in range(0, n, chunk):
+                rc = L.gzpx_par_write(h, base + lo, min(chunk, n - lo))
+                if rc:
+                    break
+            rc = rc or L.gzpx_par_finish(h)
+            dt = time.perf_counter() - t0
+            L.gzpx_par_destroy(h)
+            if rc:
+                return dict(out, error="gzpx_par rc %d" % rc)
+            if rep == 1:  # (the hashing repetition is not a timing)
+                best = dt
+            elif rep == 0:
+                pass
+        out[name] = round(n / 2**20 / best, 1)
+        out[name.replace("MiBps", "ok")] = state["h"].hexdigest() == want_sha
+    return out
+
+
+def run_fastq(args, env):
+    """BASELINE.json configs[3]: BGZF level 1 on a 32 GiB synthetic FASTQ stream, sharded over the
+    ranks at block boundaries (strong scaling: the stream is fixed), in-order gather to rank 0."""
+    torch, dist, _native = env.torch, env.dist, env.native
+    from gzp_amd import shard
+    total = args.stream_bytes
+    lo, n = shard.shard_bytes(total, BLOCK, env.world)[env.rank]
+    mode = shard.slab_mode(env.rank, env.world, total, BLOCK)
+    d_in = torch.empty(n + 64, dtype=torch.uint8, device=env.dev)
+    _native.synth_fastq_device(d_in.data_ptr(), lo, n, FASTQ_SEED, lib=env.lib)  # generated in HBM
+    ctx = _native.Context(format=_native.FORMAT_BGZF, level=1, buffer_size=BLOCK, compat=_native.COMPAT_1_24,
+                          device=env.device_index, max_slab_bytes=n, lib=env.lib)
+    cap = ctx.slab_bound(n)
+    d_out = torch.empty(cap, dtype=torch.uint8, device=env.dev)
+    nb = ctx.n_blocks(n)
+    block_sizes = np.zeros(nb, dtype=np.uint32)
+    gathered = None
+    out_len = 0
+
+    def step():
+        ol, _ = ctx.compress_slab_device(d_in.data_ptr(), n, d_out.data_ptr(), cap, mode, None, block_sizes)
+        g = None
+        if env.world > 1:
+            g = shard.ordered_gather(d_out[:ol], dst=0)
+        return ol, g
+
+    for _ in range(args.warmup):
+        step()
+    env.sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out_len, gathered = step()
+    env.sync()
+    dt = env.max_over_ranks(time.perf_counter() - t0)
+    # ---- verification, outside the timed region
+    info = {}
+    if env.world > 1:
+        stream = gathered  # rank 0: the whole stream, in order
+    else:
+        stream = d_out[:out_len]
+    if env.rank == 0:
+        host = stream.cpu().numpy()
+        info["stream_bytes_out"] = int(host.size)
+        info["stream_sha256"] = hashlib.sha256(host).hexdigest()
+        # the stream's integrity check on the GPU: every block inflated and CRC-checked (what gzip -t does)
+        d = _native.DContext(format=_native.FORMAT_BGZF, device=env.device_index, lib=env.lib)
+        offs, sizes, used = d.scan_blocks(host)
+        ok = used == host.size
+        piece = 1 << 30  # compressed bytes per call: whole blocks
+        b0 = 0
+        d_chk = torch.empty(min(total, 4 << 30) + BLOCK, dtype=torch.uint8, device=env.dev)
+        d_ref = torch.empty_like(d_chk)
+        upos = 0
+        while ok and b0 < offs.size:
+            b1 = b0
+            while b1 < offs.size and int(offs[b1]) + int(sizes[b1]) - int(offs[b0]) <= piece and (b1 - b0) * BLOCK < (4 << 30):
+                b1 += 1
+            lo_c, hi_c = int(offs[b0]), int(offs[b1 - 1]) + int(sizes[b1 - 1])
+            got = d.decompress_device(stream.data_ptr() + lo_c, hi_c - lo_c, offs[b0:b1] - np.uint64(lo_c),
+                                      sizes[b0:b1], d_chk.data_ptr(), d_chk.numel())
+            _native.synth_fastq_device(d_ref.data_ptr(), upos, got, FASTQ_SEED, lib=env.lib)
+            if not env.emulate:
+                torch.cuda.synchronize()
+            ok = ok and bool((d_chk[:got] == d_ref[:got]).all())
+            upos += got
+            b0 = b1
+        info["gpu_inflate_crc_roundtrip_ok"] = bool(ok and upos == total)
+        d.close()
+        # gzip -t on the two ends of the stream (a prefix of whole blocks; the tail incl. the EOF marker)
+        k = int(np.searchsorted(offs, 64 << 20))
+        pre = host[:int(offs[k])] if k < offs.size else host
+        k2 = int(np.searchsorted(offs, max(0, host.size - (64 << 20))))
+        suf = host[int(offs[min(k2, offs.size - 1)]):]
+        try:
+            rc = [subprocess.run(["gzip", "-t"], input=x.tobytes(), capture_output=True).returncode for x in (pre, suf)]
+            info["gzip_t_prefix_suffix_rc"] = rc
+        except FileNotFoundError:
+            info["gzip_t_prefix_suffix_rc"] = None
+        res = {
+            "metric": "BGZF compress MiB/s at level 1, 32 GiB synthetic FASTQ (configs[3])",
+            "value": round(total / 2**20 / (dt / args.steps), 1),
+            "unit": "MiB/s",
+            "n_gpus": env.world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 3),
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "u8",
+            "data": "synthetic",
+            "config": dict({
+                "workload": "8xMI355X input shard + RCCL gather: BGZF level 1 on 32 GiB synthetic FASTQ, in-order "
+                            "concat verified by gzip -t",
+                "stream_bytes": total, "shard_bytes": n, "block_size": BLOCK,
+                "blocks": -(-total // BLOCK),
+                "parallelism": "block-shard x%d%s" % (env.world, " + ordered RCCL gather" if env.world > 1 else ""),
+                "ratio": round(info["stream_bytes_out"] / total, 4),
+                "device": ctx.device_name(),
+            }, **info),
+        }
+        print(json.dumps(res))
+    ctx.close()
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` from a bare shell: re-execute under torch.distributed.run, one rank
+    per GPU (the driver may also launch it that way itself; then WORLD_SIZE is already set)."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    sys.stdout.flush()
+    os.execvpe(cmd[0], cmd, env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--slab-bytes", type=int, default=SLAB_BYTES)
+    ap.add_argument("--stream-bytes", type=int, default=FASTQ_STREAM, help="--workload fastq: the whole stream")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--workload", choices=["compress", "inflate"], default="compress",
-                    help="compress = the headline metric (default); inflate = the ParDecompress row")
+    ap.add_argument("--no-extras", action="store_true", help="only the headline region (no e2e / inflate legs)")
+    ap.add_argument("--writeout", choices=["rccl", "offsets"], default="rccl",
+                    help="N > 1 in-order write-out: rccl = ordered gather of the compressed shards to rank 0 over "
+                         "xGMI (north_star); offsets = all_gather of the shard sizes only, every rank copies its "
+                         "shard to its own page-locked buffer at its stream offset")
+    ap.add_argument("--workload", choices=["compress", "inflate", "fastq"], default="compress",
+                    help="compress = the headline metric (default); inflate = the ParDecompress row; fastq = configs[3]")
+    ap.add_argument("--emulate", action="store_true", help=argparse.SUPPRESS)  # tests: CPU emulator + gloo, no timing value
     args = ap.parse_args()
 
-    import torch
-    import torch.distributed as dist
-    from gzp_amd import _native, synth
-
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world == 1 and "RANK" not in os.environ:
+        self_launch(args)  # does not return
     if args.gpus > 1 and world != args.gpus:
-        raise SystemExit("launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)" %
-                         (args.gpus, world))
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        raise SystemExit("WORLD_SIZE=%d but --gpus %d" % (world, args.gpus))
+
+    env = Env(args)
+    torch, dist, _native = env.torch, env.dist, env.native
+    from gzp_amd import synth
+    world, rank = env.world, env.rank
     if args.workload == "inflate":
-        run_inflate(args, torch, dist, world, rank, local_rank, dev)
-        if world > 1:
-            dist.barrier()
-            dist.destroy_process_group()
+        run_inflate(args, env)
+        env.close()
+        return
+    if args.workload == "fastq":
+        run_fastq(args, env)
+        env.close()
         return
 
     # One logical stream of world x 550 MiB, sharded at block boundaries (weak scaling: every
@@ -251,31 +530,49 @@ def main():
     lo, n = shard.shard_bytes(total, BLOCK, world)[rank]
     mode = shard.slab_mode(rank, world, total, BLOCK)
     slab = synth.text_slab(n, seed=20250927 + rank)
-    d_in = torch.from_numpy(slab).to(dev)
+    d_in = torch.from_numpy(slab).to(env.dev)
     ctx = _native.Context(format=_native.FORMAT_BGZF, level=1, buffer_size=BLOCK,
-                          compat=_native.COMPAT_1_24, device=local_rank, max_slab_bytes=n)
+                          compat=_native.COMPAT_1_24, device=env.device_index, max_slab_bytes=n, lib=env.lib)
     cap = ctx.slab_bound(n)
-    # two output buffers: with N > 1 the gather of one step's shard (RCCL, asynchronous) runs while
-    # the next step compresses into the other buffer, the way ParCompress's lanes overlap
-    d_outs = [torch.empty(cap, dtype=torch.uint8, device=dev) for _ in range(2 if world > 1 else 1)]
-    d_out = d_outs[0]
-    gathered = torch.empty(cap * world, dtype=torch.uint8, device=dev) if (world > 1 and rank == 0) else None
+    # two output buffers: with N > 1 the write-out of one step's shard (asynchronous) runs while the
+    # next step compresses into the other buffer, the way ParCompress's slabs overlap
+    d_outs = [torch.empty(cap, dtype=torch.uint8, device=env.dev) for _ in range(2 if world > 1 else 1)]
+    gathered = torch.empty(cap * world, dtype=torch.uint8, device=env.dev) \
+        if (world > 1 and rank == 0 and args.writeout == "rccl") else None
+    host_out = None
+    if world > 1 and args.writeout == "offsets" and not env.emulate:
+        host_out = [torch.empty(cap, dtype=torch.uint8).pin_memory() for _ in range(2)]
+        copy_stream = torch.cuda.Stream()
     nb = ctx.n_blocks(n)
     block_sizes = np.zeros(nb, dtype=np.uint32)
     ctx.set_profiling(True)
-    state = {"i": 0, "pending": None}
+    state = {"i": 0, "pending": None, "offsets": None}
 
     def step():
-        buf = d_outs[state["i"] % len(d_outs)]
+        k = state["i"] % len(d_outs)
+        buf = d_outs[k]
         state["i"] += 1
         out_len, _ = ctx.compress_slab_device(d_in.data_ptr(), n, buf.data_ptr(), cap, mode,
                                               None, block_sizes)
         if world > 1:
-            # in-order write-out: ordered variable-size gather of the shards to rank 0 (RCCL),
-            # started now and completed while the next step compresses
-            if state["pending"] is not None:  # the previous shard has arrived (it travelled while
-                state["pending"].wait()       # this step compressed); `gathered` is free again
-            state["pending"] = shard.ordered_gather_start(buf[:out_len], dst=0, out=gathered)
+            if state["pending"] is not None:  # the previous shard has left (it travelled while this
+                state["pending"].wait()       # step compressed); its buffers are free again
+            if args.writeout == "rccl":
+                # in-order write-out: ordered variable-size gather of the shards to rank 0 (RCCL),
+                # started now and completed while the next step compresses
+                state["pending"] = shard.ordered_gather_start(buf[:out_len], dst=0, out=gathered)
+            else:
+                # only the 8-byte sizes cross the fabric: their exclusive scan is every rank's offset
+                # in the output stream, and each rank moves its own shard to the host side (where the
+                # writer would pwrite it at that offset) over its own PCIe link
+                state["offsets"] = shard.stream_offsets(out_len, env.dev)
+                if host_out is not None:
+                    copy_stream.wait_stream(torch.cuda.current_stream())
+                    with torch.cuda.stream(copy_stream):
+                        host_out[k][:out_len].copy_(buf[:out_len], non_blocking=True)
+                        ev = torch.cuda.Event()
+                        ev.record(copy_stream)
+                    state["pending"] = shard.EventHandle(ev)
         return out_len
 
     def drain():
@@ -288,25 +585,16 @@ def main():
         step()
     drain()
 
-    def sync():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    sync()
+    env.sync()
     t0 = time.perf_counter()
     out_len = 0
     for _ in range(args.steps):
         out_len = step()
         for k, v in ctx.last_stage_ms().items():
             stage_acc[k] = stage_acc.get(k, 0.0) + v
-    drain()  # the last gather belongs to the timed region
-    sync()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    drain()  # the last write-out belongs to the timed region
+    env.sync()
+    dt = env.max_over_ranks(time.perf_counter() - t0)
 
     ms_per_step = dt / args.steps * 1e3
     total_mib = total / 2**20
@@ -314,11 +602,12 @@ def main():
 
     if rank == 0:
         last_buf = d_outs[(state["i"] - 1) % len(d_outs)]
-        ok = verify(slab, last_buf[:out_len].cpu().numpy(), block_sizes, tail=(mode == _native.SLAB_LAST))
+        out_host = last_buf[:out_len].cpu().numpy()
+        ok = verify(slab, out_host, block_sizes, tail=(mode == _native.SLAB_LAST))
         stage_ms = {k: v / args.steps for k, v in stage_acc.items()}
         dom = max(stage_ms, key=stage_ms.get)
         alg_bytes = n + out_len  # 1 B read + r B written per input byte
-        achieved = alg_bytes / (stage_ms[dom] * 1e-3) / 1e9
+        achieved = alg_bytes / (max(stage_ms[dom], 1e-9) * 1e-3) / 1e9
         traffic = pmc_traffic(dom)
         res = {
             "metric": "BGZF compress MiB/s at level 1, 550 MiB text",
@@ -332,7 +621,7 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "u8",
-            "data": "synthetic",
+            "data": "synthetic" if not env.emulate else "synthetic (CPU emulator dry run: not a measurement)",
             "config": {
                 "workload": "Single MI355X: 64 KiB BGZF blocks, level 1, 550 MiB text slab, "
                             "bit-exact vs libdeflate",
@@ -343,8 +632,11 @@ def main():
                 "level": 1,
                 "format": "bgzf",
                 "ratio": round(out_len / n, 4),
-                "parallelism": "block-shard x%d%s" % (world, " + ordered RCCL gather" if world > 1 else ""),
+                "parallelism": "block-shard x%d%s" % (
+                    world, "" if world == 1 else
+                    (" + ordered RCCL gather" if args.writeout == "rccl" else " + size all_gather, per-rank write-out")),
                 "verified_bit_exact_sample": bool(ok),
+                "stream_sha256": hashlib.sha256(out_host).hexdigest(),
                 "device": ctx.device_name(),
             },
             "roofline": {
@@ -355,16 +647,31 @@ def main():
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 5),
                 "traffic": traffic,
+                "traffic_source": "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)",
+                "pipeline_frac": round(alg_bytes / (sum(stage_ms.values()) * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
                 "stage_ms": {k: round(v, 3) for k, v in stage_ms.items()},
             },
         }
+        if world == 1 and not args.no_extras:
+            ctx.set_profiling(False)
+            try:
+                res["e2e"] = e2e_legs(env, slab, res["config"]["stream_sha256"])
+            except Exception as e:  # the headline line must survive a failing extra
+                res["e2e"] = {"error": repr(e)}
+            try:
+                inf = run_inflate(args, env, emit=False, d_stream=last_buf, comp_host=out_host, slab=slab,
+                                  steps=max(2, min(args.steps, 5)))
+                res["inflate"] = {k: inf[k] for k in ("metric", "value", "unit", "ms_per_step", "roofline")}
+                res["inflate"]["verified_round_trip"] = inf["config"]["verified_round_trip"]
+                if "cpu_baseline" in inf:
+                    res["inflate"]["cpu_baseline"] = inf["cpu_baseline"]
+            except Exception as e:
+                res["inflate"] = {"error": repr(e)}
         if not args.no_cpu_baseline and world == 1:  # the CPU leg is timed at N = 1 only
             res["cpu_baseline"] = cpu_baseline(slab)
         print(json.dumps(res))
     ctx.close()
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+    env.close()
 
 
 if __name__ == "__main__":

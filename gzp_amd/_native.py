@@ -54,7 +54,7 @@ EXPORTS = [
     "gzpx_decompress_blocks_wait", "gzpx_alloc_decompressor", "gzpx_deflate_decompress",
     "gzpx_free_decompressor", "gzpx_pard_create", "gzpx_pard_read", "gzpx_pard_destroy",
     "gzpx_pard_last_error", "gzpx_host_alloc", "gzpx_host_free", "gzpx_dctx_last_inflate_ms",
-    "gzpx_debug_inflate",
+    "gzpx_debug_inflate", "gzpx_synth_fastq_device", "gzpx_synth_ascii_device",
 ]
 
 
@@ -210,6 +210,10 @@ class GzpxLib:
         L.gzpx_dctx_last_inflate_ms.argtypes = [vp, ctypes.POINTER(ctypes.c_float)]
         L.gzpx_debug_inflate.restype = i32
         L.gzpx_debug_inflate.argtypes = [vp, i32, ctypes.POINTER(ctypes.c_uint64)]
+        L.gzpx_synth_fastq_device.restype = i32
+        L.gzpx_synth_fastq_device.argtypes = [vp, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint64, vp]
+        L.gzpx_synth_ascii_device.restype = i32
+        L.gzpx_synth_ascii_device.argtypes = [vp, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint64, vp]
         L.gzpx_pard_create.restype = i32
         L.gzpx_pard_create.argtypes = [i32, i32, sz, READ_FN, vp, ctypes.POINTER(vp)]
         L.gzpx_pard_read.restype = i32
@@ -425,6 +429,19 @@ class Compressor:
             self.close()
         except Exception:
             pass
+
+
+def synth_fastq_device(d_out_ptr, stream_offset, n, seed=20250927, stream=None, lib=None):
+    """Fill device memory with bytes [stream_offset, stream_offset + n) of the synthetic FASTQ stream
+    (BASELINE configs[3]); asynchronous on `stream`."""
+    lib = lib or load()
+    lib.check(lib.L.gzpx_synth_fastq_device(d_out_ptr, stream_offset, n, seed, stream))
+
+
+def synth_ascii_device(d_out_ptr, stream_offset, n, seed=8, stream=None, lib=None):
+    """Fill device memory with bytes [stream_offset, +n) of synth.ascii_random's stream (BASELINE configs[2])."""
+    lib = lib or load()
+    lib.check(lib.L.gzpx_synth_ascii_device(d_out_ptr, stream_offset, n, seed, stream))
 
 
 def crc32(data, crc=0, lib=None):

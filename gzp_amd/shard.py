@@ -98,3 +98,29 @@ def ordered_gather_start(local, dst=0, group=None, out=None):
 def ordered_gather(local, dst=0, group=None, out=None):
     """Blocking form of ordered_gather_start: returns the stream on dst, None elsewhere."""
     return ordered_gather_start(local, dst, group, out).wait()
+
+
+def stream_offsets(local_len, device, group=None):
+    """Write-out without moving payloads between GPUs: one all_gather of the shard sizes (8 bytes
+    per rank); the exclusive scan gives every rank the offset of its shard in the output stream
+    (the writer pwrite()s it there).  Returns (my_offset, total_bytes, sizes)."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    n = torch.tensor([int(local_len)], dtype=torch.int64, device=device)
+    sizes = torch.zeros(world, dtype=torch.int64, device=device)
+    dist.all_gather_into_tensor(sizes, n, group=group)
+    sz = [int(x) for x in sizes.tolist()]
+    return sum(sz[:rank]), sum(sz), sz
+
+
+class EventHandle:
+    """wait()-able wrapper of a torch.cuda.Event (same face as GatherHandle)."""
+
+    def __init__(self, event):
+        self._ev = event
+
+    def wait(self):
+        self._ev.synchronize()
+        return None

@@ -13,10 +13,22 @@ import numpy as np
 _MASK = np.uint64(0xFFFFFFFFFFFFFFFF)
 
 
-def splitmix64(seed, n):
-    """n uint64 outputs of splitmix64 started at `seed` (vectorised: state_i = seed + (i+1)*G)."""
+def big_zeros(n):
+    """n zero bytes backed by a pre-populated anonymous mapping.  Large numpy allocations are
+    touched page by page on first use; in sandboxes with slow page faults (the build container:
+    ~0.1 ms per 4 KiB page, i.e. 30 s per 256 MiB) populating the mapping up front is 300x faster."""
+    import mmap
+    if n < (8 << 20) or not hasattr(mmap, "MAP_POPULATE"):
+        return np.zeros(n, dtype=np.uint8)
+    m = mmap.mmap(-1, n, flags=mmap.MAP_PRIVATE | mmap.MAP_ANONYMOUS | mmap.MAP_POPULATE)
+    return np.frombuffer(m, dtype=np.uint8)
+
+
+def splitmix64(seed, n, start=0):
+    """n uint64 outputs of splitmix64 started at `seed` (vectorised: state_i = seed + (i+1)*G),
+    beginning with output number `start`."""
     with np.errstate(over="ignore"):
-        idx = np.arange(1, n + 1, dtype=np.uint64)
+        idx = np.arange(start + 1, start + n + 1, dtype=np.uint64)
         z = np.uint64(seed & 0xFFFFFFFFFFFFFFFF) + idx * np.uint64(0x9E3779B97F4A7C15)
         z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
         z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
@@ -86,8 +98,11 @@ def text_slab(total_bytes=576_716_800, base_bytes=5_767_168, seed=20250927):
     """The bench slab: a `base_bytes` pseudo-English text repeated to `total_bytes`
     (550 MiB = 5.5 MiB x 100, the shape of shakespeare.txt x 100)."""
     base = english_like(min(base_bytes, total_bytes), seed)
-    reps = -(-total_bytes // base.size)
-    return np.ascontiguousarray(np.tile(base, reps)[:total_bytes])
+    out = big_zeros(total_bytes)
+    for lo in range(0, total_bytes, base.size):
+        hi = min(lo + base.size, total_bytes)
+        out[lo:hi] = base[:hi - lo]
+    return out
 
 
 def dna(n, seed=1):
@@ -125,9 +140,15 @@ def uniform_random(n, seed=3):
     return (splitmix64(seed, n) >> np.uint64(56)).astype(np.uint8)
 
 
-def ascii_random(n, seed=8):
-    """BASELINE config 3 bytes: 0x20 + (u8 % 95)."""
-    return (0x20 + ((splitmix64(seed, n) >> np.uint64(56)) % np.uint64(95))).astype(np.uint8)
+def ascii_random(n, seed=8, start=0):
+    """BASELINE config 3 bytes: 0x20 + (u8 % 95); bytes [start, start + n) of the stream."""
+    if n <= (1 << 24):
+        return (0x20 + ((splitmix64(seed, n, start) >> np.uint64(56)) % np.uint64(95))).astype(np.uint8)
+    out = big_zeros(n)
+    for lo in range(0, n, 1 << 24):  # 16 MiB pieces: the uint64 temporaries stay small
+        m = min(1 << 24, n - lo)
+        out[lo:lo + m] = ascii_random(m, seed, start + lo)
+    return out
 
 
 def byte_runs(n, seed=4):

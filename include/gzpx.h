@@ -251,6 +251,13 @@ const char *gzpx_pard_last_error(const gzpx_pard *p);
 void *gzpx_host_alloc(size_t bytes);
 void gzpx_host_free(void *p);
 
+/* ---- workload support: the synthetic FASTQ stream of BASELINE configs[3] (32 GiB sharded over 8
+ * GPUs), generated in HBM.  Fills d_out[0..n) with bytes [stream_offset, stream_offset + n) of the
+ * stream with this seed (oracle/synth_fastq.c states the stream on the CPU). ---- */
+int gzpx_synth_fastq_device(void *d_out, uint64_t stream_offset, uint64_t n, uint64_t seed, void *hip_stream);
+/* the printable-ASCII noise of BASELINE configs[2] (byte i = 0x20 + (splitmix64 output i >> 56) % 95) */
+int gzpx_synth_ascii_device(void *d_out, uint64_t stream_offset, uint64_t n, uint64_t seed, void *hip_stream);
+
 /* ---- measurement hooks (HIP events on the launching stream; bench.py roofline leg) ---- */
 #define GZPX_N_STAGES 9
 /* stage order: init_meta, candidates, match, parse, hist, huffman, crc32, scan, emit */

@@ -21,7 +21,7 @@ _lib = None
 
 
 def build(force=False):
-    srcs = [os.path.join(_HERE, f) for f in ("gzpx_oracle.c", "gzpx_oracle.h", "cpu_bench.c", "Makefile")]
+    srcs = [os.path.join(_HERE, f) for f in ("gzpx_oracle.c", "gzpx_oracle.h", "cpu_bench.c", "synth_fastq.c", "Makefile")]
     if (not force and os.path.exists(_SO)
             and os.path.getmtime(_SO) >= max(os.path.getmtime(f) for f in srcs)):
         return _SO
@@ -70,8 +70,29 @@ def lib():
         L.gzpx_cpu_bench_inflate.restype = ctypes.c_int
         L.gzpx_cpu_bench_inflate.argtypes = [u8p, u8p, u8p, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_int,
                                              ctypes.c_double, dp, u64p, ip]
+        L.gzpx_oracle_fastq.restype = None
+        L.gzpx_oracle_fastq.argtypes = [ctypes.c_uint64, ctypes.c_uint64, u8p, ctypes.c_size_t]
+        L.gzpx_oracle_ascii.restype = None
+        L.gzpx_oracle_ascii.argtypes = [ctypes.c_uint64, ctypes.c_uint64, u8p, ctypes.c_size_t]
         _lib = L
     return _lib
+
+
+def ascii_stream(offset, n, seed=8):
+    """Bytes [offset, offset + n) of synth.ascii_random's stream, natively (full-size fixtures)."""
+    from gzp_amd.synth import big_zeros
+    out = big_zeros(n)
+    lib().gzpx_oracle_ascii(seed, offset, _ptr(out), n)
+    return out
+
+
+def fastq_stream(offset, n, seed=20250927):
+    """Bytes [offset, offset + n) of the synthetic FASTQ stream of BASELINE configs[3]
+    (oracle/synth_fastq.c): the CPU statement of gzpx_synth_fastq_device."""
+    from gzp_amd.synth import big_zeros
+    out = big_zeros(n)  # (pre-populated: first-touch page faults are slow in the build sandbox)
+    lib().gzpx_oracle_fastq(seed, offset, _ptr(out), n)
+    return out
 
 
 def cpu_bench_compress(slab, fmt=FMT_BGZF, level=1, compat=COMPAT_1_24, block=65280, threads=1, wall_s=6.0):

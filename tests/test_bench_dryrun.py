@@ -1,0 +1,52 @@
+"""bench.py's control flow without GPUs: `python bench.py --gpus 2` from a bare shell must launch
+itself under torch.distributed.run (the driver's 8-GPU run starts it exactly like that), shard the
+stream, gather it in order and print ONE JSON line.  --emulate swaps the HIP library for the
+CPU-emulated build and RCCL for gloo; nothing is measured."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+
+
+def _run(*extra):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--emulate", "--steps", "1", "--warmup", "1",
+                        "--no-cpu-baseline", "--no-extras"] + list(extra), capture_output=True, text=True, timeout=900,
+                       env=env, cwd="/tmp")
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    return json.loads(lines[0])
+
+
+def test_two_ranks_self_launch_ordered_gather():
+    d = _run("--gpus", "2", "--slab-bytes", "150000")
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["slab_bytes"] == 300000
+    assert d["config"]["verified_bit_exact_sample"] is True
+    assert d["config"]["parallelism"].endswith("ordered RCCL gather")
+    for k in ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "higher_is_better", "vs_baseline", "dtype",
+              "data", "roofline"):
+        assert k in d
+
+
+def test_config4_workload_two_ranks():
+    d = _run("--gpus", "2", "--workload", "fastq", "--stream-bytes", "400000")
+    c = d["config"]
+    assert d["scaling"] == "strong" and c["gpu_inflate_crc_roundtrip_ok"] is True
+    assert c["gzip_t_prefix_suffix_rc"] in ([0, 0], None) and c["blocks"] == 7
+
+
+def test_single_rank_line_has_e2e_and_inflate_legs(capsys, monkeypatch):
+    # in-process (no second interpreter): the default line's extra legs
+    sys.path.insert(0, ROOT)
+    import bench
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        monkeypatch.delenv(k, raising=False)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--emulate", "--steps", "1", "--warmup", "0", "--no-cpu-baseline",
+                                      "--slab-bytes", "140000"])
+    bench.main()
+    d = json.loads([l for l in capsys.readouterr().out.splitlines() if l.startswith("{")][0])
+    assert d["e2e"]["device_pinned_ok"] and d["e2e"]["api_write_ok"] and d["e2e"]["api_write_64k_ok"]
+    assert d["inflate"]["verified_round_trip"] is True and d["inflate"]["roofline"]["kernel"] == "k_inflate"
