@@ -3,10 +3,15 @@
 // support, not part of the encode path: bench.py --workload fastq and the config-4 tests fill each
 // rank's 4 GiB share of the stream directly in HBM instead of generating and copying it from the host.
 //
-// The stream is defined page by page (64 KiB pages, each from its own splitmix64 state) so that any
-// byte range can be produced independently: one thread per page, records written until the page is
-// full.  Record layout, random draws and the quality chain are specified in oracle/synth_fastq.c,
-// the CPU statement the tests compare this kernel with byte for byte.
+// The stream is defined page by page (64 KiB pages, each from its own splitmix64 state
+// seed ^ page * 0xD6E8FEB86659FD93) so that any byte range can be produced independently: one thread
+// per page, records written until the page is full (the last one is cut at the page end).
+//   record k of page c, read number r = c * 512 + k + 1:
+//     "@SRR" %07d(seed % 10^7) "." r " " r "/1\n"
+//     L = 100 + next() % 51 bases, 5 per next() (12 bits each: low 10 bits zero -> 'N', else
+//     "ACGT"[bits 10..11]), "\n+\n", L qualities from a 4-state chain over "F:,#" (start 'F', 21 steps
+//     per next(), 3 bits each through the `step` table below), "\n".
+// The tests compare the kernel byte for byte with an independent CPU statement of the same rules.
 #include <hip/hip_runtime.h>
 
 #include "../../include/gzpx.h"
