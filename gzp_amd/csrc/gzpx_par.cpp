@@ -89,7 +89,7 @@ ParCompress::ParCompress(const ParConfig &cfg, WriteFn writer) : cfg_(cfg), writ
     if (batch_blocks_ > by_budget) batch_blocks_ = by_budget;
     if (batch_blocks_ == 0) batch_blocks_ = 1;
     batch_bytes_ = batch_blocks_ * cfg_.buffer_size;
-    q_cap_ = 4;  // bounded(num_threads * 2) in the reference (src/par/compress.rs:111-112)
+    q_cap_ = 2;  // bounded(num_threads * 2) in the reference (src/par/compress.rs:111-112); here: slabs
     gzpx_config c;
     gzpx_config_default(&c, cfg_.format);
     c.device = cfg_.device;
@@ -101,8 +101,18 @@ ParCompress::ParCompress(const ParConfig &cfg, WriteFn writer) : cfg_(cfg), writ
     if (rc != GZPX_OK) throw error_from_code(rc);
     (void)hipSetDevice(cfg_.device);
     try {
-        fill_ = take_buffer(batch_bytes_ + cfg_.buffer_size);
+        // The whole staging pool is page-locked now (the analogue of the reference spinning up its
+        // thread pool in from_writer), not slab by slab inside the first writes: locking a 64 MiB
+        // slab costs as much as compressing three of them.  Inputs: the slab being filled, the
+        // queued ones, the ones in flight; outputs: in flight + waiting for the writer.
+        const size_t in_cap = batch_bytes_ + cfg_.buffer_size, out_cap = gzpx_slab_bound(ctx_, batch_bytes_);
+        buf_cap_ = in_cap > out_cap ? in_cap : out_cap;  // one size: any pool buffer serves either way
+        std::vector<Pinned> warm;
+        for (size_t i = 0; i < 1 + 2 * (q_cap_ + GZPX_SLOTS); i++) warm.push_back(take_buffer(buf_cap_));
+        for (const Pinned &b : warm) give_buffer(b);
+        fill_ = take_buffer(buf_cap_);
     } catch (...) {
+        for (uint8_t *p : pinned_) (void)hipHostFree(p);
         gzpx_ctx_destroy(ctx_);
         throw;
     }
@@ -169,7 +179,10 @@ void ParCompress::dispatch(Pinned input, int mode) {
     job->input = input;
     job->mode = mode;
     std::unique_lock<std::mutex> lk(mu_);
-    cv_space_.wait(lk, [&] { return failed_ || closed_ || (work_q_.size() < q_cap_ && order_q_.size() < q_cap_); });
+    // (a slab stays in the order queue while it is in flight: that queue is GZPX_SLOTS deeper)
+    cv_space_.wait(lk, [&] {
+        return failed_ || closed_ || (work_q_.size() < q_cap_ && order_q_.size() < q_cap_ + GZPX_SLOTS);
+    });
     if (failed_ || closed_) {
         lk.unlock();
         give_buffer(input);
@@ -187,7 +200,7 @@ void ParCompress::dispatch(Pinned input, int mode) {
 // front of the next slab.
 void ParCompress::after_append() {
     while (fill_.len > batch_bytes_) {
-        Pinned next = take_buffer(batch_bytes_ + cfg_.buffer_size);
+        Pinned next = take_buffer(buf_cap_);
         next.len = fill_.len - batch_bytes_;
         memcpy(next.p, fill_.p + batch_bytes_, next.len);
         Pinned full = fill_;
@@ -201,7 +214,7 @@ size_t ParCompress::write(const uint8_t *buf, size_t n) {
     if (finished_) throw GzpError(GzpErrorKind::ChannelSend, "write after finish");
     size_t off = 0;
     while (off < n) {
-        const size_t room = fill_.cap - fill_.len;  // >= buffer_size: after_append keeps len <= batch_bytes_
+        const size_t room = fill_room();  // >= buffer_size: after_append keeps len <= batch_bytes_
         const size_t take = n - off < room ? n - off : room;
         copier_->copy(fill_.p + fill_.len, buf + off, take);
         fill_.len += take;
@@ -213,12 +226,12 @@ size_t ParCompress::write(const uint8_t *buf, size_t n) {
 
 std::pair<uint8_t *, size_t> ParCompress::reserve() {
     if (finished_) throw GzpError(GzpErrorKind::ChannelSend, "reserve after finish");
-    return {fill_.p + fill_.len, fill_.cap - fill_.len};
+    return {fill_.p + fill_.len, fill_room()};
 }
 
 void ParCompress::commit(size_t n) {
     if (finished_) throw GzpError(GzpErrorKind::ChannelSend, "commit after finish");
-    if (n > fill_.cap - fill_.len) throw GzpError(GzpErrorKind::LibDeflaterCompress, "commit past the reserved room");
+    if (n > fill_room()) throw GzpError(GzpErrorKind::LibDeflaterCompress, "commit past the reserved room");
     fill_.len += n;
     after_append();
 }
@@ -228,7 +241,7 @@ void ParCompress::flush_last(bool is_last) {
     // buffer is empty -- is an empty block (src/par/compress.rs:333-341 runs at least once)
     Pinned rest = fill_;
     fill_ = Pinned();
-    if (!is_last) fill_ = take_buffer(batch_bytes_ + cfg_.buffer_size);
+    if (!is_last) fill_ = take_buffer(buf_cap_);
     dispatch(rest, is_last ? GZPX_SLAB_LAST : GZPX_SLAB_FLUSH);
 }
 
@@ -317,7 +330,7 @@ void ParCompress::device_main() {
         }
         InFlight f;
         try {
-            f.out = take_buffer(gzpx_slab_bound(ctx_, batch_bytes_));
+            f.out = take_buffer(buf_cap_);
             const int rc = gzpx_compress_slab_submit(ctx_, job->input.p, job->input.len, job->mode, f.out.p,
                                                      f.out.cap, &f.ticket);
             if (rc != GZPX_OK) {

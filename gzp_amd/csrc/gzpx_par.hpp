@@ -193,6 +193,8 @@ class ParCompress {
     void flush_last(bool is_last);
     void dispatch(Pinned input, int mode);
     void after_append();
+    // a slab is filled up to one block past the batch: the strict `>` cut rule then leaves that tail
+    size_t fill_room() const { return batch_bytes_ + cfg_.buffer_size - fill_.len; }
     void device_main();
     void writer_main();
     void raise_pipeline_error();
@@ -202,6 +204,7 @@ class ParCompress {
     WriteFn writer_;
     size_t batch_blocks_ = 0;
     size_t batch_bytes_ = 0;
+    size_t buf_cap_ = 0;  // capacity of every staging buffer of the pool
     Pinned fill_;  // the slab being filled by write() / reserve()
     bool finished_ = false;
     std::unique_ptr<CopyPool> copier_;
