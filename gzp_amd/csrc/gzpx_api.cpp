@@ -98,6 +98,9 @@ struct gzpx_ctx {
     CrcConsts crc_consts;
     hipStream_t stream = nullptr;  // compute: every kernel of this context, in submission order
     hipStream_t s_h2d = nullptr, s_d2h = nullptr;
+    hipStream_t s_side = nullptr;  // k_crc32 next to k_candidates (needs only the input)
+    hipEvent_t ev_meta = nullptr, ev_crc = nullptr;    // fork / join of the side stream
+    hipEvent_t ev_crc_t0 = nullptr, ev_crc_t1 = nullptr;  // timing of k_crc32 when profiling
     hipEvent_t ev_dep = nullptr;  // "the caller's stream got this far" (device jobs)
     hipEvent_t ev_round[2] = {nullptr, nullptr};  // levels 2-4: end of a match/parse round
     uint32_t batch_blocks = 0;
@@ -231,7 +234,17 @@ int enqueue_batch(gzpx_ctx *ctx, const uint8_t *d_in, size_t in_len, uint32_t nb
     if (prof) HIP_TRY(hipEventRecord(ev[k], stream));
     launch_init_meta(c, in_len, nb, is_last, s, stream);
     if (prof) HIP_TRY(hipEventRecord(ev[++k], stream));
+    // fork: the CRC of every block on the side stream, concurrent with the matchfinding kernels.
+    // k_candidates is handed to the device FIRST: its workgroups take their 128 KiB of LDS on every
+    // CU and k_crc32's slip into what is left; the other way round the small workgroups fill the
+    // CUs and the two kernels simply run one after the other.
+    HIP_TRY(hipEventRecord(ctx->ev_meta, stream));
     launch_candidates(c, d_in, in_len, nb, s, stream);
+    HIP_TRY(hipStreamWaitEvent(ctx->s_side, ctx->ev_meta, 0));
+    if (prof) HIP_TRY(hipEventRecord(ctx->ev_crc_t0, ctx->s_side));
+    launch_crc32(c, d_in, in_len, nb, s, ctx->crc_consts, ctx->s_side);
+    if (prof) HIP_TRY(hipEventRecord(ctx->ev_crc_t1, ctx->s_side));
+    HIP_TRY(hipEventRecord(ctx->ev_crc, ctx->s_side));
     if (prof) HIP_TRY(hipEventRecord(ev[++k], stream));
     if (c.level <= 1) {  // (at level 0 every block is a passthrough block: both return at once)
         launch_match(c, d_in, in_len, nb, s, stream);
@@ -260,7 +273,7 @@ int enqueue_batch(gzpx_ctx *ctx, const uint8_t *d_in, size_t in_len, uint32_t nb
     if (prof) HIP_TRY(hipEventRecord(ev[++k], stream));
     launch_huffman(c, nb, s, stream);
     if (prof) HIP_TRY(hipEventRecord(ev[++k], stream));
-    launch_crc32(c, d_in, in_len, nb, s, ctx->crc_consts, stream);
+    HIP_TRY(hipStreamWaitEvent(stream, ctx->ev_crc, 0));  // join: k_emit writes the CRCs into the footers
     if (prof) HIP_TRY(hipEventRecord(ev[++k], stream));
     launch_scan(nb, s, prev, result, stream);
     if (prof) HIP_TRY(hipEventRecord(ev[++k], stream));
@@ -271,7 +284,8 @@ int enqueue_batch(gzpx_ctx *ctx, const uint8_t *d_in, size_t in_len, uint32_t nb
         HIP_TRY(hipStreamSynchronize(stream));
         for (int i = 0; i < GZPX_N_STAGES; i++) {
             float ms = 0;
-            HIP_TRY(hipEventElapsedTime(&ms, ev[i], ev[i + 1]));
+            if (i == 6) HIP_TRY(hipEventElapsedTime(&ms, ctx->ev_crc_t0, ctx->ev_crc_t1));  // (overlaps the stages before it)
+            else HIP_TRY(hipEventElapsedTime(&ms, ev[i], ev[i + 1]));
             ctx->stage_ms[i] += ms;
         }
     }
@@ -319,6 +333,14 @@ int slot_staging(Slot &sl, size_t in_len, size_t out_need) {
         sl.d_out_cap = cap;
     }
     return GZPX_OK;
+}
+
+// The side stream runs at the lowest priority the device offers: its workgroups are only meant to
+// fill what the main stream's kernels leave free.
+hipError_t create_side_stream(hipStream_t *s) {
+    int least = 0, greatest = 0;
+    if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) least = 0;
+    return hipStreamCreateWithPriority(s, hipStreamNonBlocking, least);
 }
 
 int check_slab_args(const gzpx_ctx *ctx, const void *in, size_t in_len, int mode, const void *out) {
@@ -520,6 +542,7 @@ int ctx_create(const gzpx_config *cfg, bool crc_only, gzpx_ctx **out) {
     }
     for (unsigned l = 0; l < 10; l++) ctx->crc_consts.pow64[l] = x2k(9 + l);
     ctx->crc_consts.pow_tile = x2k(19);  // x^(8 * 65536) = x^(2^19)
+    ctx->crc_consts.pow_small = x2k(17);  // x^(8 * 16384)
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, cfg->device) == hipSuccess) {
         snprintf(ctx->devname, sizeof(ctx->devname), "%s (%s, %d CUs)", prop.name, prop.gcnArchName,
@@ -536,6 +559,10 @@ int ctx_create(const gzpx_config *cfg, bool crc_only, gzpx_ctx **out) {
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
         hipStreamCreateWithFlags(&ctx->s_h2d, hipStreamNonBlocking) != hipSuccess ||
         hipStreamCreateWithFlags(&ctx->s_d2h, hipStreamNonBlocking) != hipSuccess ||
+        create_side_stream(&ctx->s_side) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->ev_meta, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->ev_crc, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreate(&ctx->ev_crc_t0) != hipSuccess || hipEventCreate(&ctx->ev_crc_t1) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_dep, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_round[0], hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_round[1], hipEventDisableTiming) != hipSuccess)
@@ -568,6 +595,12 @@ void gzpx_ctx_destroy(gzpx_ctx *ctx) {
     if (ctx->events.created)
         for (int i = 0; i <= GZPX_N_STAGES; i++) (void)hipEventDestroy(ctx->events.ev[i]);
     if (ctx->ev_dep) (void)hipEventDestroy(ctx->ev_dep);
+    for (hipEvent_t e : {ctx->ev_meta, ctx->ev_crc, ctx->ev_crc_t0, ctx->ev_crc_t1})
+        if (e) (void)hipEventDestroy(e);
+    if (ctx->s_side) {
+        (void)hipStreamSynchronize(ctx->s_side);
+        (void)hipStreamDestroy(ctx->s_side);
+    }
     for (hipEvent_t e : ctx->ev_round)
         if (e) (void)hipEventDestroy(e);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -1027,6 +1060,7 @@ int gzpx_dctx_create(int device, int format, gzpx_dctx **out) {
     c->format = format;
     for (unsigned l = 0; l < 10; l++) c->cc.pow64[l] = x2k(9 + l);
     c->cc.pow_tile = x2k(19);
+    c->cc.pow_small = x2k(17);
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
         hipStreamCreateWithFlags(&c->s_h2d, hipStreamNonBlocking) != hipSuccess ||
         hipStreamCreateWithFlags(&c->s_d2h, hipStreamNonBlocking) != hipSuccess ||

@@ -75,6 +75,7 @@ struct HcState {
 struct CrcConsts {
     uint32_t pow64[10];  // x^(8*64*2^l) mod P (reflected), l = 0..9
     uint32_t pow_tile;   // x^(8*65536) mod P: appends one full 64 KiB chunk
+    uint32_t pow_small;  // x^(8*16384) mod P: the 256-thread routine's 16 KiB chunk
 };
 
 struct Config {

@@ -36,6 +36,15 @@
 
 #include "gzpx_device.h"
 
+// Measurement-only switches (tools/exp_bounds.py builds a second library with -DGZPX_EXPERIMENT; the
+// product build compiles them away): parts of a kernel are skipped -- the results are wrong on purpose
+// -- to see which resource bounds it.
+#ifdef GZPX_EXPERIMENT
+#define GZPX_EXP(cfg, bit) (((cfg).debug >> (bit)) & 1u)
+#else
+#define GZPX_EXP(cfg, bit) 0u
+#endif
+
 namespace gzpx {
 
 // ------------------------------------------------------------------------------------------
@@ -511,6 +520,15 @@ __global__ __launch_bounds__(kMpThreads, 8) void k_match(Config cfg, const uint8
                     const uint32_t q = q0 + tid + k * kMpThreads;
                     v[k] = src4[q < nq ? q : nq - 1];
                 }
+                // (left alone, the compiler sinks each load into the guarded block of its store and
+                // waits for it there: four memory round trips in a row instead of one)
+#pragma unroll
+                for (uint32_t k = 0; k < 4; k++) {
+                    GZPX_PIN_VGPR(v[k].x);
+                    GZPX_PIN_VGPR(v[k].y);
+                    GZPX_PIN_VGPR(v[k].z);
+                    GZPX_PIN_VGPR(v[k].w);
+                }
 #pragma unroll
                 for (uint32_t k = 0; k < 4; k++) {
                     const uint32_t q = q0 + tid + k * kMpThreads;
@@ -539,7 +557,7 @@ __global__ __launch_bounds__(kMpThreads, 8) void k_match(Config cfg, const uint8
 #pragma unroll
             for (uint32_t k = 0; k < 4; k++) {
                 const uint32_t p = p0 + k * kMpThreads;
-                d1s[k] = d0s[k] ? cand[p - d0s[k]] : 0u;
+                d1s[k] = (d0s[k] && !GZPX_EXP(cfg, 4)) ? cand[p - d0s[k]] : 0u;
             }
 #pragma unroll
             for (uint32_t k = 0; k < 4; k++) d0n[k] = load_d0(p0 + (4 + k) * kMpThreads);
@@ -621,7 +639,7 @@ __global__ __launch_bounds__(kMpThreads, 8) void k_match(Config cfg, const uint8
                         act0 = false;
                         if ((len0 < max_len ? len0 : max_len) >= nice_len) act1 = false;  // the older one cannot count
                     }
-                    for (uint32_t off = 4; (act0 || act1) && off < max_len; off += 4) {
+                    for (uint32_t off = 4; (act0 || act1) && off < max_len && !GZPX_EXP(cfg, 6); off += 4) {
                         const uint32_t j = (off >> 2) + 1;
                         lo_a = hi_a;
                         hi_a = pa[j];
@@ -655,7 +673,7 @@ __global__ __launch_bounds__(kMpThreads, 8) void k_match(Config cfg, const uint8
                 // one 64-bit word of the "a match starts here" bitmap per wave step (the wave's 64
                 // positions are consecutive and 64-aligned)
                 const unsigned long long nzm = __ballot(best != 0);
-                if (p < tile_end) {
+                if (p < tile_end && !GZPX_EXP(cfg, 5)) {
                     len8[p] = (uint8_t)(best ? best - 3 : 0);
                     val[p] = (uint16_t)value;  // match distance, or the literal byte
                     if ((tid & 63u) == 0) nz_out[p >> 6] = nzm;
@@ -902,7 +920,7 @@ __global__ __launch_bounds__(kMpThreads, 8) void k_parse(
                 for (uint32_t k = 0; k < 8; k++) {
                     const uint32_t g = g0 + k * kMpWaves;
                     const uint32_t r = g * 64 + lane;
-                    vals[k] = (build && g < ngroups && r < tile_len) ? val[tile_begin + r] : 0u;
+                    vals[k] = (build && g < ngroups && r < tile_len && !GZPX_EXP(cfg, 9)) ? val[tile_begin + r] : 0u;
                 }
                 // every load has landed from here on, also on the paths that skip a group: without
                 // this the compiler must assume a pending load behind each later store's data
@@ -932,7 +950,7 @@ __global__ __launch_bounds__(kMpThreads, 8) void k_parse(
                     vals[k] = l ? (kTokMatch | (vals[k] << 9) | (l + 3)) : vals[k];
                     tis[k] = ti;
                 }
-                if (build) {
+                if (build && !GZPX_EXP(cfg, 8)) {
 #pragma unroll
                     for (uint32_t k = 0; k < 8; k++)
                         if (tis[k] != 0xFFFFFFFFu) tok[tis[k]] = vals[k];
@@ -2146,58 +2164,68 @@ __device__ __forceinline__ uint32_t gf2_multmodp(uint32_t a, uint32_t bv) {
     return p;
 }
 
-constexpr uint32_t kCrcThreads = 1024;                     // one 64-byte segment per thread and chunk
-constexpr uint32_t kCrcSeg = kTile / kCrcThreads;          // 64 bytes
-constexpr uint32_t kCrcLevels = 10;                        // log2(kCrcThreads)
-constexpr uint32_t kCrcSegWords = kCrcSeg / 4;             // 16
-constexpr uint32_t kCrcDataWords = (kTile / 4 + 2) + (kTile / 4 + 2) / kCrcSegWords + 2;
+constexpr uint32_t kCrcThreads = 1024;  // one 64-byte segment per thread and chunk (k_dcrc32)
+constexpr uint32_t kCrcSmall = 256;     // the compressor's k_crc32: 21 KiB of LDS, so that its workgroups fit
+                                        // NEXT to k_candidates' 128 KiB table on the same CU (see k_crc32)
+constexpr uint32_t kCrcSeg = 64;        // bytes per thread and chunk
+constexpr uint32_t kCrcSegWords = kCrcSeg / 4;  // 16
 
 // dword index -> padded LDS index (one pad word after every 16: segments lie 17 dwords apart, so
 // the 64 lanes of a wave, each in its own segment, spread evenly over the banks)
 __device__ __forceinline__ uint32_t crc_pad(uint32_t w) { return w + (w / kCrcSegWords); }
 
-struct CrcLds {
+template <uint32_t T>
+struct CrcLdsT {
+    static constexpr uint32_t kChunk = T * kCrcSeg;  // bytes per chunk: 64 KiB (T = 1024) / 16 KiB (T = 256)
+    static constexpr uint32_t kDataWords = (kChunk / 4 + 2) + (kChunk / 4 + 2) / kCrcSegWords + 2;
     uint32_t table[4][256];
-    uint32_t data[kCrcDataWords];
-    uint32_t part[kCrcThreads];
+    uint32_t data[kDataWords];
+    uint32_t part[T];
 };
+using CrcLds = CrcLdsT<kCrcThreads>;
 
-// CRC-32 of in[0..n) by a 1024-thread workgroup; the result is valid in every thread.
-__device__ uint32_t crc32_workgroup(CrcLds &l, const uint8_t *__restrict__ in, uint32_t n,
+// CRC-32 of in[0..n) by a T-thread workgroup (T = 1024: log2 = 10 combine levels, chunk constant
+// cc.pow_tile; T = 256: 8 levels, cc.pow_small); the result is valid in every thread.
+template <uint32_t T>
+__device__ uint32_t crc32_workgroup(CrcLdsT<T> &l, const uint8_t *__restrict__ in, uint32_t n,
                                     const CrcConsts &cc, uint32_t tid) {
-    if (tid < 256) {
-        uint32_t c = tid;
+    constexpr uint32_t kChunk = CrcLdsT<T>::kChunk;
+    constexpr uint32_t kLevels = T == 1024 ? 10 : 8;
+    static_assert(T == 1024 || T == 256, "combine constants exist for these two");
+    const uint32_t pow_chunk = T == 1024 ? cc.pow_tile : cc.pow_small;
+    for (uint32_t i = tid; i < 256; i += T) {
+        uint32_t c = i;
         for (int k = 0; k < 8; k++) c = (c >> 1) ^ (0xEDB88320u & (0u - (c & 1u)));
-        l.table[0][tid] = c;
+        l.table[0][i] = c;
     }
     __syncthreads();
-    if (tid < 256) {
-        const uint32_t t0 = l.table[0][tid];
+    for (uint32_t i = tid; i < 256; i += T) {
+        const uint32_t t0 = l.table[0][i];
         const uint32_t t1 = (t0 >> 8) ^ l.table[0][t0 & 0xFFu];
         const uint32_t t2 = (t1 >> 8) ^ l.table[0][t1 & 0xFFu];
         const uint32_t t3 = (t2 >> 8) ^ l.table[0][t2 & 0xFFu];
-        l.table[1][tid] = t1;
-        l.table[2][tid] = t2;
-        l.table[3][tid] = t3;
+        l.table[1][i] = t1;
+        l.table[2][i] = t2;
+        l.table[3][i] = t3;
     }
-    // Blocks above 64 KiB are cut into 64 KiB chunks aligned to the END of the block (only the
-    // first chunk is short), so every chunk-to-chunk combine uses the same x^(8*65536) constant.
+    // Inputs above one chunk are cut into chunks aligned to the END of the input (only the first
+    // chunk is short), so every chunk-to-chunk combine uses the same x^(8 * chunk) constant.
     uint32_t total = 0;
-    const uint32_t first_len = n ? ((n - 1) % kTile) + 1 : 0;
-    for (uint32_t cb = 0; cb < n || cb == 0; cb += (cb == 0 ? first_len : kTile)) {
-        const uint32_t clen = n == 0 ? 0 : (cb == 0 ? first_len : kTile);
+    const uint32_t first_len = n ? ((n - 1) % kChunk) + 1 : 0;
+    for (uint32_t cb = 0; cb < n || cb == 0; cb += (cb == 0 ? first_len : kChunk)) {
+        const uint32_t clen = n == 0 ? 0 : (cb == 0 ? first_len : kChunk);
         const uint8_t *cin = in + cb;
         const uint32_t mis = (uint32_t)((uintptr_t)cin & 3u);
         __syncthreads();  // tables ready / previous chunk consumed
         if (clen) {
             const uint32_t *src = (const uint32_t *)(cin - mis);
             const uint32_t ndw = (mis + clen + 3) >> 2;
-            for (uint32_t i = tid; i < ndw; i += kCrcThreads) l.data[crc_pad(i)] = src[i];
+            for (uint32_t i = tid; i < ndw; i += T) l.data[crc_pad(i)] = src[i];
         }
         __syncthreads();
-        // segment of thread t in chunk bytes: [clen - 64*(1024 - t), clen - 64*(1023 - t)) clipped
+        // segment of thread t in chunk bytes: [clen - 64*(T - t), clen - 64*(T - 1 - t)) clipped
         // at 0; LDS byte address of chunk byte i is i + mis (before padding)
-        const int32_t seg_end_i = (int32_t)clen - (int32_t)kCrcSeg * (int32_t)(kCrcThreads - 1 - tid);
+        const int32_t seg_end_i = (int32_t)clen - (int32_t)kCrcSeg * (int32_t)(T - 1 - tid);
         uint32_t crc = 0;
         if (seg_end_i > 0) {
             const uint32_t seg_end = (uint32_t)seg_end_i + mis;
@@ -2224,29 +2252,33 @@ __device__ uint32_t crc32_workgroup(CrcLds &l, const uint8_t *__restrict__ in, u
         l.part[tid] = crc;
         __syncthreads();
         // the pairs of a level are handled by the LOWEST threads, so that a level keeps only as many
-        // waves busy as it has work for (8, 4, 2, 1, 1, ...)
-        for (uint32_t level = 0; level < kCrcLevels; level++) {
+        // waves busy as it has work for
+        for (uint32_t level = 0; level < kLevels; level++) {
             const uint32_t stride = 1u << level;
             const uint32_t left = 2 * stride * tid;  // index of the pair's left part
             uint32_t merged = 0;
-            const bool act = left < kCrcThreads;
+            const bool act = left < T;
             if (act) merged = gf2_multmodp(cc.pow64[level], l.part[left]) ^ l.part[left + stride];
             __syncthreads();
             if (act) l.part[left] = merged;
             __syncthreads();
         }
-        // crc(A || chunk) = crc(A) * x^(8 * 65536) + crc(chunk); the first chunk has no A
-        total = cb == 0 ? l.part[0] : (gf2_multmodp(cc.pow_tile, total) ^ l.part[0]);
+        // crc(A || chunk) = crc(A) * x^(8 * chunk) + crc(chunk); the first chunk has no A
+        total = cb == 0 ? l.part[0] : (gf2_multmodp(pow_chunk, total) ^ l.part[0]);
         if (n == 0) break;
     }
     return total;
 }
 
-__global__ __launch_bounds__(kCrcThreads, 8) void k_crc32(Config cfg, const uint8_t *__restrict__ slab,
-                                               BlockMeta *__restrict__ meta_all, CrcConsts cc) {
-    __shared__ CrcLds l;
+// The compressor's CRC kernel needs nothing but the input, so it runs on a SIDE STREAM next to
+// k_candidates: that kernel keeps one 128 KiB table and four mostly waiting waves per CU, and this
+// one is sized (256 threads, 21 KiB of LDS) to fit into what is left of the same CUs -- the two
+// share the slab's trip through L2 and the CRC's 0.3 ms disappear from the critical path.
+__global__ __launch_bounds__(kCrcSmall) void k_crc32(Config cfg, const uint8_t *__restrict__ slab,
+                                                     BlockMeta *__restrict__ meta_all, CrcConsts cc) {
+    __shared__ CrcLdsT<kCrcSmall> l;
     const uint32_t b = blockIdx.x;
-    const uint32_t total = crc32_workgroup(l, slab + (uint64_t)b * cfg.block_size, meta_all[b].n, cc, threadIdx.x);
+    const uint32_t total = crc32_workgroup<kCrcSmall>(l, slab + (uint64_t)b * cfg.block_size, meta_all[b].n, cc, threadIdx.x);
     if (threadIdx.x == 0) meta_all[b].crc = total;
 }
 
@@ -3311,7 +3343,7 @@ __global__ __launch_bounds__(kCrcThreads, 8) void k_dcrc32(const uint8_t *__rest
                                                 uint32_t *__restrict__ crc_found, CrcConsts cc) {
     __shared__ CrcLds l;
     const uint32_t b = blockIdx.x;
-    const uint32_t total = crc32_workgroup(l, out_all + out_off[b], blk_all[b].isize, cc, threadIdx.x);
+    const uint32_t total = crc32_workgroup<kCrcThreads>(l, out_all + out_off[b], blk_all[b].isize, cc, threadIdx.x);
     if (threadIdx.x == 0) crc_found[b] = total;
 }
 
@@ -3383,7 +3415,7 @@ void launch_huffman(const Config &cfg, uint32_t nb, const Scratch &s, hipStream_
 
 void launch_crc32(const Config &cfg, const uint8_t *slab, uint64_t, uint32_t nb, const Scratch &s,
                   const CrcConsts &cc, hipStream_t stream) {
-    hipLaunchKernelGGL(k_crc32, dim3(nb), dim3(kCrcThreads), 0, stream, cfg, slab, s.meta, cc);
+    hipLaunchKernelGGL(k_crc32, dim3(nb), dim3(kCrcSmall), 0, stream, cfg, slab, s.meta, cc);
 }
 
 void launch_scan(uint32_t nb, const Scratch &s, const SlabResult *prev, SlabResult *result, hipStream_t stream) {

@@ -258,6 +258,8 @@ hipError_t hipMemsetAsync(void *d, int v, size_t n, hipStream_t st = 0);
 hipError_t hipStreamCreate(hipStream_t *s);
 hipError_t hipStreamCreateWithFlags(hipStream_t *s, unsigned flags);
 hipError_t hipStreamDestroy(hipStream_t s);
+static inline hipError_t hipDeviceGetStreamPriorityRange(int *least, int *greatest) { *least = 0; *greatest = 0; return hipSuccess; }
+static inline hipError_t hipStreamCreateWithPriority(hipStream_t *s, unsigned flags, int) { return hipStreamCreateWithFlags(s, flags); }
 hipError_t hipStreamSynchronize(hipStream_t s);
 hipError_t hipStreamWaitEvent(hipStream_t s, hipEvent_t e, unsigned flags = 0);
 hipError_t hipDeviceSynchronize();
