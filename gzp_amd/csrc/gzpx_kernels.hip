@@ -2610,8 +2610,14 @@ __global__ __launch_bounds__(kEmitThreads, 8) void k_emit(Config cfg, const uint
 //              the real ones, a prefix sum places them, and each output pass writes 64 bytes.
 //   k_crc32    (shared with the compressor) CRC-32 of the inflated bytes, checked against the footer
 // ------------------------------------------------------------------------------------------
-struct InfLds {
-    uint32_t win[8192];     // 32 KiB ring of the most recent output bytes
+template <bool GWIN>
+struct InfLdsT {
+    // GWIN = false: a 32 KiB ring of the most recent output bytes (the DEFLATE window) lives here and
+    // is flushed to HBM in dwords.  GWIN = true: no ring -- output bytes go straight to the block's
+    // place in HBM and matches read them back from there (L2-hot); what is left is ~7.7 KiB, so 20
+    // waves share a CU instead of 4 and hide each other's latencies (measured: 2 / 3 / 4 / 5 / 6 waves per SIMD
+    // = 52 / 58 / 58 / 65 / 62 GiB/s on the bench stream; the LDS-ring version with 1: 23).
+    uint32_t win[GWIN ? 1 : 8192];
     uint32_t lfast[1024];   // litlen entries for codes of <= 10 bits, 0 = longer code
     uint32_t ofast[256];    // offset entries for codes of <= 8 bits (and the 7-bit precode table)
     uint32_t inr[256];      // ring of compressed dwords (absolute dword index & 255)
@@ -2795,12 +2801,15 @@ __global__ __launch_bounds__(256) void k_dscan(uint32_t nb, const DBlock *__rest
 // codeword to real codeword reading those per-lane results with v_readlane -- scalar ALU only, no
 // memory latency per symbol.  Literals of a round are stored together (one ds_write_b8, each marked
 // lane at o + its rank); a match first commits the literals before it, then copies with the wave.
-template <bool DBG>
-__global__ __launch_bounds__(64) void k_inflate(uint32_t hdr_len, const uint8_t *__restrict__ in_all,
-                                                DBlock *__restrict__ blk_all,
-                                                const uint64_t *__restrict__ out_off,
-                                                uint8_t *__restrict__ out_all, uint64_t out_cap) {
-    __shared__ InfLds h;
+#ifndef GZPX_INF_WAVES
+#define GZPX_INF_WAVES 5  // waves per SIMD the global-window k_inflate is compiled for (VGPR budget 512 / n)
+#endif
+template <bool DBG, bool GWIN>
+__global__ __launch_bounds__(64, GWIN ? GZPX_INF_WAVES : 1) void k_inflate(uint32_t hdr_len, const uint8_t *__restrict__ in_all,
+                                                              DBlock *__restrict__ blk_all,
+                                                              const uint64_t *__restrict__ out_off,
+                                                              uint8_t *out_all, uint64_t out_cap) {
+    __shared__ InfLdsT<GWIN> h;
     const uint32_t lane = threadIdx.x;
     DBlock *blk = blk_all + blockIdx.x;
     const uint32_t isize = blk->isize;
@@ -2862,8 +2871,19 @@ __global__ __launch_bounds__(64) void k_inflate(uint32_t hdr_len, const uint8_t 
     uint32_t o = 0;        // bytes produced
     uint32_t flushed = 0;  // bytes already written to HBM
     uint32_t status = kInfOk;
+    // the window: byte `pos` of the block's output (GWIN: in HBM, where a wave reads its own earlier
+    // stores back in program order; otherwise the LDS ring)
+    auto win_load = [&](uint32_t pos) -> uint32_t { return GWIN ? (uint32_t)out[pos] : (uint32_t)win8[pos & 32767u]; };
+    auto win_store = [&](uint32_t pos, uint32_t v) {
+        if (GWIN) out[pos] = (uint8_t)v;
+        else win8[pos & 32767u] = (uint8_t)v;
+    };
     // write ring bytes [flushed, upto) to HBM: whole dwords where the destination is aligned
     auto flush = [&](uint32_t upto) {
+        if (GWIN) {
+            flushed = upto;
+            return;
+        }
         wave_sync();
         if (DBG) dbg[7]++;
         uint32_t q = flushed;
@@ -2920,12 +2940,32 @@ __global__ __launch_bounds__(64) void k_inflate(uint32_t hdr_len, const uint8_t 
                 status = kInfInsufficientSpace;
                 break;
             }
-            for (uint32_t done = 0; done < len; done += 16384u) {
-                const uint32_t piece = len - done < 16384u ? len - done : 16384u;
-                if (o + piece - flushed > 32768u - 16u) flush(o);
-                wave_sync();
-                for (uint32_t i = lane; i < piece; i += 64) win8[(o + i) & 32767u] = pay[src + done + i];
-                o += piece;
+            if (GWIN) {
+                // straight from the payload to the output: head bytes up to a dword boundary of the
+                // destination, then dwords (the source is read as aligned dword pairs), then the tail
+                const uint8_t *sp = pay + src;
+                uint8_t *dp = out + o;
+                uint32_t head = (uint32_t)((4u - ((uintptr_t)dp & 3u)) & 3u);
+                if (head > len) head = len;
+                if (lane < head) dp[lane] = sp[lane];
+                const uint32_t nw = (len - head) >> 2;
+                const uint32_t smis = (uint32_t)((uintptr_t)(sp + head) & 3u);
+                const uint32_t *s32 = (const uint32_t *)(sp + head - smis);
+                for (uint32_t k = lane; k < nw; k += 64) {
+                    const uint32_t lo = s32[k], hi = smis ? s32[k + 1] : 0u;  // (hi: inside the member, the footer follows)
+                    *(uint32_t *)(dp + head + 4 * k) = __builtin_amdgcn_alignbyte(hi, lo, smis);
+                }
+                const uint32_t donew = head + 4 * nw;
+                if (donew + lane < len) dp[donew + lane] = sp[donew + lane];
+                o += len;
+            } else {
+                for (uint32_t done = 0; done < len; done += 16384u) {
+                    const uint32_t piece = len - done < 16384u ? len - done : 16384u;
+                    if (o + piece - flushed > 32768u - 16u) flush(o);
+                    wave_sync();
+                    for (uint32_t i = lane; i < piece; i += 64) win8[(o + i) & 32767u] = pay[src + done + i];
+                    o += piece;
+                }
             }
             bp += 8u * len;
             continue;
@@ -3209,18 +3249,42 @@ __global__ __launch_bounds__(64) void k_inflate(uint32_t hdr_len, const uint8_t 
                     const uint32_t srcrel = (p1 & 0xFFFFu) - sdist + r;  // relative to o; "negative" = older
                     uint64_t done = __ballot(!active);
                     bool pending = active;
-                    do {
+                    if (GWIN) {
+                        // sources older than this pass come from HBM (one gather for all of them, issued
+                        // before the loop); sources inside the pass are handed over between lanes
                         const bool in_pass = m && (int32_t)(srcrel - pass) >= 0;
-                        const bool ready = pending && (!in_pass || ((done >> ((srcrel - pass) & 63u)) & 1ull) != 0);
-                        uint32_t v = (p1 >> 16) & 0xFFu;
-                        if (ready && m) v = win8[(o + srcrel) & 32767u];
-                        wave_sync();
-                        if (ready) win8[(o + prel) & 32767u] = (uint8_t)v;
-                        wave_sync();
-                        done |= __ballot(ready);
-                        pending = pending && !ready;
-                        if (DBG) dbg[6]++;
-                    } while (__ballot(pending) != 0);
+                        uint32_t myv = (p1 >> 16) & 0xFFu;  // the literal
+                        if (active && m && !in_pass) myv = out[o + srcrel];
+                        bool have = active && (!m || !in_pass);
+                        if (have) out[o + prel] = (uint8_t)myv;
+                        done |= __ballot(have);
+                        pending = pending && !have;
+                        while (__ballot(pending) != 0) {
+                            const uint32_t sl = (srcrel - pass) & 63u;
+                            const uint32_t got = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(sl << 2), (int)myv);
+                            const bool ready = pending && ((done >> sl) & 1ull) != 0;
+                            if (ready) {
+                                myv = got;
+                                out[o + prel] = (uint8_t)myv;
+                            }
+                            done |= __ballot(ready);
+                            pending = pending && !ready;
+                            if (DBG) dbg[6]++;
+                        }
+                    } else {
+                        do {
+                            const bool in_pass = m && (int32_t)(srcrel - pass) >= 0;
+                            const bool ready = pending && (!in_pass || ((done >> ((srcrel - pass) & 63u)) & 1ull) != 0);
+                            uint32_t v = (p1 >> 16) & 0xFFu;
+                            if (ready && m) v = win8[(o + srcrel) & 32767u];
+                            wave_sync();
+                            if (ready) win8[(o + prel) & 32767u] = (uint8_t)v;
+                            wave_sync();
+                            done |= __ballot(ready);
+                            pending = pending && !ready;
+                            if (DBG) dbg[6]++;
+                        } while (__ballot(pending) != 0);
+                    }
                 }
                 o += tout;
                 if (DBG) dbg[3] += (uint32_t)(clock64() - t_out);
@@ -3265,7 +3329,7 @@ __global__ __launch_bounds__(64) void k_inflate(uint32_t hdr_len, const uint8_t 
                 }
                 if (o + 1 - flushed > 32768u) flush(o & ~3u);
                 wave_sync();
-                if (lane == 0) win8[o & 32767u] = (uint8_t)(e >> 8);
+                if (lane == 0) win_store(o, e >> 8);
                 wave_sync();
                 o++;
                 bp += scl;
@@ -3310,9 +3374,9 @@ __global__ __launch_bounds__(64) void k_inflate(uint32_t hdr_len, const uint8_t 
                     if ((int32_t)r < 0) r += dist;
                     if (r >= dist) r -= dist;
                 }
-                const uint32_t v = win8[(src0 + (i < len ? r : 0u)) & 32767u];
+                const uint32_t v = win_load(src0 + (i < len ? r : 0u));
                 wave_sync();
-                if (i < len) win8[(o + i) & 32767u] = (uint8_t)v;
+                if (i < len) win_store(o + i, v);
             }
             o += len;
             wave_sync();
@@ -3439,10 +3503,10 @@ void launch_inflate(uint32_t hdr_len, const uint8_t *d_in, const uint64_t *d_off
     hipLaunchKernelGGL(k_dscan, dim3(1), dim3(256), 0, stream, nb, (const DBlock *)blk, d_out_off);
     if (ev_begin) (void)hipEventRecord(ev_begin, stream);
     if (debug)
-        hipLaunchKernelGGL(k_inflate<true>, dim3(nb), dim3(64), 0, stream, hdr_len, d_in, blk,
+        hipLaunchKernelGGL((k_inflate<true, true>), dim3(nb), dim3(64), 0, stream, hdr_len, d_in, blk,
                            (const uint64_t *)d_out_off, d_out, out_cap);
     else
-        hipLaunchKernelGGL(k_inflate<false>, dim3(nb), dim3(64), 0, stream, hdr_len, d_in, blk,
+        hipLaunchKernelGGL((k_inflate<false, true>), dim3(nb), dim3(64), 0, stream, hdr_len, d_in, blk,
                            (const uint64_t *)d_out_off, d_out, out_cap);
     if (ev_end) (void)hipEventRecord(ev_end, stream);
     hipLaunchKernelGGL(k_dcrc32, dim3(nb), dim3(kCrcThreads), 0, stream, (const uint8_t *)d_out,
