@@ -471,6 +471,59 @@ def run_fastq(args, env):
     ctx.close()
 
 
+def run_config(args, env, fmt, level, bs, kind, n, label):
+    """Any other (format, level, block size, input) on one GPU per rank, device-resident: BASELINE
+    configs[2] (--workload mgzip3: Mgzip, 1 MiB blocks, level 3, 4 GiB of printable-ASCII noise generated
+    in HBM) and the text slab at gzp's default level (--workload bgzf3)."""
+    torch, _native = env.torch, env.native
+    from gzp_amd import synth
+    if kind == "ascii":
+        d_in = torch.empty(n + 64, dtype=torch.uint8, device=env.dev)
+        _native.synth_ascii_device(d_in.data_ptr(), 0, n, 8 + env.rank, lib=env.lib)
+    else:
+        d_in = torch.from_numpy(synth.text_slab(n, seed=20250927 + env.rank)).to(env.dev)
+    ctx = _native.Context(format=fmt, level=level, buffer_size=bs, compat=_native.COMPAT_1_24,
+                          device=env.device_index, max_slab_bytes=n, lib=env.lib)
+    cap = ctx.slab_bound(n)
+    d_out = torch.empty(cap, dtype=torch.uint8, device=env.dev)
+    ctx.set_profiling(True)
+    acc = {}
+    out_len = 0
+    for _ in range(args.warmup):
+        ctx.compress_slab_device(d_in.data_ptr(), n, d_out.data_ptr(), cap, True)
+    env.sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out_len, nb = ctx.compress_slab_device(d_in.data_ptr(), n, d_out.data_ptr(), cap, True)
+        for k, v in ctx.last_stage_ms().items():
+            acc[k] = acc.get(k, 0.0) + v / args.steps
+    env.sync()
+    dt = env.max_over_ranks(time.perf_counter() - t0)
+    if env.rank == 0:
+        # integrity: every block inflated and CRC-checked on the GPU, compared with the input on the device
+        host = d_out[:out_len].cpu().numpy()
+        d = _native.DContext(format=fmt, device=env.device_index, lib=env.lib)
+        offs, sizes, used = d.scan_blocks(host)
+        d_back = torch.empty(n + 64, dtype=torch.uint8, device=env.dev)
+        got = d.decompress_device(d_out.data_ptr(), used, offs, sizes, d_back.data_ptr(), n + 64)
+        ok = got == n and bool(torch.equal(d_back[:n], d_in[:n]))
+        d.close()
+        dom = max(acc, key=acc.get)
+        achieved = (n + out_len) / (max(acc[dom], 1e-9) * 1e-3) / 1e9
+        print(json.dumps({
+            "metric": label, "value": round(n * env.world / 2**20 / (dt / args.steps), 1), "unit": "MiB/s",
+            "n_gpus": env.world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "config": {"workload": label, "slab_bytes": n, "block_size": bs, "level": level,
+                       "format": "bgzf" if fmt == _native.FORMAT_BGZF else "mgzip", "ratio": round(out_len / n, 4),
+                       "gpu_inflate_crc_roundtrip_ok": bool(ok), "device": ctx.device_name()},
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                         "stage_ms": {k: round(v, 3) for k, v in acc.items()}}}))
+    ctx.close()
+
+
 def self_launch(args):
     """`python bench.py --gpus N` from a bare shell: re-execute under torch.distributed.run, one rank
     per GPU (the driver may also launch it that way itself; then WORLD_SIZE is already set)."""
@@ -499,8 +552,9 @@ def main():
                     help="N > 1 in-order write-out: rccl = ordered gather of the compressed shards to rank 0 over "
                          "xGMI (north_star); offsets = all_gather of the shard sizes only, every rank copies its "
                          "shard to its own page-locked buffer at its stream offset")
-    ap.add_argument("--workload", choices=["compress", "inflate", "fastq"], default="compress",
-                    help="compress = the headline metric (default); inflate = the ParDecompress row; fastq = configs[3]")
+    ap.add_argument("--workload", choices=["compress", "inflate", "fastq", "mgzip3", "bgzf3"], default="compress",
+                    help="compress = the headline metric (default); inflate = the ParDecompress row; fastq = configs[3]; "
+                         "mgzip3 = configs[2] (Mgzip 1 MiB blocks, level 3, 4 GiB ASCII); bgzf3 = the text slab at level 3")
     ap.add_argument("--emulate", action="store_true", help=argparse.SUPPRESS)  # tests: CPU emulator + gloo, no timing value
     args = ap.parse_args()
 
@@ -520,6 +574,17 @@ def main():
         return
     if args.workload == "fastq":
         run_fastq(args, env)
+        env.close()
+        return
+    if args.workload == "mgzip3":
+        run_config(args, env, _native.FORMAT_MGZIP, 3, 1 << 20, "ascii",
+                   (4 << 30) if args.slab_bytes == SLAB_BYTES else args.slab_bytes,
+                   "Single MI355X: Mgzip 1 MiB blocks, level 3, 4 GiB /dev/urandom-seeded ASCII")
+        env.close()
+        return
+    if args.workload == "bgzf3":
+        run_config(args, env, _native.FORMAT_BGZF, 3, BLOCK, "text", args.slab_bytes,
+                   "BGZF compress MiB/s at level 3 (gzp's default level), 550 MiB text")
         env.close()
         return
 
