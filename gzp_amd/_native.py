@@ -55,6 +55,7 @@ EXPORTS = [
     "gzpx_free_decompressor", "gzpx_pard_create", "gzpx_pard_read", "gzpx_pard_destroy",
     "gzpx_pard_last_error", "gzpx_host_alloc", "gzpx_host_free", "gzpx_dctx_last_inflate_ms",
     "gzpx_debug_inflate", "gzpx_synth_fastq_device", "gzpx_synth_ascii_device",
+    "gzpx_multi_create", "gzpx_multi_destroy", "gzpx_multi_devices", "gzpx_multi_compress_slab",
 ]
 
 
@@ -212,6 +213,14 @@ class GzpxLib:
         L.gzpx_debug_inflate.argtypes = [vp, i32, ctypes.POINTER(ctypes.c_uint64)]
         L.gzpx_synth_fastq_device.restype = i32
         L.gzpx_synth_fastq_device.argtypes = [vp, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint64, vp]
+        L.gzpx_multi_create.restype = i32
+        L.gzpx_multi_create.argtypes = [ctypes.POINTER(GzpxConfig), ctypes.POINTER(ctypes.c_int), sz, ctypes.POINTER(vp)]
+        L.gzpx_multi_destroy.restype = None
+        L.gzpx_multi_destroy.argtypes = [vp]
+        L.gzpx_multi_devices.restype = sz
+        L.gzpx_multi_devices.argtypes = [vp]
+        L.gzpx_multi_compress_slab.restype = i32
+        L.gzpx_multi_compress_slab.argtypes = [vp, vp, sz, i32, vp, sz, psz, vp, sz, psz]
         L.gzpx_synth_ascii_device.restype = i32
         L.gzpx_synth_ascii_device.argtypes = [vp, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint64, vp]
         L.gzpx_pard_create.restype = i32
@@ -397,6 +406,57 @@ class Context:
                                                     ctypes.byref(n), first.ctypes.data,
                                                     ctypes.byref(ns)))
         return toks[:n.value].copy(), first[:ns.value].copy()
+
+
+class MultiContext:
+    """gzpx_multi: one slab sharded over several devices, written out in order."""
+
+    def __init__(self, devices, format=FORMAT_BGZF, level=1, buffer_size=None, compat=COMPAT_1_24,
+                 max_slab_bytes=1 << 30, lib=None):
+        self.lib = lib or load()
+        cfg = GzpxConfig()
+        self.lib.L.gzpx_config_default(ctypes.byref(cfg), format)
+        cfg.level = level
+        cfg.compat = compat
+        if buffer_size is not None:
+            cfg.buffer_size = buffer_size
+        cfg.max_slab_bytes = max_slab_bytes
+        self.buffer_size = cfg.buffer_size
+        devs = (ctypes.c_int * len(devices))(*devices)
+        h = ctypes.c_void_p()
+        self.lib.check(self.lib.L.gzpx_multi_create(ctypes.byref(cfg), devs, len(devices), ctypes.byref(h)))
+        self.h = h
+
+    def compress_slab(self, data, mode=SLAB_LAST, return_block_sizes=False):
+        a = _u8(data)
+        nb_max = 1 if a.size == 0 else -(-a.size // self.buffer_size)
+        cap = nb_max * (self.buffer_size + max(128, self.buffer_size // 10) + 28) + 128
+        out = np.empty(cap, dtype=np.uint8)
+        sizes = np.zeros(nb_max, dtype=np.uint32)
+        out_len = ctypes.c_size_t(0)
+        nb = ctypes.c_size_t(0)
+        rc = self.lib.L.gzpx_multi_compress_slab(self.h, a.ctypes.data, a.size, int(mode), out.ctypes.data, cap,
+                                                 ctypes.byref(out_len), sizes.ctypes.data, nb_max, ctypes.byref(nb))
+        self.lib.check(rc, nb.value if rc == ERR_BLOCK_SIZE_EXCEEDED else None)
+        res = out[:out_len.value].tobytes()
+        return (res, sizes[:nb.value].copy()) if return_block_sizes else res
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.L.gzpx_multi_destroy(self.h)
+            self.h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class Compressor:

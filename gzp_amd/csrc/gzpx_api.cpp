@@ -358,6 +358,7 @@ int submit_locked(gzpx_ctx *ctx, const uint8_t *host_in, const uint8_t *d_in, si
                   uint8_t *host_out, uint8_t *d_out, size_t out_cap, hipStream_t after, bool block_for_slot,
                   std::unique_lock<std::mutex> &lk, uint64_t *ticket) {
     if (ctx->crc_only) return GZPX_ERR_INVALID_ARG;
+    const size_t caller_cap = out_cap;  // (host jobs: out_cap becomes the staging buffer's below)
     int si = -1;
     for (;;) {
         for (int i = 0; i < kSlots; i++)
@@ -421,7 +422,7 @@ int submit_locked(gzpx_ctx *ctx, const uint8_t *host_in, const uint8_t *d_in, si
     sl.job_d_out = d_out;
     sl.job_out_cap = out_cap;
     sl.host_out = host_out;
-    sl.host_out_cap = host_out ? out_cap : 0;
+    sl.host_out_cap = host_out ? caller_cap : 0;
     sl.total_nb = total_nb;
     sl.n_batches = (uint32_t)n_batches;
     sl.state = 1;
@@ -430,51 +431,91 @@ int submit_locked(gzpx_ctx *ctx, const uint8_t *host_in, const uint8_t *d_in, si
     return GZPX_OK;
 }
 
-// Complete a ticket: wait for its kernels, copy the stream out (host jobs), report.
-int wait_ticket(gzpx_ctx *ctx, uint64_t ticket, size_t host_out_cap, size_t *out_len, uint32_t *block_sizes,
-                size_t max_blocks, size_t *n_blocks) {
+// Completing a ticket, in three phases (the multi-device entry runs them device by device so that the
+// shards' copies overlap): wait for the kernels and read the result record; start the copy-out of a
+// host job; wait for it and free the slot.
+struct Completion {
+    int rc = GZPX_OK;
+    size_t produced = 0, blocks_done = 0;
+};
+
+int claim_ticket(gzpx_ctx *ctx, uint64_t ticket, Slot **slot) {
     const int si = (int)(ticket & 0xFF);
     if (si >= kSlots) return GZPX_ERR_INVALID_ARG;
     Slot &sl = ctx->slots[si];
-    {
-        std::lock_guard<std::mutex> lk(ctx->mu);
-        if (sl.state != 1 || sl.gen != (ticket >> 8)) return GZPX_ERR_INVALID_ARG;
-        sl.state = 2;
-    }
-    int rc = GZPX_OK;
-    size_t produced = 0, blocks_done = (size_t)sl.total_nb;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    if (sl.state != 1 || sl.gen != (ticket >> 8)) return GZPX_ERR_INVALID_ARG;
+    sl.state = 2;
+    *slot = &sl;
+    return GZPX_OK;
+}
+
+Completion kernels_done(gzpx_ctx *ctx, Slot &sl) {
+    Completion c;
+    c.blocks_done = (size_t)sl.total_nb;
     if (hipSetDevice(ctx->cfg.device) != hipSuccess || hipEventSynchronize(sl.ev_kernels) != hipSuccess) {
-        rc = GZPX_ERR_DEVICE;
-    } else {
-        for (uint32_t bi = 0; bi < sl.n_batches && rc == GZPX_OK; bi++) {
-            const SlabResult &r = sl.h_results[bi];
-            if (r.fail_block != 0xFFFFFFFFu) {
-                blocks_done = (size_t)bi * ctx->batch_blocks + r.fail_block;
-                rc = r.fail_status == kStatusBlockSizeExceeded ? GZPX_ERR_BLOCK_SIZE_EXCEEDED : GZPX_ERR_DEVICE;
-            }
-        }
-        if (rc == GZPX_OK) {
-            produced = (size_t)sl.h_results[sl.n_batches - 1].total;
-            if (produced > sl.job_out_cap || (sl.host_out && produced > host_out_cap)) rc = GZPX_ERR_INSUFFICIENT_SPACE;
-        }
-        if (rc == GZPX_OK && block_sizes) {
-            if (max_blocks < sl.total_nb) rc = GZPX_ERR_INVALID_ARG;
-            else memcpy(block_sizes, sl.h_sizes, (size_t)sl.total_nb * sizeof(uint32_t));
-        }
-        if (rc == GZPX_OK && sl.host_out && produced) {
-            // the kernels are done (the host has seen their event): the copy needs no stream dependency
-            if (hipMemcpyAsync(sl.host_out, sl.job_d_out, produced, hipMemcpyDeviceToHost, ctx->s_d2h) != hipSuccess ||
-                hipEventRecord(sl.ev_d2h, ctx->s_d2h) != hipSuccess || hipEventSynchronize(sl.ev_d2h) != hipSuccess)
-                rc = GZPX_ERR_DEVICE;
+        c.rc = GZPX_ERR_DEVICE;
+        return c;
+    }
+    for (uint32_t bi = 0; bi < sl.n_batches && c.rc == GZPX_OK; bi++) {
+        const SlabResult &r = sl.h_results[bi];
+        if (r.fail_block != 0xFFFFFFFFu) {
+            c.blocks_done = (size_t)bi * ctx->batch_blocks + r.fail_block;
+            c.rc = r.fail_status == kStatusBlockSizeExceeded ? GZPX_ERR_BLOCK_SIZE_EXCEEDED : GZPX_ERR_DEVICE;
         }
     }
-    if (out_len) *out_len = rc == GZPX_OK ? produced : 0;
-    if (n_blocks) *n_blocks = blocks_done;
+    if (c.rc == GZPX_OK) {
+        c.produced = (size_t)sl.h_results[sl.n_batches - 1].total;
+        if (c.produced > sl.job_out_cap) c.rc = GZPX_ERR_INSUFFICIENT_SPACE;
+    }
+    return c;
+}
+
+// the kernels are done (the host has seen their event): the copy needs no stream dependency
+int start_copy_out(gzpx_ctx *ctx, Slot &sl, uint8_t *host_out, size_t produced) {
+    if (!produced) return GZPX_OK;
+    if (hipSetDevice(ctx->cfg.device) != hipSuccess ||
+        hipMemcpyAsync(host_out, sl.job_d_out, produced, hipMemcpyDeviceToHost, ctx->s_d2h) != hipSuccess ||
+        hipEventRecord(sl.ev_d2h, ctx->s_d2h) != hipSuccess)
+        return GZPX_ERR_DEVICE;
+    return GZPX_OK;
+}
+
+int finish_copy_out(gzpx_ctx *ctx, Slot &sl, size_t produced) {
+    if (!produced) return GZPX_OK;
+    if (hipSetDevice(ctx->cfg.device) != hipSuccess || hipEventSynchronize(sl.ev_d2h) != hipSuccess) return GZPX_ERR_DEVICE;
+    return GZPX_OK;
+}
+
+void release_slot(gzpx_ctx *ctx, Slot &sl) {
     {
         std::lock_guard<std::mutex> lk(ctx->mu);
         sl.state = 0;
     }
     ctx->cv_slot.notify_all();
+}
+
+// Complete a ticket: wait for its kernels, copy the stream out (host jobs), report.
+int wait_ticket(gzpx_ctx *ctx, uint64_t ticket, size_t host_out_cap, size_t *out_len, uint32_t *block_sizes,
+                size_t max_blocks, size_t *n_blocks) {
+    Slot *slp = nullptr;
+    int rc = claim_ticket(ctx, ticket, &slp);
+    if (rc != GZPX_OK) return rc;
+    Slot &sl = *slp;
+    Completion c = kernels_done(ctx, sl);
+    rc = c.rc;
+    if (rc == GZPX_OK && sl.host_out && c.produced > host_out_cap) rc = GZPX_ERR_INSUFFICIENT_SPACE;
+    if (rc == GZPX_OK && block_sizes) {
+        if (max_blocks < sl.total_nb) rc = GZPX_ERR_INVALID_ARG;
+        else memcpy(block_sizes, sl.h_sizes, (size_t)sl.total_nb * sizeof(uint32_t));
+    }
+    if (rc == GZPX_OK && sl.host_out) {
+        rc = start_copy_out(ctx, sl, sl.host_out, c.produced);
+        if (rc == GZPX_OK) rc = finish_copy_out(ctx, sl, c.produced);
+    }
+    if (out_len) *out_len = rc == GZPX_OK ? c.produced : 0;
+    if (n_blocks) *n_blocks = c.blocks_done;
+    release_slot(ctx, sl);
     return rc;
 }
 
@@ -704,6 +745,136 @@ int gzpx_encode_block(gzpx_ctx *ctx, const uint8_t *in, size_t n, int is_last, u
     memcpy(out, tmp.data(), got);
     *out_len = got;
     return GZPX_OK;
+}
+
+// ---------------------------------------------------------------- multi-device slab call
+// SURVEY 8(b) "multi-device variant", 8(e): blocks share no state, so a slab shards into contiguous
+// block ranges, one per device, balanced to one block; only the range that holds the slab's end is
+// cut with the caller's mode (short final piece / EOF marker).  Every device runs the single-device
+// pipeline on its range -- no data-path exchange between them -- and the in-order write-out is done
+// on the host side of the boundary: once the shard sizes are known (16 bytes per device), every
+// device copies its shard straight to its offset in `out`, all copies in flight together, each
+// over its own PCIe link.  (The one-process-per-GPU form of the same split, with the shards
+// gathered over RCCL, is gzp_amd/shard.py + bench.py --gpus N.)
+struct gzpx_multi {
+    std::vector<gzpx_ctx *> ctxs;
+    size_t buffer_size = 0;
+    std::mutex mu;
+};
+
+int gzpx_multi_create(const gzpx_config *cfg, const int *devices, size_t n_devices, gzpx_multi **out) {
+    if (!cfg || !devices || !n_devices || !out) return GZPX_ERR_INVALID_ARG;
+    *out = nullptr;
+    gzpx_multi *m = new (std::nothrow) gzpx_multi();
+    if (!m) return GZPX_ERR_DEVICE;
+    m->buffer_size = cfg->buffer_size;
+    for (size_t g = 0; g < n_devices; g++) {
+        gzpx_config c = *cfg;
+        c.device = devices[g];
+        // each device sees 1/n of the largest slab (+ one block of imbalance)
+        if (c.max_slab_bytes) c.max_slab_bytes = c.max_slab_bytes / n_devices + 2 * c.buffer_size;
+        gzpx_ctx *ctx = nullptr;
+        const int rc = gzpx_ctx_create(&c, &ctx);
+        if (rc != GZPX_OK) {
+            gzpx_multi_destroy(m);
+            return rc;
+        }
+        m->ctxs.push_back(ctx);
+    }
+    *out = m;
+    return GZPX_OK;
+}
+
+void gzpx_multi_destroy(gzpx_multi *m) {
+    if (!m) return;
+    for (gzpx_ctx *c : m->ctxs) gzpx_ctx_destroy(c);
+    delete m;
+}
+
+size_t gzpx_multi_devices(const gzpx_multi *m) { return m ? m->ctxs.size() : 0; }
+
+int gzpx_multi_compress_slab(gzpx_multi *m, const uint8_t *in, size_t in_len, int mode, uint8_t *out,
+                             size_t out_cap, size_t *out_len, uint32_t *block_sizes, size_t max_blocks,
+                             size_t *n_blocks) {
+    if (!m || !out_len || m->ctxs.empty()) return GZPX_ERR_INVALID_ARG;
+    int rc = check_slab_args(m->ctxs[0], in, in_len, mode, out);
+    if (rc != GZPX_OK) return rc;
+    std::lock_guard<std::mutex> guard(m->mu);
+    const size_t bs = m->buffer_size, G = m->ctxs.size();
+    const uint64_t total_nb = in_len == 0 ? 1 : (in_len + bs - 1) / bs;
+    if (block_sizes && max_blocks < total_nb) return GZPX_ERR_INVALID_ARG;
+    struct Part {
+        uint64_t first = 0, nb = 0;
+        size_t lo = 0, n = 0;
+        uint64_t ticket = 0;
+        Slot *slot = nullptr;
+        Completion c;
+        bool submitted = false;
+    };
+    std::vector<Part> parts(G);
+    uint64_t first = 0;
+    for (size_t g = 0; g < G; g++) {  // contiguous ranges, balanced to within one block
+        Part &p = parts[g];
+        p.first = first;
+        p.nb = total_nb / G + (g < total_nb % G ? 1 : 0);
+        first += p.nb;
+        p.lo = (size_t)(p.first * bs < in_len ? p.first * bs : in_len);
+        const size_t hi = (size_t)((p.first + p.nb) * bs < in_len ? (p.first + p.nb) * bs : in_len);
+        p.n = hi - p.lo;
+    }
+    // 1. every device: copy-in + kernels of its range (devices work concurrently)
+    for (size_t g = 0; g < G && rc == GZPX_OK; g++) {
+        Part &p = parts[g];
+        if (p.nb == 0) continue;
+        const bool owns_end = p.first + p.nb == total_nb;
+        gzpx_ctx *ctx = m->ctxs[g];
+        std::unique_lock<std::mutex> lk(ctx->mu);
+        if (hipSetDevice(ctx->cfg.device) != hipSuccess) {
+            rc = GZPX_ERR_DEVICE;
+            break;
+        }
+        // (`out` is only a placeholder here: the real destination is known after the sizes are)
+        rc = submit_locked(ctx, in + p.lo, nullptr, p.n, owns_end ? mode : GZPX_SLAB_FULL_BLOCKS, out, nullptr, 0, nullptr,
+                           true, lk, &p.ticket);
+        p.submitted = rc == GZPX_OK;
+    }
+    // 2. sizes -> offsets; 3. all copies started; 4. all copies finished
+    size_t fail_block = (size_t)total_nb;
+    for (size_t g = 0; g < G; g++) {
+        Part &p = parts[g];
+        if (!p.submitted) continue;
+        if (claim_ticket(m->ctxs[g], p.ticket, &p.slot) != GZPX_OK) {
+            if (rc == GZPX_OK) rc = GZPX_ERR_DEVICE;
+            p.submitted = false;
+            continue;
+        }
+        p.c = kernels_done(m->ctxs[g], *p.slot);
+        if (p.c.rc != GZPX_OK && rc == GZPX_OK) {  // the first failing block in stream order
+            rc = p.c.rc;
+            fail_block = (size_t)p.first + p.c.blocks_done;
+        }
+    }
+    size_t total = 0;
+    std::vector<size_t> offs(G, 0);
+    for (size_t g = 0; g < G; g++) {
+        offs[g] = total;
+        if (parts[g].submitted) total += parts[g].c.produced;
+    }
+    if (rc == GZPX_OK && total > out_cap) rc = GZPX_ERR_INSUFFICIENT_SPACE;
+    for (size_t g = 0; g < G && rc == GZPX_OK; g++)
+        if (parts[g].submitted) rc = start_copy_out(m->ctxs[g], *parts[g].slot, out + offs[g], parts[g].c.produced);
+    for (size_t g = 0; g < G; g++) {
+        Part &p = parts[g];
+        if (!p.submitted) continue;
+        const int r2 = finish_copy_out(m->ctxs[g], *p.slot, p.c.produced);
+        if (rc == GZPX_OK) rc = r2;
+        if (rc == GZPX_OK && block_sizes)
+            memcpy(block_sizes + p.first, p.slot->h_sizes, (size_t)p.nb * sizeof(uint32_t));
+        release_slot(m->ctxs[g], *p.slot);
+    }
+    *out_len = rc == GZPX_OK ? total : 0;
+    if (n_blocks) *n_blocks = rc == GZPX_OK ? (size_t)total_nb : fail_block;
+    return rc;
 }
 
 // ---------------------------------------------------------------- libdeflate-shaped ABI

@@ -136,6 +136,22 @@ int gzpx_compress_slab_wait(gzpx_ctx *ctx, uint64_t ticket, size_t *out_len, uin
                             size_t max_blocks, size_t *n_blocks);
 int gzpx_compress_slab_event(gzpx_ctx *ctx, uint64_t ticket, void **hip_event);
 
+/*
+ * Multi-device form: one context per entry of devices[]; a slab is cut into
+ * that many contiguous block ranges (balanced to one block; only the range holding the slab's end
+ * takes `mode`), every device compresses its range concurrently, and once the shard sizes are known
+ * each device copies its shard straight to its offset in `out` -- the in-order write-out without any
+ * payload crossing between GPUs.  Same result, byte for byte, as gzpx_compress_slab on one device.
+ * (One process per GPU + an RCCL gather of the shards: gzp_amd/shard.py, bench.py --gpus N.)
+ */
+typedef struct gzpx_multi gzpx_multi;
+int gzpx_multi_create(const gzpx_config *cfg, const int *devices, size_t n_devices, gzpx_multi **out);
+void gzpx_multi_destroy(gzpx_multi *m);
+size_t gzpx_multi_devices(const gzpx_multi *m);
+int gzpx_multi_compress_slab(gzpx_multi *m, const uint8_t *in, size_t in_len, int mode, uint8_t *out,
+                             size_t out_cap, size_t *out_len, uint32_t *block_sizes, size_t max_blocks,
+                             size_t *n_blocks);
+
 /* FormatSpec::encode: one framed block (is_last => BGZF_EOF appended for BGZF). */
 int gzpx_encode_block(gzpx_ctx *ctx, const uint8_t *in, size_t n, int is_last, uint8_t *out,
                       size_t out_cap, size_t *out_len);

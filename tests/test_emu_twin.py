@@ -6,6 +6,10 @@ def test_submit_wait_pipeline(emu_lib, oracle):
     tc.submit_wait_pipeline(emu_lib, oracle)
 
 
+def test_multi_device(emu_lib, oracle):
+    tc.multi_device(emu_lib, oracle)
+
+
 def test_reserve_commit(emu_lib, oracle):
     tc.reserve_commit(emu_lib, oracle)
 

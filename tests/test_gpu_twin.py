@@ -12,6 +12,10 @@ def test_submit_wait_pipeline(hip_lib, oracle):
     tc.submit_wait_pipeline(hip_lib, oracle, scale=16)
 
 
+def test_multi_device(hip_lib, oracle):
+    tc.multi_device(hip_lib, oracle, scale=8)
+
+
 def test_reserve_commit(hip_lib, oracle):
     tc.reserve_commit(hip_lib, oracle, scale=8)
 

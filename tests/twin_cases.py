@@ -58,6 +58,32 @@ def submit_wait_pipeline(lib, oracle, scale=1):
         assert b"".join(got) == oracle.compress_stream(whole, oracle.FMT_BGZF, 1, oracle.COMPAT_1_24, BS)
         # the synchronous call is the same thing in one step
         assert c.compress_slab(slabs[1], _native.SLAB_FULL_BLOCKS) == got[1]
+        # the caller's capacity is what counts at wait time
+        small = np.zeros(1000, dtype=np.uint8)
+        t = c.submit(slabs[0].ctypes.data, slabs[0].size, small.ctypes.data, small.size, _native.SLAB_FULL_BLOCKS)
+        with pytest.raises(_native.GzpxError) as e:
+            c.wait(t)
+        assert e.value.code == _native.ERR_INSUFFICIENT_SPACE and not small.any()
+
+
+def multi_device(lib, oracle, scale=1):
+    """gzpx_multi_*: a slab sharded over several contexts (here: all on device 0 -- the only one a test
+    box has -- which exercises the split, the modes per range, the offsets and the ordered write-out),
+    identical to the single-device stream; errors name the block in stream order."""
+    for ndev, nblk, extra, mode in ((3, 7, 123, _native.SLAB_LAST), (2, 5, 0, _native.SLAB_FULL_BLOCKS),
+                                    (4, 2, 17, _native.SLAB_FLUSH), (3, 0, 0, _native.SLAB_LAST), (2, 1, 0, _native.SLAB_LAST)):
+        a = synth.make("mixed", nblk * BS * scale + extra, 5 + nblk)
+        with _native.MultiContext([0] * ndev, level=1, buffer_size=BS, lib=lib, max_slab_bytes=max(a.size, BS)) as m:
+            got, sizes = m.compress_slab(a, mode, return_block_sizes=True)
+        with _native.Context(level=1, buffer_size=BS, lib=lib, max_slab_bytes=max(a.size, BS)) as c:
+            want, wsizes = c.compress_slab(a, mode, return_block_sizes=True)
+        assert got == want and list(sizes) == list(wsizes), (ndev, nblk, extra, mode)
+    # BlockSizeExceeded in the second device's range is reported with its stream-order index
+    a = np.concatenate([synth.make("text", 2 * 65536, 1), synth.uniform_random(65536, 2), synth.make("text", 65536, 3)])
+    with _native.MultiContext([0, 0], level=1, buffer_size=65536, lib=lib, max_slab_bytes=a.size) as m:
+        with pytest.raises(_native.GzpxError) as e:
+            m.compress_slab(a, _native.SLAB_LAST)
+    assert e.value.code == _native.ERR_BLOCK_SIZE_EXCEEDED and e.value.block == 2
 
 
 def reserve_commit(lib, oracle, scale=1):
