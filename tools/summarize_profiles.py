@@ -16,7 +16,7 @@ import sys
 ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
 G = os.path.join(ROOT, "gpurun_out")
 P = os.path.join(ROOT, "profiles")
-tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
 slab_bytes = 576_716_800
 
 os.makedirs(P, exist_ok=True)
@@ -31,11 +31,12 @@ def find(dirname, suffix):
 
 
 shutil.copy(find("prof_%s" % tag, "kernel_stats.csv"), os.path.join(P, "%s_kernel_stats.csv" % tag))
-try:
-    shutil.copy(find("prof_%s_inflate" % tag, "kernel_stats.csv"),
-                os.path.join(P, "%s_inflate_kernel_stats.csv" % tag))
-except FileNotFoundError:
-    pass
+for extra in ("inflate", "bgzf3", "mgzip3"):  # the ParDecompress row; the level-3 (hc) kernels
+    try:
+        shutil.copy(find("prof_%s_%s" % (tag, extra), "kernel_stats.csv"),
+                    os.path.join(P, "%s_%s_kernel_stats.csv" % (tag, extra)))
+    except FileNotFoundError:
+        pass
 
 
 def counters(path):
@@ -68,6 +69,10 @@ doc = {
     "raw_write_kib": write,
     "hbm_bytes_per_launch": {k: int(fetch.get(k, 0) * 1024 * cal + write.get(k, 0) * 1024) for k in fetch},
 }
+doc["round"] = tag
+doc["pipeline_total_bytes"] = int(sum(v for k, v in doc["hbm_bytes_per_launch"].items()
+                                      if k in ("k_init_meta", "k_candidates", "k_candidates_safe", "k_match", "k_parse", "k_hist",
+                                               "k_huffman", "k_crc32", "k_scan", "k_emit")))
 with open(os.path.join(P, "pmc_traffic.json"), "w") as f:
     json.dump(doc, f, indent=1)
 print(json.dumps(doc["hbm_bytes_per_launch"], indent=1))
