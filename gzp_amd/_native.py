@@ -48,7 +48,7 @@ EXPORTS = [
     "gzpx_compress_slab_submit", "gzpx_compress_slab_submit_device", "gzpx_compress_slab_wait",
     "gzpx_compress_slab_event", "gzpx_crc32_checked", "gzpx_last_status",
     "gzpx_par_create", "gzpx_par_write", "gzpx_par_flush", "gzpx_par_finish", "gzpx_par_destroy",
-    "gzpx_par_last_error", "gzpx_par_reserve", "gzpx_par_commit", "gzpx_par_index", "gzpx_gzi_size",
+    "gzpx_par_last_error", "gzpx_par_create_pinned", "gzpx_par_reserve", "gzpx_par_commit", "gzpx_par_index", "gzpx_gzi_size",
     "gzpx_gzi_write", "gzpx_dctx_create", "gzpx_dctx_destroy", "gzpx_scan_blocks",
     "gzpx_decompress_blocks", "gzpx_decompress_blocks_device", "gzpx_decompress_blocks_submit",
     "gzpx_decompress_blocks_wait", "gzpx_alloc_decompressor", "gzpx_deflate_decompress",
@@ -162,6 +162,8 @@ class GzpxLib:
         L.gzpx_version.argtypes = []
         L.gzpx_par_create.restype = i32
         L.gzpx_par_create.argtypes = [ctypes.POINTER(GzpxParConfig), WRITE_FN, vp, ctypes.POINTER(vp)]
+        L.gzpx_par_create_pinned.restype = i32
+        L.gzpx_par_create_pinned.argtypes = [ctypes.POINTER(GzpxParConfig), sz, WRITE_FN, vp, ctypes.POINTER(vp)]
         L.gzpx_par_write.restype = i32
         L.gzpx_par_write.argtypes = [vp, vp, sz]
         L.gzpx_par_reserve.restype = i32

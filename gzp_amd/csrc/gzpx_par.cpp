@@ -4,9 +4,33 @@
 
 #include <hip/hip_runtime.h>
 
+#include <pthread.h>
+#include <sched.h>
+
 #include <cstring>
 
 namespace gzp {
+
+// pin_threads(Some(n)) in the reference pins worker i to the (n + i)-th core the process may run on
+// (core_affinity::get_core_ids, src/par/compress.rs:260-276); the twin's workers are the device
+// thread (i = 0) and the copy helpers (i = 1 ..).  A core that does not exist is skipped silently,
+// as there.
+static void pin_current_thread(const std::optional<size_t> &pin_at, size_t i) {
+    if (!pin_at) return;
+    cpu_set_t allowed;
+    if (sched_getaffinity(0, sizeof(allowed), &allowed) != 0) return;
+    size_t want = *pin_at + i, seen = 0;
+    for (int c = 0; c < CPU_SETSIZE; c++) {
+        if (!CPU_ISSET(c, &allowed)) continue;
+        if (seen++ == want) {
+            cpu_set_t one;
+            CPU_ZERO(&one);
+            CPU_SET(c, &one);
+            (void)pthread_setaffinity_np(pthread_self(), sizeof(one), &one);
+            return;
+        }
+    }
+}
 
 GzpError error_from_code(int code, size_t block) {
     const std::string msg = std::string(gzpx_strerror(code));
@@ -25,8 +49,12 @@ GzpError error_from_code(int code, size_t block) {
 }
 
 // ---------------------------------------------------------------- CopyPool
-CopyPool::CopyPool(size_t helpers) {
-    for (size_t i = 0; i < helpers; i++) threads_.emplace_back([this] { main(); });
+CopyPool::CopyPool(size_t helpers, std::optional<size_t> pin_at) {
+    for (size_t i = 0; i < helpers; i++)
+        threads_.emplace_back([this, pin_at, i] {
+            pin_current_thread(pin_at, 1 + i);
+            main();
+        });
 }
 
 CopyPool::~CopyPool() {
@@ -117,7 +145,7 @@ ParCompress::ParCompress(const ParConfig &cfg, WriteFn writer) : cfg_(cfg), writ
         throw;
     }
     const size_t helpers = cfg_.num_threads > 1 ? (cfg_.num_threads - 1 < 3 ? cfg_.num_threads - 1 : 3) : 0;
-    copier_ = std::make_unique<CopyPool>(helpers);
+    copier_ = std::make_unique<CopyPool>(helpers, cfg_.pin_threads);
     device_thread_ = std::thread([this] { device_main(); });
     writer_thread_ = std::thread([this] { writer_main(); });
 }
@@ -304,6 +332,7 @@ void ParCompress::complete(InFlight &f) {
 // into one submitter that keeps up to GZPX_SLOTS slabs in flight.  With nothing queued it completes
 // the oldest slab instead of idling, so a slow producer still sees its blocks written promptly.
 void ParCompress::device_main() {
+    pin_current_thread(cfg_.pin_threads, 0);
     (void)hipSetDevice(cfg_.device);
     std::deque<InFlight> fl;
     for (;;) {
@@ -694,7 +723,20 @@ static int guarded_d(gzpx_pard *p, Fn fn) {
 
 extern "C" {
 
+static int par_create(const gzpx_par_config *cfg, std::optional<size_t> pin, gzpx_write_fn write_fn, void *user,
+                      gzpx_par **out);
+
 int gzpx_par_create(const gzpx_par_config *cfg, gzpx_write_fn write_fn, void *user, gzpx_par **out) {
+    return par_create(cfg, std::nullopt, write_fn, user, out);
+}
+
+int gzpx_par_create_pinned(const gzpx_par_config *cfg, size_t first_core, gzpx_write_fn write_fn, void *user,
+                           gzpx_par **out) {
+    return par_create(cfg, first_core, write_fn, user, out);
+}
+
+static int par_create(const gzpx_par_config *cfg, std::optional<size_t> pin, gzpx_write_fn write_fn, void *user,
+                      gzpx_par **out) {
     if (!cfg || !write_fn || !out) return GZPX_ERR_INVALID_ARG;
     *out = nullptr;
     if (cfg->num_threads == 0) return GZPX_ERR_NUM_THREADS;  // src/par/compress.rs:84-90
@@ -708,6 +750,7 @@ int gzpx_par_create(const gzpx_par_config *cfg, gzpx_write_fn write_fn, void *us
         c.device = cfg->device;
         c.compat = cfg->compat;
         c.batch_blocks = cfg->batch_blocks ? cfg->batch_blocks : 1024;
+        c.pin_threads = pin;
         p->pc = std::make_unique<gzp::ParCompress>(
             c, [write_fn, user](const uint8_t *d, size_t n, std::string *err) {
                 const int r = write_fn(user, d, n);

@@ -108,7 +108,7 @@ struct ParConfig {
     size_t buffer_size = Bgzf::DEFAULT_BUFSIZE;
     size_t num_threads = 0;  // 0 = "all cores" default of the builder; only >= 1 after validation
     Compression compression_level = Compression(3);  // src/par/compress.rs:54-62
-    std::optional<size_t> pin_threads;               // accepted, no effect (device lanes)
+    std::optional<size_t> pin_threads;               // first core of the twin's threads (src/par/compress.rs:99-107)
     // GPU-side knobs (no counterpart in the reference)
     int device = 0;
     int compat = GZPX_COMPAT_LIBDEFLATE_1_24;
@@ -119,7 +119,7 @@ struct ParConfig {
 // one core copies ~12 GB/s, the copy engines take ~50.
 class CopyPool {
   public:
-    explicit CopyPool(size_t helpers);
+    explicit CopyPool(size_t helpers, std::optional<size_t> pin_at = std::nullopt);
     ~CopyPool();
     void copy(uint8_t *dst, const uint8_t *src, size_t n);
 
@@ -290,6 +290,37 @@ class ParCompressBuilder {
 
   private:
     ParConfig cfg_;
+};
+
+// ZBuilder<F, W> (src/lib.rs:181-275): the one-stop builder.  In the reference num_threads <= 1 selects
+// the single-threaded SyncZ; the GPU path has no such variant, so every setting builds a ParCompress.
+template <class F>
+class ZBuilder {
+  public:
+    ZBuilder &buffer_size(size_t n) {
+        b_.buffer_size(n);
+        return *this;
+    }
+    ZBuilder &num_threads(size_t n) {
+        threads_ = n;
+        return *this;
+    }
+    ZBuilder &compression_level(Compression c) {
+        b_.compression_level(c);
+        return *this;
+    }
+    ZBuilder &pin_threads(std::optional<size_t> p) {
+        b_.pin_threads(p);
+        return *this;
+    }
+    std::unique_ptr<ParCompress> from_writer(WriteFn w) {
+        b_.num_threads(threads_ ? threads_ : 1);
+        return b_.from_writer(std::move(w));
+    }
+
+  private:
+    ParCompressBuilder<F> b_;
+    size_t threads_ = std::thread::hardware_concurrency() ? std::thread::hardware_concurrency() : 1;
 };
 
 // The wrapped `R: Read`: returns the number of bytes read into buf (0 = end of stream), -1 on error.

@@ -62,7 +62,7 @@ class Mgzip:
 class ParCompress:
     """`Write` + `ZWriter` (src/par/compress.rs:221-469, src/lib.rs:166-170)."""
 
-    def __init__(self, cfg, writer, lib=None):
+    def __init__(self, cfg, writer, lib=None, pin=None):
         self._lib = lib or _native.load()
         self._writer = writer
         self._io_error = None
@@ -77,7 +77,10 @@ class ParCompress:
 
         self._cb = _native.WRITE_FN(_cb)  # keep alive
         h = ctypes.c_void_p()
-        rc = self._lib.L.gzpx_par_create(ctypes.byref(cfg), self._cb, None, ctypes.byref(h))
+        if pin is None:
+            rc = self._lib.L.gzpx_par_create(ctypes.byref(cfg), self._cb, None, ctypes.byref(h))
+        else:
+            rc = self._lib.L.gzpx_par_create_pinned(ctypes.byref(cfg), int(pin), self._cb, None, ctypes.byref(h))
         self._lib.check(rc)
         self._h = h
         self._finished = False
@@ -190,7 +193,7 @@ class ParCompressBuilder:
         return self
 
     def pin_threads(self, p):
-        self._pin = p  # accepted for API parity; device lanes are not pinned
+        self._pin = p  # first core of the twin's threads (src/par/compress.rs:99-107)
         return self
 
     # GPU-side knobs (no counterpart in the reference)
@@ -209,7 +212,7 @@ class ParCompressBuilder:
     def from_writer(self, writer):
         cfg = _native.GzpxParConfig(self._fmt.FORMAT, self._level.level(), self._compat, self._device,
                                     self._buffer_size, self._num_threads, self._batch_blocks)
-        return ParCompress(cfg, writer, self._lib)
+        return ParCompress(cfg, writer, self._lib, self._pin)
 
     # from_borrowed_writer (src/par/compress.rs:162-194): the caller keeps the writer; in Python
     # (and through the C ABI's callback + user pointer) every writer is borrowed, so this is the

@@ -184,6 +184,10 @@ typedef struct gzpx_par_config {
     size_t batch_blocks; /* blocks per slab handed to the device (0 = default 1024; a slab is capped at 128 MiB) */
 } gzpx_par_config;
 int gzpx_par_create(const gzpx_par_config *cfg, gzpx_write_fn write_fn, void *user, gzpx_par **out);
+/* the same with ParCompressBuilder::pin_threads(Some(first_core)) (src/par/compress.rs:99-107): the
+ * twin's device thread and copy helpers are pinned to consecutive cores the process may run on */
+int gzpx_par_create_pinned(const gzpx_par_config *cfg, size_t first_core, gzpx_write_fn write_fn, void *user,
+                           gzpx_par **out);
 int gzpx_par_write(gzpx_par *p, const uint8_t *buf, size_t n);
 /* In-place form of write() for producers that can fill memory they are handed (read(2) into the
  * slab, a decoder's output): reserve returns room (>= buffer_size bytes) inside the page-locked slab

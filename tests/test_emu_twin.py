@@ -10,6 +10,10 @@ def test_multi_device(emu_lib, oracle):
     tc.multi_device(emu_lib, oracle)
 
 
+def test_pinned_and_threaded(emu_lib, oracle):
+    tc.pinned_and_threaded(emu_lib, oracle)
+
+
 def test_reserve_commit(emu_lib, oracle):
     tc.reserve_commit(emu_lib, oracle)
 

@@ -16,6 +16,10 @@ def test_multi_device(hip_lib, oracle):
     tc.multi_device(hip_lib, oracle, scale=8)
 
 
+def test_pinned_and_threaded(hip_lib, oracle):
+    tc.pinned_and_threaded(hip_lib, oracle, scale=8)
+
+
 def test_reserve_commit(hip_lib, oracle):
     tc.reserve_commit(hip_lib, oracle, scale=8)
 

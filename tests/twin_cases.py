@@ -168,6 +168,37 @@ def borrowed_writer_and_io_error(lib, oracle, scale=1):
     w.close()
 
 
+def pinned_and_threaded(lib, oracle, scale=1):
+    """pin_threads(Some(core)) (src/par/compress.rs:99-107) changes nothing in the stream; one context
+    serves several caller threads (the synchronous calls queue for the slots)."""
+    import threading
+    a = synth.make("text", 5 * BS * scale + 99, 21)
+    want = oracle.compress_stream(a, oracle.FMT_BGZF, 1, oracle.COMPAT_1_24, BS)
+    sink = io.BytesIO()
+    w = _builder(lib).pin_threads(0).from_writer(sink)
+    w.write_all(a)
+    w.finish()
+    w.close()
+    assert sink.getvalue() == want
+    sink = io.BytesIO()
+    w = _builder(lib).pin_threads(10**6).from_writer(sink)  # no such core: ignored, as in the reference
+    w.write_all(a)
+    w.finish()
+    w.close()
+    assert sink.getvalue() == want
+    with _native.Context(level=1, buffer_size=BS, lib=lib, max_slab_bytes=a.size) as c:
+        res = [None] * 6
+
+        def work(i):
+            res[i] = c.compress_slab(a, True)
+        ts = [threading.Thread(target=work, args=(i,)) for i in range(6)]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
+        assert all(r == want for r in res)
+
+
 def builder_errors(lib):
     with pytest.raises(par.GzpError) as e:
         par.ParCompressBuilder(par.Bgzf, lib=lib).buffer_size(100)
