@@ -2631,7 +2631,10 @@ struct InfLdsT {
     uint32_t ocount[16], ofirst[16], ooffs[16];
 };
 
-constexpr uint32_t kInfR = 2;  // groups of 64 bit positions decoded per round
+#ifndef GZPX_INF_R
+#define GZPX_INF_R 2
+#endif
+constexpr uint32_t kInfR = GZPX_INF_R;  // groups of 64 bit positions decoded per round
 
 enum InflateStatus : uint32_t { kInfOk = 0, kInfBadData = 1, kInfInsufficientSpace = 2, kInfShortOutput = 3 };
 

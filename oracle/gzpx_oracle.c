@@ -991,6 +991,156 @@ static int compress_greedy(const uint8_t *in, size_t n, unsigned nice_match_leng
     return 0;
 }
 
+/* recalculate_min_match_len: the same choice from the literal frequencies seen so far in the block
+ * (a literal counts as "used" when it is more frequent than 1/1024 of all literals) */
+static unsigned recalculate_min_match_len(const struct freqs *fr, unsigned max_search_depth)
+{
+    uint32_t literal_freq = 0, cutoff;
+    unsigned num_used = 0;
+    for (unsigned i = 0; i < 256; i++)
+        literal_freq += fr->litlen[i];
+    cutoff = literal_freq >> 10;
+    for (unsigned i = 0; i < 256; i++)
+        if (fr->litlen[i] > cutoff)
+            num_used++;
+    return choose_min_match_len(num_used, max_search_depth);
+}
+
+static unsigned bsr32(uint32_t v) { return 31u - (unsigned)__builtin_clz(v); }
+
+/* deflate_compress_lazy_generic (levels 5-7: lazy; 8-9: lazy2).  hc_matchfinder as the greedy parser;
+ * a match is only taken if the next position (and, for lazy2, the one after it) has nothing clearly
+ * better, searched with half (a quarter of) the depth. */
+static int compress_lazy(const uint8_t *in, size_t n, unsigned nice_match_length, unsigned max_search_depth,
+                         int lazy2, int compat, block_sink_fn sink, void *ctx)
+{
+    const uint8_t *in_next = in, *in_end = in + n, *in_cur_base = in;
+    unsigned max_len = MAX_MATCH_LEN;
+    unsigned nice_len = nice_match_length < max_len ? nice_match_length : max_len;
+    uint32_t next_hashes[2] = {0, 0};
+    struct hc_mf *mf;
+    uint32_t *tokens;
+    if (!slot_tabs_ready)
+        init_slot_tabs();
+    if (!tl_hc)
+        tl_hc = (struct hc_mf *)malloc(sizeof(*tl_hc));
+    if (!tl_tokens_hc)
+        tl_tokens_hc = (uint32_t *)malloc(sizeof(uint32_t) * (SOFT_MAX_BLOCK_LENGTH + MIN_BLOCK_LENGTH + 300));
+    mf = tl_hc;
+    tokens = tl_tokens_hc;
+    if (!mf || !tokens)
+        return -1;
+    {
+        int16_t *t = (int16_t *)mf;
+        for (size_t i = 0; i < sizeof(*mf) / sizeof(int16_t); i++)
+            t[i] = -WINDOW_SIZE;
+    }
+#define ADJUST_LENS()                                          \
+    do {                                                       \
+        size_t remaining_ = (size_t)(in_end - in_next);        \
+        if (remaining_ < MAX_MATCH_LEN) {                      \
+            max_len = (unsigned)remaining_;                    \
+            if (nice_len > max_len)                            \
+                nice_len = max_len;                            \
+        }                                                      \
+    } while (0)
+#define LITERAL(b)                                                   \
+    do {                                                             \
+        uint8_t lit_ = (b);                                          \
+        tally_literal(&fr, tokens, &nt, lit_);                       \
+        st.new_observations[((lit_ >> 5) & 0x6) | (lit_ & 1)]++;     \
+        st.num_new_observations++;                                   \
+    } while (0)
+#define MATCH(len_, off_)                                                          \
+    do {                                                                           \
+        tally_match(&fr, tokens, &nt, (len_), (off_));                             \
+        nseq++;                                                                    \
+        st.new_observations[NUM_LITERAL_OBSERVATION_TYPES + ((len_) >= 9)]++;      \
+        st.num_new_observations++;                                                 \
+    } while (0)
+    do {
+        const uint8_t *block_begin = in_next;
+        const uint8_t *max_block_end =
+            ((size_t)(in_end - in_next) < SOFT_MAX_BLOCK_LENGTH + MIN_BLOCK_LENGTH)
+                ? in_end
+                : in_next + SOFT_MAX_BLOCK_LENGTH;
+        const uint8_t *next_recalc_min_len =
+            in_next + ((size_t)(in_end - in_next) < 10000 ? (size_t)(in_end - in_next) : 10000);
+        struct freqs fr;
+        struct split_stats st;
+        size_t nt = 0;
+        unsigned nseq = 0, min_len;
+        memset(&fr, 0, sizeof(fr));
+        memset(&st, 0, sizeof(st));
+        min_len = calculate_min_match_len(in_next, (size_t)(max_block_end - in_next), max_search_depth, compat);
+        do {
+            unsigned cur_len, cur_offset, next_len, next_offset;
+            if (in_next >= next_recalc_min_len) {
+                size_t a = (size_t)(in_end - next_recalc_min_len), b = (size_t)(in_next - block_begin);
+                min_len = recalculate_min_match_len(&fr, max_search_depth);
+                next_recalc_min_len += a < b ? a : b;
+            }
+            ADJUST_LENS();
+            cur_len = hc_longest_match(mf, &in_cur_base, in_next, min_len - 1, max_len, nice_len, max_search_depth,
+                                       next_hashes, &cur_offset);
+            if (cur_len < min_len || (cur_len == MIN_MATCH_LEN && cur_offset > 8192)) {
+                LITERAL(*in_next);
+                in_next++;
+                continue;
+            }
+            in_next++;
+        have_cur_match:
+            if (cur_len >= nice_len) {
+                MATCH(cur_len, cur_offset);
+                hc_skip_bytes(mf, &in_cur_base, in_next, in_end, cur_len - 1, next_hashes);
+                in_next += cur_len - 1;
+                continue;
+            }
+            ADJUST_LENS();
+            next_len = hc_longest_match(mf, &in_cur_base, in_next++, cur_len - 1, max_len, nice_len,
+                                        max_search_depth >> 1, next_hashes, &next_offset);
+            if (next_len >= cur_len &&
+                4 * (int)(next_len - cur_len) + ((int)bsr32(cur_offset) - (int)bsr32(next_offset)) > 2) {
+                LITERAL(*(in_next - 2));
+                cur_len = next_len;
+                cur_offset = next_offset;
+                goto have_cur_match;
+            }
+            if (lazy2) {
+                ADJUST_LENS();
+                next_len = hc_longest_match(mf, &in_cur_base, in_next++, cur_len - 1, max_len, nice_len,
+                                            max_search_depth >> 2, next_hashes, &next_offset);
+                if (next_len >= cur_len &&
+                    4 * (int)(next_len - cur_len) + ((int)bsr32(cur_offset) - (int)bsr32(next_offset)) > 6) {
+                    LITERAL(*(in_next - 3));
+                    LITERAL(*(in_next - 2));
+                    cur_len = next_len;
+                    cur_offset = next_offset;
+                    goto have_cur_match;
+                }
+                MATCH(cur_len, cur_offset);
+                if (cur_len > 3) {
+                    hc_skip_bytes(mf, &in_cur_base, in_next, in_end, cur_len - 3, next_hashes);
+                    in_next += cur_len - 3;
+                }
+            } else {
+                MATCH(cur_len, cur_offset);
+                hc_skip_bytes(mf, &in_cur_base, in_next, in_end, cur_len - 2, next_hashes);
+                in_next += cur_len - 2;
+            }
+        } while (in_next < max_block_end && nseq < SEQ_STORE_LENGTH &&
+                 !(st.num_new_observations >= NUM_OBSERVATIONS_PER_BLOCK_CHECK &&
+                   (size_t)(in_next - block_begin) >= MIN_BLOCK_LENGTH &&
+                   (size_t)(in_end - in_next) >= MIN_BLOCK_LENGTH &&
+                   do_end_block_check(&st, (uint32_t)(in_next - block_begin))));
+        sink(ctx, block_begin, (size_t)(in_next - block_begin), tokens, nt, &fr, in_next == in_end);
+    } while (in_next != in_end);
+#undef ADJUST_LENS
+#undef LITERAL
+#undef MATCH
+    return 0;
+}
+
 /* ------------------------------------------------------------------ entry points */
 
 struct emit_ctx {
@@ -1022,8 +1172,8 @@ size_t gzpx_oracle_deflate_compress(int level, int compat, const uint8_t *in, si
     c.w.out = out;
     c.w.cap = cap;
     c.compat = compat;
-    if (level < 0 || level > 4)
-        return 0; /* levels 5..12 (lazy / near-optimal parsers): not restated */
+    if (level < 0 || level > 9)
+        return 0; /* levels 10..12 (near-optimal parser): not restated */
     /* A.0: very short inputs (and level 0) are emitted as stored blocks only */
     if (level == 0 || n <= (size_t)(55 - 4 * level)) {
         write_stored(&c.w, in, n, 1);
@@ -1031,10 +1181,17 @@ size_t gzpx_oracle_deflate_compress(int level, int compat, const uint8_t *in, si
         if (compress_fastest(in, n, emit_sink, &c) != 0)
             return 0;
         bw_align(&c.w);
-    } else {
+    } else if (level <= 4) {
         /* level 2: depth 6 nice 10; level 3: depth 12 nice 14; level 4: depth 16 nice 30 */
         static const unsigned depth[5] = {0, 0, 6, 12, 16}, nice[5] = {0, 0, 10, 14, 30};
         if (compress_greedy(in, n, nice[level], depth[level], compat, emit_sink, &c) != 0)
+            return 0;
+        bw_align(&c.w);
+    } else {
+        /* levels 5-7 lazy, 8-9 lazy2 */
+        static const unsigned depth[10] = {0, 0, 0, 0, 0, 16, 35, 100, 300, 600};
+        static const unsigned nice[10] = {0, 0, 0, 0, 0, 30, 65, 130, 258, 258};
+        if (compress_lazy(in, n, nice[level], depth[level], level >= 8, compat, emit_sink, &c) != 0)
             return 0;
         bw_align(&c.w);
     }
