@@ -1157,13 +1157,14 @@ __global__ __launch_bounds__(1024) void k_match_hc(Config cfg, const uint8_t *__
     uint32_t *mbits_out = mbits_all + (uint64_t)b * (cfg.stride / 32);
     uint16_t *dist = dist_all + (uint64_t)b * cfg.stride;
 
+    // The search starts from best_len = 2 (min_len 3) whatever the sub-block's min_len will be: the
+    // chain nodes visited, their order and the depth they cost do not depend on the starting
+    // best_len -- it only raises the bar a node must clear -- so the search that libdeflate starts at
+    // min_len - 1 returns this very match whenever it is long enough and nothing otherwise.  k_parse_hc
+    // applies `len >= min_len`; a sub-block with another min_len re-parses, it does not re-match.
     const uint32_t resume = st->resume_pos;
-    uint32_t min_len = st->min_len;
-    if (min_len == 0) {  // first round: the sub-block that starts the block
-        min_len = hc_calc_min_len(cfg, in, 0, n, used, tid, 1024);
-        __syncthreads();
-        if (tid == 0) st->min_len = min_len;
-    }
+    const uint32_t min_len = 3;
+    (void)used;
     const uint32_t nice_level = cfg.hc_nice, depth = cfg.hc_depth;
 
     for (uint32_t tile_begin = resume / kHcTile * kHcTile; tile_begin < n; tile_begin += kHcTile) {
@@ -1275,7 +1276,12 @@ __global__ __launch_bounds__(kMpThreads, 8) void k_parse_hc(
     uint32_t cur_sub = st->cur_sub;
     uint32_t sub_start = st->resume_pos, sub_start_tok = tok_carry, sub_start_mat = mat_carry;
     uint32_t sub_limit = hc_sub_limit_of(sub_start, n);
-    const uint32_t min_len = st->min_len;
+    uint32_t min_len = st->min_len;
+    if (min_len == 0) {  // first round: the sub-block that starts the block (calculate_min_match_len)
+        min_len = hc_calc_min_len(cfg, in, 0, n, used, tid, kMpThreads);
+        __syncthreads();
+        if (tid == 0) st->min_len = min_len;
+    }
     const uint64_t lane_below = (1ull << lane) - 1ull;
     if (tid == 0) {
         s_next_check = kNoCheckYet;
@@ -1299,6 +1305,18 @@ __global__ __launch_bounds__(kMpThreads, 8) void k_parse_hc(
             }
         }
         __syncthreads();
+        if (min_len > 3) {  // k_match_hc's matches are those of min_len 3: keep the long enough ones
+            for (uint32_t i = tid; i < (tile_len + 31) / 32; i += kMpThreads) {
+                uint32_t w = mb[i], keep = 0;
+                while (w) {
+                    const uint32_t bit = (uint32_t)__ffs((int)w) - 1;
+                    w &= w - 1;
+                    if ((uint32_t)len8[i * 32 + bit] + 3u >= min_len) keep |= 1u << bit;
+                }
+                mb[i] = keep;
+            }
+            __syncthreads();
+        }
 
         // ---- greedy parse: speculative segment walk
         const uint32_t seg_begin = tid * kSeg;
@@ -3463,10 +3481,14 @@ void launch_parse(const Config &cfg, const uint8_t *slab, uint64_t, uint32_t nb,
 
 void launch_hc_round(const Config &cfg, const uint8_t *slab, uint32_t nb, const Scratch &s, int first,
                      hipStream_t stream) {
-    if (first) hipLaunchKernelGGL(k_hc_init, dim3((nb + 255) / 256), dim3(256), 0, stream, nb, s.hc, s.pending);
-    else (void)hipMemsetAsync(s.pending, 0, sizeof(uint32_t), stream);
-    hipLaunchKernelGGL(k_match_hc, dim3(nb), dim3(1024), 0, stream, cfg, slab, (const BlockMeta *)s.meta, s.hc,
-                       (const uint16_t *)s.cand, (const uint16_t *)s.d4, s.len8, s.which, s.alt);
+    if (first) {
+        hipLaunchKernelGGL(k_hc_init, dim3((nb + 255) / 256), dim3(256), 0, stream, nb, s.hc, s.pending);
+        // (once: the match of a position does not depend on the sub-block's min_len, see k_match_hc)
+        hipLaunchKernelGGL(k_match_hc, dim3(nb), dim3(1024), 0, stream, cfg, slab, (const BlockMeta *)s.meta, s.hc,
+                           (const uint16_t *)s.cand, (const uint16_t *)s.d4, s.len8, s.which, s.alt);
+    } else {
+        (void)hipMemsetAsync(s.pending, 0, sizeof(uint32_t), stream);
+    }
     hipLaunchKernelGGL(k_parse_hc, dim3(nb), dim3(kMpThreads), 0, stream, cfg, slab, s.meta, s.sub, s.hc,
                        (const uint8_t *)s.len8, (const uint32_t *)s.which, (const uint16_t *)s.alt, s.tok,
                        s.pending);
