@@ -1245,13 +1245,16 @@ __global__ __launch_bounds__(kMpThreads, 8) void k_parse_hc(
     __shared__ uint32_t len8_w[kHpTile / 4];
     __shared__ uint32_t tok_bits[kHpTile / 32];
     __shared__ uint32_t mb[kHpTile / 32];
-    __shared__ uint32_t seg_exit[256];
+    __shared__ uint32_t seg_exit[kHpTile / kPSeg];
+    __shared__ uint32_t rescue[2];
     __shared__ uint32_t rank_pre[kHpChunks * kMpWaves];
     __shared__ uint32_t wsum_t[kMpWaves], wsum_m[kMpWaves];
     __shared__ unsigned long long bnd;  // limit / sequence-count boundary: (position << 32 | token)
     __shared__ uint32_t bnd_tok, bnd_mat;
     __shared__ uint32_t first_check;                // candidate for the first split check (token index)
     __shared__ uint32_t bins[kHpMaxBins][10];       // observation classes per 512-token bin
+    __shared__ uint32_t cum[kHpMaxBins + 1][10];    // their exclusive prefix over the bins
+    __shared__ uint32_t first_evt;                  // first check that ends the sub-block or the checking
     __shared__ uint32_t chk_end[kHpMaxBins];        // end position of every check token
     __shared__ uint32_t split_pos;                  // where should_end_block ended the sub-block
     __shared__ uint32_t s_next_check, s_num_obs, s_num_new, s_obs[10], s_new[10];
@@ -1318,33 +1321,80 @@ __global__ __launch_bounds__(kMpThreads, 8) void k_parse_hc(
             __syncthreads();
         }
 
-        // ---- greedy parse: speculative segment walk
-        const uint32_t seg_begin = tid * kSeg;
-        const bool active = tid < 256 && seg_begin < tile_len;
-        const uint32_t seg_end = active ? (seg_begin + kSeg < tile_len ? seg_begin + kSeg : tile_len) : 0;
-        const uint32_t entry_rel = entry_carry - tile_begin;
-        // the segment that holds the true entry knows it; segments before it have no tokens
-        uint32_t entry = seg_begin;
-        if (active && entry_rel >= seg_begin) entry = entry_rel < seg_end ? entry_rel : seg_end;
-        const bool fixed_entry = entry_rel >= seg_begin;  // (covers thread 0 always)
-        if (active) seg_exit[tid] = walk_segment_hc(len8, mb, entry, seg_end, tok_bits);
-        for (;;) {
+        // ---- greedy parse: speculative segment walk, as in k_parse: thread s owns the 64 positions of
+        // segment s and walks them from an entry (first guess: its own start; thread 0 knows the
+        // tile's true entry), then from the exit of segment s-1, until no entry changes.  The marks of
+        // a walk are one 64-bit word; a segment's "match here" bits sit in a register, so a run of
+        // literals is one mask operation and a hop costs one LDS byte read (the match length).
+        const uint32_t n_seg = (tile_len + kPSeg - 1) / kPSeg;
+        auto walk_seg = [&](uint32_t sg, uint32_t pos) -> uint32_t {
+            const uint32_t sb = sg * kPSeg, se = sb + kPSeg < tile_len ? sb + kPSeg : tile_len;
+            const unsigned long long mbm = (unsigned long long)mb[2 * sg] | ((unsigned long long)mb[2 * sg + 1] << 32);
+            const unsigned long long in_seg = se - sb >= 64u ? ~0ull : (1ull << (se - sb)) - 1ull;
+            unsigned long long marks = 0;
+            while (pos < se) {
+                const uint32_t rel = pos - sb;
+                const unsigned long long rest = mbm >> rel;
+                if (rest == 0) {  // literals to the end of the segment
+                    marks |= ~0ull << rel;
+                    pos = se;
+                    break;
+                }
+                const uint32_t k = (uint32_t)__ffsll((long long)rest) - 1;  // literals rel .. rel+k-1, a match at rel+k
+                marks |= (((1ull << k) - 1ull) | (1ull << k)) << rel;
+                pos = sb + rel + k + (uint32_t)len8[sb + rel + k] + 3u;
+            }
+            marks &= in_seg;
+            tok_bits[2 * sg] = (uint32_t)marks;
+            tok_bits[2 * sg + 1] = (uint32_t)(marks >> 32);
+            return pos;
+        };
+        const bool active = tid < n_seg;
+        const uint32_t seg_begin = tid * kPSeg;
+        uint32_t entry = tid == 0 ? entry_carry - tile_begin : seg_begin;
+        if (active) seg_exit[tid] = walk_seg(tid, entry);
+        for (uint32_t round = 0;; round++) {
             __syncthreads();
             bool changed = false;
             uint32_t new_entry = entry;
-            if (active && !fixed_entry) {
+            if (active && tid > 0) {
                 new_entry = seg_exit[tid - 1];
                 changed = new_entry != entry;
             }
+            if (round >= 24) {
+                // slow convergence (long runs shift the phase of the segments behind them one segment
+                // per round): one thread parses on from the first inconsistent segment for a while
+                if (tid == 0) rescue[0] = 0xFFFFFFFFu;
+                __syncthreads();
+                if (changed) atomicMin(&rescue[0], tid);
+                __syncthreads();
+                const uint32_t s_first = rescue[0];
+                if (s_first == 0xFFFFFFFFu) break;  // nothing changed: converged
+                if (tid == 0) {
+                    uint32_t sg = s_first, pos = seg_exit[s_first - 1];
+                    for (uint32_t budget = 0; sg < n_seg && budget < 64; sg++, budget++) {
+                        pos = walk_seg(sg, pos);
+                        seg_exit[sg] = pos;
+                    }
+                    rescue[1] = sg;  // segments [s_first, sg) are consistent with their entries now
+                }
+                __syncthreads();
+                const uint32_t s_end = rescue[1];
+                if (tid >= s_first && tid < s_end) {
+                    entry = seg_exit[tid - 1];
+                } else if (changed && tid > s_end) {  // the others keep correcting themselves in parallel
+                    entry = new_entry;
+                    seg_exit[tid] = walk_seg(tid, entry);
+                }
+                continue;
+            }
             __syncthreads();
             if (changed) {
-                clear_marks(seg_begin, seg_end, tok_bits);
                 entry = new_entry;
-                seg_exit[tid] = walk_segment_hc(len8, mb, entry, seg_end, tok_bits);
+                seg_exit[tid] = walk_seg(tid, entry);
             }
             if (!__syncthreads_or(changed)) break;
         }
-        const uint32_t n_seg = (tile_len + kSeg - 1) / kSeg;
         const uint32_t exit_rel = seg_exit[n_seg - 1];
 
         // ---- ranks
@@ -1444,57 +1494,84 @@ __global__ __launch_bounds__(kMpThreads, 8) void k_parse_hc(
                 }
                 uint32_t bin = 0;
                 if (nc < kNoMoreChecks && ti > nc) bin = 1u + (ti - nc - 1u) / 512u;
+                // (one count per class, bin and wave from ten ballots instead of an LDS atomic per token
+                // was measured: slower, 101 -> 120 ms on configs[2])
                 if (bin < kHpMaxBins) atomicAdd(&bins[bin][cls], 1u);
                 if (nc < kNoMoreChecks && ti >= nc && (ti - nc) % 512u == 0 && (ti - nc) / 512u < kHpMaxBins)
                     chk_end[(ti - nc) / 512u] = p + len;
             }
             __syncthreads();
-            // the checks themselves: a short recurrence (thread 0)
-            if (tid == 0) {
-                const uint32_t last_tok = (lim_tok < tok_carry + tile_tok ? lim_tok : tok_carry + tile_tok);  // exclusive
-                uint32_t nck = s_next_check;
-                for (uint32_t k = 0; k < kHpMaxBins; k++) {
-                    uint32_t cnt = 0;
-                    for (int c = 0; c < 10; c++) {
-                        s_new[c] += bins[k][c];
-                        cnt += bins[k][c];
-                    }
-                    s_num_new += cnt;
-                    if (nck >= kNoMoreChecks || nck >= last_tok) break;  // no check token in range
-                    const uint32_t e = chk_end[k];
-                    const uint32_t blen = e - sub_start;
-                    if (n - e < kMinBlockLen) {  // in_end - in_next < MIN_BLOCK_LENGTH: never again
-                        nck = kNoMoreChecks;
-                        continue;
-                    }
-                    // do_end_block_check
-                    bool end_block = false;
-                    if (s_num_obs > 0) {
-                        uint32_t total_delta = 0;
-                        for (int c = 0; c < 10; c++) {
-                            const uint32_t expected = s_obs[c] * s_num_new, actual = s_new[c] * s_num_obs;
-                            total_delta += actual > expected ? actual - expected : expected - actual;
-                        }
-                        const uint32_t num_items = s_num_obs + s_num_new;
-                        uint32_t cutoff = s_num_new * 200u / 512u * s_num_obs;
-                        if (blen < 10000u && num_items < 8192u)
-                            cutoff += (uint32_t)((unsigned long long)cutoff * (8192u - num_items) / 8192u);
-                        end_block = total_delta + (blen / 4096u) * s_num_obs >= cutoff;
-                    }
-                    if (end_block) {
-                        split_pos = e;
-                        bnd_tok = nck + 1;
-                        break;
-                    }
-                    for (int c = 0; c < 10; c++) {
-                        s_obs[c] += s_new[c];
-                        s_num_obs += s_new[c];
-                        s_new[c] = 0;
-                    }
-                    s_num_new = 0;
-                    nck += 512;
+            // The checks themselves.  do_end_block_check for check k needs the observations merged so
+            // far (everything before bin k) and the new ones (bin k): both follow from prefix sums over
+            // the bins as long as no earlier check ended the block -- and the first one that does ends
+            // the evaluation anyway -- so all checks of the tile are evaluated side by side (one thread
+            // each) instead of as a 100-step recurrence on one thread.
+            const uint32_t last_tok = (lim_tok < tok_carry + tile_tok ? lim_tok : tok_carry + tile_tok);  // exclusive
+            const uint32_t nck0 = s_next_check;
+            uint32_t n_checks = 0;
+            if (nck0 < kNoMoreChecks && nck0 < last_tok) {
+                n_checks = (last_tok - 1 - nck0) / 512u + 1u;
+                if (n_checks > kHpMaxBins) n_checks = kHpMaxBins;
+            }
+            if (tid < 10) {  // exclusive prefix of every class over the bins
+                uint32_t acc = 0;
+                for (uint32_t k = 0; k <= n_checks; k++) {  // (n_checks <= kHpMaxBins)
+                    cum[k][tid] = acc;
+                    if (k < kHpMaxBins) acc += bins[k][tid];
                 }
-                s_next_check = nck;
+            }
+            if (tid == 0) first_evt = 0xFFFFFFFFu;
+            __syncthreads();
+            if (tid < n_checks) {
+                const uint32_t k = tid;
+                uint32_t num_obs = 0, num_new = 0, total_delta = 0;
+                uint32_t obs[10], nw[10];
+                for (int c = 0; c < 10; c++) {
+                    obs[c] = s_obs[c] + (k > 0 ? s_new[c] : 0u) + cum[k][c];
+                    nw[c] = bins[k][c] + (k == 0 ? s_new[c] : 0u);
+                    num_obs += obs[c];
+                    num_new += nw[c];
+                }
+                const uint32_t e = chk_end[k];
+                const uint32_t blen = e - sub_start;
+                bool evt = n - e < kMinBlockLen;  // in_end - in_next < MIN_BLOCK_LENGTH: never again
+                if (!evt && num_obs > 0) {
+                    for (int c = 0; c < 10; c++) {
+                        const uint32_t expected = obs[c] * num_new, actual = nw[c] * num_obs;
+                        total_delta += actual > expected ? actual - expected : expected - actual;
+                    }
+                    const uint32_t num_items = num_obs + num_new;
+                    uint32_t cutoff = num_new * 200u / 512u * num_obs;
+                    if (blen < 10000u && num_items < 8192u)
+                        cutoff += (uint32_t)((unsigned long long)cutoff * (8192u - num_items) / 8192u);
+                    evt = total_delta + (blen / 4096u) * num_obs >= cutoff;
+                }
+                if (evt) atomicMin(&first_evt, k);
+            }
+            __syncthreads();
+            if (tid == 0) {
+                const uint32_t fe = first_evt;
+                if (fe != 0xFFFFFFFFu && n - chk_end[fe] >= kMinBlockLen) {  // check fe ends the sub-block
+                    split_pos = chk_end[fe];
+                    bnd_tok = nck0 + 512u * fe + 1;
+                    s_next_check = nck0 + 512u * fe;
+                } else {
+                    // no split in this tile: the state after the last check (or at the point where
+                    // checks stop for good -- what is carried then is never looked at again)
+                    const uint32_t kk = fe != 0xFFFFFFFFu ? fe : n_checks;  // bins [0, kk) are merged
+                    uint32_t merged = 0, fresh = 0;
+                    for (int c = 0; c < 10; c++) {
+                        const uint32_t o = s_obs[c] + (kk > 0 ? s_new[c] : 0u) + cum[kk][c];
+                        const uint32_t w = (kk < kHpMaxBins ? bins[kk][c] : 0u) + (kk == 0 ? s_new[c] : 0u);
+                        s_obs[c] = o;
+                        s_new[c] = w;
+                        merged += o;
+                        fresh += w;
+                    }
+                    s_num_obs = merged;
+                    s_num_new = fresh;
+                    s_next_check = fe != 0xFFFFFFFFu ? kNoMoreChecks : (nck0 < kNoMoreChecks ? nck0 + 512u * n_checks : nck0);
+                }
             }
             __syncthreads();
             // which boundary, if any, ends the sub-block inside this tile
