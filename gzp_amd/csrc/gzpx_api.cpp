@@ -147,7 +147,7 @@ uint64_t blocks_of(const gzpx_ctx *ctx, size_t in_len) {
 
 // bytes of device scratch one block needs (see gzpx_device.h Scratch)
 size_t scratch_bytes_per_block(const Config &c) {
-    return (size_t)c.stride * (2 + 1 + 2 + 4 + (c.level >= 2 ? 2 : 0)) + c.stride / 8 +
+    return (size_t)c.stride * (2 + 1 + 2 + 4 + (c.level >= 2 ? 2 : 0) + (c.lazy ? 6 : 0)) + c.stride / 8 +
            (size_t)c.max_sub * (sizeof(SubMeta) + (kHistStride + kCodeWords + kHdrWords) * 4) +
            sizeof(BlockMeta) + 8 + 4;
 }
@@ -173,6 +173,10 @@ int alloc_scratch(gzpx_ctx *ctx) {
         HIP_TRY(hipMalloc((void **)&s.d4, nb * (size_t)c.stride * sizeof(uint16_t)));
         HIP_TRY(hipMalloc((void **)&s.hc, nb * sizeof(HcState)));
         HIP_TRY(hipMalloc((void **)&s.pending, 64));
+    }
+    if (c.lazy) {  // levels 5-9: the matches of the half / quarter depth searches
+        HIP_TRY(hipMalloc((void **)&s.lz_len, nb * 2 * (size_t)c.stride));
+        HIP_TRY(hipMalloc((void **)&s.lz_dist, nb * 2 * (size_t)c.stride * sizeof(uint16_t)));
     }
     HIP_TRY(hipMalloc((void **)&s.hist, nb * (size_t)c.max_sub * kHistStride * 4));
     HIP_TRY(hipMalloc((void **)&s.codes, nb * (size_t)c.max_sub * kCodeWords * 4));
@@ -208,6 +212,8 @@ void free_scratch(gzpx_ctx *ctx) {
     if (s.d4) (void)hipFree(s.d4);
     if (s.hc) (void)hipFree(s.hc);
     if (s.pending) (void)hipFree(s.pending);
+    if (s.lz_len) (void)hipFree(s.lz_len);
+    if (s.lz_dist) (void)hipFree(s.lz_dist);
     if (s.hist) (void)hipFree(s.hist);
     if (s.codes) (void)hipFree(s.codes);
     if (s.hdr) (void)hipFree(s.hdr);
@@ -250,6 +256,10 @@ int enqueue_batch(gzpx_ctx *ctx, const uint8_t *d_in, size_t in_len, uint32_t nb
         launch_match(c, d_in, in_len, nb, s, stream);
         if (prof) HIP_TRY(hipEventRecord(ev[++k], stream));
         launch_parse(c, d_in, in_len, nb, s, stream);
+        if (prof) HIP_TRY(hipEventRecord(ev[++k], stream));
+    } else if (c.lazy) {  // levels 5-9: every match variant once, then the serial-per-block lazy parse
+        launch_lazy(c, d_in, nb, s, stream);
+        if (prof) HIP_TRY(hipEventRecord(ev[++k], stream));
         if (prof) HIP_TRY(hipEventRecord(ev[++k], stream));
     } else {
         // levels 2-4: match + parse rounds until no block needs its tail redone with another
@@ -551,7 +561,7 @@ int ctx_create(const gzpx_config *cfg, bool crc_only, gzpx_ctx **out) {
     if (cfg->level < 0 || cfg->level > 12) return GZPX_ERR_COMPRESSION_LEVEL;
     if (cfg->compat != GZPX_COMPAT_LIBDEFLATE_1_24 && cfg->compat != GZPX_COMPAT_LIBDEFLATE_1_10)
         return GZPX_ERR_INVALID_ARG;
-    if (cfg->level > 4) return GZPX_ERR_UNSUPPORTED;  // 5..12 (lazy / near-optimal parsers): not built yet
+    if (cfg->level > 9) return GZPX_ERR_UNSUPPORTED;  // 10..12 (near-optimal parser): not built
     if (cfg->buffer_size > kMaxBlockSize) return GZPX_ERR_UNSUPPORTED;  // > 16 MiB blocks: not built
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return GZPX_ERR_NO_DEVICE;
@@ -577,9 +587,12 @@ int ctx_create(const gzpx_config *cfg, bool crc_only, gzpx_ctx **out) {
     // deflate_compress_none
     ctx->dcfg.passthrough = cfg->level == 0 ? 0xFFFFFFFFu : (uint32_t)(55 - 4 * cfg->level);
     {
-        static const uint32_t depth[5] = {0, 0, 6, 12, 16}, nice[5] = {0, 0, 10, 14, 30};
+        // libdeflate_alloc_compressor: max_search_depth / nice_match_length of levels 2-9
+        static const uint32_t depth[10] = {0, 0, 6, 12, 16, 16, 35, 100, 300, 600};
+        static const uint32_t nice[10] = {0, 0, 10, 14, 30, 30, 65, 130, 258, 258};
         ctx->dcfg.hc_depth = depth[cfg->level];
         ctx->dcfg.hc_nice = nice[cfg->level];
+        ctx->dcfg.lazy = cfg->level >= 8 ? 2u : cfg->level >= 5 ? 1u : 0u;
     }
     for (unsigned l = 0; l < 10; l++) ctx->crc_consts.pow64[l] = x2k(9 + l);
     ctx->crc_consts.pow_tile = x2k(19);  // x^(8 * 65536) = x^(2^19)

@@ -88,8 +88,9 @@ struct Config {
     uint32_t stride;      // per-block stride (positions) of cand / len8 / alt / tok: >= block_size + 1024
     uint32_t max_sub;     // per-block capacity of sub / hist / codes / hdr (sub-blocks >= 32768 bytes)
     uint32_t passthrough; // n <= 55 - 4*level is emitted as stored blocks only (deflate_compress_none)
-    uint32_t hc_depth;    // levels 2-4: max_search_depth
-    uint32_t hc_nice;     // levels 2-4: nice_match_length
+    uint32_t hc_depth;    // levels 2-9: max_search_depth
+    uint32_t hc_nice;     // levels 2-9: nice_match_length
+    uint32_t lazy;        // 0: greedy parser (levels 2-4), 1: lazy (5-7), 2: lazy2 (8-9)
 };
 
 // Device scratch for one batch of blocks.
@@ -100,7 +101,9 @@ struct Scratch {
     uint8_t *len8;        // [nb][stride]        0 = no match at p, else match length - 3
     uint32_t *which;      // [nb][stride/32]     bit p: the older candidate won at p
     uint16_t *alt;        // [nb][stride]        match distance at p where that bit is set
-    uint16_t *d4;         // [nb][stride]        levels 2-4: distance to the hash4 chain predecessor
+    uint16_t *d4;         // [nb][stride]        levels 2-9: distance to the hash4 chain predecessor
+    uint8_t *lz_len;      // [nb][2][stride]     levels 5-9: length - 3 of the half / quarter depth searches
+    uint16_t *lz_dist;    // [nb][2][stride]     levels 5-9: their distances (0 = no match)
     HcState *hc;          // [nb]                levels 2-4: parse state
     uint32_t *pending;    // [1]                 levels 2-4: blocks that need another round
     uint32_t *tok;        // [nb][stride]        worst case one token per byte
@@ -122,6 +125,7 @@ void launch_parse(const Config &cfg, const uint8_t *slab, uint64_t slab_len, uin
                   const Scratch &s, hipStream_t stream);
 void launch_hc_round(const Config &cfg, const uint8_t *slab, uint32_t nb, const Scratch &s, int first,
                      hipStream_t stream);
+void launch_lazy(const Config &cfg, const uint8_t *slab, uint32_t nb, const Scratch &s, hipStream_t stream);
 void launch_hist(const Config &cfg, uint32_t nb, const Scratch &s, hipStream_t stream);
 void launch_huffman(const Config &cfg, uint32_t nb, const Scratch &s, hipStream_t stream);
 void launch_crc32(const Config &cfg, const uint8_t *slab, uint64_t slab_len, uint32_t nb,

@@ -1059,77 +1059,65 @@ __device__ uint32_t hc_calc_min_len(const Config &cfg, const uint8_t *in, uint32
     return short_scan ? 3u : hc_choose_min_len(num_used, cfg.hc_depth);
 }
 
-// hc_matchfinder_longest_match for the position at LDS byte address a / link index li.
-__device__ __forceinline__ uint32_t hc_search(const uint32_t *in_w, const uint16_t *link, uint32_t a,
-                                              uint32_t li, uint32_t d3v, uint32_t min_len,
-                                              uint32_t max_len, uint32_t nice_len, uint32_t depth,
-                                              uint32_t &dist_out) {
-    uint32_t best_len = min_len - 1, best_dist = 0;
-    uint32_t cur = link[li];  // distance to the next chain node (0 = end of chain)
-    uint32_t tot = cur;       // distance from p to that node; it is alive while tot <= 32767
-    const uint32_t seq4 = lds_le32(in_w, a);
-    bool more = true;
-    if (best_len < 4) {
-        if (d3v == 0) {
-            more = false;
-        } else {
-            if (best_len < 3 && ((lds_le32(in_w, a - d3v) ^ seq4) & 0xFFFFFFu) == 0) {
-                best_len = 3;
-                best_dist = d3v;
-            }
-            if (cur == 0 || tot > 32767u) {
-                more = false;
-            } else {
-                for (;;) {  // first node whose 4 bytes match
-                    if (lds_le32(in_w, a - tot) == seq4) break;
-                    cur = link[li - tot];
-                    tot += cur;
-                    if (cur == 0 || tot > 32767u || !--depth) {
-                        more = false;
-                        break;
-                    }
-                }
-                if (more) {
-                    best_dist = tot;
-                    best_len = lds_extend(in_w, a, a - tot, max_len);
-                    if (best_len >= nice_len) {
-                        more = false;
-                    } else {
-                        cur = link[li - tot];
-                        tot += cur;
-                        if (cur == 0 || tot > 32767u || !--depth) more = false;
-                    }
-                }
-            }
+// hc_matchfinder_longest_match (started from best_len = 2) for the position at LDS byte address a /
+// link index li, as ONE loop with one chain node per iteration.  libdeflate's two loops ("first
+// node whose 4 bytes match", then "a node longer than best_len") differ only in the byte offset
+// of the pre-filter word -- 0 while best_len < 4, best_len - 3 after -- and every node costs one
+// unit of depth in both, so the lanes of a wave, which sit in different phases, share the loop
+// instead of waiting for each other's.
+//   NV > 1 (the lazy parsers): the searches with depth >> 1 (and >> 2) visit the same nodes in the
+//   same order and just stop earlier, so their results are this search's best match at the moment
+//   the smaller budget runs out.
+template <int NV>
+__device__ __forceinline__ void hc_search_all(const uint32_t *in_w, const uint16_t *link, uint32_t a,
+                                              uint32_t li, uint32_t d3v, uint32_t max_len, uint32_t nice_len,
+                                              const uint32_t depth0, uint32_t (&len_out)[NV],
+                                              uint32_t (&dist_out)[NV]) {
+    uint32_t best_len = 2, best_dist = 0;
+    uint32_t snapped = 0;  // bit v: len_out[v] / dist_out[v] are final
+    if (d3v != 0) {  // (an empty hash3 bucket ends the search before the hash4 chain is looked at)
+        const uint32_t seq4 = lds_le32(in_w, a);
+        if (((lds_le32(in_w, a - d3v) ^ seq4) & 0xFFFFFFu) == 0) {
+            best_len = 3;
+            best_dist = d3v;
         }
-    } else if (cur == 0 || tot > 32767u || best_len >= nice_len) {
-        more = false;
-    }
-    while (more) {  // look for something longer than best_len
-        for (;;) {
-            if (lds_le32(in_w, a - tot + best_len - 3) == lds_le32(in_w, a + best_len - 3) &&
-                lds_le32(in_w, a - tot) == seq4)
-                break;
+        uint32_t cur = link[li];  // distance to the next chain node (0 = end of chain)
+        uint32_t tot = cur;       // distance from p to that node; it is alive while tot <= 32767
+        uint32_t depth = depth0;
+        while (cur != 0 && tot <= 32767u) {
+            const uint32_t off = best_len < 4 ? 0 : best_len - 3;
+            bool hit = lds_le32(in_w, a - tot) == seq4;
+            if (hit && off) hit = lds_le32(in_w, a - tot + off) == lds_le32(in_w, a + off);
+            if (hit) {
+                const uint32_t len = lds_extend(in_w, a, a - tot, max_len);
+                if (len > best_len) {
+                    best_len = len;
+                    best_dist = tot;
+                    if (best_len >= nice_len) break;
+                }
+            }
             cur = link[li - tot];
             tot += cur;
-            if (cur == 0 || tot > 32767u || !--depth) {
-                more = false;
-                break;
+            if (cur == 0 || tot > 32767u) break;
+            --depth;
+#pragma unroll
+            for (int v = 1; v < NV; v++) {
+                if (depth0 - depth == (depth0 >> v)) {
+                    len_out[v] = best_len;
+                    dist_out[v] = best_dist;
+                    snapped |= 1u << v;
+                }
             }
+            if (depth == 0) break;
         }
-        if (!more) break;
-        const uint32_t len = lds_extend(in_w, a, a - tot, max_len);
-        if (len > best_len) {
-            best_len = len;
-            best_dist = tot;
-            if (best_len >= nice_len) break;
-        }
-        cur = link[li - tot];
-        tot += cur;
-        if (cur == 0 || tot > 32767u || !--depth) break;
     }
-    dist_out = best_dist;
-    return best_len;
+#pragma unroll
+    for (int v = 0; v < NV; v++) {
+        if (v == 0 || !((snapped >> v) & 1u)) {
+            len_out[v] = best_len;
+            dist_out[v] = best_dist;
+        }
+    }
 }
 
 __global__ __launch_bounds__(1024) void k_match_hc(Config cfg, const uint8_t *__restrict__ slab,
@@ -1139,7 +1127,9 @@ __global__ __launch_bounds__(1024) void k_match_hc(Config cfg, const uint8_t *__
                                                    const uint16_t *__restrict__ d4_all,
                                                    uint8_t *__restrict__ len8_all,
                                                    uint32_t *__restrict__ mbits_all,
-                                                   uint16_t *__restrict__ dist_all) {
+                                                   uint16_t *__restrict__ dist_all,
+                                                   uint8_t *__restrict__ lz_len_all,
+                                                   uint16_t *__restrict__ lz_dist_all) {
     __shared__ uint32_t in_w[kHcInWords];                // 48 KiB window of the block's bytes
     __shared__ uint32_t link_w[(32768 + kHcTile) / 2];  // d4 of every position in the window (u16)
     __shared__ uint32_t mbits[kHcTile / 32];
@@ -1184,6 +1174,34 @@ __global__ __launch_bounds__(1024) void k_match_hc(Config cfg, const uint8_t *__
             for (uint32_t i = tid; i < kHcTile / 32; i += 1024) mbits[i] = 0;
         }
         __syncthreads();
+        if (cfg.lazy) {
+            // Levels 5-9: the lazy parsers search a position up to three times -- where a decision
+            // starts (full depth), as the position after a match (half), as the one after that
+            // (lazy2: a quarter) -- from best_len = min_len - 1 or the current match's length - 1.
+            // By the argument above each is the min_len-3 search of that depth plus a filter, so all
+            // two / three are computed here for every position and k_parse_lazy picks.  No length-3
+            // distance rule: the parser applies its own (8192, first search only).
+            uint8_t *lzl = lz_len_all + (uint64_t)b * 2u * cfg.stride;
+            uint16_t *lzd = lz_dist_all + (uint64_t)b * 2u * cfg.stride;
+            for (uint32_t p = tile_begin + tid; p < tile_end; p += 1024) {
+                uint32_t len[3] = {0, 0, 0}, dst[3] = {0, 0, 0};
+                if (p + 5 <= n) {
+                    const uint32_t rem = n - p;
+                    const uint32_t max_len = rem < 258u ? rem : 258u;
+                    const uint32_t nice_len = max_len < nice_level ? max_len : nice_level;
+                    const uint32_t a = p - win_begin + mis;
+                    hc_search_all<3>(in_w, link, a, p - win_begin, d3[p], max_len, nice_len, depth, len, dst);
+                }
+                for (uint32_t v = 0; v <= cfg.lazy; v++) {
+                    const bool have = len[v] >= 3u;
+                    uint8_t *lo = v == 0 ? len8 : lzl + (uint64_t)(v - 1) * cfg.stride;
+                    uint16_t *dd = v == 0 ? dist : lzd + (uint64_t)(v - 1) * cfg.stride;
+                    lo[p] = (uint8_t)(have ? len[v] - 3u : 0u);
+                    dd[p] = (uint16_t)(have ? dst[v] : 0u);
+                }
+            }
+            continue;  // (uniform; the next tile's loads start behind a barrier)
+        }
         for (uint32_t p = tile_begin + tid; p < tile_end; p += 1024) {
             uint32_t len = 0, dst = 0;
             if (p + 5 <= n) {  // max_len >= 5, otherwise hc_matchfinder_longest_match bails out
@@ -1191,7 +1209,10 @@ __global__ __launch_bounds__(1024) void k_match_hc(Config cfg, const uint8_t *__
                 const uint32_t max_len = rem < 258u ? rem : 258u;
                 const uint32_t nice_len = max_len < nice_level ? max_len : nice_level;
                 const uint32_t a = p - win_begin + mis;
-                len = hc_search(in_w, link, a, p - win_begin, d3[p], min_len, max_len, nice_len, depth, dst);
+                uint32_t l1[1], d1[1];
+                hc_search_all<1>(in_w, link, a, p - win_begin, d3[p], max_len, nice_len, depth, l1, d1);
+                len = l1[0];
+                dst = d1[0];
             }
             // deflate_compress_greedy: a length-3 match is only worth it at a short distance
             const bool take = len >= min_len && (len > 3 || dst <= 4096u);
@@ -1652,6 +1673,240 @@ __global__ __launch_bounds__(kMpThreads, 8) void k_parse_hc(
         meta->ntok = tok_carry;
         meta->nsub = cur_sub + 1;
         st->done = 1;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// k_parse_lazy: deflate_compress_lazy_generic (levels 5-7 lazy, 8-9 lazy2) over the matches
+// k_match_hc found; one wave per block.
+//   A decision that starts at p:  cur = M0[p]; literal unless len >= min_len and not (len 3,
+//   offset > 8192); then, while cur is shorter than nice_len: next = M1[cur_pos+1] if at least as long
+//   as cur, taken (cur_pos becomes a literal) when 4*(next_len-cur_len) + bsr(cur_off) -
+//   bsr(next_off) > 2; lazy2 also tries M2[cur_pos+2] against > 6 (two literals).
+// Whether p starts a decision depends on every choice before it, but WHAT a decision started at
+// p does depends only on p and min_len.  So for a window of 64 positions every lane works out
+// "the decision if one starts here" (literal count, match, where the next one starts); the
+// positions where decisions really start are then a pointer chase through 64 registers
+// (v_readlane), and their lanes write tokens at wave-prefix offsets and tally observations with
+// LDS atomics.  What cuts a window short is checked per reached decision from the same prefixes:
+// the sub-block ends (soft limit, 50000 sequences), should_end_block is due (512 new
+// observations, 5000 bytes either side) or min_len is due for recalculate_min_match_len.
+//   A decision's chain looks at most kLzReach positions ahead: each step raises 4*len - bsr(off),
+//   which lives in [-2, 1032], by >= 3 per position it advances, so <= 345 positions and 2 of
+//   lookahead.  Windows only start where that much of the LDS tile is left.
+// ------------------------------------------------------------------------------------------
+constexpr uint32_t kLzSpan = 1024;  // positions per LDS tile
+constexpr uint32_t kLzReach = 352;
+
+struct LzLds {
+    uint32_t in8[kLzSpan / 4 + 2];
+    uint32_t len[3][kLzSpan / 4];
+    uint32_t dist[3][kLzSpan / 2];
+    uint32_t freq[256];  // literal frequencies of the current sub-block
+    uint32_t used[8];
+    uint32_t obs[10], nw[10];
+};
+
+__global__ __launch_bounds__(64) void k_parse_lazy(Config cfg, const uint8_t *__restrict__ slab,
+                                                   BlockMeta *__restrict__ meta_all,
+                                                   SubMeta *__restrict__ sub_all,
+                                                   const uint8_t *__restrict__ len0_all,
+                                                   const uint16_t *__restrict__ dist0_all,
+                                                   const uint8_t *__restrict__ lz_len_all,
+                                                   const uint16_t *__restrict__ lz_dist_all,
+                                                   uint32_t *__restrict__ tok_all) {
+    __shared__ LzLds L;
+    const uint32_t lane = threadIdx.x;
+    const uint32_t b = blockIdx.x;
+    BlockMeta *meta = meta_all + b;
+    const uint32_t n = meta->n;
+    if (n <= cfg.passthrough) return;  // uniform
+    SubMeta *sub = sub_all + (uint64_t)b * cfg.max_sub;
+    const uint8_t *in = slab + (uint64_t)b * cfg.block_size;
+    uint32_t *tok = tok_all + (uint64_t)b * cfg.stride;
+    const uint8_t *gl[3] = {len0_all + (uint64_t)b * cfg.stride, lz_len_all + (uint64_t)b * 2u * cfg.stride,
+                            lz_len_all + ((uint64_t)b * 2u + 1u) * cfg.stride};
+    const uint16_t *gd[3] = {dist0_all + (uint64_t)b * cfg.stride, lz_dist_all + (uint64_t)b * 2u * cfg.stride,
+                             lz_dist_all + ((uint64_t)b * 2u + 1u) * cfg.stride};
+    const bool lazy2 = cfg.lazy >= 2;
+    const uint32_t nice_level = cfg.hc_nice;
+    const uint8_t *t_l0 = (const uint8_t *)L.len[0], *t_l1 = (const uint8_t *)L.len[1], *t_l2 = (const uint8_t *)L.len[2];
+    const uint16_t *t_d0 = (const uint16_t *)L.dist[0], *t_d1 = (const uint16_t *)L.dist[1],
+                   *t_d2 = (const uint16_t *)L.dist[2];
+    const uint64_t lane_below = (1ull << lane) - 1ull;
+
+    uint32_t pos = 0, ti = 0, cur_sub = 0;
+    uint32_t t0 = 0xFFFFFFFFu, mis = 0;  // the tile holds positions [t0, t0 + kLzSpan)
+    for (;;) {                            // DEFLATE sub-blocks
+        const uint32_t sub_start = pos, sub_start_tok = ti;
+        const uint32_t max_block_end = hc_sub_limit_of(sub_start, n);
+        uint32_t min_len = hc_calc_min_len(cfg, in, sub_start, n, L.used, lane, 64);
+        uint32_t next_recalc = sub_start + (n - sub_start < 10000u ? n - sub_start : 10000u);
+        uint32_t nseq = 0, num_new = 0, num_obs = 0;
+        __syncthreads();
+        for (uint32_t i = lane; i < 256; i += 64) L.freq[i] = 0;
+        if (lane < 10) {
+            L.obs[lane] = 0;
+            L.nw[lane] = 0;
+        }
+        for (;;) {  // windows of 64 positions from pos
+            if (t0 == 0xFFFFFFFFu || pos - t0 + 64u + kLzReach > kLzSpan) {
+                t0 = pos & ~3u;
+                const uint32_t t_end = t0 + kLzSpan < n ? t0 + kLzSpan : n;  // (exclusive)
+                mis = (uint32_t)((uintptr_t)(in + t0) & 3u);
+                __syncthreads();
+                const uint32_t *src = (const uint32_t *)(in + t0 - mis);
+                const uint32_t ndw = (mis + (t_end - t0) + 3u) >> 2;
+                for (uint32_t i = lane; i < kLzSpan / 4 + 2; i += 64) L.in8[i] = i < ndw ? src[i] : 0u;
+                const uint32_t nd4 = (t_end - t0 + 3u) / 4u, nd2 = (t_end - t0 + 1u) / 2u;
+                for (uint32_t v = 0; v <= cfg.lazy; v++) {
+                    const uint32_t *sl = (const uint32_t *)gl[v] + t0 / 4u;
+                    const uint32_t *sd = (const uint32_t *)gd[v] + t0 / 2u;
+                    for (uint32_t i = lane; i < kLzSpan / 4; i += 64) L.len[v][i] = i < nd4 ? sl[i] : 0u;
+                    for (uint32_t i = lane; i < kLzSpan / 2; i += 64) L.dist[v][i] = i < nd2 ? sd[i] : 0u;
+                }
+                __syncthreads();
+            }
+            const uint8_t *t_in = (const uint8_t *)L.in8 + mis;
+            // ---- the decision a lane's position would start
+            const uint32_t p = pos + lane, r = p - t0;
+            uint32_t nlit = 0, mlen = 0, moff = 0, nrel = lane + 1u;
+            if (p < n) {
+                const uint32_t d = t_d0[r], l = (uint32_t)t_l0[r] + 3u;
+                if (d == 0 || l < min_len || (l == 3u && d > 8192u)) {
+                    nlit = 1;
+                } else {
+                    uint32_t cp = p, cl = l, co = d;
+                    for (;;) {  // have_cur_match
+                        const uint32_t rem = n - cp;
+                        const uint32_t max_len = rem < 258u ? rem : 258u;
+                        const uint32_t nice_len = max_len < nice_level ? max_len : nice_level;
+                        if (cl >= nice_len) break;  // take it as it is
+                        const uint32_t rr = cp + 1u - t0;
+                        if (rr + 1u >= kLzSpan) break;  // (beyond kLzReach: cannot happen)
+                        const int bsr_cur = 31 - __clz((int)co);
+                        {
+                            const uint32_t d1 = t_d1[rr], l1 = (uint32_t)t_l1[rr] + 3u;
+                            if (d1 != 0 && l1 >= cl && 4 * (int)(l1 - cl) + (bsr_cur - (31 - __clz((int)d1))) > 2) {
+                                nlit += 1u;
+                                cp += 1u;
+                                cl = l1;
+                                co = d1;
+                                continue;
+                            }
+                        }
+                        if (lazy2) {
+                            const uint32_t d2 = t_d2[rr + 1u], l2 = (uint32_t)t_l2[rr + 1u] + 3u;
+                            if (d2 != 0 && l2 >= cl && 4 * (int)(l2 - cl) + (bsr_cur - (31 - __clz((int)d2))) > 6) {
+                                nlit += 2u;
+                                cp += 2u;
+                                cl = l2;
+                                co = d2;
+                                continue;
+                            }
+                        }
+                        break;
+                    }
+                    mlen = cl;
+                    moff = co;
+                    nrel = cp + cl - pos;
+                }
+                if (mlen == 0) nrel = lane + 1u;
+            }
+            // ---- where decisions really start: chase from the window's first position
+            uint64_t reach = 0;
+            uint32_t q = 0;
+            while (q < 64u) {
+                reach |= 1ull << q;
+                q = (uint32_t)__builtin_amdgcn_readlane((int)nrel, (int)q);
+            }
+            const uint32_t exit_rel = q;
+            const bool in_r = (reach >> lane) & 1ull;
+            const uint32_t cnt = in_r ? nlit + (mlen ? 1u : 0u) : 0u;
+            const uint32_t inc = wave_inclusive_scan(cnt, lane);
+            const uint32_t tb = inc - cnt;  // tokens of this window before the lane's decision
+            const uint64_t mm = __ballot(in_r && mlen != 0);
+            const uint32_t mb = (uint32_t)__popcll(mm & lane_below);
+            // ---- the first reached decision in front of which something is due
+            const bool due = in_r && (p >= max_block_end || nseq + mb >= kHcSeqPerSub ||
+                                      (num_new + tb >= 512u && p - sub_start >= kMinBlockLen && n - p >= kMinBlockLen) ||
+                                      p >= next_recalc);
+            const uint64_t dm = __ballot(due);
+            const uint32_t e = dm ? (uint32_t)__ffsll((long long)dm) - 1u : 64u;
+            const uint64_t commit = e < 64u ? reach & ((1ull << e) - 1ull) : reach;
+            if ((commit >> lane) & 1ull) {
+                const uint32_t o = ti + tb;
+                for (uint32_t j = 0; j < nlit; j++) {
+                    const uint32_t c = t_in[r + j];
+                    tok[o + j] = c;
+                    atomicAdd(&L.freq[c], 1u);
+                    atomicAdd(&L.nw[((c >> 5) & 6u) | (c & 1u)], 1u);
+                }
+                if (mlen) {
+                    tok[o + nlit] = kTokMatch | (moff << 9) | mlen;
+                    atomicAdd(&L.nw[8u + (mlen >= 9u ? 1u : 0u)], 1u);
+                }
+            }
+            const uint32_t done_tok = e < 64u ? (uint32_t)__builtin_amdgcn_readlane((int)tb, (int)e)
+                                              : (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
+            ti += done_tok;
+            num_new += done_tok;
+            nseq += (uint32_t)__popcll(mm & commit);
+            pos += e < 64u ? e : exit_rel;
+            if (e == 64u) continue;
+            // ---- what is due at pos, in deflate_compress_lazy_generic's order
+            if (pos >= max_block_end || nseq >= kHcSeqPerSub) break;
+            if (num_new >= 512u && pos - sub_start >= kMinBlockLen && n - pos >= kMinBlockLen) {  // do_end_block_check
+                __syncthreads();
+                const uint32_t o = lane < 10 ? L.obs[lane] : 0u, w = lane < 10 ? L.nw[lane] : 0u;
+                const uint32_t expected = o * num_new, actual = w * num_obs;
+                const uint32_t total_delta = wave_reduce_add(actual > expected ? actual - expected : expected - actual);
+                bool end = false;
+                if (num_obs > 0) {
+                    const uint32_t blen = pos - sub_start, num_items = num_obs + num_new;
+                    uint32_t cutoff = num_new * 200u / 512u * num_obs;
+                    if (blen < 10000u && num_items < 8192u)
+                        cutoff += (uint32_t)((unsigned long long)cutoff * (8192u - num_items) / 8192u);
+                    end = total_delta + (blen / 4096u) * num_obs >= cutoff;
+                }
+                if (end) break;
+                if (lane < 10) {
+                    L.obs[lane] = o + w;
+                    L.nw[lane] = 0;
+                }
+                num_obs += num_new;
+                num_new = 0;
+                continue;
+            }
+            {  // recalculate_min_match_len: literals more frequent than 1/1024 of all of them count as used
+                __syncthreads();
+                uint32_t f[4], total = 0;
+                for (uint32_t k = 0; k < 4; k++) {
+                    f[k] = L.freq[lane + 64u * k];
+                    total += f[k];
+                }
+                total = wave_reduce_add(total);
+                const uint32_t cutoff = total >> 10;
+                uint32_t num_used = 0;
+                for (uint32_t k = 0; k < 4; k++) num_used += (uint32_t)__popcll(__ballot(f[k] > cutoff));
+                min_len = hc_choose_min_len(num_used, cfg.hc_depth);
+                const uint32_t a = n - next_recalc, bb = pos - sub_start;
+                next_recalc += a < bb ? a : bb;
+            }
+        }
+        if (lane == 0) {
+            sub[cur_sub].tok_begin = sub_start_tok;
+            sub[cur_sub].tok_end = ti;
+            sub[cur_sub].byte_begin = sub_start;
+            sub[cur_sub].byte_len = pos - sub_start;
+            sub[cur_sub].is_final = pos == n ? 1u : 0u;
+        }
+        cur_sub++;
+        if (pos == n) break;
+    }
+    if (lane == 0) {
+        meta->ntok = ti;
+        meta->nsub = cur_sub;
     }
 }
 
@@ -3562,13 +3817,24 @@ void launch_hc_round(const Config &cfg, const uint8_t *slab, uint32_t nb, const 
         hipLaunchKernelGGL(k_hc_init, dim3((nb + 255) / 256), dim3(256), 0, stream, nb, s.hc, s.pending);
         // (once: the match of a position does not depend on the sub-block's min_len, see k_match_hc)
         hipLaunchKernelGGL(k_match_hc, dim3(nb), dim3(1024), 0, stream, cfg, slab, (const BlockMeta *)s.meta, s.hc,
-                           (const uint16_t *)s.cand, (const uint16_t *)s.d4, s.len8, s.which, s.alt);
+                           (const uint16_t *)s.cand, (const uint16_t *)s.d4, s.len8, s.which, s.alt,
+                           (uint8_t *)nullptr, (uint16_t *)nullptr);
     } else {
         (void)hipMemsetAsync(s.pending, 0, sizeof(uint32_t), stream);
     }
     hipLaunchKernelGGL(k_parse_hc, dim3(nb), dim3(kMpThreads), 0, stream, cfg, slab, s.meta, s.sub, s.hc,
                        (const uint8_t *)s.len8, (const uint32_t *)s.which, (const uint16_t *)s.alt, s.tok,
                        s.pending);
+}
+
+void launch_lazy(const Config &cfg, const uint8_t *slab, uint32_t nb, const Scratch &s, hipStream_t stream) {
+    hipLaunchKernelGGL(k_hc_init, dim3((nb + 255) / 256), dim3(256), 0, stream, nb, s.hc, s.pending);
+    hipLaunchKernelGGL(k_match_hc, dim3(nb), dim3(1024), 0, stream, cfg, slab, (const BlockMeta *)s.meta, s.hc,
+                       (const uint16_t *)s.cand, (const uint16_t *)s.d4, s.len8, s.which, s.alt, s.lz_len,
+                       s.lz_dist);
+    hipLaunchKernelGGL(k_parse_lazy, dim3(nb), dim3(64), 0, stream, cfg, slab, s.meta, s.sub,
+                       (const uint8_t *)s.len8, (const uint16_t *)s.alt, (const uint8_t *)s.lz_len,
+                       (const uint16_t *)s.lz_dist, s.tok);
 }
 
 void launch_hist(const Config &cfg, uint32_t nb, const Scratch &s, hipStream_t stream) {

@@ -117,7 +117,53 @@ def entry(data):
     return e
 
 
+def lazy_vectors():
+    """Levels 5-9 (deflate_compress_lazy_generic: lazy 5-7, lazy2 8-9) -> l59_vectors.json."""
+    raw = []
+    for level in (5, 6, 7, 8, 9):
+        edge = 55 - 4 * level  # deflate_compress_none up to here
+        for cls in synth.CLASSES:
+            for n in (0, edge, edge + 1, 300, 512, 4096, 5000, 10001, 32769, 65280):
+                seed = 3000 + n
+                a = synth.make(cls, n, seed)
+                e = {"class": cls, "n": n, "seed": seed, "level": level}
+                e.update(entry(ld_deflate(a, level)))
+                raw.append(e)
+    for level, cls, n in [(6, "text", 1 << 20), (6, "fastq", 1 << 20), (5, "mixed", 700000), (7, "ascii", 400000),
+                          (8, "text", 400000), (9, "dna", 305001), (9, "repeats", 400000), (6, "text", 304999),
+                          (7, "mixed", 131072), (9, "mixed", 200000)]:
+        a = synth.make(cls, n, 79)
+        e = {"class": cls, "n": n, "seed": 79, "level": level}
+        e.update(entry(ld_deflate(a, level)))
+        raw.append(e)
+    streams = []
+    for fmt, bs, level, cases in [
+        ("bgzf", 65280, 6, [("text", 0), ("text", 65280), ("text", 3 * 65280 + 1234), ("mixed", 300000),
+                            ("fastq", 200000), ("random", 70000)]),
+        ("bgzf", 65280, 5, [("text", 200000)]),
+        ("bgzf", 65280, 7, [("repeats", 200000)]),
+        ("bgzf", 65280, 9, [("text", 0), ("fastq", 150000)]),  # XFL = 2 from level 9 on (src/bgzf.rs:278-284)
+        ("mgzip", 1 << 20, 6, [("ascii", (1 << 20) + 7)]),
+        ("mgzip", 131072, 8, [("mixed", 500000)]),
+    ]:
+        for cls, n in cases:
+            a = synth.make(cls, n, 4444)
+            st, blk = frame_stream(a, level, fmt, bs)
+            e = {"fmt": fmt, "buffer_size": bs, "class": cls, "n": n, "seed": 4444, "level": level,
+                 "block_sizes": blk}
+            e.update(entry(st))
+            streams.append(e)
+    with open(os.path.join(HERE, "l59_vectors.json"), "w") as f:
+        json.dump({"generator": "tests/golden/make_golden.py lazy",
+                   "libdeflate": "v1.10 binary (Ubuntu libdeflate0 1.10-2), compat=1.10",
+                   "raw_deflate": raw, "streams": streams}, f, indent=0, separators=(",", ":"))
+        f.write("\n")
+    print("wrote %d raw, %d stream vectors for levels 5-9" % (len(raw), len(streams)))
+
+
 def main():
+    if sys.argv[1:] == ["lazy"]:
+        return lazy_vectors()
     sizes = [0, 1, 51, 52, 53, 100, 300, 511, 512, 513, 1000, 4096, 5000, 32767, 32768, 32769, 32773,
              40000, 65279, 65280]
     raw = []
@@ -226,6 +272,7 @@ def main():
         json.dump(doc, f, indent=0, separators=(",", ":"))
         f.write("\n")
     print("wrote %d raw, %d literal, %d stream vectors" % (len(raw), len(literal), len(streams)))
+    lazy_vectors()
 
 
 if __name__ == "__main__":

@@ -67,3 +67,40 @@ def test_default_level_of_the_builder_is_3(emu_lib, oracle):
     w.finish()
     w.close()
     assert sink.getvalue() == oracle.compress_stream(a, oracle.FMT_BGZF, 3, oracle.COMPAT_1_10, 65280)
+
+
+# ---- levels 5-9: the lazy / lazy2 parsers (k_match_hc's depth variants + k_parse_lazy)
+
+def test_golden_raw_deflate_lazy_levels(emu_lib, golden_lazy):
+    comps = {L: _native.Compressor(L, _native.COMPAT_1_10, lib=emu_lib) for L in (5, 6, 7, 8, 9)}
+    for e in golden_lazy["raw_deflate"]:
+        if e["n"] > 140000 or (e["n"] > 11000 and e["class"] not in ("text", "fastq", "mixed", "repeats", "dna")):
+            continue  # the rest runs on the GPU (tests/test_gpu_levels.py)
+        a = synth.make(e["class"], e["n"], e["seed"])
+        assert hashlib.sha256(comps[e["level"]].deflate_compress(a)).hexdigest() == e["sha256"], e
+    for c in comps.values():
+        c.close()
+
+
+def test_golden_streams_lazy_levels(emu_lib, golden_lazy):
+    for e in golden_lazy["streams"]:
+        if e["n"] > 320000:
+            continue
+        a = synth.make(e["class"], e["n"], e["seed"])
+        fmt = _native.FORMAT_BGZF if e["fmt"] == "bgzf" else _native.FORMAT_MGZIP
+        with _native.Context(format=fmt, level=e["level"], buffer_size=e["buffer_size"],
+                             compat=_native.COMPAT_1_10, lib=emu_lib, max_slab_bytes=max(a.size, 1)) as c:
+            out, sizes = c.compress_slab(a, True, return_block_sizes=True)
+        assert hashlib.sha256(out).hexdigest() == e["sha256"], e
+        assert list(sizes) == e["block_sizes"]
+
+
+@pytest.mark.parametrize("level", [5, 6, 8])
+def test_heterogeneous_blocks_vs_oracle_lazy(emu_lib, oracle, level):
+    """Sub-block splits, min_len recalculation (every 10000+ bytes) and >300000-byte blocks."""
+    for fmt, ofmt, bs, n in [(_native.FORMAT_BGZF, 0, 65280, 2 * 65280 + 99), (_native.FORMAT_MGZIP, 1, 330001, 400000)]:
+        a = hetero(n, 10 * level + bs % 7)
+        with _native.Context(format=fmt, level=level, buffer_size=bs, compat=_native.COMPAT_1_24, lib=emu_lib,
+                             max_slab_bytes=n) as c:
+            got = c.compress_slab(a, True)
+        assert got == oracle.compress_stream(a, ofmt, level, _native.COMPAT_1_24, bs), (level, fmt, bs)

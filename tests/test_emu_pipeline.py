@@ -118,7 +118,7 @@ def test_builder_validation(emu_lib):
         _native.Context(level=13, lib=emu_lib)
     assert ei.value.code == _native.ERR_COMPRESSION_LEVEL
     with pytest.raises(_native.GzpxError) as ei:
-        _native.Context(level=6, lib=emu_lib)
+        _native.Context(level=10, lib=emu_lib)
     assert ei.value.code == _native.ERR_UNSUPPORTED
 
 

@@ -1,4 +1,5 @@
-"""Levels 2-4 (greedy hc_matchfinder; gzp's default level is 3) on the real HIP library."""
+"""Levels 2-4 (greedy hc_matchfinder; gzp's default level is 3) and 5-9 (lazy / lazy2) on the real HIP
+library."""
 import gzip
 import hashlib
 import io
@@ -68,3 +69,47 @@ def test_builder_default_level(hip_lib, oracle):
     w.finish()
     w.close()
     assert sink.getvalue() == oracle.compress_stream(a, oracle.FMT_BGZF, 3, oracle.COMPAT_1_24, 65280)
+
+
+# ---- levels 5-9
+
+def test_golden_vectors_lazy_levels(hip_lib, golden_lazy):
+    comps = {L: _native.Compressor(L, _native.COMPAT_1_10, lib=hip_lib) for L in (5, 6, 7, 8, 9)}
+    for e in golden_lazy["raw_deflate"]:
+        a = synth.make(e["class"], e["n"], e["seed"])
+        assert hashlib.sha256(comps[e["level"]].deflate_compress(a)).hexdigest() == e["sha256"], e
+    for c in comps.values():
+        c.close()
+    for e in golden_lazy["streams"]:
+        a = synth.make(e["class"], e["n"], e["seed"])
+        fmt = _native.FORMAT_BGZF if e["fmt"] == "bgzf" else _native.FORMAT_MGZIP
+        with _native.Context(format=fmt, level=e["level"], buffer_size=e["buffer_size"],
+                             compat=_native.COMPAT_1_10, lib=hip_lib, max_slab_bytes=max(a.size, 1)) as c:
+            out, sizes = c.compress_slab(a, True, return_block_sizes=True)
+        assert hashlib.sha256(out).hexdigest() == e["sha256"], e
+        assert list(sizes) == e["block_sizes"]
+
+
+@pytest.mark.parametrize("level", [5, 6, 7, 8, 9])
+def test_heterogeneous_blocks_vs_oracle_lazy(hip_lib, oracle, level):
+    for fmt, ofmt, bs, n in [(_native.FORMAT_BGZF, 0, 65280, 24 * 65280 + 99),
+                             (_native.FORMAT_MGZIP, 1, 1 << 20, 2 * (1 << 20) + 4321)]:
+        a = hetero(n, 10 * level + bs % 7)
+        with _native.Context(format=fmt, level=level, buffer_size=bs, compat=_native.COMPAT_1_24, lib=hip_lib,
+                             max_slab_bytes=n) as c:
+            got = c.compress_slab(a, True)
+        assert got == oracle.compress_stream(a, ofmt, level, oracle.COMPAT_1_24, bs), (level, fmt, bs)
+        assert gzip.decompress(got) == a.tobytes()
+
+
+def test_builder_best_level(hip_lib, oracle):
+    """Compression::best() = 9 through the twin: XFL 2 in every header (src/bgzf.rs:278-284)."""
+    a = synth.text_slab(6 * 65280 + 5, 2_000_000, 4)
+    sink = io.BytesIO()
+    w = par.ParCompressBuilder(par.Bgzf, lib=hip_lib).compression_level(par.Compression.best()).from_writer(sink)
+    w.write_all(a)
+    w.finish()
+    w.close()
+    got = sink.getvalue()
+    assert got[8] == 2
+    assert got == oracle.compress_stream(a, oracle.FMT_BGZF, 9, oracle.COMPAT_1_24, 65280)

@@ -94,3 +94,19 @@ def test_levels_2_to_4_match_libdeflate_vectors(oracle, golden_hc):
         out, sizes = oracle.compress_stream(a, fmt, e["level"], oracle.COMPAT_1_10, e["buffer_size"], True)
         assert hashlib.sha256(out).hexdigest() == e["sha256"], e
         assert list(sizes) == e["block_sizes"]
+
+
+def test_levels_5_to_9_match_libdeflate_vectors(oracle, golden_lazy):
+    """The lazy / lazy2 parsers (deflate_compress_lazy_generic) against the v1.10 binary's output."""
+    for e in golden_lazy["raw_deflate"]:
+        a = synth.make(e["class"], e["n"], e["seed"])
+        out = oracle.deflate_compress(a, e["level"], oracle.COMPAT_1_10)
+        assert hashlib.sha256(out).hexdigest() == e["sha256"], e
+        if e["n"] <= 70000:
+            assert zlib.decompress(out, -15) == a.tobytes()
+    for e in golden_lazy["streams"]:
+        a = synth.make(e["class"], e["n"], e["seed"])
+        fmt = oracle.FMT_BGZF if e["fmt"] == "bgzf" else oracle.FMT_MGZIP
+        out, sizes = oracle.compress_stream(a, fmt, e["level"], oracle.COMPAT_1_10, e["buffer_size"], True)
+        assert hashlib.sha256(out).hexdigest() == e["sha256"], e
+        assert list(sizes) == e["block_sizes"]
