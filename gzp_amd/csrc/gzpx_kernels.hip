@@ -1059,12 +1059,42 @@ __device__ uint32_t hc_calc_min_len(const Config &cfg, const uint8_t *in, uint32
     return short_scan ? 3u : hc_choose_min_len(num_used, cfg.hc_depth);
 }
 
+// lz_extend for k_match_hc: 16 bytes per round.  Every round of the loop waits for its LDS reads
+// before it knows whether there is another, and the wave pays for its longest lane, so a round
+// fetches five dwords per side at once and most matches end in the first (level 3: 22.3 -> 19.4 ms
+// of match + parse on 512 MiB of text).
+__device__ __forceinline__ uint32_t lds_extend16(const uint32_t *in_w, uint32_t a, uint32_t c, uint32_t max_len) {
+    uint32_t len = 4;  // (max_len >= 5 here)
+    bool more;
+    do {  // one exit, no break: every extra way out of a divergent loop costs scalar mask bookkeeping per round
+        const uint32_t aa = a + len, cc = c + len;
+        const uint32_t *pa = in_w + (aa >> 2), *pc = in_w + (cc >> 2);
+        const uint32_t a0 = pa[0], a1 = pa[1], a2 = pa[2], a3 = pa[3], a4 = pa[4];
+        const uint32_t c0 = pc[0], c1 = pc[1], c2 = pc[2], c3 = pc[3], c4 = pc[4];
+        const uint32_t sa = aa & 3u, sc = cc & 3u;
+        const uint32_t x0 = __builtin_amdgcn_alignbyte(a1, a0, sa) ^ __builtin_amdgcn_alignbyte(c1, c0, sc);
+        const uint32_t x1 = __builtin_amdgcn_alignbyte(a2, a1, sa) ^ __builtin_amdgcn_alignbyte(c2, c1, sc);
+        const uint32_t x2 = __builtin_amdgcn_alignbyte(a3, a2, sa) ^ __builtin_amdgcn_alignbyte(c3, c2, sc);
+        const uint32_t x3 = __builtin_amdgcn_alignbyte(a4, a3, sa) ^ __builtin_amdgcn_alignbyte(c4, c3, sc);
+        const uint32_t x = x0 ? x0 : x1 ? x1 : x2 ? x2 : x3;
+        const uint32_t same = (x0 ? 0u : x1 ? 4u : x2 ? 8u : x3 ? 12u : 16u) + (x ? ((uint32_t)(__ffs((int)x) - 1) >> 3) : 0u);
+        len += same;
+        more = x == 0 && len < max_len;
+    } while (more);
+    return len < max_len ? len : max_len;
+}
+
 // hc_matchfinder_longest_match (started from best_len = 2) for the position at LDS byte address a /
 // link index li, as ONE loop with one chain node per iteration.  libdeflate's two loops ("first
 // node whose 4 bytes match", then "a node longer than best_len") differ only in the byte offset
 // of the pre-filter word -- 0 while best_len < 4, best_len - 3 after -- and every node costs one
 // unit of depth in both, so the lanes of a wave, which sit in different phases, share the loop
 // instead of waiting for each other's.
+//   The loop is bound by instruction issue (about 37 instructions per node for the wave): fewer LDS
+//   reads per node at the price of more arithmetic (a partial compare of the node's first aligned
+//   dword) was slower, 22.1 -> 24.0 ms at level 3, and so was walking two positions per lane with
+//   both nodes' reads in flight together (19.4 -> 20.1 ms; 45 -> 153 ms at level 6, where the
+//   doubled state no longer fits the registers).
 //   NV > 1 (the lazy parsers): the searches with depth >> 1 (and >> 2) visit the same nodes in the
 //   same order and just stop earlier, so their results are this search's best match at the moment
 //   the smaller budget runs out.
@@ -1072,48 +1102,59 @@ template <int NV>
 __device__ __forceinline__ void hc_search_all(const uint32_t *in_w, const uint16_t *link, uint32_t a,
                                               uint32_t li, uint32_t d3v, uint32_t max_len, uint32_t nice_len,
                                               const uint32_t depth0, uint32_t (&len_out)[NV],
-                                              uint32_t (&dist_out)[NV]) {
+                                              uint32_t (&dist_out)[NV], const uint32_t dbg = 0) {
     uint32_t best_len = 2, best_dist = 0;
-    uint32_t snapped = 0;  // bit v: len_out[v] / dist_out[v] are final
     if (d3v != 0) {  // (an empty hash3 bucket ends the search before the hash4 chain is looked at)
         const uint32_t seq4 = lds_le32(in_w, a);
         if (((lds_le32(in_w, a - d3v) ^ seq4) & 0xFFFFFFu) == 0) {
             best_len = 3;
             best_dist = d3v;
         }
-        uint32_t cur = link[li];  // distance to the next chain node (0 = end of chain)
-        uint32_t tot = cur;       // distance from p to that node; it is alive while tot <= 32767
+        uint32_t tot = link[li];  // distance from p to the chain's next node (0: none); alive while <= 32767
+        bool alive = tot != 0 && tot <= 32767u;
         uint32_t depth = depth0;
-        while (cur != 0 && tot <= 32767u) {
-            const uint32_t off = best_len < 4 ? 0 : best_len - 3;
-            bool hit = lds_le32(in_w, a - tot) == seq4;
-            if (hit && off) hit = lds_le32(in_w, a - tot + off) == lds_le32(in_w, a + off);
-            if (hit) {
-                const uint32_t len = lds_extend(in_w, a, a - tot, max_len);
-                if (len > best_len) {
-                    best_len = len;
-                    best_dist = tot;
-                    if (best_len >= nice_len) break;
-                }
-            }
-            cur = link[li - tot];
-            tot += cur;
-            if (cur == 0 || tot > 32767u) break;
-            --depth;
+        uint32_t off = 0, mine = seq4;  // the pre-filter word: its offset, this position's bytes there
+        // One stretch of the walk per variant, shortest budget first: the search with depth >> v stops
+        // when depth0 >> v nodes are behind it, and what it returns is the best match at that moment
+        // (if the walk died before, nothing changes any more and that is the final match as well).
 #pragma unroll
-            for (int v = 1; v < NV; v++) {
-                if (depth0 - depth == (depth0 >> v)) {
-                    len_out[v] = best_len;
-                    dist_out[v] = best_dist;
-                    snapped |= 1u << v;
+        for (int v = NV - 1; v >= 0; v--) {
+            const uint32_t stop = v ? depth0 - (depth0 >> v) : 0u;
+            bool go = alive && depth != stop;
+            while (go) {  // (one way out, flags instead of breaks: see lds_extend16)
+                const uint32_t ca = a - tot;
+                const uint32_t nxt = link[li - tot];
+                bool hit = lds_le32(in_w, ca + off) == mine;  // (libdeflate's order: the selective word first)
+#ifdef GZPX_EXPERIMENT
+                if ((dbg >> 11) & 1u) hit = false;
+#endif
+                if (hit && off) hit = lds_le32(in_w, ca) == seq4;
+                if (hit) {
+#ifdef GZPX_EXPERIMENT
+                    const uint32_t len = ((dbg >> 10) & 1u) ? (best_len + 1 < max_len ? best_len + 1 : max_len)
+                                                            : lds_extend16(in_w, a, ca, max_len);
+#else
+                    const uint32_t len = lds_extend16(in_w, a, ca, max_len);
+#endif
+                    if (len > best_len) {
+                        best_len = len;
+                        best_dist = tot;
+                        alive = best_len < nice_len;
+                        off = best_len - 3u;
+                        mine = lds_le32(in_w, a + off);
+                    }
                 }
+                tot += nxt;
+                --depth;  // (only looked at while the chain goes on)
+                alive = alive && nxt != 0 && tot <= 32767u;
+                go = alive && depth != stop;
             }
-            if (depth == 0) break;
+            len_out[v] = best_len;
+            dist_out[v] = best_dist;
         }
-    }
+    } else {
 #pragma unroll
-    for (int v = 0; v < NV; v++) {
-        if (v == 0 || !((snapped >> v) & 1u)) {
+        for (int v = 0; v < NV; v++) {
             len_out[v] = best_len;
             dist_out[v] = best_dist;
         }
@@ -1155,7 +1196,7 @@ __global__ __launch_bounds__(1024) void k_match_hc(Config cfg, const uint8_t *__
     const uint32_t resume = st->resume_pos;
     const uint32_t min_len = 3;
     (void)used;
-    const uint32_t nice_level = cfg.hc_nice, depth = cfg.hc_depth;
+    const uint32_t nice_level = cfg.hc_nice, depth = GZPX_EXP(cfg, 12) ? 1u : cfg.hc_depth;
 
     for (uint32_t tile_begin = resume / kHcTile * kHcTile; tile_begin < n; tile_begin += kHcTile) {
         const uint32_t tile_end = tile_begin + kHcTile < n ? tile_begin + kHcTile : n;
@@ -1190,7 +1231,7 @@ __global__ __launch_bounds__(1024) void k_match_hc(Config cfg, const uint8_t *__
                     const uint32_t max_len = rem < 258u ? rem : 258u;
                     const uint32_t nice_len = max_len < nice_level ? max_len : nice_level;
                     const uint32_t a = p - win_begin + mis;
-                    hc_search_all<3>(in_w, link, a, p - win_begin, d3[p], max_len, nice_len, depth, len, dst);
+                    hc_search_all<3>(in_w, link, a, p - win_begin, d3[p], max_len, nice_len, depth, len, dst, cfg.debug);
                 }
                 for (uint32_t v = 0; v <= cfg.lazy; v++) {
                     const bool have = len[v] >= 3u;
@@ -1210,7 +1251,7 @@ __global__ __launch_bounds__(1024) void k_match_hc(Config cfg, const uint8_t *__
                 const uint32_t nice_len = max_len < nice_level ? max_len : nice_level;
                 const uint32_t a = p - win_begin + mis;
                 uint32_t l1[1], d1[1];
-                hc_search_all<1>(in_w, link, a, p - win_begin, d3[p], max_len, nice_len, depth, l1, d1);
+                hc_search_all<1>(in_w, link, a, p - win_begin, d3[p], max_len, nice_len, depth, l1, d1, cfg.debug);
                 len = l1[0];
                 dst = d1[0];
             }
