@@ -555,6 +555,7 @@ def main():
     ap.add_argument("--workload", choices=["compress", "inflate", "fastq", "mgzip3", "bgzf3"], default="compress",
                     help="compress = the headline metric (default); inflate = the ParDecompress row; fastq = configs[3]; "
                          "mgzip3 = configs[2] (Mgzip 1 MiB blocks, level 3, 4 GiB ASCII); bgzf3 = the text slab at level 3")
+    ap.add_argument("--level", type=int, default=3, help="--workload bgzf3: any built level (0-9) instead of 3")
     ap.add_argument("--emulate", action="store_true", help=argparse.SUPPRESS)  # tests: CPU emulator + gloo, no timing value
     args = ap.parse_args()
 
@@ -583,8 +584,9 @@ def main():
         env.close()
         return
     if args.workload == "bgzf3":
-        run_config(args, env, _native.FORMAT_BGZF, 3, BLOCK, "text", args.slab_bytes,
-                   "BGZF compress MiB/s at level 3 (gzp's default level), 550 MiB text")
+        run_config(args, env, _native.FORMAT_BGZF, args.level, BLOCK, "text", args.slab_bytes,
+                   "BGZF compress MiB/s at level 3 (gzp's default level), 550 MiB text" if args.level == 3 else
+                   "BGZF compress MiB/s at level %d, 550 MiB text" % args.level)
         env.close()
         return
 

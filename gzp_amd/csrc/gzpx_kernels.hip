@@ -1258,10 +1258,11 @@ __global__ __launch_bounds__(1024) void k_match_hc(Config cfg, const uint8_t *__
             // deflate_compress_greedy: a length-3 match is only worth it at a short distance
             const bool take = len >= min_len && (len > 3 || dst <= 4096u);
             len8[p] = (uint8_t)(take ? len - 3 : 0);
+            // val: the match distance, or the literal byte (what k_parse_hc's token needs either way)
+            dist[p] = (uint16_t)(take ? dst : lds_le32(in_w, p - win_begin + mis) & 0xFFu);
             if (take) {
                 const uint32_t r = p - tile_begin;
                 atomicOr(&mbits[r >> 5], 1u << (r & 31u));
-                dist[p] = (uint16_t)dst;
             }
         }
         __syncthreads();
@@ -1284,32 +1285,29 @@ __global__ __launch_bounds__(1024) void k_match_hc(Config cfg, const uint8_t *__
 // host runs another k_match_hc / k_parse_hc round for this block.
 // ------------------------------------------------------------------------------------------
 constexpr uint32_t kHpTile = 49152;
-constexpr uint32_t kHpChunks = kHpTile / kMpThreads;  // 48
+constexpr uint32_t kHpGroups = kHpTile / 64;  // 768 groups / walk segments of 64 positions
 constexpr uint32_t kHpMaxBins = kHpTile / 512 + 3;
 constexpr uint32_t kNoCheckYet = 0xFFFFFFFFu, kNoMoreChecks = 0xFFFFFFFEu;
 
-__device__ __forceinline__ uint32_t walk_segment_hc(const uint8_t *len8, const uint32_t *mb, uint32_t pos,
-                                                    uint32_t seg_end, uint32_t *tok_bits) {
-    while (pos < seg_end) {
-        const uint32_t l = len8[pos];
-        const uint32_t m = (mb[pos >> 5] >> (pos & 31u)) & 1u;
-        atomicOr(&tok_bits[pos >> 5], 1u << (pos & 31u));
-        pos += m ? l + 3 : 1;
-    }
-    return pos;
+// mask of the bit positions above the k-th set bit of m (k >= 1; 0 if m has fewer)
+__device__ __forceinline__ unsigned long long mask_after_kth(unsigned long long m, uint32_t k) {
+    unsigned long long t = m;
+    for (uint32_t i = 1; i < k && t; i++) t &= t - 1;  // drop the k - 1 lowest
+    if (!t) return 0;
+    const unsigned long long kth = t & (~t + 1);
+    return ~((kth << 1) - 1);
 }
 
 __global__ __launch_bounds__(kMpThreads, 8) void k_parse_hc(
     Config cfg, const uint8_t *__restrict__ slab, BlockMeta *__restrict__ meta_all,
     SubMeta *__restrict__ sub_all, HcState *__restrict__ hc_all, const uint8_t *__restrict__ len8_all,
-    const uint32_t *__restrict__ mbits_all, const uint16_t *__restrict__ dist_all,
+    const uint32_t *__restrict__ mbits_all, const uint16_t *__restrict__ val_all,
     uint32_t *__restrict__ tok_all, uint32_t *__restrict__ pending) {
     __shared__ uint32_t len8_w[kHpTile / 4];
-    __shared__ uint32_t tok_bits[kHpTile / 32];
-    __shared__ uint32_t mb[kHpTile / 32];
-    __shared__ uint32_t seg_exit[kHpTile / kPSeg];
+    __shared__ unsigned long long tok_bits[kHpGroups];  // 1 = a token starts here (tile-relative)
+    __shared__ unsigned long long mb[kHpGroups];        // 1 = k_match_hc's match here is long enough for min_len
+    __shared__ uint32_t rank_pre[kHpGroups];            // walk: exit of segment s; then (tokens | matches << 17) before group s
     __shared__ uint32_t rescue[2];
-    __shared__ uint32_t rank_pre[kHpChunks * kMpWaves];
     __shared__ uint32_t wsum_t[kMpWaves], wsum_m[kMpWaves];
     __shared__ unsigned long long bnd;  // limit / sequence-count boundary: (position << 32 | token)
     __shared__ uint32_t bnd_tok, bnd_mat;
@@ -1322,6 +1320,7 @@ __global__ __launch_bounds__(kMpThreads, 8) void k_parse_hc(
     __shared__ uint32_t s_next_check, s_num_obs, s_num_new, s_obs[10], s_new[10];
     __shared__ uint32_t used[8];
     const uint8_t *len8 = (const uint8_t *)len8_w;
+    uint32_t *seg_exit = rank_pre;
 
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint32_t b = blockIdx.x;
@@ -1331,8 +1330,8 @@ __global__ __launch_bounds__(kMpThreads, 8) void k_parse_hc(
     const uint32_t n = meta->n;
     if (n <= cfg.passthrough || st->done) return;  // uniform
     const uint8_t *in = slab + (uint64_t)b * cfg.block_size;
-    const uint16_t *dist = dist_all + (uint64_t)b * cfg.stride;
-    const uint32_t *mbits_g = mbits_all + (uint64_t)b * (cfg.stride / 32);
+    const uint16_t *val = val_all + (uint64_t)b * cfg.stride;
+    const unsigned long long *mbits_g = (const unsigned long long *)(mbits_all + (uint64_t)b * (cfg.stride / 32));
     uint32_t *tok = tok_all + (uint64_t)b * cfg.stride;
 
     // state (uniform across the workgroup)
@@ -1347,7 +1346,7 @@ __global__ __launch_bounds__(kMpThreads, 8) void k_parse_hc(
         __syncthreads();
         if (tid == 0) st->min_len = min_len;
     }
-    const uint64_t lane_below = (1ull << lane) - 1ull;
+    const unsigned long long lane_below = (1ull << lane) - 1ull;
     if (tid == 0) {
         s_next_check = kNoCheckYet;
         s_num_obs = 0;
@@ -1360,38 +1359,42 @@ __global__ __launch_bounds__(kMpThreads, 8) void k_parse_hc(
 
     for (uint32_t tile_begin = entry_carry / kHpTile * kHpTile; tile_begin < n; tile_begin += kHpTile) {
         const uint32_t tile_len = n - tile_begin < kHpTile ? n - tile_begin : kHpTile;
+        const uint32_t ngroups = (tile_len + 63) / 64;
         __syncthreads();
         {
             const uint32_t *src = (const uint32_t *)(len8_all + (uint64_t)b * cfg.stride + tile_begin);
             for (uint32_t i = tid; i < (tile_len + 3) / 4; i += kMpThreads) len8_w[i] = src[i];
-            for (uint32_t i = tid; i < kHpTile / 32; i += kMpThreads) {
-                tok_bits[i] = 0;
-                mb[i] = i < (tile_len + 31) / 32 ? mbits_g[tile_begin / 32 + i] : 0u;
-            }
         }
         __syncthreads();
-        if (min_len > 3) {  // k_match_hc's matches are those of min_len 3: keep the long enough ones
-            for (uint32_t i = tid; i < (tile_len + 31) / 32; i += kMpThreads) {
-                uint32_t w = mb[i], keep = 0;
-                while (w) {
-                    const uint32_t bit = (uint32_t)__ffs((int)w) - 1;
-                    w &= w - 1;
-                    if ((uint32_t)len8[i * 32 + bit] + 3u >= min_len) keep |= 1u << bit;
+        if (tid < kHpGroups) {
+            // k_match_hc's matches are those of min_len 3: keep the long enough ones.  (The bitmap
+            // word of the tile's last group may carry bits of positions >= n: dropped.)
+            unsigned long long w = tid < ngroups ? mbits_g[tile_begin / 64 + tid] : 0ull;
+            const uint32_t left = tile_len - (tid < ngroups ? tid * 64 : tile_len);
+            if (left < 64) w &= (1ull << left) - 1ull;
+            if (min_len > 3) {
+                unsigned long long t = w, keep = 0;
+                while (t) {
+                    const uint32_t bit = (uint32_t)__ffsll((long long)t) - 1;
+                    t &= t - 1;
+                    if ((uint32_t)len8[tid * 64 + bit] + 3u >= min_len) keep |= 1ull << bit;
                 }
-                mb[i] = keep;
+                w = keep;
             }
-            __syncthreads();
+            mb[tid] = w;
+            tok_bits[tid] = 0;
         }
+        __syncthreads();
 
         // ---- greedy parse: speculative segment walk, as in k_parse: thread s owns the 64 positions of
         // segment s and walks them from an entry (first guess: its own start; thread 0 knows the
         // tile's true entry), then from the exit of segment s-1, until no entry changes.  The marks of
         // a walk are one 64-bit word; a segment's "match here" bits sit in a register, so a run of
         // literals is one mask operation and a hop costs one LDS byte read (the match length).
-        const uint32_t n_seg = (tile_len + kPSeg - 1) / kPSeg;
+        const uint32_t n_seg = ngroups;
         auto walk_seg = [&](uint32_t sg, uint32_t pos) -> uint32_t {
             const uint32_t sb = sg * kPSeg, se = sb + kPSeg < tile_len ? sb + kPSeg : tile_len;
-            const unsigned long long mbm = (unsigned long long)mb[2 * sg] | ((unsigned long long)mb[2 * sg + 1] << 32);
+            const unsigned long long mbm = mb[sg];
             const unsigned long long in_seg = se - sb >= 64u ? ~0ull : (1ull << (se - sb)) - 1ull;
             unsigned long long marks = 0;
             while (pos < se) {
@@ -1407,8 +1410,7 @@ __global__ __launch_bounds__(kMpThreads, 8) void k_parse_hc(
                 pos = sb + rel + k + (uint32_t)len8[sb + rel + k] + 3u;
             }
             marks &= in_seg;
-            tok_bits[2 * sg] = (uint32_t)marks;
-            tok_bits[2 * sg + 1] = (uint32_t)(marks >> 32);
+            tok_bits[sg] = marks;
             return pos;
         };
         const bool active = tid < n_seg;
@@ -1457,24 +1459,16 @@ __global__ __launch_bounds__(kMpThreads, 8) void k_parse_hc(
             }
             if (!__syncthreads_or(changed)) break;
         }
-        const uint32_t exit_rel = seg_exit[n_seg - 1];
+        const uint32_t exit_rel = uniform(seg_exit[n_seg - 1]);
+        __syncthreads();  // seg_exit is rank_pre from here on
 
-        // ---- ranks
-        const uint32_t nchunks = (tile_len + kMpThreads - 1) / kMpThreads;
-        for (uint32_t c = 0; c < nchunks; c++) {
-            const uint32_t r = c * kMpThreads + tid;
-            const bool is_tok = r < tile_len && ((tok_bits[r >> 5] >> (r & 31u)) & 1u);
-            const bool is_match = is_tok && ((mb[r >> 5] >> (r & 31u)) & 1u);
-            const uint64_t mt = __ballot(is_tok), mm = __ballot(is_match);
-            if (lane == 0)
-                rank_pre[c * kMpWaves + wave] = (uint32_t)__popcll(mt) | ((uint32_t)__popcll(mm) << 17);
-        }
-        __syncthreads();
-        uint32_t tile_tok, tile_mat;
+        // ---- tokens / matches per 64-position group (one thread each, from the two bitmaps), then
+        // one workgroup-wide scan
+        const unsigned long long my_tok = tid < kHpGroups ? tok_bits[tid] : 0ull;
+        const unsigned long long my_mat = tid < kHpGroups ? my_tok & mb[tid] : 0ull;
+        uint32_t tile_tok, tile_mat, my_pre;
         {
-            const bool have = tid < nchunks * kMpWaves;
-            const uint32_t v = have ? rank_pre[tid] : 0;
-            const uint32_t vt = v & 0x1FFFFu, vm = v >> 17;
+            const uint32_t vt = (uint32_t)__popcll(my_tok), vm = (uint32_t)__popcll(my_mat);
             const uint32_t it = wave_inclusive_scan(vt, lane), im = wave_inclusive_scan(vm, lane);
             if (lane == 63) {
                 wsum_t[wave] = it;
@@ -1491,13 +1485,14 @@ __global__ __launch_bounds__(kMpThreads, 8) void k_parse_hc(
                 tt += st_;
                 tm += sm_;
             }
-            tile_tok = tt;
-            tile_mat = tm;
-            if (have) rank_pre[tid] = (bt + it - vt) | ((bm + im - vm) << 17);
+            tile_tok = uniform(tt);
+            tile_mat = uniform(tm);
+            my_pre = (bt + it - vt) | ((bm + im - vm) << 17);  // tokens <= 49152 < 2^17, matches <= 16384 < 2^15
+            if (tid < kHpGroups) rank_pre[tid] = my_pre;
         }
         __syncthreads();
 
-        // ---- tokens, then (per sub-block that starts or continues in this tile) the boundaries
+        // ---- per sub-block that starts or continues in this tile: where it ends, its tokens
         bool build = true;
         uint32_t stat_from = sub_start_tok > tok_carry ? sub_start_tok : tok_carry;  // first token not yet tallied
         for (;;) {
@@ -1506,61 +1501,103 @@ __global__ __launch_bounds__(kMpThreads, 8) void k_parse_hc(
                 first_check = 0xFFFFFFFFu;
                 split_pos = 0xFFFFFFFFu;
             }
+            for (uint32_t i = tid; i < kHpMaxBins * 10; i += kMpThreads) (&bins[0][0])[i] = 0;
             __syncthreads();
-            const uint32_t next_check0 = s_next_check;
-            // pass 1: build tokens (first time), soft-limit / sequence-count boundary, first check
-            for (uint32_t c = 0; c < nchunks; c++) {
-                const uint32_t r = c * kMpThreads + tid;
-                const uint32_t p = tile_begin + r;
-                const bool is_tok = r < tile_len && ((tok_bits[r >> 5] >> (r & 31u)) & 1u);
-                const bool is_match = is_tok && ((mb[r >> 5] >> (r & 31u)) & 1u);
-                const uint64_t mt = __ballot(is_tok), mm = __ballot(is_match);
-                if (!is_tok) continue;
-                const uint32_t pre = rank_pre[c * kMpWaves + wave];
-                const uint32_t ti = tok_carry + (pre & 0x1FFFFu) + (uint32_t)__popcll(mt & lane_below);
-                const uint32_t mi = mat_carry + (pre >> 17) + (uint32_t)__popcll(mm & lane_below);
-                const uint32_t len = is_match ? (uint32_t)len8[r] + 3u : 1u;
-                if (build) tok[ti] = is_match ? (kTokMatch | ((uint32_t)dist[p] << 9) | len) : (uint32_t)in[p];
-                if (p > sub_start && (p >= sub_limit || mi - sub_start_mat >= kHcSeqPerSub))
-                    atomicMin(&bnd, ((unsigned long long)p << 32) | ti);
-                // should_end_block's preconditions for the first check of this sub-block
-                if (next_check0 == kNoCheckYet && ti >= sub_start_tok && ti - sub_start_tok >= 511u &&
-                    p + len - sub_start >= kMinBlockLen)
-                    atomicMin(&first_check, ti);
+            // (1) one thread per group, from the bitmaps and prefixes: the first token behind the soft
+            // limit or the 50000th match (both monotone along the token stream), and -- until the
+            // sub-block has had its first should_end_block check -- the first token with 511 tokens
+            // before it whose end lies 5000 bytes into the sub-block
+            if (tid < ngroups && my_tok) {
+                const uint32_t gb = tile_begin + tid * 64;
+                const uint32_t pt = tok_carry + (my_pre & 0x1FFFFu), pm = mat_carry + (my_pre >> 17);
+                unsigned long long cand = 0;
+                const uint32_t lo = sub_limit > sub_start + 1 ? sub_limit : sub_start + 1;
+                if (gb + 64 > lo) cand = lo > gb ? my_tok & (~0ull << (lo - gb)) : my_tok;
+                const uint32_t T = sub_start_mat + kHcSeqPerSub;
+                if (pm >= T) {
+                    if (gb > sub_start) cand |= my_tok;
+                    else if (gb + 63 > sub_start) cand |= my_tok & (~0ull << (sub_start + 1 - gb));
+                } else if (pm + (uint32_t)__popcll(my_mat) >= T) {
+                    cand |= my_tok & mask_after_kth(my_mat, T - pm);
+                }
+                if (cand) {
+                    const uint32_t bit = (uint32_t)__ffsll((long long)cand) - 1;
+                    const uint32_t ti = pt + (uint32_t)__popcll(my_tok & ((1ull << bit) - 1ull));
+                    atomicMin(&bnd, ((unsigned long long)(gb + bit) << 32) | ti);
+                }
+                if (s_next_check == kNoCheckYet) {
+                    const uint32_t A0 = sub_start_tok + 511u, B0 = sub_start + kMinBlockLen;
+                    const uint32_t cnt = (uint32_t)__popcll(my_tok);
+                    if (pt + cnt > A0 && gb + 64 + 258 > B0) {
+                        unsigned long long ca = my_tok;
+                        if (A0 > pt) {
+                            for (uint32_t i = 0; i < A0 - pt; i++) ca &= ca - 1;  // tokens with fewer than 511 before them
+                        }
+                        uint32_t found = 0xFFFFFFFFu;
+                        while (ca) {
+                            const uint32_t bit = (uint32_t)__ffsll((long long)ca) - 1;
+                            ca &= ca - 1;
+                            const uint32_t len = ((my_mat >> bit) & 1ull) ? (uint32_t)len8[tid * 64 + bit] + 3u : 1u;
+                            if (gb + bit + len >= B0) {
+                                found = bit;
+                                break;
+                            }
+                        }
+                        if (found != 0xFFFFFFFFu)
+                            atomicMin(&first_check, pt + (uint32_t)__popcll(my_tok & ((1ull << found) - 1ull)));
+                    }
+                }
             }
             __syncthreads();
             const unsigned long long bv = bnd;
             const uint32_t lim_tok = bv == ~0ull ? 0xFFFFFFFFu : (uint32_t)bv;  // tokens from here are in the next sub-block
             if (tid == 0 && s_next_check == kNoCheckYet && first_check != 0xFFFFFFFFu) s_next_check = first_check;
-            for (uint32_t i = tid; i < kHpMaxBins * 10; i += kMpThreads) (&bins[0][0])[i] = 0;
             __syncthreads();
             const uint32_t nc = s_next_check;  // token index of the first check from here, or a sentinel
-            // pass 2: observation classes per bin (bin 0 = up to and including the first check token)
-            for (uint32_t c = 0; c < nchunks; c++) {
-                const uint32_t r = c * kMpThreads + tid;
-                const uint32_t p = tile_begin + r;
-                const bool is_tok = r < tile_len && ((tok_bits[r >> 5] >> (r & 31u)) & 1u);
-                const bool is_match = is_tok && ((mb[r >> 5] >> (r & 31u)) & 1u);
-                const uint64_t mt = __ballot(is_tok);
-                if (!is_tok) continue;
-                const uint32_t pre = rank_pre[c * kMpWaves + wave];
-                const uint32_t ti = tok_carry + (pre & 0x1FFFFu) + (uint32_t)__popcll(mt & lane_below);
-                if (ti < stat_from || ti >= lim_tok) continue;
-                const uint32_t len = is_match ? (uint32_t)len8[r] + 3u : 1u;
-                uint32_t cls;
-                if (is_match) {
-                    cls = 8u + (len >= 9u ? 1u : 0u);
-                } else {
-                    const uint32_t lit = in[p];
-                    cls = ((lit >> 5) & 6u) | (lit & 1u);
+            // (2) one pass in position order, a wave per group: lane l takes position l (coalesced val
+            // reads and token stores), ranks from the group's prefix + popcounts below the lane.  Builds
+            // the tokens (first time through) and tallies the observation classes per 512-token bin
+            // (bin 0 = up to and including the first check token).
+            for (uint32_t g0 = wave; g0 < ngroups; g0 += 8 * kMpWaves) {
+                uint32_t vals[8], tis[8];
+#pragma unroll
+                for (uint32_t k = 0; k < 8; k++) {
+                    const uint32_t g = g0 + k * kMpWaves;
+                    const uint32_t r = g * 64 + lane;
+                    vals[k] = (g < ngroups && r < tile_len) ? val[tile_begin + r] : 0u;
                 }
-                uint32_t bin = 0;
-                if (nc < kNoMoreChecks && ti > nc) bin = 1u + (ti - nc - 1u) / 512u;
-                // (one count per class, bin and wave from ten ballots instead of an LDS atomic per token
-                // was measured: slower, 101 -> 120 ms on configs[2])
-                if (bin < kHpMaxBins) atomicAdd(&bins[bin][cls], 1u);
-                if (nc < kNoMoreChecks && ti >= nc && (ti - nc) % 512u == 0 && (ti - nc) / 512u < kHpMaxBins)
-                    chk_end[(ti - nc) / 512u] = p + len;
+                __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): no load is pending behind a later store's data
+#pragma unroll
+                for (uint32_t k = 0; k < 8; k++) {
+                    const uint32_t g = g0 + k * kMpWaves;
+                    tis[k] = 0xFFFFFFFFu;
+                    if (g >= ngroups) continue;  // wave-uniform
+                    const unsigned long long mt = tok_bits[g], mm = mt & mb[g];
+                    const uint32_t r = g * 64 + lane, p = tile_begin + r;
+                    if (!((mt >> lane) & 1ull)) continue;
+                    const bool is_match = (mm >> lane) & 1ull;
+                    const uint32_t ti = tok_carry + (rank_pre[g] & 0x1FFFFu) + (uint32_t)__popcll(mt & lane_below);
+                    const uint32_t len = is_match ? (uint32_t)len8[r] + 3u : 1u;
+                    uint32_t v = vals[k];
+                    // a match too short for this sub-block's min_len is a literal: val holds its distance
+                    if (!is_match && min_len > 3 && ((mbits_g[(tile_begin >> 6) + g] >> lane) & 1ull)) v = in[p];
+                    vals[k] = is_match ? (kTokMatch | (v << 9) | len) : v;
+                    tis[k] = ti;
+                    if (ti < stat_from || ti >= lim_tok) continue;
+                    const uint32_t cls = is_match ? 8u + (len >= 9u ? 1u : 0u) : (((v >> 5) & 6u) | (v & 1u));
+                    uint32_t bin = 0;
+                    if (nc < kNoMoreChecks && ti > nc) bin = 1u + (ti - nc - 1u) / 512u;
+                    // (one count per class, bin and wave from ten ballots instead of an LDS atomic per token
+                    // was measured: slower, 101 -> 120 ms on configs[2])
+                    if (bin < kHpMaxBins) atomicAdd(&bins[bin][cls], 1u);
+                    if (nc < kNoMoreChecks && ti >= nc && (ti - nc) % 512u == 0 && (ti - nc) / 512u < kHpMaxBins)
+                        chk_end[(ti - nc) / 512u] = p + len;
+                }
+                if (build) {
+#pragma unroll
+                    for (uint32_t k = 0; k < 8; k++)
+                        if (tis[k] != 0xFFFFFFFFu) tok[tis[k]] = vals[k];
+                }
             }
             __syncthreads();
             // The checks themselves.  do_end_block_check for check k needs the observations merged so
@@ -1646,25 +1683,14 @@ __global__ __launch_bounds__(kMpThreads, 8) void k_parse_hc(
                 bti = (uint32_t)bv;
             }
             if (bp == 0xFFFFFFFFu) break;  // the sub-block continues in the next tile
-            // matches before the boundary token
-            if (bp >= tile_begin + tile_len) {
-                if (tid == 0) bnd_mat = mat_carry + tile_mat;  // it starts in the next tile
-            } else {
-                const uint32_t r = bp - tile_begin;
-                const uint32_t c = r / kMpThreads;
-                if (wave == (r % kMpThreads) / 64) {
-                    const uint32_t rr = c * kMpThreads + tid;
-                    const bool is_tok = rr < tile_len && ((tok_bits[rr >> 5] >> (rr & 31u)) & 1u);
-                    const bool is_match = is_tok && ((mb[rr >> 5] >> (rr & 31u)) & 1u);
-                    const uint64_t mm = __ballot(is_match);
-                    if (rr == r)
-                        bnd_mat = mat_carry + (rank_pre[c * kMpWaves + wave] >> 17) +
-                                  (uint32_t)__popcll(mm & lane_below);
+            if (tid == 0) {  // matches before the boundary token
+                if (bp >= tile_begin + tile_len) {
+                    bnd_mat = mat_carry + tile_mat;  // it starts in the next tile
+                } else {
+                    const uint32_t r = bp - tile_begin, g = r >> 6;
+                    const unsigned long long mm = tok_bits[g] & mb[g];
+                    bnd_mat = mat_carry + (rank_pre[g] >> 17) + (uint32_t)__popcll(mm & ((1ull << (r & 63u)) - 1ull));
                 }
-            }
-            __syncthreads();
-            const uint32_t bm = bnd_mat;
-            if (tid == 0) {
                 sub[cur_sub].tok_begin = sub_start_tok;
                 sub[cur_sub].tok_end = bti;
                 sub[cur_sub].byte_begin = sub_start;
@@ -1678,6 +1704,8 @@ __global__ __launch_bounds__(kMpThreads, 8) void k_parse_hc(
                     s_new[k] = 0;
                 }
             }
+            __syncthreads();
+            const uint32_t bm = bnd_mat;
             cur_sub++;
             sub_start = bp;
             sub_start_tok = bti;
@@ -1687,7 +1715,8 @@ __global__ __launch_bounds__(kMpThreads, 8) void k_parse_hc(
             const uint32_t new_min_len = hc_calc_min_len(cfg, in, bp, n, used, tid, kMpThreads);
             __syncthreads();
             if (new_min_len != min_len) {
-                // match results from bp on were computed with the wrong min_len: another round
+                // the "long enough" filter of the matches from bp on was another sub-block's: parse
+                // again from there (k_match_hc's results stand, they do not depend on min_len)
                 if (tid == 0) {
                     st->min_len = new_min_len;
                     st->resume_pos = bp;

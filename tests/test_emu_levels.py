@@ -104,3 +104,13 @@ def test_heterogeneous_blocks_vs_oracle_lazy(emu_lib, oracle, level):
                              max_slab_bytes=n) as c:
             got = c.compress_slab(a, True)
         assert got == oracle.compress_stream(a, ofmt, level, _native.COMPAT_1_24, bs), (level, fmt, bs)
+
+
+def test_regression_50000_sequences_end_a_sub_block_between_literals(emu_lib, oracle):
+    # found by the GPU soak: the token after the 50000th match of a sub-block starts the next one
+    # also when it is a literal (DNA at level 2: > 50000 matches in 600000 bytes)
+    a = synth.make("dna", 600000, 3)
+    with _native.Context(format=_native.FORMAT_MGZIP, level=2, buffer_size=1 << 20, compat=_native.COMPAT_1_10,
+                         lib=emu_lib, max_slab_bytes=a.size) as c:
+        got = c.compress_slab(a, True)
+    assert got == oracle.compress_stream(a, oracle.FMT_MGZIP, 2, oracle.COMPAT_1_10, 1 << 20)

@@ -1,5 +1,5 @@
 """A seeded slice of the randomised GPU parity soak (tools/gpu_fuzz.py) under -m gpu: random
-(class, size, level 0-4, format, block size, compat) through the real library against the oracle,
+(class, size, level 0-9, format, block size, compat) through the real library against the oracle,
 byte for byte, each result also inflated on the GPU; plus the regression cases the soak has found."""
 import os
 import sys
