@@ -1768,15 +1768,17 @@ __global__ __launch_bounds__(kMpThreads, 8) void k_parse_hc(
 constexpr uint32_t kLzSpan = 1024;  // positions per LDS tile
 constexpr uint32_t kLzReach = 352;
 
+template <int NV>  // match variants staged: 2 (lazy) or 3 (lazy2)
 struct LzLds {
     uint32_t in8[kLzSpan / 4 + 2];
-    uint32_t len[3][kLzSpan / 4];
-    uint32_t dist[3][kLzSpan / 2];
+    uint32_t len[NV][kLzSpan / 4];
+    uint32_t dist[NV][kLzSpan / 2];
     uint32_t freq[256];  // literal frequencies of the current sub-block
     uint32_t used[8];
     uint32_t obs[10], nw[10];
 };
 
+template <int NV>
 __global__ __launch_bounds__(64) void k_parse_lazy(Config cfg, const uint8_t *__restrict__ slab,
                                                    BlockMeta *__restrict__ meta_all,
                                                    SubMeta *__restrict__ sub_all,
@@ -1785,7 +1787,7 @@ __global__ __launch_bounds__(64) void k_parse_lazy(Config cfg, const uint8_t *__
                                                    const uint8_t *__restrict__ lz_len_all,
                                                    const uint16_t *__restrict__ lz_dist_all,
                                                    uint32_t *__restrict__ tok_all) {
-    __shared__ LzLds L;
+    __shared__ LzLds<NV> L;
     const uint32_t lane = threadIdx.x;
     const uint32_t b = blockIdx.x;
     BlockMeta *meta = meta_all + b;
@@ -1798,11 +1800,11 @@ __global__ __launch_bounds__(64) void k_parse_lazy(Config cfg, const uint8_t *__
                             lz_len_all + ((uint64_t)b * 2u + 1u) * cfg.stride};
     const uint16_t *gd[3] = {dist0_all + (uint64_t)b * cfg.stride, lz_dist_all + (uint64_t)b * 2u * cfg.stride,
                              lz_dist_all + ((uint64_t)b * 2u + 1u) * cfg.stride};
-    const bool lazy2 = cfg.lazy >= 2;
+    constexpr bool lazy2 = NV == 3;
     const uint32_t nice_level = cfg.hc_nice;
-    const uint8_t *t_l0 = (const uint8_t *)L.len[0], *t_l1 = (const uint8_t *)L.len[1], *t_l2 = (const uint8_t *)L.len[2];
+    const uint8_t *t_l0 = (const uint8_t *)L.len[0], *t_l1 = (const uint8_t *)L.len[1], *t_l2 = (const uint8_t *)L.len[NV - 1];
     const uint16_t *t_d0 = (const uint16_t *)L.dist[0], *t_d1 = (const uint16_t *)L.dist[1],
-                   *t_d2 = (const uint16_t *)L.dist[2];
+                   *t_d2 = (const uint16_t *)L.dist[NV - 1];
     const uint64_t lane_below = (1ull << lane) - 1ull;
 
     uint32_t pos = 0, ti = 0, cur_sub = 0;
@@ -1829,7 +1831,8 @@ __global__ __launch_bounds__(64) void k_parse_lazy(Config cfg, const uint8_t *__
                 const uint32_t ndw = (mis + (t_end - t0) + 3u) >> 2;
                 for (uint32_t i = lane; i < kLzSpan / 4 + 2; i += 64) L.in8[i] = i < ndw ? src[i] : 0u;
                 const uint32_t nd4 = (t_end - t0 + 3u) / 4u, nd2 = (t_end - t0 + 1u) / 2u;
-                for (uint32_t v = 0; v <= cfg.lazy; v++) {
+#pragma unroll
+                for (int v = 0; v < NV; v++) {
                     const uint32_t *sl = (const uint32_t *)gl[v] + t0 / 4u;
                     const uint32_t *sd = (const uint32_t *)gd[v] + t0 / 2u;
                     for (uint32_t i = lane; i < kLzSpan / 4; i += 64) L.len[v][i] = i < nd4 ? sl[i] : 0u;
@@ -1893,7 +1896,7 @@ __global__ __launch_bounds__(64) void k_parse_lazy(Config cfg, const uint8_t *__
             const uint32_t exit_rel = q;
             const bool in_r = (reach >> lane) & 1ull;
             const uint32_t cnt = in_r ? nlit + (mlen ? 1u : 0u) : 0u;
-            const uint32_t inc = wave_inclusive_scan(cnt, lane);
+            const uint32_t inc = wave_incl_add(cnt);
             const uint32_t tb = inc - cnt;  // tokens of this window before the lane's decision
             const uint64_t mm = __ballot(in_r && mlen != 0);
             const uint32_t mb = (uint32_t)__popcll(mm & lane_below);
@@ -3902,9 +3905,14 @@ void launch_lazy(const Config &cfg, const uint8_t *slab, uint32_t nb, const Scra
     hipLaunchKernelGGL(k_match_hc, dim3(nb), dim3(1024), 0, stream, cfg, slab, (const BlockMeta *)s.meta, s.hc,
                        (const uint16_t *)s.cand, (const uint16_t *)s.d4, s.len8, s.which, s.alt, s.lz_len,
                        s.lz_dist);
-    hipLaunchKernelGGL(k_parse_lazy, dim3(nb), dim3(64), 0, stream, cfg, slab, s.meta, s.sub,
-                       (const uint8_t *)s.len8, (const uint16_t *)s.alt, (const uint8_t *)s.lz_len,
-                       (const uint16_t *)s.lz_dist, s.tok);
+    if (cfg.lazy >= 2)
+        hipLaunchKernelGGL(k_parse_lazy<3>, dim3(nb), dim3(64), 0, stream, cfg, slab, s.meta, s.sub,
+                           (const uint8_t *)s.len8, (const uint16_t *)s.alt, (const uint8_t *)s.lz_len,
+                           (const uint16_t *)s.lz_dist, s.tok);
+    else
+        hipLaunchKernelGGL(k_parse_lazy<2>, dim3(nb), dim3(64), 0, stream, cfg, slab, s.meta, s.sub,
+                           (const uint8_t *)s.len8, (const uint16_t *)s.alt, (const uint8_t *)s.lz_len,
+                           (const uint16_t *)s.lz_dist, s.tok);
 }
 
 void launch_hist(const Config &cfg, uint32_t nb, const Scratch &s, hipStream_t stream) {
