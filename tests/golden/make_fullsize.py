@@ -84,6 +84,10 @@ def digest_stream(a, level, fmt, bs, tail):
 def main():
     out = []
     t0 = time.time()
+    only_levels = sys.argv[1:] == ["levels"]  # add / refresh the text slab at levels 3, 6, 9 only
+    if only_levels:
+        with open(os.path.join(HERE, "fullsize.json")) as f:
+            out = [e for e in json.load(f)["streams"] if not e["name"].startswith("text_550MiB_bgzf_l")]
 
     def add(name, a, level, fmt, bs, tail, inp):
         e = {"name": name, "fmt": fmt, "level": level, "buffer_size": bs, "tail": tail, "input": inp,
@@ -95,8 +99,19 @@ def main():
 
     # BASELINE configs[1]: 550 MiB text, BGZF, level 1 (the bench slab, seed as bench.py rank 0)
     a = synth.text_slab(576_716_800, seed=20250927)
-    add("config2_text_550MiB_bgzf_l1", a, 1, "bgzf", 65280, True,
-        {"kind": "text_slab", "n": 576_716_800, "seed": 20250927})
+    if not only_levels:
+        add("config2_text_550MiB_bgzf_l1", a, 1, "bgzf", 65280, True,
+            {"kind": "text_slab", "n": 576_716_800, "seed": 20250927})
+    # the same slab at gzp's default level and through the lazy / lazy2 parsers (best() = 9: XFL 2)
+    for level in (3, 6, 9):
+        add("text_550MiB_bgzf_l%d" % level, a, level, "bgzf", 65280, True,
+            {"kind": "text_slab", "n": 576_716_800, "seed": 20250927})
+    if only_levels:
+        with open(os.path.join(HERE, "fullsize.json"), "w") as f:
+            json.dump({"generator": "tests/golden/make_fullsize.py",
+                       "libdeflate": "v1.10 binary (Ubuntu libdeflate0 1.10-2), compat=1.10", "streams": out}, f, indent=1)
+            f.write("\n")
+        return
     # BASELINE configs[2]: Mgzip 1 MiB blocks, level 3, printable-ASCII noise; 1 GiB and the full 4 GiB
     a = oracle.ascii_stream(0, 4 << 30, 8)  # (== synth.ascii_random(4 << 30, 8), natively)
     add("config3_ascii_1GiB_mgzip_l3", a[:1 << 30], 3, "mgzip", 1 << 20, True, {"kind": "ascii", "n": 1 << 30, "seed": 8})

@@ -74,6 +74,13 @@ def test_config2_text_550mib_every_block(hip_lib):
     assert out_len2 == out_len and torch.equal(d_out[:out_len], d_out2[:out_len])
 
 
+@pytest.mark.parametrize("level", [3, 6, 9])
+def test_text_550mib_levels_3_6_9_every_block(hip_lib, level):
+    """The bench slab through the greedy (3), lazy (6) and lazy2 (9) parsers: all 8,835 blocks + EOF."""
+    d_in, d_out, out_len, sizes = _run(GOLD["text_550MiB_bgzf_l%d" % level], hip_lib, check_input=False)
+    assert int(d_out[8]) == (2 if level == 9 else 0)  # XFL (src/bgzf.rs:278-284)
+
+
 @pytest.mark.parametrize("name", ["config3_ascii_1GiB_mgzip_l3", "config3_ascii_4GiB_mgzip_l3"])
 def test_config3_mgzip_level3_every_block(hip_lib, name):
     _run(GOLD[name], hip_lib)
