@@ -270,6 +270,39 @@ def verify(slab, out_bytes, block_sizes, tail=True):
     return True
 
 
+def level_legs(env, d_in, n):
+    """The same device-resident slab at gzp's default level (3: greedy parser) and through the lazy (6)
+    and lazy2 (9 = Compression::best()) parsers, measured after the headline region: two timed slabs
+    each; every output is inflated and CRC-checked on the GPU and compared with the input."""
+    torch, _native = env.torch, env.native
+    out = {}
+    for level in (3, 6, 9):
+        ctx = _native.Context(format=_native.FORMAT_BGZF, level=level, buffer_size=BLOCK, compat=_native.COMPAT_1_24,
+                              device=env.device_index, max_slab_bytes=n, lib=env.lib)
+        cap = ctx.slab_bound(n)
+        d_out = torch.empty(cap, dtype=torch.uint8, device=env.dev)
+        ctx.compress_slab_device(d_in.data_ptr(), n, d_out.data_ptr(), cap, True)
+        env.sync()
+        steps = 2
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            out_len, _ = ctx.compress_slab_device(d_in.data_ptr(), n, d_out.data_ptr(), cap, True)
+        env.sync()
+        dt = (time.perf_counter() - t0) / steps
+        host = d_out[:out_len].cpu().numpy()
+        d = _native.DContext(format=_native.FORMAT_BGZF, device=env.device_index, lib=env.lib)
+        offs, sizes, used = d.scan_blocks(host)
+        d_back = torch.empty(n + 64, dtype=torch.uint8, device=env.dev)
+        got = d.decompress_device(d_out.data_ptr(), used, offs, sizes, d_back.data_ptr(), n + 64)
+        ok = got == n and bool(torch.equal(d_back[:n], d_in[:n]))
+        d.close()
+        ctx.close()
+        out["level_%d" % level] = {"MiBps": round(n / 2**20 / dt, 1), "ms_per_step": round(dt * 1e3, 3),
+                                   "ratio": round(out_len / n, 4), "gpu_inflate_crc_roundtrip_ok": bool(ok)}
+        del d_out, d_back
+    return out
+
+
 def e2e_legs(env, slab, want_sha):
     """Host-to-host rates of the same slab, measured after the headline region (SURVEY 8(d) timings
     ii and iii):
@@ -734,6 +767,11 @@ def main():
                     res["inflate"]["cpu_baseline"] = inf["cpu_baseline"]
             except Exception as e:
                 res["inflate"] = {"error": repr(e)}
+            if not env.emulate:  # (the emulator would take minutes per level: covered by tests/test_emu_levels.py)
+                try:
+                    res["levels"] = level_legs(env, d_in, n)
+                except Exception as e:
+                    res["levels"] = {"error": repr(e)}
         if not args.no_cpu_baseline and world == 1:  # the CPU leg is timed at N = 1 only
             res["cpu_baseline"] = cpu_baseline(slab)
         print(json.dumps(res))
