@@ -240,17 +240,7 @@ int enqueue_batch(gzpx_ctx *ctx, const uint8_t *d_in, size_t in_len, uint32_t nb
     if (prof) HIP_TRY(hipEventRecord(ev[k], stream));
     launch_init_meta(c, in_len, nb, is_last, s, stream);
     if (prof) HIP_TRY(hipEventRecord(ev[++k], stream));
-    // fork: the CRC of every block on the side stream, concurrent with the matchfinding kernels.
-    // k_candidates is handed to the device FIRST: its workgroups take their 128 KiB of LDS on every
-    // CU and k_crc32's slip into what is left; the other way round the small workgroups fill the
-    // CUs and the two kernels simply run one after the other.
-    HIP_TRY(hipEventRecord(ctx->ev_meta, stream));
     launch_candidates(c, d_in, in_len, nb, s, stream);
-    HIP_TRY(hipStreamWaitEvent(ctx->s_side, ctx->ev_meta, 0));
-    if (prof) HIP_TRY(hipEventRecord(ctx->ev_crc_t0, ctx->s_side));
-    launch_crc32(c, d_in, in_len, nb, s, ctx->crc_consts, ctx->s_side);
-    if (prof) HIP_TRY(hipEventRecord(ctx->ev_crc_t1, ctx->s_side));
-    HIP_TRY(hipEventRecord(ctx->ev_crc, ctx->s_side));
     if (prof) HIP_TRY(hipEventRecord(ev[++k], stream));
     if (c.level <= 1) {  // (at level 0 every block is a passthrough block: both return at once)
         launch_match(c, d_in, in_len, nb, s, stream);
@@ -279,6 +269,16 @@ int enqueue_batch(gzpx_ctx *ctx, const uint8_t *d_in, size_t in_len, uint32_t nb
         if (prof) HIP_TRY(hipEventRecord(ev[++k], stream));
         if (prof) HIP_TRY(hipEventRecord(ev[++k], stream));
     }
+    // fork: the CRC of every block on the low-priority side stream, beside k_hist and k_huffman --
+    // k_huffman is a chain of dependent LDS reads on one lane per block and leaves the CUs' issue
+    // slots and HBM idle.  (Measured alternatives, 550 MiB slab: beside k_candidates 5.36 ms per step
+    // -- that kernel slows down by the CRC's time; in front of k_parse 5.34; here 5.32.)
+    HIP_TRY(hipEventRecord(ctx->ev_meta, stream));
+    HIP_TRY(hipStreamWaitEvent(ctx->s_side, ctx->ev_meta, 0));
+    if (prof) HIP_TRY(hipEventRecord(ctx->ev_crc_t0, ctx->s_side));
+    launch_crc32(c, d_in, in_len, nb, s, ctx->crc_consts, ctx->s_side);
+    if (prof) HIP_TRY(hipEventRecord(ctx->ev_crc_t1, ctx->s_side));
+    HIP_TRY(hipEventRecord(ctx->ev_crc, ctx->s_side));
     launch_hist(c, nb, s, stream);
     if (prof) HIP_TRY(hipEventRecord(ev[++k], stream));
     launch_huffman(c, nb, s, stream);
