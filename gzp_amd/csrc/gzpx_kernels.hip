@@ -2098,6 +2098,23 @@ static_assert(sizeof(HuffLds) <= 6400, "HuffLds: 25 workgroups per CU");
 static_assert(kHdrWords <= kNumLitlen, "header bits fit region A");
 
 
+// A lane-distributed array of up to 320 words in five registers: element k (wave-uniform) lives in
+// lane k & 63 of r[k >> 6]; reading it is four selects and one v_readlane, no LDS round trip.
+// Used by the run-length scan of the code lengths, which runs WAVE-UNIFORM (every lane computes the
+// same thing: scalar branches, no exec-mask bookkeeping) with a run's end found by a ballot.
+// (The tree build written the same way -- both queues in registers -- was slower, k_huffman 0.55 ->
+// 0.66 ms: with six waves per SIMD the kernel is bound by instructions issued, not by the latency of
+// lane 0's LDS reads, and the register queues cost more instructions per node.)
+__device__ __forceinline__ uint32_t reg5_get(const uint32_t (&r)[5], uint32_t k) {
+    const uint32_t j = k >> 6;
+    uint32_t v = r[0];
+    v = j == 1 ? r[1] : v;
+    v = j == 2 ? r[2] : v;
+    v = j == 3 ? r[3] : v;
+    v = j == 4 ? r[4] : v;
+    return rdlane(v, k & 63u);
+}
+
 // Builds lens[] / cw[] for `num_syms` symbols from h.freq[].  All 64 lanes must call.
 __device__ void make_code(HuffLds &h, uint32_t num_syms, uint32_t max_len, uint32_t compat,
                           uint8_t *lens, uint32_t *cw, uint32_t lane) {
@@ -2369,53 +2386,73 @@ __global__ __launch_bounds__(64, 6) void k_huffman(Config cfg, BlockMeta *__rest
         if (lane < num_offset) h.lens[num_litlen + lane] = h.olens[lane];
         if (lane < 32) h.pfreq[lane] = 0;
         wave_sync();
-        if (lane == 0) {
-            // deflate_compute_precode_items: RLE of the concatenated code lengths
+        uint32_t num_items;
+        {
+            // deflate_compute_precode_items: RLE of the concatenated code lengths, wave-uniform: the
+            // lengths sit in registers, a run's end is the first lane of a ballot, items and precode
+            // frequencies are written by lane 0
             const uint32_t num_lens = num_litlen + num_offset;
+            uint32_t lr[5];
+#pragma unroll
+            for (uint32_t k = 0; k < 5; k++) {
+                const uint32_t idx = lane + 64 * k;
+                lr[k] = idx < num_lens ? (uint32_t)h.lens[idx] : 0xFFu;  // (no length: ends every run)
+            }
             uint32_t ni = 0, run_start = 0;
+            auto emit = [&](uint32_t item, uint32_t sym) {
+                if (lane == 0) {
+                    h.items[ni] = (uint16_t)item;
+                    atomicAdd(&h.pfreq[sym], 1u);
+                }
+                ni++;
+            };
             do {
-                const uint32_t len = h.lens[run_start];
-                uint32_t run_end = run_start, extra;
-                do {
-                    run_end++;
-                } while (run_end != num_lens && len == h.lens[run_end]);
+                const uint32_t len = reg5_get(lr, run_start);
+                uint32_t run_end = num_lens, extra;
+                for (uint32_t j = run_start >> 6; j < 5; j++) {  // first length after run_start that differs
+                    uint32_t v = lr[0];
+                    v = j == 1 ? lr[1] : v;
+                    v = j == 2 ? lr[2] : v;
+                    v = j == 3 ? lr[3] : v;
+                    v = j == 4 ? lr[4] : v;
+                    unsigned long long ne = __ballot(v != len);
+                    if (j == (run_start >> 6)) ne &= ~0ull << (run_start & 63u);  // (bit run_start itself is 0)
+                    if (ne) {
+                        run_end = 64 * j + (uint32_t)__ffsll((long long)ne) - 1;
+                        break;
+                    }
+                }
                 if (len == 0) {
                     while (run_end - run_start >= 11) {
                         extra = run_end - run_start - 11;
                         if (extra > 0x7F) extra = 0x7F;
-                        h.pfreq[18]++;
-                        h.items[ni++] = (uint16_t)(18 | (extra << 5));
+                        emit(18 | (extra << 5), 18);
                         run_start += 11 + extra;
                     }
                     if (run_end - run_start >= 3) {
                         extra = run_end - run_start - 3;
                         if (extra > 0x7) extra = 0x7;
-                        h.pfreq[17]++;
-                        h.items[ni++] = (uint16_t)(17 | (extra << 5));
+                        emit(17 | (extra << 5), 17);
                         run_start += 3 + extra;
                     }
                 } else if (run_end - run_start >= 4) {
-                    h.pfreq[len]++;
-                    h.items[ni++] = (uint16_t)len;
+                    emit(len, len);
                     run_start++;
                     do {
                         extra = run_end - run_start - 3;
                         if (extra > 0x3) extra = 0x3;
-                        h.pfreq[16]++;
-                        h.items[ni++] = (uint16_t)(16 | (extra << 5));
+                        emit(16 | (extra << 5), 16);
                         run_start += 3 + extra;
                     } while (run_end - run_start >= 3);
                 }
                 while (run_start != run_end) {
-                    h.pfreq[len]++;
-                    h.items[ni++] = (uint16_t)len;
+                    emit(len, len);
                     run_start++;
                 }
             } while (run_start != num_lens);
-            h.misc[0] = ni;
+            num_items = ni;
         }
         wave_sync();
-        const uint32_t num_items = h.misc[0];
         const uint32_t pf = lane < 19 ? h.pfreq[lane] : 0;
         wave_sync();
         if (lane < 32) h.freq[lane] = lane < 19 ? pf : 0;

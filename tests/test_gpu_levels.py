@@ -113,3 +113,17 @@ def test_builder_best_level(hip_lib, oracle):
     got = sink.getvalue()
     assert got[8] == 2
     assert got == oracle.compress_stream(a, oracle.FMT_BGZF, 9, oracle.COMPAT_1_24, 65280)
+
+
+@pytest.mark.parametrize("level", [1, 3, 6])
+def test_largest_block_16mib(hip_lib, oracle, level):
+    """buffer_size = 16 MiB (the largest the kernels accept): one full block and a ragged second one,
+    heterogeneous content so that sub-blocks split and min_len changes along the block."""
+    bs = 1 << 24
+    a = hetero(bs + 1_234_567, 77 + level)
+    with _native.Context(format=_native.FORMAT_MGZIP, level=level, buffer_size=bs, compat=_native.COMPAT_1_24,
+                         lib=hip_lib, max_slab_bytes=a.size) as c:
+        got, sizes = c.compress_slab(a, True, return_block_sizes=True)
+    want, wsizes = oracle.compress_stream(a, oracle.FMT_MGZIP, level, oracle.COMPAT_1_24, bs, True)
+    assert list(sizes) == list(wsizes)
+    assert got == want
