@@ -1376,7 +1376,7 @@ __global__ __launch_bounds__(kMpThreads, 8) void k_parse_hc(
             unsigned long long w = tid < ngroups ? mbits_g[tile_begin / 64 + tid] : 0ull;
             const uint32_t left = tile_len - (tid < ngroups ? tid * 64 : tile_len);
             if (left < 64) w &= (1ull << left) - 1ull;
-            if (min_len > 3) {
+            if (min_len > 3 && !GZPX_EXP(cfg, 13)) {
                 unsigned long long t = w, keep = 0;
                 while (t) {
                     const uint32_t bit = (uint32_t)__ffsll((long long)t) - 1;
@@ -1587,7 +1587,7 @@ __global__ __launch_bounds__(kMpThreads, 8) void k_parse_hc(
                     if (!is_match && min_len > 3 && ((mbits_g[(tile_begin >> 6) + g] >> lane) & 1ull)) v = in[p];
                     vals[k] = is_match ? (kTokMatch | (v << 9) | len) : v;
                     tis[k] = ti;
-                    if (ti < stat_from || ti >= lim_tok) continue;
+                    if (ti < stat_from || ti >= lim_tok || GZPX_EXP(cfg, 14)) continue;
                     const uint32_t cls = is_match ? 8u + (len >= 9u ? 1u : 0u) : (((v >> 5) & 6u) | (v & 1u));
                     uint32_t bin = 0;
                     if (nc < kNoMoreChecks && ti > nc) bin = 1u + (ti - nc - 1u) / 512u;
@@ -1597,7 +1597,7 @@ __global__ __launch_bounds__(kMpThreads, 8) void k_parse_hc(
                     if (nc < kNoMoreChecks && ti >= nc && (ti - nc) % 512u == 0 && (ti - nc) / 512u < kHpMaxBins)
                         chk_end[(ti - nc) / 512u] = p + len;
                 }
-                if (build) {
+                if (build && !GZPX_EXP(cfg, 15)) {
 #pragma unroll
                     for (uint32_t k = 0; k < 8; k++)
                         if (tis[k] != 0xFFFFFFFFu) tok[tis[k]] = vals[k];

@@ -1,6 +1,8 @@
 """What bounds k_match_hc?  -DGZPX_EXPERIMENT build (never the product), level 3 and 6 on 512 MiB of text:
    bit 10: no lz_extend (hits count, their extension loop does not run)   bit 11: chain walk only, no hits
-   bit 12: depth 1 (tile loads and stores only).  Results are wrong on purpose; times are what matters."""
+   bit 12: depth 1 (tile loads and stores only)
+   k_parse_hc (level 3 only): bit 13 no min_len filter, bit 14 no observation-class tally, bit 15 no token stores.
+   Results are wrong on purpose; times are what matters."""
 import os
 import subprocess
 import sys
@@ -23,7 +25,11 @@ for level in (3, 6):
     cap = ctx.slab_bound(n)
     d_out = torch.empty(cap, dtype=torch.uint8, device="cuda")
     ctx.set_profiling(True)
-    for name, flags in [("baseline", 0), ("no extension", 1 << 10), ("chain walk only", 1 << 11), ("depth 1", 1 << 12)]:
+    for name, flags in [("baseline", 0), ("no extension", 1 << 10), ("chain walk only", 1 << 11), ("depth 1", 1 << 12),
+                        ("parse: no min_len filter", 1 << 13), ("parse: no class tally", 1 << 14),
+                        ("parse: no token stores", 1 << 15), ("parse: none of the three", 7 << 13)]:
+        if level != 3 and flags >= (1 << 13):
+            continue
         ctx.debug_set_flags(flags)
         acc = {}
         for it in range(3):
