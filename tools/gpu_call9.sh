@@ -1,4 +1,6 @@
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-timeout 400 python tools/gpu_fuzz.py 300 777 > gpurun_out/r2_soak_levels.log 2>&1
-tail -3 gpurun_out/r2_soak_levels.log
+timeout 200 python tools/gpu_fuzz_twin.py 120 4242 > gpurun_out/r2_soak_twin.log 2>&1
+tail -2 gpurun_out/r2_soak_twin.log
+timeout 200 python tools/gpu_fuzz.py 120 31337 > gpurun_out/r2_soak_levels2.log 2>&1
+tail -1 gpurun_out/r2_soak_levels2.log

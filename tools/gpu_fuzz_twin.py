@@ -22,7 +22,7 @@ cases = bad = 0
 while time.time() < t_end:
     fmt_cls, fmt, bs = (par.Bgzf, oracle.FMT_BGZF, 65280) if rng.random() < 0.6 else (par.Mgzip, oracle.FMT_MGZIP,
                                                                                      int(rng.choice([131072, 70000])))
-    level = int(rng.integers(0, 5))
+    level = int(rng.integers(0, 10))
     n = int(rng.integers(0, 12 * bs))
     cls = classes[rng.integers(len(classes))]
     if cls == "random" and fmt == oracle.FMT_BGZF and level == 0:
