@@ -50,14 +50,21 @@ class GatherHandle:
     """An ordered gather in flight (ordered_gather_start): wait() completes it and returns the
     stream on dst (a view of `out`), None elsewhere."""
 
-    def __init__(self, reqs, out, total):
+    def __init__(self, reqs, out, total, cuda=False):
         self._reqs = reqs
         self._out = out
         self._total = total
+        self._cuda = cuda
 
     def wait(self):
         for q in self._reqs:
             q.wait()
+        if self._reqs and self._cuda:
+            # RCCL work.wait() only orders the CURRENT torch stream behind the transfer; the slab
+            # kernels run on the context's own streams and the caller is about to reuse the buffers,
+            # so block the host until the transfer has really finished
+            import torch
+            torch.cuda.current_stream().synchronize()
         self._reqs = []
         return None if self._out is None else self._out[:self._total]
 
@@ -82,7 +89,7 @@ def ordered_gather_start(local, dst=0, group=None, out=None):
         reqs = []
         if local.numel():
             reqs = dist.batch_isend_irecv([dist.P2POp(dist.isend, local, dst, group)])
-        return GatherHandle(reqs, None, 0)
+        return GatherHandle(reqs, None, 0, local.is_cuda)
     sz = [int(x) for x in sizes.tolist()]
     offs = np.concatenate([[0], np.cumsum(sz)]).astype(np.int64)
     total = int(offs[-1])
@@ -92,7 +99,7 @@ def ordered_gather_start(local, dst=0, group=None, out=None):
            for r in range(world) if r != dst and sz[r]]
     reqs = dist.batch_isend_irecv(ops) if ops else []
     out[offs[dst]:offs[dst + 1]].copy_(local)
-    return GatherHandle(reqs, out, total)
+    return GatherHandle(reqs, out, total, local.is_cuda)
 
 
 def ordered_gather(local, dst=0, group=None, out=None):

@@ -1,3 +1,2 @@
 cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out
-timeout 900 python tools/exp_hc_bounds.py 2>&1 | grep level | tee gpurun_out/r2_hc_bounds.log
+timeout 600 python -m pytest tests/test_gpu_rccl_single.py -x -q 2>&1 | grep -E "passed|failed|Error|error" | tail -8
