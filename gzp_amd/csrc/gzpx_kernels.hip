@@ -264,7 +264,7 @@ __device__ __forceinline__ uint2 cand_fetch(const uint32_t *__restrict__ in32, u
     return v;
 }
 
-constexpr uint32_t kCandWaves = 4;  // one per SIMD; they take turns at the table
+constexpr uint32_t kCandWaves = 8;  // two per SIMD; they take turns at the table
 
 // Which chain a candidate pass builds (MODE):
 //   0  level 1, ht_matchfinder: 15-bit hash of 4 bytes
