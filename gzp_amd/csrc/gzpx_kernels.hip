@@ -249,7 +249,7 @@ __global__ void k_init_meta(Config cfg, uint64_t slab_len, uint32_t nb, uint32_t
 // Output: cand[p] = d0 (u16, 0 = no live predecessor).
 // ------------------------------------------------------------------------------------------
 constexpr uint32_t kBuckets = 1u << 15;
-constexpr uint32_t kCandSteps = 32;  // steps per iteration; also the depth of the input prefetch
+constexpr uint32_t kCandSteps = 16;  // steps per iteration; also the depth of the input prefetch
 
 // aligned dword pair covering in[p .. p+3] (in32 = the block's bytes rounded down to a dword
 // boundary, mis = bytes skipped by that rounding).  Unconditional (index clamped to the block's
@@ -264,7 +264,7 @@ __device__ __forceinline__ uint2 cand_fetch(const uint32_t *__restrict__ in32, u
     return v;
 }
 
-constexpr uint32_t kCandWaves = 8;  // two per SIMD; they take turns at the table
+constexpr uint32_t kCandWaves = 16;  // four per SIMD; they take turns at the table
 
 // Which chain a candidate pass builds (MODE):
 //   0  level 1, ht_matchfinder: 15-bit hash of 4 bytes
