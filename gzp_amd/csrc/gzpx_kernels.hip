@@ -15,8 +15,8 @@
 // the input ("the two most recent earlier positions with the same 15-bit hash, within 32767
 // bytes") and do not depend on the parse.  That turns the sequential compressor into a pipeline
 // of data-parallel stages, each a kernel over all blocks of a slab:
-//   k_candidates   4 waves  / block : LDS-resident 128 KiB bucket table, ordered atomicMax chain,
-//                                     2048 positions per ticket turn
+//   k_candidates   16 waves / block : LDS-resident 128 KiB bucket table, ordered atomicMax chain,
+//                                     1024 positions per ticket turn
 //   k_match        1024 thr / block : block input in LDS; both candidates of every position
 //                                     extended by one lockstep loop; run groups for long runs
 //   k_parse        1024 thr / block : per-position match lengths in LDS; the greedy parse as a
@@ -241,7 +241,7 @@ __global__ void k_init_meta(Config cfg, uint64_t slab_len, uint32_t nb, uint32_t
 // tools/probes/lds_atomic_order.hip, 2000/2000 patterns), so `old` already is the lane's
 // predecessor in its bucket -- whether that predecessor sits in an earlier step or in a lower
 // lane of the same instruction.  No cross-lane matching is needed, and kCandSteps steps
-// (kCandSteps * 64 positions) of atomics are kept in flight per iteration; four waves (one per
+// (kCandSteps * 64 positions) of atomics are kept in flight per iteration; sixteen waves (four per
 // SIMD) take turns at the table so that only the atomic phase is serial.  The ordering
 // assumption is CHECKED, never trusted: a lane that is handed a predecessor >= its own position
 // flags the block, and k_candidates_safe (ballot match-any, order-independent) redoes flagged
@@ -264,6 +264,11 @@ __device__ __forceinline__ uint2 cand_fetch(const uint32_t *__restrict__ in32, u
     return v;
 }
 
+// Waves per workgroup x steps per turn, measured on the 550 MiB slab (ms per launch, level 1):
+// 4 x 32: 1.00, 8 x 32: 0.74, 12 x 32: 0.84 (32 turns do not divide by 12), 16 x 8: 0.73, 16 x 16: 0.64.
+// The work AROUND the turn (loads, hashing, distance, stores) is what a block waits for, and it
+// spreads over the waves; 16 x 16 is what the 512 VGPRs of a SIMD lane allow (ring + address /
+// value / result of every step stay in registers).
 constexpr uint32_t kCandWaves = 16;  // four per SIMD; they take turns at the table
 
 // Which chain a candidate pass builds (MODE):
@@ -311,8 +316,8 @@ __global__ __launch_bounds__(64 * kCandWaves) void k_candidates(Config cfg,
 
     // The table is one LDS array, so the atomics of iteration i+1 must reach it after those of
     // iteration i -- but hashing / input prefetch before and distance / store work after are
-    // independent.  Wave w owns iterations w, w+4, ...; a ticket in LDS (`turn`) serialises only
-    // the atomic phase, so three waves hash, prefetch and store while the fourth is at the table.
+    // independent.  Wave w owns iterations w, w+16, ...; a ticket in LDS (`turn`) serialises only
+    // the atomic phase, so fifteen waves hash, prefetch and store while one is at the table.
     constexpr uint32_t kIterPos = 64 * kCandSteps;
     const uint32_t n_iters = (n + kIterPos - 1) / kIterPos;
     uint2 ring[kCandSteps];
@@ -324,7 +329,7 @@ __global__ __launch_bounds__(64 * kCandWaves) void k_candidates(Config cfg,
     for (uint32_t it = wave; it < n_iters; it += kCandWaves) {
         const uint32_t base0 = it * kIterPos;
         // The serial phase must be nothing but the atomics: a lone wave issues about one dependent
-        // instruction per ten cycles, so every instruction inside the turn costs all four waves.
+        // instruction per ten cycles, so every instruction inside the turn costs every wave.
         // LDS byte address and value of every step are therefore finished (and pinned in registers)
         // before the wave asks for its turn; lanes without a bucket aim a zero at a spare word.
         uint32_t addr[kCandSteps], val[kCandSteps], old[kCandSteps];
