@@ -1099,74 +1099,113 @@ __device__ __forceinline__ uint32_t lds_extend16(const uint32_t *in_w, uint32_t 
 // of the pre-filter word -- 0 while best_len < 4, best_len - 3 after -- and every node costs one
 // unit of depth in both, so the lanes of a wave, which sit in different phases, share the loop
 // instead of waiting for each other's.
-//   The loop is bound by instruction issue (about 37 instructions per node for the wave): fewer LDS
-//   reads per node at the price of more arithmetic (a partial compare of the node's first aligned
-//   dword) was slower, 22.1 -> 24.0 ms at level 3, and so was walking two positions per lane with
-//   both nodes' reads in flight together (19.4 -> 20.1 ms; 45 -> 153 ms at level 6, where the
-//   doubled state no longer fits the registers).
+//   Measured on the way (level 3 match + parse on 512 MiB of text): fewer LDS reads per node at the
+//   price of more arithmetic (a partial compare of the node's first aligned dword) 22.1 -> 24.0 ms;
+//   one exit per loop instead of breaks 22.3 -> 17.0 ms (the scalar mask bookkeeping of every extra
+//   way out was most of a node's cost); two positions per lane (hc_search_pair) about even on text,
+//   -9 % on configs[2]'s ASCII noise and at level 9, where the walk is mostly latency.
 //   NV > 1 (the lazy parsers): the searches with depth >> 1 (and >> 2) visit the same nodes in the
 //   same order and just stop earlier, so their results are this search's best match at the moment
-//   the smaller budget runs out.
+//   the smaller budget runs out: one stretch of the walk per variant, shortest budget first (if the
+//   walk died before a budget ran out nothing changes any more, and that is the final match as well).
+//   Two positions per lane, walked together: a node is a dependent LDS read (link, then bytes), and one
+// workgroup per CU leaves four waves per SIMD to hide it -- so a lane keeps two independent chains in
+// flight and issues both nodes' reads before it looks at either.  Both chains spend the same depth
+// budget (one node per round while alive), so the depth counter stays one scalar.
 template <int NV>
-__device__ __forceinline__ void hc_search_all(const uint32_t *in_w, const uint16_t *link, uint32_t a,
-                                              uint32_t li, uint32_t d3v, uint32_t max_len, uint32_t nice_len,
-                                              const uint32_t depth0, uint32_t (&len_out)[NV],
-                                              uint32_t (&dist_out)[NV], const uint32_t dbg = 0) {
-    uint32_t best_len = 2, best_dist = 0;
-    if (d3v != 0) {  // (an empty hash3 bucket ends the search before the hash4 chain is looked at)
-        const uint32_t seq4 = lds_le32(in_w, a);
-        if (((lds_le32(in_w, a - d3v) ^ seq4) & 0xFFFFFFu) == 0) {
-            best_len = 3;
-            best_dist = d3v;
-        }
-        uint32_t tot = link[li];  // distance from p to the chain's next node (0: none); alive while <= 32767
-        bool alive = tot != 0 && tot <= 32767u;
-        uint32_t depth = depth0;
-        uint32_t off = 0, mine = seq4;  // the pre-filter word: its offset, this position's bytes there
-        // One stretch of the walk per variant, shortest budget first: the search with depth >> v stops
-        // when depth0 >> v nodes are behind it, and what it returns is the best match at that moment
-        // (if the walk died before, nothing changes any more and that is the final match as well).
+__device__ __forceinline__ void hc_search_pair(const uint32_t *in_w, const uint16_t *link, const uint32_t (&a)[2],
+                                               const uint32_t (&li)[2], const uint32_t (&d3v)[2],
+                                               const uint32_t (&max_len)[2], const uint32_t (&nice_len)[2],
+                                               const uint32_t depth0, uint32_t (&len_out)[2][NV],
+                                               uint32_t (&dist_out)[2][NV], const uint32_t dbg = 0) {
+    uint32_t best_len[2], best_dist[2], seq4[2], tot[2], off[2], mine[2];
+    bool alive[2];
 #pragma unroll
-        for (int v = NV - 1; v >= 0; v--) {
-            const uint32_t stop = v ? depth0 - (depth0 >> v) : 0u;
-            bool go = alive && depth != stop;
-            while (go) {  // (one way out, flags instead of breaks: see lds_extend16)
-                const uint32_t ca = a - tot;
-                const uint32_t nxt = link[li - tot];
-                bool hit = lds_le32(in_w, ca + off) == mine;  // (libdeflate's order: the selective word first)
+    for (int c = 0; c < 2; c++) {
+        best_len[c] = 2;
+        best_dist[c] = 0;
+        off[c] = 0;
+        tot[c] = 0;
+        alive[c] = false;
+        seq4[c] = lds_le32(in_w, a[c]);
+        mine[c] = seq4[c];
+        if (d3v[c] != 0) {  // (an empty hash3 bucket ends the search before the hash4 chain is looked at)
+            if (((lds_le32(in_w, a[c] - d3v[c]) ^ seq4[c]) & 0xFFFFFFu) == 0) {
+                best_len[c] = 3;
+                best_dist[c] = d3v[c];
+            }
+            const uint32_t t = link[li[c]];  // distance to the chain's next node (0: none); alive while <= 32767
+            alive[c] = t != 0 && t <= 32767u;
+            tot[c] = alive[c] ? t : 0u;  // (a dead chain keeps reading its own position: inside the window)
+        }
+    }
+    uint32_t depth = depth0;
+#pragma unroll
+    for (int v = NV - 1; v >= 0; v--) {
+        const uint32_t stop = v ? depth0 - (depth0 >> v) : 0u;
+        bool go = (alive[0] || alive[1]) && depth != stop;
+        while (go) {  // (one way out, flags instead of breaks: see lds_extend16)
+            uint32_t ca[2], nxt[2], w[2];
+#pragma unroll
+            for (int c = 0; c < 2; c++) {  // every read of this round
+                ca[c] = a[c] - tot[c];
+                nxt[c] = link[li[c] - tot[c]];
+                w[c] = lds_le32(in_w, ca[c] + off[c]);
+            }
+#pragma unroll
+            for (int c = 0; c < 2; c++) {
+                bool hit = alive[c] && w[c] == mine[c];  // (libdeflate's order: the selective word first)
 #ifdef GZPX_EXPERIMENT
                 if ((dbg >> 11) & 1u) hit = false;
 #endif
-                if (hit && off) hit = lds_le32(in_w, ca) == seq4;
+                if (hit && off[c]) hit = lds_le32(in_w, ca[c]) == seq4[c];
                 if (hit) {
 #ifdef GZPX_EXPERIMENT
-                    const uint32_t len = ((dbg >> 10) & 1u) ? (best_len + 1 < max_len ? best_len + 1 : max_len)
-                                                            : lds_extend16(in_w, a, ca, max_len);
+                    const uint32_t len = ((dbg >> 10) & 1u) ? (best_len[c] + 1 < max_len[c] ? best_len[c] + 1 : max_len[c])
+                                                            : lds_extend16(in_w, a[c], ca[c], max_len[c]);
 #else
-                    const uint32_t len = lds_extend16(in_w, a, ca, max_len);
+                    const uint32_t len = lds_extend16(in_w, a[c], ca[c], max_len[c]);
 #endif
-                    if (len > best_len) {
-                        best_len = len;
-                        best_dist = tot;
-                        alive = best_len < nice_len;
-                        off = best_len - 3u;
-                        mine = lds_le32(in_w, a + off);
+                    if (len > best_len[c]) {
+                        best_len[c] = len;
+                        best_dist[c] = tot[c];
+                        alive[c] = best_len[c] < nice_len[c];
+                        off[c] = best_len[c] - 3u;
+                        mine[c] = lds_le32(in_w, a[c] + off[c]);
                     }
                 }
-                tot += nxt;
-                --depth;  // (only looked at while the chain goes on)
-                alive = alive && nxt != 0 && tot <= 32767u;
-                go = alive && depth != stop;
+                const uint32_t t = tot[c] + nxt[c];
+                alive[c] = alive[c] && nxt[c] != 0 && t <= 32767u;
+                tot[c] = alive[c] ? t : 0u;
             }
-            len_out[v] = best_len;
-            dist_out[v] = best_dist;
+            --depth;
+            go = (alive[0] || alive[1]) && depth != stop;
         }
-    } else {
 #pragma unroll
-        for (int v = 0; v < NV; v++) {
-            len_out[v] = best_len;
-            dist_out[v] = best_dist;
+        for (int c = 0; c < 2; c++) {
+            len_out[c][v] = best_len[c];
+            dist_out[c][v] = best_dist[c];
         }
+    }
+}
+
+// The two positions a lane searches together: p0 and p0 + 1024.  One past the tile, or with fewer
+// than 5 bytes left (hc_matchfinder_longest_match bails out), idles: d3v = 0, addresses of p0.
+__device__ __forceinline__ void hc_pair_setup(uint32_t p0, uint32_t tile_end, uint32_t n, uint32_t win_begin,
+                                              uint32_t mis, uint32_t nice_level, const uint16_t *d3,
+                                              uint32_t (&a)[2], uint32_t (&li)[2], uint32_t (&d3v)[2],
+                                              uint32_t (&max_len)[2], uint32_t (&nice_len)[2], bool (&ok)[2]) {
+#pragma unroll
+    for (int c = 0; c < 2; c++) {
+        const uint32_t p = p0 + 1024u * c;
+        ok[c] = p < tile_end && p + 5 <= n;
+        const uint32_t q = ok[c] ? p : p0;  // (p0 < tile_end <= n: inside the window)
+        const uint32_t rem = n - q;
+        max_len[c] = rem < 258u ? rem : 258u;
+        nice_len[c] = max_len[c] < nice_level ? max_len[c] : nice_level;
+        a[c] = q - win_begin + mis;
+        li[c] = q - win_begin;
+        d3v[c] = ok[c] ? d3[p] : 0u;
     }
 }
 
@@ -1233,45 +1272,45 @@ __global__ __launch_bounds__(1024) void k_match_hc(Config cfg, const uint8_t *__
             // distance rule: the parser applies its own (8192, first search only).
             uint8_t *lzl = lz_len_all + (uint64_t)b * 2u * cfg.stride;
             uint16_t *lzd = lz_dist_all + (uint64_t)b * 2u * cfg.stride;
-            for (uint32_t p = tile_begin + tid; p < tile_end; p += 1024) {
-                uint32_t len[3] = {0, 0, 0}, dst[3] = {0, 0, 0};
-                if (p + 5 <= n) {
-                    const uint32_t rem = n - p;
-                    const uint32_t max_len = rem < 258u ? rem : 258u;
-                    const uint32_t nice_len = max_len < nice_level ? max_len : nice_level;
-                    const uint32_t a = p - win_begin + mis;
-                    hc_search_all<3>(in_w, link, a, p - win_begin, d3[p], max_len, nice_len, depth, len, dst, cfg.debug);
-                }
-                for (uint32_t v = 0; v <= cfg.lazy; v++) {
-                    const bool have = len[v] >= 3u;
-                    uint8_t *lo = v == 0 ? len8 : lzl + (uint64_t)(v - 1) * cfg.stride;
-                    uint16_t *dd = v == 0 ? dist : lzd + (uint64_t)(v - 1) * cfg.stride;
-                    lo[p] = (uint8_t)(have ? len[v] - 3u : 0u);
-                    dd[p] = (uint16_t)(have ? dst[v] : 0u);
+            for (uint32_t p0 = tile_begin + tid; p0 < tile_end; p0 += 2048) {
+                uint32_t a[2], li[2], d3v[2], max_len[2], nice_len[2], len[2][3], dst[2][3];
+                bool ok[2];
+                hc_pair_setup(p0, tile_end, n, win_begin, mis, nice_level, d3, a, li, d3v, max_len, nice_len, ok);
+                hc_search_pair<3>(in_w, link, a, li, d3v, max_len, nice_len, depth, len, dst, cfg.debug);
+#pragma unroll
+                for (int c = 0; c < 2; c++) {
+                    const uint32_t p = p0 + 1024u * c;
+                    if (p >= tile_end) continue;
+                    for (uint32_t v = 0; v <= cfg.lazy; v++) {
+                        const bool have = ok[c] && len[c][v] >= 3u;
+                        uint8_t *lo = v == 0 ? len8 : lzl + (uint64_t)(v - 1) * cfg.stride;
+                        uint16_t *dd = v == 0 ? dist : lzd + (uint64_t)(v - 1) * cfg.stride;
+                        lo[p] = (uint8_t)(have ? len[c][v] - 3u : 0u);
+                        dd[p] = (uint16_t)(have ? dst[c][v] : 0u);
+                    }
                 }
             }
             continue;  // (uniform; the next tile's loads start behind a barrier)
         }
-        for (uint32_t p = tile_begin + tid; p < tile_end; p += 1024) {
-            uint32_t len = 0, dst = 0;
-            if (p + 5 <= n) {  // max_len >= 5, otherwise hc_matchfinder_longest_match bails out
-                const uint32_t rem = n - p;
-                const uint32_t max_len = rem < 258u ? rem : 258u;
-                const uint32_t nice_len = max_len < nice_level ? max_len : nice_level;
-                const uint32_t a = p - win_begin + mis;
-                uint32_t l1[1], d1[1];
-                hc_search_all<1>(in_w, link, a, p - win_begin, d3[p], max_len, nice_len, depth, l1, d1, cfg.debug);
-                len = l1[0];
-                dst = d1[0];
-            }
-            // deflate_compress_greedy: a length-3 match is only worth it at a short distance
-            const bool take = len >= min_len && (len > 3 || dst <= 4096u);
-            len8[p] = (uint8_t)(take ? len - 3 : 0);
-            // val: the match distance, or the literal byte (what k_parse_hc's token needs either way)
-            dist[p] = (uint16_t)(take ? dst : lds_le32(in_w, p - win_begin + mis) & 0xFFu);
-            if (take) {
-                const uint32_t r = p - tile_begin;
-                atomicOr(&mbits[r >> 5], 1u << (r & 31u));
+        for (uint32_t p0 = tile_begin + tid; p0 < tile_end; p0 += 2048) {
+            uint32_t a[2], li[2], d3v[2], max_len[2], nice_len[2], ln[2][1], ds[2][1];
+            bool ok[2];
+            hc_pair_setup(p0, tile_end, n, win_begin, mis, nice_level, d3, a, li, d3v, max_len, nice_len, ok);
+            hc_search_pair<1>(in_w, link, a, li, d3v, max_len, nice_len, depth, ln, ds, cfg.debug);
+#pragma unroll
+            for (int c = 0; c < 2; c++) {
+                const uint32_t p = p0 + 1024u * c;
+                if (p >= tile_end) continue;
+                const uint32_t len = ok[c] ? ln[c][0] : 0u, dst = ds[c][0];
+                // deflate_compress_greedy: a length-3 match is only worth it at a short distance
+                const bool take = len >= min_len && (len > 3 || dst <= 4096u);
+                len8[p] = (uint8_t)(take ? len - 3 : 0);
+                // val: the match distance, or the literal byte (what k_parse_hc's token needs either way)
+                dist[p] = (uint16_t)(take ? dst : lds_le32(in_w, p - win_begin + mis) & 0xFFu);
+                if (take) {
+                    const uint32_t r = p - tile_begin;
+                    atomicOr(&mbits[r >> 5], 1u << (r & 31u));
+                }
             }
         }
         __syncthreads();
