@@ -311,6 +311,7 @@ def e2e_legs(env, slab, want_sha):
       api_write      the Write API: ParCompress twin (C ABI gzpx_par_*), ordinary pageable input,
                      one write_all of the whole slab + finish(), the writer callback is a sink
       api_write_64k  the same through 64 KiB write() calls, the shape of benches/bench.rs:36-45
+                     (called from Python; api_write_64k_native: the same calls looped in C)
     Every output is checked against the device-resident result (SHA-256)."""
     _native = env.native
     L = env.lib.L
@@ -371,7 +372,7 @@ def e2e_legs(env, slab, want_sha):
         return 0
 
     cb = _native.WRITE_FN(sink)
-    for name, chunk in (("api_write_MiBps", n), ("api_write_64k_MiBps", 65536)):
+    for name, chunk in (("api_write_MiBps", n), ("api_write_64k_MiBps", 65536), ("api_write_64k_native_MiBps", -65536)):
         best = None
         for rep in range(3):
             state["h"] = hashlib.sha256() if rep == 2 else None
@@ -381,10 +382,13 @@ def e2e_legs(env, slab, want_sha):
             env.lib.check(L.gzpx_par_create(ctypes.byref(cfg), cb, None, ctypes.byref(h)))
             base = slab.ctypes.data
             t0 = time.perf_counter()
-            for lo in range(0, n, chunk):
-                rc = L.gzpx_par_write(h, base + lo, min(chunk, n - lo))
-                if rc:
-                    break
+            if chunk < 0:  # the same 64 KiB write() calls looped on the native side (no ctypes cost per call)
+                rc = L.gzpx_par_write_chunked(h, base, n, -chunk)
+            else:
+                for lo in range(0, n, chunk):
+                    rc = L.gzpx_par_write(h, base + lo, min(chunk, n - lo))
+                    if rc:
+                        break
             rc = rc or L.gzpx_par_finish(h)
             dt = time.perf_counter() - t0
             L.gzpx_par_destroy(h)

@@ -47,7 +47,7 @@ EXPORTS = [
     "gzpx_debug_set_flags", "gzpx_strerror", "gzpx_device_name", "gzpx_version",
     "gzpx_compress_slab_submit", "gzpx_compress_slab_submit_device", "gzpx_compress_slab_wait",
     "gzpx_compress_slab_event", "gzpx_crc32_checked", "gzpx_last_status",
-    "gzpx_par_create", "gzpx_par_write", "gzpx_par_flush", "gzpx_par_finish", "gzpx_par_destroy",
+    "gzpx_par_create", "gzpx_par_write", "gzpx_par_write_chunked", "gzpx_par_flush", "gzpx_par_finish", "gzpx_par_destroy",
     "gzpx_par_last_error", "gzpx_par_create_pinned", "gzpx_par_reserve", "gzpx_par_commit", "gzpx_par_index", "gzpx_gzi_size",
     "gzpx_gzi_write", "gzpx_dctx_create", "gzpx_dctx_destroy", "gzpx_scan_blocks",
     "gzpx_decompress_blocks", "gzpx_decompress_blocks_device", "gzpx_decompress_blocks_submit",
@@ -166,6 +166,8 @@ class GzpxLib:
         L.gzpx_par_create_pinned.argtypes = [ctypes.POINTER(GzpxParConfig), sz, WRITE_FN, vp, ctypes.POINTER(vp)]
         L.gzpx_par_write.restype = i32
         L.gzpx_par_write.argtypes = [vp, vp, sz]
+        L.gzpx_par_write_chunked.restype = i32
+        L.gzpx_par_write_chunked.argtypes = [vp, vp, sz, sz]
         L.gzpx_par_reserve.restype = i32
         L.gzpx_par_reserve.argtypes = [vp, ctypes.POINTER(vp), psz]
         L.gzpx_par_commit.restype = i32

@@ -1,5 +1,8 @@
 // gzpx_par.cpp -- ParCompress / ParDecompress twins (see gzpx_par.hpp) + their C ABI (gzpx_par_* /
 // gzpx_pard_* in include/gzpx.h).
+#if defined(__SSE2__)
+#include <emmintrin.h>
+#endif
 #include "gzpx_par.hpp"
 
 #include <hip/hip_runtime.h>
@@ -57,6 +60,37 @@ CopyPool::CopyPool(size_t helpers, std::optional<size_t> pin_at) {
         });
 }
 
+// Copy into a staging slab: the bytes are read next by the copy engine, never again by this CPU, so the
+// bulk goes out with streaming (non-temporal) stores -- no read-for-ownership of the destination
+// lines, no cache pollution.  (glibc's memcpy only does that for copies of several MiB; the write()
+// calls of the reference's own benchmark are 64 KiB.)
+static void stage_copy(uint8_t *dst, const uint8_t *src, size_t n) {
+#if defined(__SSE2__)
+    if (n >= 4096) {
+        const size_t head = (size_t)(-(uintptr_t)dst & 63u);  // up to the destination's next cache line
+        memcpy(dst, src, head);
+        dst += head;
+        src += head;
+        n -= head;
+        const size_t body = n & ~(size_t)63;
+        for (size_t i = 0; i < body; i += 64) {
+            const __m128i a = _mm_loadu_si128((const __m128i *)(src + i));
+            const __m128i b = _mm_loadu_si128((const __m128i *)(src + i + 16));
+            const __m128i c = _mm_loadu_si128((const __m128i *)(src + i + 32));
+            const __m128i d = _mm_loadu_si128((const __m128i *)(src + i + 48));
+            _mm_stream_si128((__m128i *)(dst + i), a);
+            _mm_stream_si128((__m128i *)(dst + i + 16), b);
+            _mm_stream_si128((__m128i *)(dst + i + 32), c);
+            _mm_stream_si128((__m128i *)(dst + i + 48), d);
+        }
+        _mm_sfence();  // the stores are globally visible before the slab is handed to the device thread
+        memcpy(dst + body, src + body, n - body);
+        return;
+    }
+#endif
+    memcpy(dst, src, n);
+}
+
 CopyPool::~CopyPool() {
     {
         std::lock_guard<std::mutex> lk(mu_);
@@ -76,7 +110,7 @@ void CopyPool::main() {
             t = tasks_.front();
             tasks_.pop_front();
         }
-        memcpy(t.dst, t.src, t.n);
+        stage_copy(t.dst, t.src, t.n);
         {
             std::lock_guard<std::mutex> lk(mu_);
             pending_--;
@@ -88,7 +122,7 @@ void CopyPool::main() {
 void CopyPool::copy(uint8_t *dst, const uint8_t *src, size_t n) {
     const size_t parts = threads_.size() + 1;
     if (n < ((size_t)1 << 20) || parts == 1) {
-        memcpy(dst, src, n);
+        stage_copy(dst, src, n);
         return;
     }
     const size_t piece = ((n / parts) + 4095) & ~(size_t)4095;
@@ -101,7 +135,7 @@ void CopyPool::copy(uint8_t *dst, const uint8_t *src, size_t n) {
         }
     }
     cv_task_.notify_all();
-    memcpy(dst, src, off);
+    stage_copy(dst, src, off);
     std::unique_lock<std::mutex> lk(mu_);
     cv_done_.wait(lk, [&] { return pending_ == 0; });
 }
@@ -769,6 +803,13 @@ static int par_create(const gzpx_par_config *cfg, std::optional<size_t> pin, gzp
 int gzpx_par_write(gzpx_par *p, const uint8_t *buf, size_t n) {
     if (!p || (!buf && n)) return GZPX_ERR_INVALID_ARG;
     return guarded(p, [&] { p->pc->write(buf, n); });
+}
+
+int gzpx_par_write_chunked(gzpx_par *p, const uint8_t *buf, size_t n, size_t chunk) {
+    if (!p || (!buf && n) || chunk == 0) return GZPX_ERR_INVALID_ARG;
+    return guarded(p, [&] {
+        for (size_t lo = 0; lo < n; lo += chunk) p->pc->write(buf + lo, n - lo < chunk ? n - lo : chunk);
+    });
 }
 
 int gzpx_par_reserve(gzpx_par *p, uint8_t **ptr, size_t *cap) {

@@ -100,6 +100,12 @@ class ParCompress:
 
     write_all = write
 
+    def write_chunked(self, buf, chunk=65536):
+        """The reference benchmark's write shape (benches/bench.rs:36-45), looped on the native side."""
+        a = _native._u8(buf)
+        self._check(self._lib.L.gzpx_par_write_chunked(self._h, a.ctypes.data, a.size, int(chunk)))
+        return a.size
+
     def reserve(self):
         """Room inside the page-locked slab being filled, as a writable numpy view (gzpx_par_reserve);
         fill a prefix of it and commit(n)."""

@@ -189,6 +189,10 @@ int gzpx_par_create(const gzpx_par_config *cfg, gzpx_write_fn write_fn, void *us
 int gzpx_par_create_pinned(const gzpx_par_config *cfg, size_t first_core, gzpx_write_fn write_fn, void *user,
                            gzpx_par **out);
 int gzpx_par_write(gzpx_par *p, const uint8_t *buf, size_t n);
+/* The loop of the reference's own benchmark (benches/bench.rs:36-45: read 64 KiB, write_all it) on the
+ * native side of the boundary: n bytes through write() calls of `chunk` bytes each.  What a Rust caller
+ * of gzpx_par_write sees without this binding's per-call cost; same stream as one write() of n bytes. */
+int gzpx_par_write_chunked(gzpx_par *p, const uint8_t *buf, size_t n, size_t chunk);
 /* In-place form of write() for producers that can fill memory they are handed (read(2) into the
  * slab, a decoder's output): reserve returns room (>= buffer_size bytes) inside the page-locked slab
  * that is being filled, commit appends the first n bytes of it to the stream.  Same cut rule as

@@ -40,3 +40,7 @@ def test_decompress_submit_wait(emu_lib, oracle):
 
 def test_libdeflate_shim_edges(emu_lib, oracle):
     tc.libdeflate_shim_edges(emu_lib, oracle)
+
+
+def test_write_chunked(emu_lib, oracle):
+    tc.write_chunked(emu_lib, oracle)

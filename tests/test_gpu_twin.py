@@ -46,3 +46,7 @@ def test_decompress_submit_wait(hip_lib, oracle):
 
 def test_libdeflate_shim_edges(hip_lib, oracle):
     tc.libdeflate_shim_edges(hip_lib, oracle)
+
+
+def test_write_chunked(hip_lib, oracle):
+    tc.write_chunked(hip_lib, oracle, scale=8)

@@ -109,6 +109,24 @@ def reserve_commit(lib, oracle, scale=1):
     assert sink.getvalue() == oracle.compress_stream(a, oracle.FMT_BGZF, 1, oracle.COMPAT_1_24, BS)
 
 
+def write_chunked(lib, oracle, scale=1):
+    """gzpx_par_write_chunked: the reference benchmark's 64 KiB writes looped natively give the stream of
+    one write(); odd chunk sizes and a chunk larger than the data too; chunk 0 is an argument error."""
+    a = synth.make("fastq", (5 * BS + 777) * scale, 9)
+    want = oracle.compress_stream(a, oracle.FMT_BGZF, 1, oracle.COMPAT_1_24, BS)
+    for chunk in (65536, 1000, 10 * BS * scale):
+        sink = io.BytesIO()
+        w = _builder(lib, batch=2).from_writer(sink)
+        assert w.write_chunked(a, chunk) == a.size
+        w.finish()
+        w.close()
+        assert sink.getvalue() == want, chunk
+    w = _builder(lib).from_writer(io.BytesIO())
+    with pytest.raises(par.GzpError):
+        w.write_chunked(a, 0)
+    w.close()
+
+
 def block_index(lib, oracle, scale=1):
     """The index side-product (README.md:161): offsets of every block, checked against a header walk of
     the stream that was written; .gzi layout."""
