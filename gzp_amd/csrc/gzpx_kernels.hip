@@ -1,5 +1,5 @@
 // gzpx_kernels.hip -- hand-written HIP kernels (gfx950 / CDNA4) for gzp's per-block encode and
-// decode: libdeflate DEFLATE (levels 1-4) + CRC-32 + BGZF/Mgzip framing, and inflate with the
+// decode: libdeflate DEFLATE (levels 0-9) + CRC-32 + BGZF/Mgzip framing, and inflate with the
 // per-block CRC check; thousands of blocks per launch.
 //
 // What this replaces (reference file:line, relative to the gzp tree):
@@ -25,11 +25,12 @@
 //   k_hist         256 thr  / block : symbol frequencies per DEFLATE sub-block
 //   k_huffman      one wave / block : libdeflate's length-limited Huffman construction, header
 //                                     RLE, exact cost comparison (dynamic / static / stored)
-//   k_crc32        1024 thr / block : per-segment CRC + GF(2) combine tree
+//   k_crc32        256 thr  / block : per-segment CRC + GF(2) combine tree (side stream)
 //   k_scan         one workgroup    : exclusive scan of framed sizes -> output offsets
 //   k_emit         1024 thr / block : bit-exact bitstream assembly in LDS, coalesced write-out
 // Levels 2-4 swap k_match / k_parse for k_match_hc / k_parse_hc (hc_matchfinder chains, block
-// splitting); ParDecompress is k_dinit / k_dscan / k_inflate / k_dcrc32.
+// splitting), levels 5-9 for k_match_hc / k_parse_lazy (the lazy and lazy2 parsers); ParDecompress
+// is k_dinit / k_dscan / k_inflate / k_dcrc32.
 // Integer/byte work only: no MFMA; LDS, the texture path and instruction issue are what matter.
 #include <hip/hip_runtime.h>
 #include <type_traits>
