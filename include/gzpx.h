@@ -61,14 +61,14 @@ extern "C" {
 #define GZPX_FORMAT_MGZIP 1
 
 /* libdeflate behaviour pinned by Cargo.lock is 1.24; the image's binary oracle is 1.10.  The two
- * differ (for levels 1-4) only in how a Huffman code with no used symbol is emitted. */
+ * differ (for levels 1-9) only in how a Huffman code with no used symbol is emitted. */
 #define GZPX_COMPAT_LIBDEFLATE_1_24 0
 #define GZPX_COMPAT_LIBDEFLATE_1_10 1
 
 typedef struct gzpx_config {
     int device;                /* HIP device ordinal                                              */
     int format;                /* GZPX_FORMAT_*                                                   */
-    int level;                 /* flate2::Compression level (0..12 accepted by libdeflate)        */
+    int level;                 /* flate2::Compression level (0..12 accepted by libdeflate; 0..9 built) */
     int compat;                /* GZPX_COMPAT_*                                                   */
     size_t buffer_size;        /* ParCompressBuilder::buffer_size (65280 default for BGZF)        */
     size_t max_slab_bytes;     /* largest slab a single gzpx_compress_slab* call will be given    */
@@ -115,7 +115,7 @@ int gzpx_compress_slab_device(gzpx_ctx *ctx, const void *d_in, size_t in_len, in
  *
  *   gzpx_compress_slab_submit   enqueues the copy-in of `in` (page-locked memory makes it a DMA
  *                               transfer: gzpx_host_alloc) and every kernel of the slab, and returns
- *                               without waiting for the device at levels 0/1 (the match/parse rounds
+ *                               without waiting for the device at levels 0/1 and 5-9 (the match/parse rounds
  *                               of levels 2-4 read one word back per round).  GZPX_ERR_BUSY when all
  *                               slots are taken.  `in` and `out` must stay valid until the wait.
  *   gzpx_compress_slab_wait     blocks until that slab's kernels are done, copies exactly the
