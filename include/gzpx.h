@@ -61,7 +61,9 @@ extern "C" {
 #define GZPX_FORMAT_MGZIP 1
 
 /* libdeflate behaviour pinned by Cargo.lock is 1.24; the image's binary oracle is 1.10.  The two
- * differ (for levels 1-9) only in how a Huffman code with no used symbol is emitted. */
+ * differ (for levels 1-4) only in how a Huffman code with no used symbol is emitted and in
+ * min_len for scans shorter than 512 bytes; levels 5-9 are pinned against 1.10 only (no 1.24 binary or
+ * source here to compare the lazy parsers with), with the same two rules applied. */
 #define GZPX_COMPAT_LIBDEFLATE_1_24 0
 #define GZPX_COMPAT_LIBDEFLATE_1_10 1
 
