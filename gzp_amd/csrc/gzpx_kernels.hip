@@ -2197,13 +2197,32 @@ __device__ void make_code(HuffLds &h, uint32_t num_syms, uint32_t max_len, uint3
         wave_sync();
         return;
     }
-    // rank sort: used keys are distinct, unused keys (~0) rank after every used key
-    for (uint32_t base = 0; base < num_syms; base += 64) {
+    // Rank sort of the USED keys (distinct: the symbol is part of the key).  They are first packed to
+    // the front of key[] (ballot ranks; every chunk is read before anything is written), so the
+    // comparison loop runs over `used` keys and ceil(used / 64) chunks instead of num_syms and 5 --
+    // about a quarter of the comparisons for a typical literal/length alphabet (~130 of 286 used).
+    {
+        uint32_t at = 0;  // wave-uniform
+        uint32_t k0 = lane < num_syms ? h.key[lane] : 0xFFFFFFFFu;
+        for (uint32_t base = 0; base < num_syms; base += 64) {
+            // (the next chunk is read before this one is written: packed slots never run ahead of it)
+            const uint32_t s1 = base + 64 + lane;
+            const uint32_t k1 = s1 < num_syms ? h.key[s1] : 0xFFFFFFFFu;
+            wave_sync();
+            const bool u = k0 != 0xFFFFFFFFu;
+            const unsigned long long m = __ballot(u);
+            if (u) h.key[at + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = k0;
+            at += (uint32_t)__popcll(m);
+            k0 = k1;
+        }
+    }
+    wave_sync();
+    for (uint32_t base = 0; base < used; base += 64) {
         const uint32_t s = base + lane;
-        const uint32_t k = s < num_syms ? h.key[s] : 0xFFFFFFFFu;
+        const uint32_t k = s < used ? h.key[s] : 0u;  // (0: nothing counts as smaller)
         uint32_t rank = 0;
-        for (uint32_t j = 0; j < num_syms; j++) rank += h.key[j] < k ? 1u : 0u;
-        if (k != 0xFFFFFFFFu) {
+        for (uint32_t j = 0; j < used; j++) rank += h.key[j] < k ? 1u : 0u;
+        if (s < used) {
             h.sfreq[rank] = k >> 10;
             h.ssym[rank] = (uint16_t)(k & 1023u);
         }
