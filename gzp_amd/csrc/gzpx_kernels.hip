@@ -1322,16 +1322,17 @@ __global__ __launch_bounds__(1024) void k_match_hc(Config cfg, const uint8_t *__
 
 // ------------------------------------------------------------------------------------------
 // k_parse_hc: the greedy parse, token stream and sub-block boundaries of deflate_compress_greedy,
-// per block in tiles of 48 KiB positions.  Walkers / ranks / token build as in k_parse (a match
+// per block in tiles of 32 KiB positions.  Walkers / ranks / token build as in k_parse (a match
 // is flagged by a bit, because length 3 shares len8 == 0 with "literal").  A sub-block ends at
 //   - the 300000-byte soft limit (choose_max_block_end) or after 50000 matches, or
 //   - where should_end_block says so: every 512 tokens (once 5000 bytes are in and 5000 remain)
 //     the histogram of 10 observation classes since the last check is compared with the
 //     block's so far (do_end_block_check).
-// The checks are a short sequential recurrence over per-512-token class counts, which are
-// gathered in parallel.  When the sub-block that follows a boundary needs a different min_len,
-// the match results from there on are stale: the state is saved, `pending` is bumped and the
-// host runs another k_match_hc / k_parse_hc round for this block.
+// The class counts per 512-token bin are gathered in parallel and all checks of a tile evaluated side
+// by side from their prefix sums.  When the sub-block that follows a boundary needs a different
+// min_len, the "long enough" filter of the matches from there on was the wrong one: the state is
+// saved, `pending` is bumped and the host runs another k_parse_hc round for this block (k_match_hc's
+// results stand: they do not depend on min_len).
 // ------------------------------------------------------------------------------------------
 constexpr uint32_t kHpTile = 32768;  // (a BGZF block is two full tiles; ~50 KiB of LDS: three workgroups per CU.  48 KiB tiles: +0.3 ms per 550 MiB)
 constexpr uint32_t kHpGroups = kHpTile / 64;  // 512 groups / walk segments of 64 positions
