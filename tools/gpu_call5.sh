@@ -1,3 +1,4 @@
 cd $GRAFT_REPO_ROOT
-python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
-timeout 1500 python -m pytest tests -x -q -m gpu 2>&1 | grep -E "passed|failed|error" | tail -3
+mkdir -p gpurun_out
+python bench.py > gpurun_out/r2_bench_final.log 2>&1; tail -1 gpurun_out/r2_bench_final.log | python -c "
+import json,sys; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d['roofline']['frac'], d['roofline']['stage_ms']); print(d['e2e']); print(d['inflate']['value']); print({k:(v['MiBps'],v['ms_per_step']) for k,v in d['levels'].items()}); print(d['cpu_baseline']['value'])"
