@@ -139,7 +139,7 @@ class Env:
             self.dev = torch.device("cpu")
             self.device_index = 0
         else:
-            self.lib = _native.load()
+            self.lib = _native.GzpxLib(args.lib) if args.lib else _native.load()
             torch.cuda.set_device(self.local_rank)
             self.dev = torch.device("cuda", self.local_rank)
             self.device_index = self.local_rank
@@ -594,6 +594,10 @@ def main():
                          "mgzip3 = configs[2] (Mgzip 1 MiB blocks, level 3, 4 GiB ASCII); bgzf3 = the text slab at level 3")
     ap.add_argument("--level", type=int, default=3, help="--workload bgzf3: any built level (0-9) instead of 3")
     ap.add_argument("--emulate", action="store_true", help=argparse.SUPPRESS)  # tests: CPU emulator + gloo, no timing value
+    # development: A/B runs (gzpx_debug_set_flags: 2 = level 1 through the dense k_match / k_parse pair) and
+    # experiment builds of the library; the driver's line uses neither
+    ap.add_argument("--debug-flags", type=int, default=0, help=argparse.SUPPRESS)
+    ap.add_argument("--lib", default=None, help=argparse.SUPPRESS)
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -650,6 +654,8 @@ def main():
     nb = ctx.n_blocks(n)
     block_sizes = np.zeros(nb, dtype=np.uint32)
     ctx.set_profiling(True)
+    if args.debug_flags:
+        ctx.debug_set_flags(args.debug_flags)
     state = {"i": 0, "pending": None, "offsets": None}
 
     def step():
@@ -740,6 +746,7 @@ def main():
                     world, "" if world == 1 else
                     (" + ordered RCCL gather" if args.writeout == "rccl" else " + size all_gather, per-rank write-out")),
                 "verified_bit_exact_sample": bool(ok),
+                "blocks_handed_back_to_dense_kernels": ctx.debug_redo_count(),
                 "stream_sha256": hashlib.sha256(out_host).hexdigest(),
                 "device": ctx.device_name(),
             },

@@ -44,7 +44,7 @@ EXPORTS = [
     "gzpx_alloc_compressor", "gzpx_deflate_compress", "gzpx_deflate_compress_bound",
     "gzpx_free_compressor", "gzpx_compressor_set_compat", "gzpx_crc32",
     "gzpx_ctx_set_profiling", "gzpx_ctx_last_stage_ms", "gzpx_stage_name", "gzpx_debug_tokens",
-    "gzpx_debug_set_flags", "gzpx_strerror", "gzpx_device_name", "gzpx_version",
+    "gzpx_debug_set_flags", "gzpx_debug_redo_count", "gzpx_strerror", "gzpx_device_name", "gzpx_version",
     "gzpx_compress_slab_submit", "gzpx_compress_slab_submit_device", "gzpx_compress_slab_wait",
     "gzpx_compress_slab_event", "gzpx_crc32_checked", "gzpx_last_status",
     "gzpx_par_create", "gzpx_par_write", "gzpx_par_write_chunked", "gzpx_par_flush", "gzpx_par_finish", "gzpx_par_destroy",
@@ -141,6 +141,8 @@ class GzpxLib:
         L.gzpx_debug_tokens.argtypes = [vp, sz, vp, sz, psz, vp, psz]
         L.gzpx_debug_set_flags.restype = i32
         L.gzpx_debug_set_flags.argtypes = [vp, u32]
+        L.gzpx_debug_redo_count.restype = i32
+        L.gzpx_debug_redo_count.argtypes = [vp, ctypes.POINTER(ctypes.c_uint32)]
         pu64 = ctypes.POINTER(ctypes.c_uint64)
         L.gzpx_compress_slab_submit.restype = i32
         L.gzpx_compress_slab_submit.argtypes = [vp, vp, sz, i32, vp, sz, pu64]
@@ -368,6 +370,12 @@ class Context:
 
     def debug_set_flags(self, flags):
         self.lib.check(self.lib.L.gzpx_debug_set_flags(self.h, flags))
+
+    def debug_redo_count(self):
+        """Level 1: blocks of the last batch that k_mparse handed back to the dense kernels."""
+        c = ctypes.c_uint32(0)
+        self.lib.check(self.lib.L.gzpx_debug_redo_count(self.h, ctypes.byref(c)))
+        return c.value
 
     def submit(self, in_ptr, in_len, out_ptr, out_cap, mode=SLAB_LAST):
         """gzpx_compress_slab_submit on raw host pointers (page-locked for DMA overlap); returns the

@@ -169,6 +169,8 @@ int alloc_scratch(gzpx_ctx *ctx) {
     HIP_TRY(hipMalloc((void **)&s.which, nb * (size_t)(c.stride / 32) * 4));
     HIP_TRY(hipMalloc((void **)&s.alt, nb * (size_t)c.stride * sizeof(uint16_t)));
     HIP_TRY(hipMalloc((void **)&s.tok, nb * (size_t)c.stride * 4));
+    HIP_TRY(hipMalloc((void **)&s.redo, (nb + 1) * sizeof(uint32_t)));
+    HIP_TRY(hipMemset(s.redo, 0, sizeof(uint32_t)));
     if (c.level >= 2) {  // hc_matchfinder levels: hash4 chain links + per-block parse state
         HIP_TRY(hipMalloc((void **)&s.d4, nb * (size_t)c.stride * sizeof(uint16_t)));
         HIP_TRY(hipMalloc((void **)&s.hc, nb * sizeof(HcState)));
@@ -206,6 +208,7 @@ void free_scratch(gzpx_ctx *ctx) {
     if (ctx->h_sub) (void)hipHostFree(ctx->h_sub);
     if (s.cand) (void)hipFree(s.cand);
     if (s.tok) (void)hipFree(s.tok);
+    if (s.redo) (void)hipFree(s.redo);
     if (s.len8) (void)hipFree(s.len8);
     if (s.which) (void)hipFree(s.which);
     if (s.alt) (void)hipFree(s.alt);
@@ -403,7 +406,9 @@ int submit_locked(gzpx_ctx *ctx, const uint8_t *host_in, const uint8_t *d_in, si
         d_in = sl.d_in;
         d_out = sl.d_out;
         out_cap = sl.d_out_cap;
-    } else if (after && after != stream) {  // the slab is ready once `after` has reached this point
+    } else if (after != stream) {  // the slab is ready once `after` has reached this point; NULL is the
+        // legacy default stream (PyTorch's current stream unless told otherwise) -- the context's
+        // streams are non-blocking, so nothing orders them behind it implicitly
         HIP_TRY(hipEventRecord(ctx->ev_dep, after));
         HIP_TRY(hipStreamWaitEvent(stream, ctx->ev_dep, 0));
     }
@@ -1142,7 +1147,7 @@ int dsubmit_locked(gzpx_dctx *c, const uint8_t *host_in, const uint8_t *d_in, si
             HIP_TRY(hipMemcpyAsync(sl.d_in, host_in, in_len, hipMemcpyHostToDevice, c->s_h2d));
             d_in = sl.d_in;
             d_out = sl.d_out;
-        } else if (after && after != stream) {
+        } else if (after != stream) {  // (NULL = the legacy default stream, as on the compress side)
             HIP_TRY(hipEventRecord(c->ev_dep, after));
             HIP_TRY(hipStreamWaitEvent(stream, c->ev_dep, 0));
         }
@@ -1202,6 +1207,7 @@ int dwait_ticket(gzpx_dctx *c, uint64_t ticket, size_t *out_len, gzpx_check_info
                 int err = GZPX_OK;
                 if (d.status == 1) err = GZPX_ERR_BAD_DATA;
                 else if (d.status == 2) err = GZPX_ERR_INSUFFICIENT_SPACE;
+                else if (d.status != 0) err = GZPX_ERR_BAD_DATA;  // 3: fewer bytes than ISIZE (libdeflate SHORT_OUTPUT)
                 else if (sl.h_crc[b] != d.crc) err = GZPX_ERR_INVALID_CHECK;
                 if (err != GZPX_OK) {
                     if (info) {
@@ -1472,6 +1478,15 @@ int gzpx_debug_tokens(gzpx_ctx *ctx, size_t block, uint32_t *tokens, size_t max_
 int gzpx_debug_set_flags(gzpx_ctx *ctx, uint32_t flags) {
     if (!ctx) return GZPX_ERR_INVALID_ARG;
     ctx->dcfg.debug = flags;
+    return GZPX_OK;
+}
+
+int gzpx_debug_redo_count(gzpx_ctx *ctx, uint32_t *count) {
+    if (!ctx || !count || ctx->crc_only) return GZPX_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    if (hipSetDevice(ctx->cfg.device) != hipSuccess) return GZPX_ERR_DEVICE;
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    HIP_TRY(hipMemcpy(count, ctx->scratch.redo, sizeof(uint32_t), hipMemcpyDeviceToHost));
     return GZPX_OK;
 }
 

@@ -84,7 +84,9 @@ struct Config {
     uint32_t compat;      // 0: libdeflate >= 1.1x Huffman rule, 1: libdeflate 1.10
     uint32_t block_size;  // buffer_size of the reference's builder
     uint32_t xfl;         // gzip XFL byte derived from level (src/bgzf.rs:278-284)
-    uint32_t debug;       // diagnostics only: bit 0 = force k_candidates_safe on every block
+    uint32_t debug;       // diagnostics only: bit 0 = force k_candidates_safe on every block, bit 1 =
+                          // level 1 through the dense k_match / k_parse pair instead of k_mparse, bit 2 =
+                          // k_mparse hands every block back (exercises the redo list)
     uint32_t stride;      // per-block stride (positions) of cand / len8 / alt / tok: >= block_size + 1024
     uint32_t max_sub;     // per-block capacity of sub / hist / codes / hdr (sub-blocks >= 32768 bytes)
     uint32_t passthrough; // n <= 55 - 4*level is emitted as stored blocks only (deflate_compress_none)
@@ -107,6 +109,7 @@ struct Scratch {
     HcState *hc;          // [nb]                levels 2-4: parse state
     uint32_t *pending;    // [1]                 levels 2-4: blocks that need another round
     uint32_t *tok;        // [nb][stride]        worst case one token per byte
+    uint32_t *redo;       // [1 + nb]            level 1: blocks k_mparse hands back to k_match / k_parse
     uint32_t *hist;       // [nb][max_sub][kHistStride]
     uint32_t *codes;      // [nb][max_sub][kCodeWords]
     uint32_t *hdr;        // [nb][max_sub][kHdrWords]

@@ -490,16 +490,14 @@ __device__ __forceinline__ uint32_t lds_extend(const uint32_t *in_w, uint32_t a,
     return len < max_len ? len : max_len;
 }
 
-__global__ __launch_bounds__(kMpThreads, 8) void k_match(Config cfg, const uint8_t *__restrict__ slab,
-                                                      BlockMeta *__restrict__ meta_all,
-                                                      const uint16_t *__restrict__ cand_all,
-                                                      uint8_t *__restrict__ len8_all,
-                                                      uint32_t *__restrict__ nz_all,
-                                                      uint16_t *__restrict__ val_all) {
+__device__ __forceinline__ void match_block(const Config &cfg, const uint8_t *__restrict__ slab,
+                                            BlockMeta *__restrict__ meta_all,
+                                            const uint16_t *__restrict__ cand_all,
+                                            uint8_t *__restrict__ len8_all, uint32_t *__restrict__ nz_all,
+                                            uint16_t *__restrict__ val_all, const uint32_t b) {
     __shared__ uint32_t in_w[kInWords];  // window bytes (+ lead misalignment, + pad)
     __shared__ uint32_t run_mode;        // sticky: some wave of this block has met a long run
     const uint32_t tid = threadIdx.x;
-    const uint32_t b = blockIdx.x;
     BlockMeta *meta = meta_all + b;
     const uint32_t n = meta->n;
     if (n <= cfg.passthrough) return;  // uniform for the workgroup
@@ -692,12 +690,38 @@ __global__ __launch_bounds__(kMpThreads, 8) void k_match(Config cfg, const uint8
                 }
             }
         };
-        for (uint32_t p0 = tile_begin + tid; p0 < tile_end; p0 += 4 * kMpThreads) {
+        // (whole waves: the step's ballots and the uniform read below want every lane of a wave
+        // that has a position in range; positions past tile_end do nothing)
+        for (uint32_t p0 = tile_begin + tid; p0 - (tid & 63u) < tile_end; p0 += 4 * kMpThreads) {
             if (uniform(__hip_atomic_load(&run_mode, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) != 0)
                 step(p0, std::true_type{});
             else
                 step(p0, std::false_type{});
         }
+    }
+}
+
+// Which blocks a dense level-1 kernel (k_match, k_parse) works on: every block of the batch (`redo`
+// null, grid = nb: blocks larger than one tile take this path), or the blocks that k_mparse handed
+// back (`redo[0]` = how many, `redo[1..]` = which; a small grid strides over the list).
+__device__ __forceinline__ uint32_t dense_count(const uint32_t *__restrict__ redo, uint32_t nb) {
+    return redo ? redo[0] : nb;
+}
+__device__ __forceinline__ uint32_t dense_block(const uint32_t *__restrict__ redo, uint32_t i) {
+    return redo ? redo[1 + i] : i;
+}
+
+__global__ __launch_bounds__(kMpThreads, 8) void k_match(Config cfg, const uint8_t *__restrict__ slab,
+                                                      BlockMeta *__restrict__ meta_all,
+                                                      const uint16_t *__restrict__ cand_all,
+                                                      uint8_t *__restrict__ len8_all,
+                                                      uint32_t *__restrict__ nz_all,
+                                                      uint16_t *__restrict__ val_all, uint32_t nb,
+                                                      const uint32_t *__restrict__ redo) {
+    const uint32_t cnt = dense_count(redo, nb);
+    for (uint32_t i = blockIdx.x; i < cnt; i += gridDim.x) {
+        match_block(cfg, slab, meta_all, cand_all, len8_all, nz_all, val_all, dense_block(redo, i));
+        __syncthreads();  // the next block of this workgroup reuses the LDS window
     }
 }
 
@@ -745,11 +769,11 @@ __device__ __forceinline__ uint32_t sub_limit_of(uint32_t start, uint32_t n) {
 constexpr uint32_t kPSeg = 64;  // positions per walk segment = one 64-bit word of the token bitmap
 constexpr uint32_t kRescueTokens = 512;
 
-__global__ __launch_bounds__(kMpThreads, 8) void k_parse(
-    Config cfg, const uint8_t *__restrict__ slab, BlockMeta *__restrict__ meta_all,
+__device__ __forceinline__ void parse_block(
+    const Config &cfg, const uint8_t *__restrict__ slab, BlockMeta *__restrict__ meta_all,
     SubMeta *__restrict__ sub_all, const uint8_t *__restrict__ len8_all,
     const uint32_t *__restrict__ nz_all, const uint16_t *__restrict__ val_all,
-    uint32_t *__restrict__ tok_all) {
+    uint32_t *__restrict__ tok_all, const uint32_t b) {
     __shared__ uint32_t len8_w[kTile / 4];                 // 0 = literal, else match length - 3 (bytes)
     __shared__ unsigned long long tok_bits[kTile / 64];    // 1 = a token starts here (tile-relative)
     __shared__ uint32_t rank_pre[kTile / 64];  // phase 2: exit of segment s; phase 3: (tokens |
@@ -762,7 +786,6 @@ __global__ __launch_bounds__(kMpThreads, 8) void k_parse(
     uint32_t *seg_exit = rank_pre;
 
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    const uint32_t b = blockIdx.x;
     BlockMeta *meta = meta_all + b;
     SubMeta *sub = sub_all + (uint64_t)b * cfg.max_sub;
     const uint32_t n = meta->n;
@@ -1010,6 +1033,337 @@ __global__ __launch_bounds__(kMpThreads, 8) void k_parse(
         sub[cur_sub].byte_len = n - sub_start;
         sub[cur_sub].is_final = 1;
         meta->ntok = tok_carry;
+        meta->nsub = cur_sub + 1;
+    }
+}
+
+__global__ __launch_bounds__(kMpThreads, 8) void k_parse(
+    Config cfg, const uint8_t *__restrict__ slab, BlockMeta *__restrict__ meta_all,
+    SubMeta *__restrict__ sub_all, const uint8_t *__restrict__ len8_all,
+    const uint32_t *__restrict__ nz_all, const uint16_t *__restrict__ val_all,
+    uint32_t *__restrict__ tok_all, uint32_t nb, const uint32_t *__restrict__ redo) {
+    const uint32_t cnt = dense_count(redo, nb);
+    for (uint32_t i = blockIdx.x; i < cnt; i += gridDim.x) {
+        parse_block(cfg, slab, meta_all, sub_all, len8_all, nz_all, val_all, tok_all, dense_block(redo, i));
+        __syncthreads();  // the next block of this workgroup reuses the LDS arrays
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// k_mparse: level 1, blocks of at most one tile -- k_match and k_parse fused into "match on demand".
+// libdeflate's deflate_compress_fastest calls ht_matchfinder_longest_match only where a token
+// starts (about a quarter of the positions of text); k_match searches EVERY position because the
+// parse is not known yet, and hands len8 / val / the bitmap to k_parse through HBM.  Here the
+// speculative segment walk of k_parse does the searching itself:
+//   phase 1  thread s walks the 64 positions of segment s from an entry position and runs
+//            longest_match (both bucket candidates from `cand`, bytes out of the LDS window) at every
+//            position it lands on; what it keeps is three 64-bit registers (token starts, "is a
+//            match", "the older candidate won") and its exit.  Entries are corrected round by round
+//            as in k_parse; a re-walk that lands on a token start of the previous walk has
+//            re-synchronised and keeps the rest of that walk (no second search).
+//   phase 2  token / match counts per segment -> one workgroup scan.
+//   phase 3  token build by the wave that OWNS the segments (their masks come out of its own
+//            registers by v_readlane): lane = position, length = distance to the next token start,
+//            distance = d0 or d0 + cand[p - d0], literals from the LDS window; sub-block boundaries
+//            (8192 matches) as in k_parse.
+// LDS: the block's bytes + one exit word per segment (~70 KiB, two workgroups per CU).  Nothing
+// but tokens goes to HBM.  A block whose entries have not settled after kMpMaxRounds rounds (long
+// runs: every 258-byte match shifts the phase of the segments behind it) is handed back to the
+// dense kernels through the `redo` list -- the cooperative run logic lives there.
+// ------------------------------------------------------------------------------------------
+constexpr uint32_t kMpMaxRounds = 10;
+
+// ht_matchfinder_longest_match at block position p (block byte i sits at LDS byte i + mis).
+// Returns the match length (0 = none); `older` = the bucket's older entry won.
+__device__ __forceinline__ uint32_t l1_search(const uint32_t *in_w, const uint16_t *__restrict__ cand,
+                                              uint32_t p, uint32_t n, uint32_t mis, bool &older) {
+    older = false;
+    const uint32_t d0 = p + 5 <= n ? cand[p] : 0u;
+    if (!d0) return 0;
+    const uint32_t r = cand[p - d0];
+    const uint32_t d1 = (r && d0 + r <= 32767u) ? d0 + r : 0u;
+    const uint32_t rem = n - p;
+    const uint32_t max_len = rem < 258u ? rem : 258u;
+    const uint32_t nice_len = max_len < 32u ? max_len : 32u;
+    const uint32_t a = p + mis;
+    const uint32_t c0 = a - d0, c1 = a - (d1 ? d1 : d0);
+    const uint32_t *pa = in_w + (a >> 2), *p0 = in_w + (c0 >> 2), *p1 = in_w + (c1 >> 2);
+    uint32_t lo_a = pa[0], hi_a = pa[1], lo_0 = p0[0], hi_0 = p0[1], lo_1 = p1[0], hi_1 = p1[1];
+    const uint32_t seq = __builtin_amdgcn_alignbyte(hi_a, lo_a, a & 3u);
+    bool act0 = __builtin_amdgcn_alignbyte(hi_0, lo_0, c0 & 3u) == seq;
+    bool act1 = d1 != 0 && __builtin_amdgcn_alignbyte(hi_1, lo_1, c1 & 3u) == seq;
+    uint32_t len0 = act0 ? max_len : 0u, len1 = act1 ? max_len : 0u;  // still matching => max_len
+    for (uint32_t off = 4; (act0 || act1) && off < max_len; off += 4) {
+        const uint32_t j = (off >> 2) + 1;
+        lo_a = hi_a;
+        hi_a = pa[j];
+        lo_0 = hi_0;
+        hi_0 = p0[j];
+        lo_1 = hi_1;
+        hi_1 = p1[j];
+        const uint32_t own = __builtin_amdgcn_alignbyte(hi_a, lo_a, a & 3u);
+        const uint32_t x0 = own ^ __builtin_amdgcn_alignbyte(hi_0, lo_0, c0 & 3u);
+        const uint32_t x1 = own ^ __builtin_amdgcn_alignbyte(hi_1, lo_1, c1 & 3u);
+        if (act0 && x0) {
+            len0 = off + ((uint32_t)(__ffs((int)x0) - 1) >> 3);
+            act0 = false;
+        }
+        if (act1 && x1) {
+            len1 = off + ((uint32_t)(__ffs((int)x1) - 1) >> 3);
+            act1 = false;
+        }
+    }
+    if (len0 > max_len) len0 = max_len;
+    if (len1 > max_len) len1 = max_len;
+    uint32_t best = len0;
+    if (best < nice_len && len1 > best) {  // the older candidate won
+        best = len1;
+        older = true;
+    }
+    return best;
+}
+
+__device__ __forceinline__ unsigned long long rdlane64(unsigned long long v, uint32_t l) {
+    return ((unsigned long long)rdlane((uint32_t)(v >> 32), l) << 32) | rdlane((uint32_t)v, l);
+}
+
+__global__ __launch_bounds__(kMpThreads, 8) void k_mparse(
+    Config cfg, const uint8_t *__restrict__ slab, BlockMeta *__restrict__ meta_all,
+    SubMeta *__restrict__ sub_all, const uint16_t *__restrict__ cand_all, uint32_t *__restrict__ tok_all,
+    uint32_t *__restrict__ redo) {
+    __shared__ uint32_t in_w[kInWords];    // the block's bytes (+ lead misalignment, + pad)
+    __shared__ uint32_t seg_exit[kMpThreads];  // where the walk of segment s leaves it
+    __shared__ uint32_t wsum_t[kMpWaves], wsum_m[kMpWaves];
+    __shared__ unsigned long long bnd;  // (position << 32 | token index) of the sub-block boundary
+    __shared__ uint32_t bnd_mat;        // matches before that boundary
+
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t b = blockIdx.x;
+    BlockMeta *meta = meta_all + b;
+    SubMeta *sub = sub_all + (uint64_t)b * cfg.max_sub;
+    const uint32_t n = meta->n;
+    if (n <= cfg.passthrough) return;  // uniform for the workgroup
+    const uint8_t *in = slab + (uint64_t)b * cfg.block_size;
+    const uint16_t *cand = cand_all + (uint64_t)b * cfg.stride;
+    uint32_t *tok = tok_all + (uint64_t)b * cfg.stride;
+    const uint32_t mis = (uint32_t)((uintptr_t)in & 3u);
+
+    {   // stage the block (n <= kTile): 16 bytes per load, four loads per thread in flight
+        const uint32_t *src = (const uint32_t *)(in - mis);
+        const uint32_t ndw = (mis + n + 3) >> 2;
+        const dword4 *src4 = (const dword4 *)src;
+        dword4 *dst4 = (dword4 *)in_w;
+        const uint32_t nq = ndw >> 2;
+        for (uint32_t q0 = 0; q0 < nq; q0 += 4 * kMpThreads) {
+            dword4 v[4];
+#pragma unroll
+            for (uint32_t k = 0; k < 4; k++) {
+                const uint32_t q = q0 + tid + k * kMpThreads;
+                v[k] = src4[q < nq ? q : nq - 1];
+            }
+#pragma unroll
+            for (uint32_t k = 0; k < 4; k++) {
+                GZPX_PIN_VGPR(v[k].x);
+                GZPX_PIN_VGPR(v[k].y);
+                GZPX_PIN_VGPR(v[k].z);
+                GZPX_PIN_VGPR(v[k].w);
+            }
+#pragma unroll
+            for (uint32_t k = 0; k < 4; k++) {
+                const uint32_t q = q0 + tid + k * kMpThreads;
+                if (q < nq) dst4[q] = v[k];
+            }
+        }
+        for (uint32_t i = 4 * nq + tid; i < ndw; i += kMpThreads) in_w[i] = src[i];
+        for (uint32_t i = ndw + tid; i < ndw + 3 && i < kInWords; i += kMpThreads) in_w[i] = 0;
+        if (tid == 0) bnd = ~0ull;
+    }
+    __syncthreads();
+
+    // ---- phase 1: the greedy parse as a speculative segment walk that searches where it lands
+    const uint32_t seg_begin = tid * kPSeg;
+    const bool active = seg_begin < n;
+    const uint32_t seg_end = active ? (seg_begin + kPSeg < n ? seg_begin + kPSeg : n) : 0;
+    unsigned long long marks = 0, mbits = 0, wbits = 0;  // token starts / matches / older candidate won
+    uint32_t my_exit = seg_begin;
+    bool have_old = false;
+    auto walk = [&](uint32_t pos) {
+        const unsigned long long o_marks = marks, o_mbits = mbits, o_wbits = wbits;
+        marks = mbits = wbits = 0;
+        while (pos < seg_end) {
+            const unsigned long long bit = 1ull << (pos - seg_begin);
+            if (have_old && (o_marks & bit)) {
+                // landed on a token start of the previous walk: from here on the two walks are one
+                const unsigned long long keep = ~(bit - 1ull);
+                marks |= o_marks & keep;
+                mbits |= o_mbits & keep;
+                wbits |= o_wbits & keep;
+                pos = my_exit;
+                break;
+            }
+            bool older;
+            const uint32_t len = l1_search(in_w, cand, pos, n, mis, older);
+            marks |= bit;
+            if (len) mbits |= bit;
+            if (older) wbits |= bit;
+            pos += len ? len : 1u;
+        }
+        my_exit = pos;
+        have_old = true;
+    };
+    uint32_t entry = seg_begin;  // thread 0 knows the true entry (0); the others guess
+    if (active) {
+        walk(entry);
+        seg_exit[tid] = my_exit;
+    }
+    bool settled = true;
+    for (uint32_t round = 0;; round++) {
+        __syncthreads();
+        uint32_t new_entry = entry;
+        if (active && tid > 0) new_entry = seg_exit[tid - 1];
+        const bool changed = new_entry != entry;
+        if (!__syncthreads_or(changed)) break;  // (also: every exit has been read before one is rewritten)
+        if (round >= kMpMaxRounds) {
+            settled = false;
+            break;
+        }
+        if (changed) {
+            entry = new_entry;
+            walk(entry);
+            seg_exit[tid] = my_exit;
+        }
+    }
+    if (!settled || (cfg.debug & 4u)) {  // uniform: the dense kernels take this block (debug bit 2: every block)
+        if (tid == 0) redo[1u + atomicAdd(&redo[0], 1u)] = b;
+        return;
+    }
+
+    // ---- phase 2: tokens / matches before every segment (one workgroup scan)
+    uint32_t tile_tok, tile_mat, my_pre;
+    {
+        const uint32_t vt = (uint32_t)__popcll(marks), vm = (uint32_t)__popcll(mbits);
+        const uint32_t it = wave_incl_add(vt), im = wave_incl_add(vm);
+        if (lane == 63) {
+            wsum_t[wave] = it;
+            wsum_m[wave] = im;
+        }
+        __syncthreads();
+        uint32_t bt = 0, bm = 0, tt = 0, tm = 0;
+        for (uint32_t w = 0; w < kMpWaves; w++) {
+            const uint32_t st = wsum_t[w], sm = wsum_m[w];
+            if (w < wave) {
+                bt += st;
+                bm += sm;
+            }
+            tt += st;
+            tm += sm;
+        }
+        tile_tok = uniform(tt);
+        tile_mat = uniform(tm);
+        // exclusive prefixes: tokens <= 65536 fit 17 bits, matches <= 16384 fit 15 bits
+        my_pre = (bt + it - vt) | ((bm + im - vm) << 17);
+    }
+
+    // ---- phase 3: token build, lane = position of a segment this wave owns
+    uint32_t cur_sub = 0, sub_start = 0, sub_start_tok = 0, sub_start_mat = 0;
+    uint32_t sub_limit = sub_limit_of(0, n);
+    const uint32_t ngroups = (n + 63) / 64;
+    const unsigned long long lane_below = (1ull << lane) - 1ull;
+    const uint8_t *in_b = (const uint8_t *)in_w + mis;
+    bool build = true;
+    for (;;) {
+        // 8 segments per step: the d0 loads of all of them, then the gathers of the lanes whose
+        // older candidate won, then every token word, then the stores (loads and stores share one
+        // counter on gfx9: a loaded value consumed behind a pending store drains the stores first)
+        for (uint32_t j0 = 0; j0 < 64 && wave * 64 + j0 < ngroups; j0 += 8) {
+            uint32_t vals[8], tis[8];
+#pragma unroll
+            for (uint32_t k = 0; k < 8; k++) {
+                const uint32_t j = j0 + k;
+                const unsigned long long mm = rdlane64(mbits, j);
+                const uint32_t p = (wave * 64 + j) * 64 + lane;
+                vals[k] = (build && ((mm >> lane) & 1ull)) ? cand[p] : 0u;
+            }
+            __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+#pragma unroll
+            for (uint32_t k = 0; k < 8; k++) {
+                const uint32_t j = j0 + k;
+                const unsigned long long mw = rdlane64(wbits, j);
+                const uint32_t p = (wave * 64 + j) * 64 + lane;
+                tis[k] = (build && ((mw >> lane) & 1ull)) ? cand[p - vals[k]] : 0u;
+            }
+            __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+#pragma unroll
+            for (uint32_t k = 0; k < 8; k++) {
+                const uint32_t j = j0 + k;
+                const uint32_t g = wave * 64 + j;
+                const uint32_t dist = vals[k] + tis[k];
+                tis[k] = 0xFFFFFFFFu;
+                if (g >= ngroups) continue;  // wave-uniform
+                const unsigned long long mt = rdlane64(marks, j), mm = rdlane64(mbits, j);
+                const uint32_t pre = rdlane(my_pre, j), ex = rdlane(my_exit, j);
+                const uint32_t mat_after = (pre >> 17) + (uint32_t)__popcll(mm);
+                const bool count_rule = mat_after - sub_start_mat >= kSeqPerSub;  // wave-uniform, rare
+                const uint32_t p = g * 64 + lane;
+                if (!((mt >> lane) & 1ull)) continue;
+                const uint32_t ti = (pre & 0x1FFFFu) + (uint32_t)__popcll(mt & lane_below);
+                // sub-block boundary: this token would start past the soft limit, or 8192 matches
+                // precede it in the current sub-block (src: deflate_compress_fastest)
+                bool boundary = p >= sub_limit;
+                if (count_rule) {
+                    const uint32_t mi = (pre >> 17) + (uint32_t)__popcll(mm & lane_below);
+                    boundary = boundary || mi - sub_start_mat >= kSeqPerSub;
+                }
+                if (p > sub_start && boundary) atomicMin(&bnd, ((unsigned long long)p << 32) | ti);
+                if (!build) continue;
+                if ((mm >> lane) & 1ull) {
+                    // the match ends where the next token starts: the next mark, or the segment's exit
+                    const unsigned long long above = lane < 63u ? mt >> (lane + 1u) : 0ull;
+                    const uint32_t len = above ? (uint32_t)__ffsll((long long)above) : ex - p;
+                    vals[k] = kTokMatch | (dist << 9) | len;
+                } else {
+                    vals[k] = in_b[p];
+                }
+                tis[k] = ti;
+            }
+            if (build) {
+#pragma unroll
+                for (uint32_t k = 0; k < 8; k++)
+                    if (tis[k] != 0xFFFFFFFFu) tok[tis[k]] = vals[k];
+            }
+        }
+        __syncthreads();
+        const unsigned long long bv = bnd;
+        if (bv == ~0ull) break;  // the current sub-block runs to the end of the block
+        const uint32_t bp = uniform((uint32_t)(bv >> 32)), bti = uniform((uint32_t)bv);
+        if (tid == (bp >> 6))  // the owner of the boundary's segment: matches before the boundary token
+            bnd_mat = (my_pre >> 17) + (uint32_t)__popcll(mbits & ((1ull << (bp & 63u)) - 1ull));
+        __syncthreads();
+        const uint32_t bm = uniform(bnd_mat);
+        if (tid == 0) {
+            sub[cur_sub].tok_begin = sub_start_tok;
+            sub[cur_sub].tok_end = bti;
+            sub[cur_sub].byte_begin = sub_start;
+            sub[cur_sub].byte_len = bp - sub_start;
+            sub[cur_sub].is_final = 0;
+            bnd = ~0ull;
+        }
+        cur_sub++;
+        sub_start = bp;
+        sub_start_tok = bti;
+        sub_start_mat = bm;
+        sub_limit = sub_limit_of(bp, n);
+        __syncthreads();
+        if (tile_mat - bm < kSeqPerSub && sub_limit >= n) break;  // no further boundary in this block
+        build = false;
+    }
+    if (tid == 0) {
+        sub[cur_sub].tok_begin = sub_start_tok;
+        sub[cur_sub].tok_end = tile_tok;
+        sub[cur_sub].byte_begin = sub_start;
+        sub[cur_sub].byte_len = n - sub_start;
+        sub[cur_sub].is_final = 1;
+        meta->ntok = tile_tok;
         meta->nsub = cur_sub + 1;
     }
 }
@@ -3977,16 +4331,32 @@ void launch_candidates(const Config &cfg, const uint8_t *slab, uint64_t, uint32_
     }
 }
 
+// Level 1.  Blocks of at most one tile (every BGZF block): k_mparse, match on demand, and the dense
+// pair k_match / k_parse over the blocks it handed back (normally none: two small launches that
+// find an empty list).  Larger blocks, or Config.debug bit 1: the dense pair over every block.
+bool level1_fused(const Config &cfg) { return cfg.block_size <= kTile && !(cfg.debug & 2u); }
+
 void launch_match(const Config &cfg, const uint8_t *slab, uint64_t, uint32_t nb, const Scratch &s,
                   hipStream_t stream) {
-    hipLaunchKernelGGL(k_match, dim3(nb), dim3(kMpThreads), 0, stream, cfg, slab, s.meta,
-                       (const uint16_t *)s.cand, s.len8, s.which, s.alt);
+    const bool fused = level1_fused(cfg);
+    if (fused) {
+        (void)hipMemsetAsync(s.redo, 0, sizeof(uint32_t), stream);
+        hipLaunchKernelGGL(k_mparse, dim3(nb), dim3(kMpThreads), 0, stream, cfg, slab, s.meta, s.sub,
+                           (const uint16_t *)s.cand, s.tok, s.redo);
+    }
+    const uint32_t grid = fused ? (nb < 512u ? nb : 512u) : nb;
+    hipLaunchKernelGGL(k_match, dim3(grid), dim3(kMpThreads), 0, stream, cfg, slab, s.meta,
+                       (const uint16_t *)s.cand, s.len8, s.which, s.alt, nb,
+                       fused ? (const uint32_t *)s.redo : (const uint32_t *)nullptr);
 }
 
 void launch_parse(const Config &cfg, const uint8_t *slab, uint64_t, uint32_t nb, const Scratch &s,
                   hipStream_t stream) {
-    hipLaunchKernelGGL(k_parse, dim3(nb), dim3(kMpThreads), 0, stream, cfg, slab, s.meta, s.sub,
-                       (const uint8_t *)s.len8, (const uint32_t *)s.which, (const uint16_t *)s.alt, s.tok);
+    const bool fused = level1_fused(cfg);
+    const uint32_t grid = fused ? (nb < 512u ? nb : 512u) : nb;
+    hipLaunchKernelGGL(k_parse, dim3(grid), dim3(kMpThreads), 0, stream, cfg, slab, s.meta, s.sub,
+                       (const uint8_t *)s.len8, (const uint32_t *)s.which, (const uint16_t *)s.alt, s.tok, nb,
+                       fused ? (const uint32_t *)s.redo : (const uint32_t *)nullptr);
 }
 
 void launch_hc_round(const Config &cfg, const uint8_t *slab, uint32_t nb, const Scratch &s, int first,

@@ -296,8 +296,12 @@ int gzpx_debug_tokens(gzpx_ctx *ctx, size_t block, uint32_t *tokens, size_t max_
                       size_t *n_tokens, uint32_t *sub_first_token, size_t *n_sub);
 
 /* Diagnostics switches (0 in production): bit 0 = run the order-independent candidate kernel
- * (k_candidates_safe) on every block instead of the atomic-chain kernel. */
+ * (k_candidates_safe) on every block instead of the atomic-chain kernel; bit 1 = level 1 through the
+ * dense k_match / k_parse pair instead of the match-on-demand kernel k_mparse; bit 2 = k_mparse
+ * hands every block back to the dense pair (exercises the redo list). */
 int gzpx_debug_set_flags(gzpx_ctx *ctx, uint32_t flags);
+/* Level 1: how many blocks of the last batch k_mparse handed back to the dense kernels. */
+int gzpx_debug_redo_count(gzpx_ctx *ctx, uint32_t *count);
 
 /* HIP-event duration of k_inflate in the last decompress launch of this context */
 int gzpx_dctx_last_inflate_ms(gzpx_dctx *ctx, float *ms);

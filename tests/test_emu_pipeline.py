@@ -45,6 +45,33 @@ def test_classes_vs_oracle(ctx10, ctx24, oracle, cls):
             assert got == want, (cls, n, compat)
 
 
+@pytest.mark.parametrize("flags", [2, 4])
+def test_level1_dense_and_handed_back_paths(emu_lib, oracle, flags):
+    """Level 1 has three routes to the same tokens: k_mparse (match on demand, the default), the dense
+    k_match / k_parse pair over every block (debug bit 1: what blocks above 64 KiB take), and k_mparse
+    handing blocks back to the dense pair through the redo list (debug bit 2 forces it for every block)."""
+    with _native.Context(level=1, compat=_native.COMPAT_1_10, lib=emu_lib, max_slab_bytes=3 * 65280) as c:
+        c.debug_set_flags(flags)
+        for cls in sorted(synth.CLASSES):
+            for n in (100, 5000, 65280, 2 * 65280 + 4321):
+                a = synth.make(cls, n, 7 + n)
+                assert c.compress_slab(a, True) == oracle.compress_stream(a, oracle.FMT_BGZF, 1, oracle.COMPAT_1_10,
+                                                                          65280), (cls, n, flags)
+                if flags == 4:
+                    assert c.debug_redo_count() == (n + 65279) // 65280
+
+
+def test_level1_on_demand_keeps_text_and_hands_back_long_runs(emu_lib, oracle):
+    """k_mparse settles on text-like data (no block goes to the dense kernels); long runs shift the
+    phase of the walk segments by one per round and are handed back -- with the same stream either way."""
+    with _native.Context(level=1, compat=_native.COMPAT_1_10, lib=emu_lib, max_slab_bytes=3 * 65280) as c:
+        for cls, expect_redo in (("text", False), ("fastq", False), ("dna", False), ("random", False),
+                                 ("zeros", True), ("period2", True)):
+            a = synth.make(cls, 3 * 65280, 5)
+            assert c.compress_slab(a, True) == oracle.compress_stream(a, oracle.FMT_BGZF, 1, oracle.COMPAT_1_10, 65280)
+            assert (c.debug_redo_count() > 0) == expect_redo, (cls, c.debug_redo_count())
+
+
 def test_tokens_match_oracle(ctx10, oracle):
     a = synth.repeated_phrases(65280, 3)
     ctx10.compress_slab(a, True)
