@@ -1187,7 +1187,10 @@ int dsubmit_locked(gzpx_dctx *c, const uint8_t *host_in, const uint8_t *d_in, si
     return GZPX_OK;
 }
 
-int dwait_ticket(gzpx_dctx *c, uint64_t ticket, size_t *out_len, gzpx_check_info *info) {
+// `short_ok`: the libdeflate-shaped call offers its capacity as ISIZE and accepts fewer bytes (libdeflate
+// with actual_out_nbytes_ret); a framed member that inflates to fewer bytes than its footer says is
+// BadData (libdeflate SHORT_OUTPUT through decode_block, src/par/decompress.rs:162-186).
+int dwait_ticket(gzpx_dctx *c, uint64_t ticket, size_t *out_len, gzpx_check_info *info, bool short_ok = false) {
     const int si = (int)(ticket & 0xFF);
     if (si >= kSlots) return GZPX_ERR_INVALID_ARG;
     DSlot &sl = c->slots[si];
@@ -1207,7 +1210,7 @@ int dwait_ticket(gzpx_dctx *c, uint64_t ticket, size_t *out_len, gzpx_check_info
                 int err = GZPX_OK;
                 if (d.status == 1) err = GZPX_ERR_BAD_DATA;
                 else if (d.status == 2) err = GZPX_ERR_INSUFFICIENT_SPACE;
-                else if (d.status != 0) err = GZPX_ERR_BAD_DATA;  // 3: fewer bytes than ISIZE (libdeflate SHORT_OUTPUT)
+                else if (d.status != 0 && !short_ok) err = GZPX_ERR_BAD_DATA;  // 3: fewer bytes than ISIZE
                 else if (sl.h_crc[b] != d.crc) err = GZPX_ERR_INVALID_CHECK;
                 if (err != GZPX_OK) {
                     if (info) {
@@ -1412,7 +1415,7 @@ int gzpx_deflate_decompress(gzpx_decompressor *d, const void *in, size_t n, void
     if (rc != GZPX_OK) return rc;
     const DSlot &sl = c->slots[ticket & 0xFF];
     gzpx_check_info info = {0, 0, 0};
-    rc = dwait_ticket(c, ticket, nullptr, &info);
+    rc = dwait_ticket(c, ticket, nullptr, &info, true);
     if (rc == GZPX_ERR_INVALID_CHECK) rc = GZPX_OK;  // a raw stream carries no checksum
     if (rc != GZPX_OK) return rc;
     {

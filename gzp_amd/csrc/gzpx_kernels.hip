@@ -34,6 +34,7 @@
 // Integer/byte work only: no MFMA; LDS, the texture path and instruction issue are what matter.
 #include <hip/hip_runtime.h>
 #include <type_traits>
+#include <cstring>
 
 #include "gzpx_device.h"
 
@@ -1054,33 +1055,51 @@ __global__ __launch_bounds__(kMpThreads, 8) void k_parse(
 // libdeflate's deflate_compress_fastest calls ht_matchfinder_longest_match only where a token
 // starts (about a quarter of the positions of text); k_match searches EVERY position because the
 // parse is not known yet, and hands len8 / val / the bitmap to k_parse through HBM.  Here the
-// speculative segment walk of k_parse does the searching itself:
-//   phase 1  thread s walks the 64 positions of segment s from an entry position and runs
-//            longest_match (both bucket candidates from `cand`, bytes out of the LDS window) at every
-//            position it lands on; what it keeps is three 64-bit registers (token starts, "is a
-//            match", "the older candidate won") and its exit.  Entries are corrected round by round
-//            as in k_parse; a re-walk that lands on a token start of the previous walk has
-//            re-synchronised and keeps the rest of that walk (no second search).
+// speculative segment walk of k_parse does the searching itself.  A walk lands on positions that
+// nothing predicts, so everything a search touches must be randomly addressable at LDS cost (read
+// from `cand` in global memory, 64 lanes = 64 cache lines per load, the walks were bound by the
+// vector L1): the workgroup owns the CU's LDS -- the block's bytes (64 KiB) plus the candidate
+// distances d0 of HALF the block (64 KiB) -- and takes the block in two passes of 32 Ki positions:
+//   phase 1  thread s walks the 32 positions of segment s from an entry position and runs
+//            longest_match (d0 and the older candidate's d0[p - d0] out of LDS; the few older
+//            candidates of the second pass that lie in the first half come from global memory) at
+//            every position it lands on; it keeps three 32-bit registers (token starts, "is a match",
+//            "the older candidate won") and its exit.  Entries are corrected round by round as in
+//            k_parse; a re-walk that lands on a token start of the previous walk has re-synchronised
+//            and keeps the rest of that walk (no second search).
 //   phase 2  token / match counts per segment -> one workgroup scan.
-//   phase 3  token build by the wave that OWNS the segments (their masks come out of its own
-//            registers by v_readlane): lane = position, length = distance to the next token start,
-//            distance = d0 or d0 + cand[p - d0], literals from the LDS window; sub-block boundaries
-//            (8192 matches) as in k_parse.
-// LDS: the block's bytes + one exit word per segment (~70 KiB, two workgroups per CU).  Nothing
-// but tokens goes to HBM.  A block whose entries have not settled after kMpMaxRounds rounds (long
-// runs: every 258-byte match shifts the phase of the segments behind it) is handed back to the
-// dense kernels through the `redo` list -- the cooperative run logic lives there.
+//   phase 3  sub-block boundaries (the first token with 8192 matches of the current sub-block before
+//            it: match ranks are known from the scan, every lane names its own candidate), then
+//            every lane writes the tokens of its own segment: length = distance to the next token
+//            start, distance = d0 or d0 + d0[p - d0] out of LDS again, literals from the LDS window.
+// Nothing but tokens goes to HBM.  A block whose entries have not settled after kMpMaxRounds rounds
+// (long runs: every 258-byte match shifts the phase of the segments behind it) is handed back to
+// the dense kernels through the `redo` list -- the cooperative run logic lives there.
 // ------------------------------------------------------------------------------------------
 constexpr uint32_t kMpMaxRounds = 10;
+constexpr uint32_t kMhHalf = 32768;  // positions per pass (their d0: 64 KiB of LDS)
+constexpr uint32_t kMhSeg = kMhHalf / kMpThreads;  // 32 positions per walk segment = one 32-bit mask
+#ifdef GZPX_EXPERIMENT
+// k_mparse: stage, first walk, later rounds, settle, build, barrier rounds, re-walks (x 1024 rows, a
+// block adds to row blockIdx & 1023: same-address atomics serialise at the L2)
+__device__ unsigned long long g_exp_cycles[1024 * 8];
+#endif
 
-// ht_matchfinder_longest_match at block position p (block byte i sits at LDS byte i + mis).
-// Returns the match length (0 = none); `older` = the bucket's older entry won.
-__device__ __forceinline__ uint32_t l1_search(const uint32_t *in_w, const uint16_t *__restrict__ cand,
-                                              uint32_t p, uint32_t n, uint32_t mis, bool &older) {
+// ht_matchfinder_longest_match at block position p (block byte i sits at LDS byte i + mis; d0_h[i] =
+// d0 of position hb + i).  Returns the match length (0 = none); `older` = the bucket's older entry won.
+__device__ __forceinline__ uint32_t l1_search(const uint32_t *in_w, const uint16_t *d0_h, uint32_t hb,
+                                              const uint16_t *__restrict__ cand, uint32_t p, uint32_t n,
+                                              uint32_t mis, bool &older, bool no_gather = false) {
     older = false;
-    const uint32_t d0 = p + 5 <= n ? cand[p] : 0u;
+    const uint32_t d0 = p + 5 <= n ? d0_h[p - hb] : 0u;
     if (!d0) return 0;
-    const uint32_t r = cand[p - d0];
+    const uint32_t q = p - d0;  // the bucket's newer entry; the older one is ITS predecessor
+    // (an LDS read for every lane and a masked global one for the few whose q lies before the pass:
+    // selecting between the two POINTERS makes the compiler emit a flat load, which goes down both
+    // paths and waits for both counters)
+    uint32_t r = d0_h[q >= hb ? q - hb : 0u];
+    if (q < hb) r = cand[q];
+    if (no_gather) r = 0;
     const uint32_t d1 = (r && d0 + r <= 32767u) ? d0 + r : 0u;
     const uint32_t rem = n - p;
     const uint32_t max_len = rem < 258u ? rem : 258u;
@@ -1123,19 +1142,17 @@ __device__ __forceinline__ uint32_t l1_search(const uint32_t *in_w, const uint16
     return best;
 }
 
-__device__ __forceinline__ unsigned long long rdlane64(unsigned long long v, uint32_t l) {
-    return ((unsigned long long)rdlane((uint32_t)(v >> 32), l) << 32) | rdlane((uint32_t)v, l);
-}
-
-__global__ __launch_bounds__(kMpThreads, 8) void k_mparse(
+__global__ __launch_bounds__(kMpThreads, 4) void k_mparse(
     Config cfg, const uint8_t *__restrict__ slab, BlockMeta *__restrict__ meta_all,
     SubMeta *__restrict__ sub_all, const uint16_t *__restrict__ cand_all, uint32_t *__restrict__ tok_all,
     uint32_t *__restrict__ redo) {
-    __shared__ uint32_t in_w[kInWords];    // the block's bytes (+ lead misalignment, + pad)
+    __shared__ uint32_t in_w[kInWords];        // the block's bytes (+ lead misalignment, + pad)
+    __shared__ uint32_t d0_w[kMhHalf / 2];     // d0 (u16) of the positions of the current pass
     __shared__ uint32_t seg_exit[kMpThreads];  // where the walk of segment s leaves it
     __shared__ uint32_t wsum_t[kMpWaves], wsum_m[kMpWaves];
     __shared__ unsigned long long bnd;  // (position << 32 | token index) of the sub-block boundary
     __shared__ uint32_t bnd_mat;        // matches before that boundary
+    const uint16_t *d0_h = (const uint16_t *)d0_w;
 
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint32_t b = blockIdx.x;
@@ -1147,6 +1164,17 @@ __global__ __launch_bounds__(kMpThreads, 8) void k_mparse(
     const uint16_t *cand = cand_all + (uint64_t)b * cfg.stride;
     uint32_t *tok = tok_all + (uint64_t)b * cfg.stride;
     const uint32_t mis = (uint32_t)((uintptr_t)in & 3u);
+#ifdef GZPX_EXPERIMENT
+    // measurement builds: cycles per phase, summed over the blocks of a launch (thread 0's clock)
+    unsigned long long exp_t = __builtin_readcyclecounter();
+    auto exp_lap = [&](uint32_t slot) {
+        const unsigned long long t = __builtin_readcyclecounter();
+        if (tid == 0) atomicAdd(&g_exp_cycles[(b & 1023u) * 8u + slot], t - exp_t);
+        exp_t = t;
+    };
+#else
+    auto exp_lap = [](uint32_t) {};
+#endif
 
     {   // stage the block (n <= kTile): 16 bytes per load, four loads per thread in flight
         const uint32_t *src = (const uint32_t *)(in - mis);
@@ -1178,192 +1206,217 @@ __global__ __launch_bounds__(kMpThreads, 8) void k_mparse(
         for (uint32_t i = ndw + tid; i < ndw + 3 && i < kInWords; i += kMpThreads) in_w[i] = 0;
         if (tid == 0) bnd = ~0ull;
     }
-    __syncthreads();
 
-    // ---- phase 1: the greedy parse as a speculative segment walk that searches where it lands
-    const uint32_t seg_begin = tid * kPSeg;
-    const bool active = seg_begin < n;
-    const uint32_t seg_end = active ? (seg_begin + kPSeg < n ? seg_begin + kPSeg : n) : 0;
-    unsigned long long marks = 0, mbits = 0, wbits = 0;  // token starts / matches / older candidate won
-    uint32_t my_exit = seg_begin;
-    bool have_old = false;
-    auto walk = [&](uint32_t pos) {
-        const unsigned long long o_marks = marks, o_mbits = mbits, o_wbits = wbits;
-        marks = mbits = wbits = 0;
-        while (pos < seg_end) {
-            const unsigned long long bit = 1ull << (pos - seg_begin);
-            if (have_old && (o_marks & bit)) {
-                // landed on a token start of the previous walk: from here on the two walks are one
-                const unsigned long long keep = ~(bit - 1ull);
-                marks |= o_marks & keep;
-                mbits |= o_mbits & keep;
-                wbits |= o_wbits & keep;
-                pos = my_exit;
-                break;
+    // state carried from pass to pass (uniform across the workgroup)
+    uint32_t entry_carry = 0;  // where the parse enters the next pass
+    uint32_t tok_carry = 0, mat_carry = 0;
+    uint32_t cur_sub = 0, sub_start = 0, sub_start_tok = 0, sub_start_mat = 0;
+    const uint8_t *in_b = (const uint8_t *)in_w + mis;
+
+    for (uint32_t hb = 0; hb < n; hb += kMhHalf) {
+        const uint32_t he = hb + kMhHalf < n ? hb + kMhHalf : n;  // this pass: positions [hb, he)
+        __syncthreads();  // the previous pass is done with d0_w / seg_exit
+        {   // d0 of the pass: 64 bytes per thread (the per-block stride is padded: whole uint4s are readable)
+            const uint4 *src = (const uint4 *)(cand + hb);
+            uint4 *dst = (uint4 *)d0_w;
+            const uint32_t nq = (he - hb + 7) / 8;
+            uint4 v[4];
+#pragma unroll
+            for (uint32_t k = 0; k < 4; k++) {
+                const uint32_t q = tid + k * kMpThreads;
+                v[k] = src[q < nq ? q : nq - 1];
             }
-            bool older;
-            const uint32_t len = l1_search(in_w, cand, pos, n, mis, older);
-            marks |= bit;
-            if (len) mbits |= bit;
-            if (older) wbits |= bit;
-            pos += len ? len : 1u;
+#pragma unroll
+            for (uint32_t k = 0; k < 4; k++) dst[tid + k * kMpThreads] = v[k];
         }
-        my_exit = pos;
-        have_old = true;
-    };
-    uint32_t entry = seg_begin;  // thread 0 knows the true entry (0); the others guess
-    if (active) {
-        walk(entry);
-        seg_exit[tid] = my_exit;
-    }
-    bool settled = true;
-    for (uint32_t round = 0;; round++) {
         __syncthreads();
-        uint32_t new_entry = entry;
-        if (active && tid > 0) new_entry = seg_exit[tid - 1];
-        const bool changed = new_entry != entry;
-        if (!__syncthreads_or(changed)) break;  // (also: every exit has been read before one is rewritten)
-        if (round >= kMpMaxRounds) {
-            settled = false;
-            break;
-        }
-        if (changed) {
-            entry = new_entry;
+        exp_lap(0);
+
+        // ---- phase 1: the greedy parse as a speculative segment walk that searches where it lands
+        const uint32_t seg_begin = hb + tid * kMhSeg;
+        const bool active = seg_begin < he;
+        const uint32_t seg_end = active ? (seg_begin + kMhSeg < he ? seg_begin + kMhSeg : he) : 0;
+        uint32_t marks = 0, mbits = 0, wbits = 0;  // token starts / matches / older candidate won
+        // (segments past the end exist only in the last pass, whose final token ends at n: that is
+        // the "exit" the token build reads for them)
+        uint32_t my_exit = active ? seg_begin : n;
+        bool have_old = false;
+        auto walk = [&](uint32_t pos) {
+            const uint32_t o_marks = marks, o_mbits = mbits, o_wbits = wbits;
+            marks = mbits = wbits = 0;
+            while (pos < seg_end) {
+                const uint32_t bit = 1u << (pos - seg_begin);
+                if (have_old && (o_marks & bit)) {
+                    // landed on a token start of the previous walk: from here on the two walks are one
+                    const uint32_t keep = ~(bit - 1u);
+                    marks |= o_marks & keep;
+                    mbits |= o_mbits & keep;
+                    wbits |= o_wbits & keep;
+                    pos = my_exit;
+                    break;
+                }
+                bool older;
+                const uint32_t len = l1_search(in_w, d0_h, hb, cand, pos, n, mis, older, GZPX_EXP(cfg, 13) != 0);
+                marks |= bit;
+                if (len) mbits |= bit;
+                if (older) wbits |= bit;
+                pos += len ? len : 1u;
+            }
+            my_exit = pos;
+            have_old = true;
+        };
+        uint32_t entry = tid == 0 ? entry_carry : seg_begin;  // thread 0 knows the true entry; the others guess
+        if (active) {
             walk(entry);
             seg_exit[tid] = my_exit;
         }
-    }
-    if (!settled || (cfg.debug & 4u)) {  // uniform: the dense kernels take this block (debug bit 2: every block)
-        if (tid == 0) redo[1u + atomicAdd(&redo[0], 1u)] = b;
-        return;
-    }
+        bool settled = true;
+        for (uint32_t round = 0;; round++) {
+            __syncthreads();
+            exp_lap(round == 0 ? 1 : 2);
+            uint32_t new_entry = entry;
+            if (active && tid > 0) new_entry = seg_exit[tid - 1];
+            const bool changed = new_entry != entry;
+#ifdef GZPX_EXPERIMENT
+            if (tid == 0) atomicAdd(&g_exp_cycles[(b & 1023u) * 8u + 5u], 1ull);  // barrier rounds
+            {
+                const unsigned long long cm = __ballot(changed);
+                if (lane == 0 && cm) atomicAdd(&g_exp_cycles[(b & 1023u) * 8u + 6u], (unsigned long long)__popcll(cm));  // re-walks
+            }
+#endif
+            if (!__syncthreads_or(changed)) break;  // (also: every exit has been read before one is rewritten)
+            if (round >= kMpMaxRounds) {
+                settled = false;
+                break;
+            }
+            if (changed) {
+                entry = new_entry;
+                walk(entry);
+                seg_exit[tid] = my_exit;
+            }
+        }
+        if (!settled || (cfg.debug & 4u)) {  // uniform: the dense kernels take this block (debug bit 2: every block)
+            if (tid == 0) redo[1u + atomicAdd(&redo[0], 1u)] = b;
+            return;
+        }
+        const uint32_t n_seg = (he - hb + kMhSeg - 1) / kMhSeg;
+        const uint32_t exit_pos = uniform(seg_exit[n_seg - 1]);  // where the parse leaves this pass
+        exp_lap(3);
+        if (GZPX_EXP(cfg, 14)) {  // measurement: without the token build
+            entry_carry = exit_pos;
+            continue;
+        }
 
-    // ---- phase 2: tokens / matches before every segment (one workgroup scan)
-    uint32_t tile_tok, tile_mat, my_pre;
-    {
-        const uint32_t vt = (uint32_t)__popcll(marks), vm = (uint32_t)__popcll(mbits);
-        const uint32_t it = wave_incl_add(vt), im = wave_incl_add(vm);
-        if (lane == 63) {
-            wsum_t[wave] = it;
-            wsum_m[wave] = im;
-        }
-        __syncthreads();
-        uint32_t bt = 0, bm = 0, tt = 0, tm = 0;
-        for (uint32_t w = 0; w < kMpWaves; w++) {
-            const uint32_t st = wsum_t[w], sm = wsum_m[w];
-            if (w < wave) {
-                bt += st;
-                bm += sm;
+        // ---- phase 2: tokens / matches before every segment (one workgroup scan)
+        uint32_t tile_tok, tile_mat, my_pre;
+        {
+            const uint32_t vt = (uint32_t)__popc(marks), vm = (uint32_t)__popc(mbits);
+            const uint32_t it = wave_incl_add(vt), im = wave_incl_add(vm);
+            if (lane == 63) {
+                wsum_t[wave] = it;
+                wsum_m[wave] = im;
             }
-            tt += st;
-            tm += sm;
+            __syncthreads();
+            uint32_t bt = 0, bm = 0, tt = 0, tm = 0;
+            for (uint32_t w = 0; w < kMpWaves; w++) {
+                const uint32_t st = wsum_t[w], sm = wsum_m[w];
+                if (w < wave) {
+                    bt += st;
+                    bm += sm;
+                }
+                tt += st;
+                tm += sm;
+            }
+            tile_tok = uniform(tt);
+            tile_mat = uniform(tm);
+            // exclusive prefixes: tokens <= 32768 fit 17 bits, matches <= 8192 fit 15 bits
+            my_pre = (bt + it - vt) | ((bm + im - vm) << 17);
         }
-        tile_tok = uniform(tt);
-        tile_mat = uniform(tm);
-        // exclusive prefixes: tokens <= 65536 fit 17 bits, matches <= 16384 fit 15 bits
-        my_pre = (bt + it - vt) | ((bm + im - vm) << 17);
-    }
 
-    // ---- phase 3: token build, lane = position of a segment this wave owns
-    uint32_t cur_sub = 0, sub_start = 0, sub_start_tok = 0, sub_start_mat = 0;
-    uint32_t sub_limit = sub_limit_of(0, n);
-    const uint32_t ngroups = (n + 63) / 64;
-    const unsigned long long lane_below = (1ull << lane) - 1ull;
-    const uint8_t *in_b = (const uint8_t *)in_w + mis;
-    bool build = true;
-    for (;;) {
-        // 8 segments per step: the d0 loads of all of them, then the gathers of the lanes whose
-        // older candidate won, then every token word, then the stores (loads and stores share one
-        // counter on gfx9: a loaded value consumed behind a pending store drains the stores first)
-        for (uint32_t j0 = 0; j0 < 64 && wave * 64 + j0 < ngroups; j0 += 8) {
-            uint32_t vals[8], tis[8];
-#pragma unroll
-            for (uint32_t k = 0; k < 8; k++) {
-                const uint32_t j = j0 + k;
-                const unsigned long long mm = rdlane64(mbits, j);
-                const uint32_t p = (wave * 64 + j) * 64 + lane;
-                vals[k] = (build && ((mm >> lane) & 1ull)) ? cand[p] : 0u;
-            }
-            __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
-#pragma unroll
-            for (uint32_t k = 0; k < 8; k++) {
-                const uint32_t j = j0 + k;
-                const unsigned long long mw = rdlane64(wbits, j);
-                const uint32_t p = (wave * 64 + j) * 64 + lane;
-                tis[k] = (build && ((mw >> lane) & 1ull)) ? cand[p - vals[k]] : 0u;
-            }
-            __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
-#pragma unroll
-            for (uint32_t k = 0; k < 8; k++) {
-                const uint32_t j = j0 + k;
-                const uint32_t g = wave * 64 + j;
-                const uint32_t dist = vals[k] + tis[k];
-                tis[k] = 0xFFFFFFFFu;
-                if (g >= ngroups) continue;  // wave-uniform
-                const unsigned long long mt = rdlane64(marks, j), mm = rdlane64(mbits, j);
-                const uint32_t pre = rdlane(my_pre, j), ex = rdlane(my_exit, j);
-                const uint32_t mat_after = (pre >> 17) + (uint32_t)__popcll(mm);
-                const bool count_rule = mat_after - sub_start_mat >= kSeqPerSub;  // wave-uniform, rare
-                const uint32_t p = g * 64 + lane;
-                if (!((mt >> lane) & 1ull)) continue;
-                const uint32_t ti = (pre & 0x1FFFFu) + (uint32_t)__popcll(mt & lane_below);
-                // sub-block boundary: this token would start past the soft limit, or 8192 matches
-                // precede it in the current sub-block (src: deflate_compress_fastest)
-                bool boundary = p >= sub_limit;
-                if (count_rule) {
-                    const uint32_t mi = (pre >> 17) + (uint32_t)__popcll(mm & lane_below);
-                    boundary = boundary || mi - sub_start_mat >= kSeqPerSub;
+        // ---- phase 3a: sub-block boundaries.  A new DEFLATE sub-block starts at the first token that
+        // has kSeqPerSub matches of the current one before it (deflate_compress_fastest; the byte
+        // limit of choose_max_block_end cannot fire in a block of at most one tile).  Match ranks are
+        // known from the scan, so every lane names its own first such token and the smallest wins.
+        const uint32_t my_mat0 = mat_carry + (my_pre >> 17);   // matches before my first token
+        const uint32_t my_tok0 = tok_carry + (my_pre & 0x1FFFFu);  // tokens before it
+        for (;;) {
+            const uint32_t target = sub_start_mat + kSeqPerSub;
+            if (mat_carry + tile_mat < target) break;  // (uniform) the sub-block outlasts this pass
+            if (marks) {
+                uint32_t k = 32;  // bit of my first token with >= target matches before it
+                if (my_mat0 >= target) {
+                    k = (uint32_t)__ffs((int)marks) - 1u;
+                } else if (my_mat0 + (uint32_t)__popc(mbits) >= target) {
+                    uint32_t mb = mbits;  // drop my matches below the target-th one (at most 7 of them)
+                    for (uint32_t i = target - my_mat0; i > 1; i--) mb &= mb - 1u;
+                    const uint32_t kb = (uint32_t)__ffs((int)mb) - 1u;
+                    const uint32_t above = kb < 31u ? marks & ~((2u << kb) - 1u) : 0u;
+                    if (above) k = (uint32_t)__ffs((int)above) - 1u;  // (else: the first token of a later segment)
                 }
-                if (p > sub_start && boundary) atomicMin(&bnd, ((unsigned long long)p << 32) | ti);
-                if (!build) continue;
-                if ((mm >> lane) & 1ull) {
-                    // the match ends where the next token starts: the next mark, or the segment's exit
-                    const unsigned long long above = lane < 63u ? mt >> (lane + 1u) : 0ull;
-                    const uint32_t len = above ? (uint32_t)__ffsll((long long)above) : ex - p;
-                    vals[k] = kTokMatch | (dist << 9) | len;
-                } else {
-                    vals[k] = in_b[p];
-                }
-                tis[k] = ti;
+                if (k < 32u)
+                    atomicMin(&bnd, ((unsigned long long)(seg_begin + k) << 32) |
+                                        (my_tok0 + (uint32_t)__popc(marks & ((1u << k) - 1u))));
             }
-            if (build) {
-#pragma unroll
-                for (uint32_t k = 0; k < 8; k++)
-                    if (tis[k] != 0xFFFFFFFFu) tok[tis[k]] = vals[k];
+            __syncthreads();
+            const unsigned long long bv = bnd;
+            if (bv == ~0ull) break;  // the token behind the target-th match starts the next pass
+            const uint32_t bp = uniform((uint32_t)(bv >> 32)), bti = uniform((uint32_t)bv);
+            if (tid == (bp - hb) / kMhSeg)  // the boundary token's segment: matches before that token
+                bnd_mat = my_mat0 + (uint32_t)__popc(mbits & ((1u << ((bp - hb) & (kMhSeg - 1u))) - 1u));
+            __syncthreads();
+            const uint32_t bm = uniform(bnd_mat);
+            if (tid == 0) {
+                sub[cur_sub].tok_begin = sub_start_tok;
+                sub[cur_sub].tok_end = bti;
+                sub[cur_sub].byte_begin = sub_start;
+                sub[cur_sub].byte_len = bp - sub_start;
+                sub[cur_sub].is_final = 0;
+                bnd = ~0ull;
+            }
+            cur_sub++;
+            sub_start = bp;
+            sub_start_tok = bti;
+            sub_start_mat = bm;
+            __syncthreads();
+        }
+
+        // ---- phase 3b: every lane writes the tokens of its own segment: the length of a match is
+        // the distance to the next token start (the next mark, or the segment's exit), its distance
+        // d0 or d0 + d0[p - d0] out of LDS again, a literal is the byte itself
+        {
+            uint32_t m = marks, ti = my_tok0;
+            while (m) {
+                const uint32_t k = (uint32_t)__ffs((int)m) - 1u;
+                m &= m - 1u;
+                const uint32_t p = seg_begin + k;
+                const uint32_t next = m ? seg_begin + (uint32_t)__ffs((int)m) - 1u : my_exit;
+                uint32_t word = in_b[p];
+                if ((mbits >> k) & 1u) {
+                    const uint32_t d0 = d0_h[p - hb];
+                    uint32_t dist = d0;
+                    if ((wbits >> k) & 1u) {
+                        const uint32_t q = p - d0;
+                        uint32_t r = d0_h[q >= hb ? q - hb : 0u];
+                        if (q < hb) r = cand[q];
+                        dist += r;
+                    }
+                    word = kTokMatch | (dist << 9) | (next - p);
+                }
+                tok[ti++] = word;
             }
         }
-        __syncthreads();
-        const unsigned long long bv = bnd;
-        if (bv == ~0ull) break;  // the current sub-block runs to the end of the block
-        const uint32_t bp = uniform((uint32_t)(bv >> 32)), bti = uniform((uint32_t)bv);
-        if (tid == (bp >> 6))  // the owner of the boundary's segment: matches before the boundary token
-            bnd_mat = (my_pre >> 17) + (uint32_t)__popcll(mbits & ((1ull << (bp & 63u)) - 1ull));
-        __syncthreads();
-        const uint32_t bm = uniform(bnd_mat);
-        if (tid == 0) {
-            sub[cur_sub].tok_begin = sub_start_tok;
-            sub[cur_sub].tok_end = bti;
-            sub[cur_sub].byte_begin = sub_start;
-            sub[cur_sub].byte_len = bp - sub_start;
-            sub[cur_sub].is_final = 0;
-            bnd = ~0ull;
-        }
-        cur_sub++;
-        sub_start = bp;
-        sub_start_tok = bti;
-        sub_start_mat = bm;
-        sub_limit = sub_limit_of(bp, n);
-        __syncthreads();
-        if (tile_mat - bm < kSeqPerSub && sub_limit >= n) break;  // no further boundary in this block
-        build = false;
+        tok_carry += tile_tok;
+        mat_carry += tile_mat;
+        entry_carry = exit_pos;
+        exp_lap(4);
     }
     if (tid == 0) {
         sub[cur_sub].tok_begin = sub_start_tok;
-        sub[cur_sub].tok_end = tile_tok;
+        sub[cur_sub].tok_end = tok_carry;
         sub[cur_sub].byte_begin = sub_start;
         sub[cur_sub].byte_len = n - sub_start;
         sub[cur_sub].is_final = 1;
-        meta->ntok = tile_tok;
+        meta->ntok = tok_carry;
         meta->nsub = cur_sub + 1;
     }
 }
@@ -4335,6 +4388,21 @@ void launch_candidates(const Config &cfg, const uint8_t *slab, uint64_t, uint32_
 // pair k_match / k_parse over the blocks it handed back (normally none: two small launches that
 // find an empty list).  Larger blocks, or Config.debug bit 1: the dense pair over every block.
 bool level1_fused(const Config &cfg) { return cfg.block_size <= kTile && !(cfg.debug & 2u); }
+
+#ifdef GZPX_EXPERIMENT
+extern "C" int gzpx_exp_cycles(unsigned long long out[8], int reset) {
+    static unsigned long long rows[1024 * 8];
+    if (hipMemcpyFromSymbol(rows, HIP_SYMBOL(g_exp_cycles), sizeof(rows)) != hipSuccess) return -1;
+    for (int k = 0; k < 8; k++) out[k] = 0;
+    for (int r = 0; r < 1024; r++)
+        for (int k = 0; k < 8; k++) out[k] += rows[r * 8 + k];
+    if (reset) {
+        memset(rows, 0, sizeof(rows));
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_exp_cycles), rows, sizeof(rows)) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#endif
 
 void launch_match(const Config &cfg, const uint8_t *slab, uint64_t, uint32_t nb, const Scratch &s,
                   hipStream_t stream) {
