@@ -61,10 +61,7 @@ uint32_t crc32_combine(uint32_t crc1, uint32_t crc2, uint64_t len2) {
     return multmodp(x8n(len2), crc1) ^ crc2;
 }
 
-struct StageEvents {
-    hipEvent_t ev[GZPX_N_STAGES + 1];
-    bool created = false;
-};
+constexpr int kProfPairs = 64;  // launch groups of one batch that measurement mode can bracket
 
 constexpr int kSlots = 3;  // slabs of one context that may be in flight (copy in / kernels / copy out)
 
@@ -103,6 +100,9 @@ struct gzpx_ctx {
     hipEvent_t ev_crc_t0 = nullptr, ev_crc_t1 = nullptr;  // timing of k_crc32 when profiling
     hipEvent_t ev_dep = nullptr;  // "the caller's stream got this far" (device jobs)
     hipEvent_t ev_round[2] = {nullptr, nullptr};  // levels 2-4: end of a match/parse round
+    hipEvent_t prof_ev[2 * 64] = {nullptr};  // measurement mode: begin / end of launch groups
+    int prof_stage[64] = {0};
+    int prof_n = 0;
     uint32_t batch_blocks = 0;
     Scratch scratch = {};
     Slot slots[kSlots];
@@ -110,7 +110,6 @@ struct gzpx_ctx {
     BlockMeta *h_meta = nullptr;  // pinned; CRC-only contexts and the debug hooks
     SubMeta *h_sub = nullptr;     // pinned, max_sub entries (debug hooks)
     uint32_t *h_pending = nullptr;  // pinned
-    StageEvents events;
     bool profiling = false;
     bool crc_only = false;
     float stage_ms[GZPX_N_STAGES] = {0};
@@ -228,8 +227,25 @@ void free_scratch(gzpx_ctx *ctx) {
     s = Scratch{};
 }
 
+// HIP-event pairs around groups of launches (measurement mode only): a stage may consist of several
+// launches on several streams, its time is the sum of its pairs.
+struct ProfPairs {
+    gzpx_ctx *ctx;
+    bool on;
+    int begin(int stage, hipStream_t st) {
+        if (!on || ctx->prof_n >= kProfPairs) return -1;
+        const int i = ctx->prof_n++;
+        ctx->prof_stage[i] = stage;
+        (void)hipEventRecord(ctx->prof_ev[2 * i], st);
+        return i;
+    }
+    void end(int i, hipStream_t st) {
+        if (i >= 0) (void)hipEventRecord(ctx->prof_ev[2 * i + 1], st);
+    }
+};
+
 // One batch of blocks through the pipeline, enqueued on `stream`.  Nothing here waits for the
-// device at level 0/1; the match/parse rounds of levels 2-4 read one word back per round.
+// device at level 0/1 and 5-9; the match/parse rounds of levels 2-4 read one word back per round.
 // `prev` / `result`: the batch before this one of the same slab (device, may be null) and this
 // batch's own record; output offsets continue from prev->total.
 int enqueue_batch(gzpx_ctx *ctx, const uint8_t *d_in, size_t in_len, uint32_t nb, int is_last,
@@ -237,69 +253,79 @@ int enqueue_batch(gzpx_ctx *ctx, const uint8_t *d_in, size_t in_len, uint32_t nb
                   SlabResult *result) {
     const Config &c = ctx->dcfg;
     const Scratch &s = ctx->scratch;
-    const bool prof = ctx->profiling;
-    hipEvent_t *ev = ctx->events.ev;
-    int k = 0;
-    if (prof) HIP_TRY(hipEventRecord(ev[k], stream));
+    ProfPairs pp{ctx, ctx->profiling};
+    ctx->prof_n = 0;
+    int t = pp.begin(0, stream);
     launch_init_meta(c, in_len, nb, is_last, s, stream);
-    if (prof) HIP_TRY(hipEventRecord(ev[++k], stream));
+    pp.end(t, stream);
+    t = pp.begin(1, stream);
     launch_candidates(c, d_in, in_len, nb, s, stream);
-    if (prof) HIP_TRY(hipEventRecord(ev[++k], stream));
-    if (c.level <= 1) {  // (at level 0 every block is a passthrough block: both return at once)
-        launch_match(c, d_in, in_len, nb, s, stream);
-        if (prof) HIP_TRY(hipEventRecord(ev[++k], stream));
+    pp.end(t, stream);
+    if (c.level <= 1) {  // (at level 0 every block is a passthrough block: the kernels return at once)
+        // (Tried in round 3: the batch cut into 2..8 block ranges, k_hist / k_huffman of range k on a
+        // side stream beside the matching of range k + 1.  4.27 -> 4.83 / 5.90 / 7.44 ms per step: the
+        // 24 six-KiB workgroups k_huffman puts on a CU take the LDS that k_candidates / k_mparse need
+        // whole, so the big kernels lose CUs to the small one instead of sharing them.)
+        t = pp.begin(2, stream);
+        launch_match(c, d_in, in_len, nb, s, stream);  // k_mparse, and k_match over the blocks it handed back
+        pp.end(t, stream);
+        t = pp.begin(3, stream);
         launch_parse(c, d_in, in_len, nb, s, stream);
-        if (prof) HIP_TRY(hipEventRecord(ev[++k], stream));
-    } else if (c.lazy) {  // levels 5-9: every match variant once, then the serial-per-block lazy parse
-        launch_lazy(c, d_in, nb, s, stream);
-        if (prof) HIP_TRY(hipEventRecord(ev[++k], stream));
-        if (prof) HIP_TRY(hipEventRecord(ev[++k], stream));
+        pp.end(t, stream);
     } else {
-        // levels 2-4: match + parse rounds until no block needs its tail redone with another
-        // min_len (one round unless should_end_block splits a block into unlike halves).  Round
-        // r + 1 is enqueued before round r's "blocks left" word is looked at, so the device never
-        // idles while the host decides; a round with nothing left costs two empty launches.
-        uint32_t *pend = ctx->h_pending;  // [round & 1]
-        for (uint32_t round = 0;; round++) {
-            launch_hc_round(c, d_in, nb, s, round == 0, stream);
-            HIP_TRY(hipMemcpyAsync(&pend[round & 1], s.pending, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
-            HIP_TRY(hipEventRecord(ctx->ev_round[round & 1], stream));
-            if (round == 0) continue;
-            HIP_TRY(hipEventSynchronize(ctx->ev_round[(round - 1) & 1]));
-            if (pend[(round - 1) & 1] == 0) break;  // (the round just enqueued finds every block done)
-            if (round > c.max_sub + 3) return GZPX_ERR_DEVICE;  // cannot happen: one sub-block per round
+        t = pp.begin(2, stream);
+        if (c.lazy) {  // levels 5-9: every match variant once, then the serial-per-block lazy parse
+            launch_lazy(c, d_in, nb, s, stream);
+        } else {
+            // levels 2-4: match + parse rounds until no block needs its tail redone with another
+            // min_len (one round unless should_end_block splits a block into unlike halves).  Round
+            // r + 1 is enqueued before round r's "blocks left" word is looked at, so the device never
+            // idles while the host decides; a round with nothing left costs two empty launches.
+            uint32_t *pend = ctx->h_pending;  // [round & 1]
+            for (uint32_t round = 0;; round++) {
+                launch_hc_round(c, d_in, nb, s, round == 0, stream);
+                HIP_TRY(hipMemcpyAsync(&pend[round & 1], s.pending, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+                HIP_TRY(hipEventRecord(ctx->ev_round[round & 1], stream));
+                if (round == 0) continue;
+                HIP_TRY(hipEventSynchronize(ctx->ev_round[(round - 1) & 1]));
+                if (pend[(round - 1) & 1] == 0) break;  // (the round just enqueued finds every block done)
+                if (round > c.max_sub + 3) return GZPX_ERR_DEVICE;  // cannot happen: one sub-block per round
+            }
         }
-        if (prof) HIP_TRY(hipEventRecord(ev[++k], stream));
-        if (prof) HIP_TRY(hipEventRecord(ev[++k], stream));
+        pp.end(t, stream);
     }
-    // fork: the CRC of every block on the low-priority side stream, beside k_hist and k_huffman --
-    // k_huffman is a chain of dependent LDS reads on one lane per block and leaves the CUs' issue
-    // slots and HBM idle.  (Measured alternatives, 550 MiB slab: beside k_candidates 5.36 ms per step
-    // -- that kernel slows down by the CRC's time; in front of k_parse 5.34; here 5.32.)
-    HIP_TRY(hipEventRecord(ctx->ev_meta, stream));
-    HIP_TRY(hipStreamWaitEvent(ctx->s_side, ctx->ev_meta, 0));
-    if (prof) HIP_TRY(hipEventRecord(ctx->ev_crc_t0, ctx->s_side));
-    launch_crc32(c, d_in, in_len, nb, s, ctx->crc_consts, ctx->s_side);
-    if (prof) HIP_TRY(hipEventRecord(ctx->ev_crc_t1, ctx->s_side));
-    HIP_TRY(hipEventRecord(ctx->ev_crc, ctx->s_side));
-    launch_hist(c, nb, s, stream);
-    if (prof) HIP_TRY(hipEventRecord(ev[++k], stream));
-    launch_huffman(c, nb, s, stream);
-    if (prof) HIP_TRY(hipEventRecord(ev[++k], stream));
+    {
+        // fork: the CRC of every block on the low-priority side stream, beside k_hist and k_huffman --
+        // k_huffman is a chain of dependent LDS reads on one lane per block and leaves the CUs' issue
+        // slots and HBM idle.  (Measured alternatives, round 2: beside k_candidates that kernel slows
+        // down by the CRC's time -- both live on LDS operations; in front of k_parse 5.34 ms, here 5.32.)
+        HIP_TRY(hipEventRecord(ctx->ev_meta, stream));
+        HIP_TRY(hipStreamWaitEvent(ctx->s_side, ctx->ev_meta, 0));
+        const int tc = pp.begin(6, ctx->s_side);
+        launch_crc32(c, d_in, in_len, nb, s, ctx->crc_consts, ctx->s_side);
+        pp.end(tc, ctx->s_side);
+        HIP_TRY(hipEventRecord(ctx->ev_crc, ctx->s_side));
+        t = pp.begin(4, stream);
+        launch_hist(c, nb, s, stream);
+        pp.end(t, stream);
+        t = pp.begin(5, stream);
+        launch_huffman(c, nb, s, stream);
+        pp.end(t, stream);
+    }
     HIP_TRY(hipStreamWaitEvent(stream, ctx->ev_crc, 0));  // join: k_emit writes the CRCs into the footers
-    if (prof) HIP_TRY(hipEventRecord(ev[++k], stream));
+    t = pp.begin(7, stream);
     launch_scan(nb, s, prev, result, stream);
-    if (prof) HIP_TRY(hipEventRecord(ev[++k], stream));
+    pp.end(t, stream);
+    t = pp.begin(8, stream);
     launch_emit(c, d_in, in_len, nb, s, d_out, out_cap, stream);
-    if (prof) HIP_TRY(hipEventRecord(ev[++k], stream));
+    pp.end(t, stream);
     HIP_TRY(hipGetLastError());
-    if (prof) {  // measurement mode: one host wait per batch
+    if (pp.on) {  // measurement mode: one host wait per batch
         HIP_TRY(hipStreamSynchronize(stream));
-        for (int i = 0; i < GZPX_N_STAGES; i++) {
+        for (int i = 0; i < ctx->prof_n; i++) {
             float ms = 0;
-            if (i == 6) HIP_TRY(hipEventElapsedTime(&ms, ctx->ev_crc_t0, ctx->ev_crc_t1));  // (overlaps the stages before it)
-            else HIP_TRY(hipEventElapsedTime(&ms, ev[i], ev[i + 1]));
-            ctx->stage_ms[i] += ms;
+            HIP_TRY(hipEventElapsedTime(&ms, ctx->prof_ev[2 * i], ctx->prof_ev[2 * i + 1]));
+            ctx->stage_ms[ctx->prof_stage[i]] += ms;
         }
     }
     ctx->last_nb = nb;
@@ -628,9 +654,8 @@ int ctx_create(const gzpx_config *cfg, bool crc_only, gzpx_ctx **out) {
         rc = GZPX_ERR_DEVICE;
     if (rc == GZPX_OK) rc = alloc_scratch(ctx);
     if (rc == GZPX_OK) {
-        for (int i = 0; i <= GZPX_N_STAGES; i++)
-            if (hipEventCreate(&ctx->events.ev[i]) != hipSuccess) rc = GZPX_ERR_DEVICE;
-        ctx->events.created = (rc == GZPX_OK);
+        for (int i = 0; i < 2 * kProfPairs; i++)
+            if (hipEventCreate(&ctx->prof_ev[i]) != hipSuccess) rc = GZPX_ERR_DEVICE;
     }
     if (rc != GZPX_OK) {
         gzpx_ctx_destroy(ctx);
@@ -651,8 +676,8 @@ void gzpx_ctx_destroy(gzpx_ctx *ctx) {
     if (ctx->s_h2d) (void)hipStreamSynchronize(ctx->s_h2d);
     if (ctx->s_d2h) (void)hipStreamSynchronize(ctx->s_d2h);
     free_scratch(ctx);
-    if (ctx->events.created)
-        for (int i = 0; i <= GZPX_N_STAGES; i++) (void)hipEventDestroy(ctx->events.ev[i]);
+    for (hipEvent_t e : ctx->prof_ev)
+        if (e) (void)hipEventDestroy(e);
     if (ctx->ev_dep) (void)hipEventDestroy(ctx->ev_dep);
     for (hipEvent_t e : {ctx->ev_meta, ctx->ev_crc, ctx->ev_crc_t0, ctx->ev_crc_t1})
         if (e) (void)hipEventDestroy(e);

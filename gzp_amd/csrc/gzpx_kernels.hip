@@ -1087,30 +1087,36 @@ __device__ unsigned long long g_exp_cycles[1024 * 8];
 
 // ht_matchfinder_longest_match at block position p (block byte i sits at LDS byte i + mis; d0_h[i] =
 // d0 of position hb + i).  Returns the match length (0 = none); `older` = the bucket's older entry won.
+// TAIL = the segment lies within 266 bytes of the block's end (lengths clamp to what is left and the
+// last four positions are not searched); everywhere else max_len = 258 and nice_len = 32.
+// (Tried: both candidates compared 8 bytes per round -- three dwords per stream up front, two per
+// later round.  Same VALU count, more LDS reads for the literal steps: k_mparse 2.20 -> 2.35 ms.)
+template <bool TAIL>
 __device__ __forceinline__ uint32_t l1_search(const uint32_t *in_w, const uint16_t *d0_h, uint32_t hb,
                                               const uint16_t *__restrict__ cand, uint32_t p, uint32_t n,
                                               uint32_t mis, bool &older, bool no_gather = false) {
     older = false;
-    const uint32_t d0 = p + 5 <= n ? d0_h[p - hb] : 0u;
+    const uint32_t d0 = (!TAIL || p + 5 <= n) ? (uint32_t)d0_h[p - hb] : 0u;
     if (!d0) return 0;
     const uint32_t q = p - d0;  // the bucket's newer entry; the older one is ITS predecessor
-    // (an LDS read for every lane and a masked global one for the few whose q lies before the pass:
-    // selecting between the two POINTERS makes the compiler emit a flat load, which goes down both
-    // paths and waits for both counters)
+    // (an LDS read for every lane and a masked global one for the few whose q lies before the pass.
+    // Left alone, the compiler turns the two loads into ONE flat load of a selected pointer, which
+    // goes down the vector-memory path for every lane and waits for both counters)
     uint32_t r = d0_h[q >= hb ? q - hb : 0u];
-    if (q < hb) r = cand[q];
+    if (q < hb) r = *(const volatile uint16_t *)(cand + q);  // (volatile: keeps the two loads apart)
     if (no_gather) r = 0;
-    const uint32_t d1 = (r && d0 + r <= 32767u) ? d0 + r : 0u;
-    const uint32_t rem = n - p;
-    const uint32_t max_len = rem < 258u ? rem : 258u;
-    const uint32_t nice_len = max_len < 32u ? max_len : 32u;
+    const uint32_t d1 = d0 + r;
+    const bool two = r != 0 && d1 <= 32767u;  // the older entry is alive
+    const uint32_t max_len = TAIL ? (n - p < 258u ? n - p : 258u) : 258u;
+    const uint32_t nice_len = TAIL ? (max_len < 32u ? max_len : 32u) : 32u;
     const uint32_t a = p + mis;
-    const uint32_t c0 = a - d0, c1 = a - (d1 ? d1 : d0);
+    const uint32_t c0 = a - d0, c1 = two ? a - d1 : c0;
     const uint32_t *pa = in_w + (a >> 2), *p0 = in_w + (c0 >> 2), *p1 = in_w + (c1 >> 2);
+    const uint32_t sa = a & 3u, s0 = c0 & 3u, s1 = c1 & 3u;
     uint32_t lo_a = pa[0], hi_a = pa[1], lo_0 = p0[0], hi_0 = p0[1], lo_1 = p1[0], hi_1 = p1[1];
-    const uint32_t seq = __builtin_amdgcn_alignbyte(hi_a, lo_a, a & 3u);
-    bool act0 = __builtin_amdgcn_alignbyte(hi_0, lo_0, c0 & 3u) == seq;
-    bool act1 = d1 != 0 && __builtin_amdgcn_alignbyte(hi_1, lo_1, c1 & 3u) == seq;
+    const uint32_t seq = __builtin_amdgcn_alignbyte(hi_a, lo_a, sa);
+    bool act0 = __builtin_amdgcn_alignbyte(hi_0, lo_0, s0) == seq;
+    bool act1 = two && __builtin_amdgcn_alignbyte(hi_1, lo_1, s1) == seq;
     uint32_t len0 = act0 ? max_len : 0u, len1 = act1 ? max_len : 0u;  // still matching => max_len
     for (uint32_t off = 4; (act0 || act1) && off < max_len; off += 4) {
         const uint32_t j = (off >> 2) + 1;
@@ -1120,9 +1126,9 @@ __device__ __forceinline__ uint32_t l1_search(const uint32_t *in_w, const uint16
         hi_0 = p0[j];
         lo_1 = hi_1;
         hi_1 = p1[j];
-        const uint32_t own = __builtin_amdgcn_alignbyte(hi_a, lo_a, a & 3u);
-        const uint32_t x0 = own ^ __builtin_amdgcn_alignbyte(hi_0, lo_0, c0 & 3u);
-        const uint32_t x1 = own ^ __builtin_amdgcn_alignbyte(hi_1, lo_1, c1 & 3u);
+        const uint32_t own = __builtin_amdgcn_alignbyte(hi_a, lo_a, sa);
+        const uint32_t x0 = own ^ __builtin_amdgcn_alignbyte(hi_0, lo_0, s0);
+        const uint32_t x1 = own ^ __builtin_amdgcn_alignbyte(hi_1, lo_1, s1);
         if (act0 && x0) {
             len0 = off + ((uint32_t)(__ffs((int)x0) - 1) >> 3);
             act0 = false;
@@ -1241,7 +1247,10 @@ __global__ __launch_bounds__(kMpThreads, 4) void k_mparse(
         // the "exit" the token build reads for them)
         uint32_t my_exit = active ? seg_begin : n;
         bool have_old = false;
-        auto walk = [&](uint32_t pos) {
+        // (whole waves take the TAIL form of the search together: the last wave of the block)
+        const bool tail_wave = __ballot(active && seg_end + 266u > n) != 0;
+        auto walk_as = [&](uint32_t pos, auto tail_tag) {
+            constexpr bool kTail = decltype(tail_tag)::value;
             const uint32_t o_marks = marks, o_mbits = mbits, o_wbits = wbits;
             marks = mbits = wbits = 0;
             while (pos < seg_end) {
@@ -1256,7 +1265,7 @@ __global__ __launch_bounds__(kMpThreads, 4) void k_mparse(
                     break;
                 }
                 bool older;
-                const uint32_t len = l1_search(in_w, d0_h, hb, cand, pos, n, mis, older, GZPX_EXP(cfg, 13) != 0);
+                const uint32_t len = l1_search<kTail>(in_w, d0_h, hb, cand, pos, n, mis, older, GZPX_EXP(cfg, 13) != 0);
                 marks |= bit;
                 if (len) mbits |= bit;
                 if (older) wbits |= bit;
@@ -1264,6 +1273,10 @@ __global__ __launch_bounds__(kMpThreads, 4) void k_mparse(
             }
             my_exit = pos;
             have_old = true;
+        };
+        auto walk = [&](uint32_t pos) {
+            if (tail_wave) walk_as(pos, std::true_type{});
+            else walk_as(pos, std::false_type{});
         };
         uint32_t entry = tid == 0 ? entry_carry : seg_begin;  // thread 0 knows the true entry; the others guess
         if (active) {
@@ -1397,7 +1410,7 @@ __global__ __launch_bounds__(kMpThreads, 4) void k_mparse(
                     if ((wbits >> k) & 1u) {
                         const uint32_t q = p - d0;
                         uint32_t r = d0_h[q >= hb ? q - hb : 0u];
-                        if (q < hb) r = cand[q];
+                        if (q < hb) r = *(const volatile uint16_t *)(cand + q);
                         dist += r;
                     }
                     word = kTokMatch | (dist << 9) | (next - p);

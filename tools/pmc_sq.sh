@@ -1,0 +1,22 @@
+#!/bin/bash
+# SQ counters of the level-1 kernels (two passes of <= 8 SQ counters; counters only with --kernel-trace)
+#   tools/pmc_sq.sh <outdir-under-gpurun_out>
+R=${GRAFT_REPO_ROOT:-/root/repo}
+O=$R/gpurun_out/${1:-pmc_sq}
+mkdir -p $O
+cd /tmp && export TMPDIR=/tmp
+B="python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras"
+rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS -d $O/a -o a --output-format csv -- $B > $O/a.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_SCA SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR -d $O/b -o b --output-format csv -- $B > $O/b.log 2>&1
+python3 - <<PY
+import csv, glob, collections
+for tag in ("a","b"):
+    fs = glob.glob("$O/%s/**/*counter_collection.csv" % tag, recursive=True)
+    if not fs: print(tag, "no counter file"); continue
+    acc = collections.defaultdict(lambda: collections.defaultdict(float)); cnt = collections.Counter()
+    for row in csv.DictReader(open(fs[0])):
+        k = row["Kernel_Name"].split("(")[0][:40]
+        acc[k][row["Counter_Name"]] += float(row["Counter_Value"])
+    for k, d in acc.items():
+        if "gzpx" in k: print(tag, k, {c: "%.3g" % v for c, v in d.items()})
+PY
