@@ -1154,7 +1154,7 @@ __global__ __launch_bounds__(kMpThreads, 4) void k_mparse(
     uint32_t *__restrict__ redo) {
     __shared__ uint32_t in_w[kInWords];        // the block's bytes (+ lead misalignment, + pad)
     __shared__ uint32_t d0_w[kMhHalf / 2];     // d0 (u16) of the positions of the current pass
-    __shared__ uint32_t seg_exit[kMpThreads];  // where the walk of segment s leaves it
+    __shared__ uint32_t seg_exit[2 * kMpThreads];  // where the walk of segment s leaves it (two copies, see the rounds)
     __shared__ uint32_t wsum_t[kMpWaves], wsum_m[kMpWaves];
     __shared__ unsigned long long bnd;  // (position << 32 | token index) of the sub-block boundary
     __shared__ uint32_t bnd_mat;        // matches before that boundary
@@ -1279,16 +1279,18 @@ __global__ __launch_bounds__(kMpThreads, 4) void k_mparse(
             else walk_as(pos, std::false_type{});
         };
         uint32_t entry = tid == 0 ? entry_carry : seg_begin;  // thread 0 knows the true entry; the others guess
-        if (active) {
-            walk(entry);
-            seg_exit[tid] = my_exit;
-        }
+        if (active) walk(entry);
+        // Rounds: every thread reads its left neighbour's exit from one copy of the exit array and
+        // leaves its own (re-walked or not) in the other, so one barrier per round is enough -- the
+        // one that also tells whether any entry moved.
+        uint32_t cur = 0;
+        seg_exit[tid] = my_exit;
+        __syncthreads();
+        exp_lap(1);
         bool settled = true;
         for (uint32_t round = 0;; round++) {
-            __syncthreads();
-            exp_lap(round == 0 ? 1 : 2);
             uint32_t new_entry = entry;
-            if (active && tid > 0) new_entry = seg_exit[tid - 1];
+            if (active && tid > 0) new_entry = seg_exit[cur * kMpThreads + tid - 1];
             const bool changed = new_entry != entry;
 #ifdef GZPX_EXPERIMENT
             if (tid == 0) atomicAdd(&g_exp_cycles[(b & 1023u) * 8u + 5u], 1ull);  // barrier rounds
@@ -1297,15 +1299,18 @@ __global__ __launch_bounds__(kMpThreads, 4) void k_mparse(
                 if (lane == 0 && cm) atomicAdd(&g_exp_cycles[(b & 1023u) * 8u + 6u], (unsigned long long)__popcll(cm));  // re-walks
             }
 #endif
-            if (!__syncthreads_or(changed)) break;  // (also: every exit has been read before one is rewritten)
+            if (changed && round < kMpMaxRounds) {
+                entry = new_entry;
+                walk(entry);
+            }
+            cur ^= 1u;
+            seg_exit[cur * kMpThreads + tid] = my_exit;
+            const bool any = __syncthreads_or(changed);
+            exp_lap(2);
+            if (!any) break;
             if (round >= kMpMaxRounds) {
                 settled = false;
                 break;
-            }
-            if (changed) {
-                entry = new_entry;
-                walk(entry);
-                seg_exit[tid] = my_exit;
             }
         }
         if (!settled || (cfg.debug & 4u)) {  // uniform: the dense kernels take this block (debug bit 2: every block)
@@ -1313,7 +1318,7 @@ __global__ __launch_bounds__(kMpThreads, 4) void k_mparse(
             return;
         }
         const uint32_t n_seg = (he - hb + kMhSeg - 1) / kMhSeg;
-        const uint32_t exit_pos = uniform(seg_exit[n_seg - 1]);  // where the parse leaves this pass
+        const uint32_t exit_pos = uniform(seg_exit[cur * kMpThreads + n_seg - 1]);  // where the parse leaves this pass
         exp_lap(3);
         if (GZPX_EXP(cfg, 14)) {  // measurement: without the token build
             entry_carry = exit_pos;
