@@ -49,6 +49,73 @@ def pmc_traffic(kernel):
         return None
 
 
+def golden_stream(name):
+    """The entry `name` of tests/golden/fullsize.json: SHA-256 of a COMPLETE stream (and of its framed
+    block sizes) made by the libdeflate binary + gzp's framing (tests/golden/make_fullsize.py)."""
+    try:
+        with open(os.path.join(ROOT, "tests", "golden", "fullsize.json")) as f:
+            for e in json.load(f)["streams"]:
+                if e["name"] == name:
+                    return e
+    except Exception:
+        pass
+    return None
+
+
+def check_full_stream(name, n, seed, out_host, block_sizes=None):
+    """Compare a whole output stream with the committed digest of the libdeflate-made one.  Returns
+    (True / False, digest) or (None, digest) when this run is not the golden configuration."""
+    sha = hashlib.sha256(out_host).hexdigest()
+    g = golden_stream(name)
+    if g is None or g["input"].get("n") != n or g["input"].get("seed") != seed:
+        return None, sha
+    ok = sha == g["sha256"] and int(out_host.size) == g["size"]
+    if ok and block_sizes is not None:
+        ok = hashlib.sha256(np.ascontiguousarray(block_sizes, dtype="<u4").tobytes()).hexdigest() == g["block_sizes_sha256"]
+    return bool(ok), sha
+
+
+def box_libdeflate():
+    """Which libdeflate the GPU box itself carries (none / behaves like v1.10 / like >= v1.1x = the
+    pinned 1.24 rule), told by inputs on which the oracle's two compat modes disagree -- the
+    fingerprint of tests/test_gpu_box_libdeflate.py.  Outside every timed region."""
+    try:
+        from gzp_amd import synth
+        from oracle import oracle
+        L = None
+        for path in ("libdeflate.so.0", "/lib/x86_64-linux-gnu/libdeflate.so.0", "/usr/lib/x86_64-linux-gnu/libdeflate.so.0",
+                     "/usr/lib64/libdeflate.so.0"):
+            try:
+                L = ctypes.CDLL(path)
+                break
+            except OSError:
+                continue
+        if L is None:
+            return None
+        L.libdeflate_alloc_compressor.restype = ctypes.c_void_p
+        L.libdeflate_alloc_compressor.argtypes = [ctypes.c_int]
+        L.libdeflate_deflate_compress.restype = ctypes.c_size_t
+        L.libdeflate_deflate_compress.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p,
+                                                  ctypes.c_size_t]
+        comp = L.libdeflate_alloc_compressor(1)
+        votes = set()
+        for seed in range(1, 40):
+            a = synth.make("ascii", 150 + 10 * seed, seed)
+            o24 = oracle.deflate_compress(a, 1, oracle.COMPAT_1_24)
+            o10 = oracle.deflate_compress(a, 1, oracle.COMPAT_1_10)
+            if o24 == o10:
+                continue
+            out = np.empty(a.size + 256, dtype=np.uint8)
+            k = L.libdeflate_deflate_compress(comp, a.ctypes.data, a.size, out.ctypes.data, out.size)
+            got = out[:k].tobytes()
+            votes.add("1.24-like" if got == o24 else "1.10-like" if got == o10 else "unknown")
+            if len(votes) > 1 or "unknown" in votes:
+                return "unknown"
+        return votes.pop() if votes else None
+    except Exception:
+        return None
+
+
 def available_cores():
     """Hardware threads this process may actually use: the affinity mask, capped by the cgroup
     CPU quota (cpu.max) of the container."""
@@ -283,13 +350,18 @@ def level_legs(env, d_in, n):
         d_out = torch.empty(cap, dtype=torch.uint8, device=env.dev)
         ctx.compress_slab_device(d_in.data_ptr(), n, d_out.data_ptr(), cap, True)
         env.sync()
+        ctx.set_profiling(True)  # HIP events around every launch group, as in the headline region
         steps = 2
+        stage_acc = {}
         t0 = time.perf_counter()
         for _ in range(steps):
             out_len, _ = ctx.compress_slab_device(d_in.data_ptr(), n, d_out.data_ptr(), cap, True)
+            for k, v in ctx.last_stage_ms().items():
+                stage_acc[k] = stage_acc.get(k, 0.0) + v / steps
         env.sync()
         dt = (time.perf_counter() - t0) / steps
         host = d_out[:out_len].cpu().numpy()
+        full_ok, sha = check_full_stream("text_550MiB_bgzf_l%d" % level, n, 20250927, host)
         d = _native.DContext(format=_native.FORMAT_BGZF, device=env.device_index, lib=env.lib)
         offs, sizes, used = d.scan_blocks(host)
         d_back = torch.empty(n + 64, dtype=torch.uint8, device=env.dev)
@@ -297,8 +369,15 @@ def level_legs(env, d_in, n):
         ok = got == n and bool(torch.equal(d_back[:n], d_in[:n]))
         d.close()
         ctx.close()
+        dom = max(stage_acc, key=stage_acc.get)
+        achieved = (n + out_len) / (max(stage_acc[dom], 1e-9) * 1e-3) / 1e9
         out["level_%d" % level] = {"MiBps": round(n / 2**20 / dt, 1), "ms_per_step": round(dt * 1e3, 3),
-                                   "ratio": round(out_len / n, 4), "gpu_inflate_crc_roundtrip_ok": bool(ok)}
+                                   "ratio": round(out_len / n, 4), "gpu_inflate_crc_roundtrip_ok": bool(ok),
+                                   "stream_sha256": sha, "verified_bit_exact_full": full_ok,
+                                   "roofline": {"bound": "hbm", "kernel": dom, "kernel_ms": round(stage_acc[dom], 3),
+                                                "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                                "frac": round(achieved / HBM_PEAK_GBS, 5),
+                                                "pipeline_frac": round((n + out_len) / dt / 1e9 / HBM_PEAK_GBS, 5)}}
         del d_out, d_back
     return out
 
@@ -714,11 +793,16 @@ def main():
         last_buf = d_outs[(state["i"] - 1) % len(d_outs)]
         out_host = last_buf[:out_len].cpu().numpy()
         ok = verify(slab, out_host, block_sizes, tail=(mode == _native.SLAB_LAST))
+        # every block, not a sample: the whole stream against the digest of the libdeflate-made one
+        full_ok, stream_sha = (None, hashlib.sha256(out_host).hexdigest())
+        if world == 1 and not env.emulate:
+            full_ok, stream_sha = check_full_stream("config2_text_550MiB_bgzf_l1", n, 20250927, out_host, block_sizes)
         stage_ms = {k: v / args.steps for k, v in stage_acc.items()}
         dom = max(stage_ms, key=stage_ms.get)
         alg_bytes = n + out_len  # 1 B read + r B written per input byte
         achieved = alg_bytes / (max(stage_ms[dom], 1e-9) * 1e-3) / 1e9
         traffic = pmc_traffic(dom)
+        traffic_all = pmc_traffic("pipeline")
         res = {
             "metric": "BGZF compress MiB/s at level 1, 550 MiB text",
             "value": round(value, 1),
@@ -746,8 +830,12 @@ def main():
                     world, "" if world == 1 else
                     (" + ordered RCCL gather" if args.writeout == "rccl" else " + size all_gather, per-rank write-out")),
                 "verified_bit_exact_sample": bool(ok),
+                "verified_bit_exact_full": full_ok,  # all blocks: SHA-256 of the stream and of the framed sizes == tests/golden/fullsize.json
+                "compat": "libdeflate >= 1.1x rule (the pinned 1.24); the golden digest is the v1.10 binary's, whose "
+                          "stream is the same on this input",
+                "box_libdeflate": box_libdeflate() if not env.emulate else None,
                 "blocks_handed_back_to_dense_kernels": ctx.debug_redo_count(),
-                "stream_sha256": hashlib.sha256(out_host).hexdigest(),
+                "stream_sha256": stream_sha,
                 "device": ctx.device_name(),
             },
             "roofline": {
@@ -758,8 +846,14 @@ def main():
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 5),
                 "traffic": traffic,
-                "traffic_source": "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)",
-                "pipeline_frac": round(alg_bytes / (sum(stage_ms.values()) * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                "traffic_ratio": round(traffic / alg_bytes, 2) if traffic else None,  # this kernel's HBM bytes / the path's algorithmic bytes
+                "traffic_pipeline": traffic_all,
+                "traffic_ratio_pipeline": round(traffic_all / alg_bytes, 2) if traffic_all else None,
+                "traffic_source": "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes of "
+                                  "this same command; committed, not collected in this run)",
+                # the whole timed step (kernels, launch gaps, the side stream's join), not a sum of stages
+                "pipeline_frac": round(alg_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                "hbm_read_frac": round(n / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),  # input bytes only (north_star's wording)
                 "stage_ms": {k: round(v, 3) for k, v in stage_ms.items()},
             },
         }

@@ -43,7 +43,7 @@ EXPORTS = [
     "gzpx_compress_slab", "gzpx_compress_slab_device", "gzpx_encode_block",
     "gzpx_alloc_compressor", "gzpx_deflate_compress", "gzpx_deflate_compress_bound",
     "gzpx_free_compressor", "gzpx_compressor_set_compat", "gzpx_crc32",
-    "gzpx_ctx_set_profiling", "gzpx_ctx_last_stage_ms", "gzpx_stage_name", "gzpx_debug_tokens",
+    "gzpx_ctx_set_profiling", "gzpx_ctx_last_stage_ms", "gzpx_stage_name", "gzpx_ctx_stage_kernel", "gzpx_debug_tokens",
     "gzpx_debug_set_flags", "gzpx_debug_redo_count", "gzpx_strerror", "gzpx_device_name", "gzpx_version",
     "gzpx_compress_slab_submit", "gzpx_compress_slab_submit_device", "gzpx_compress_slab_wait",
     "gzpx_compress_slab_event", "gzpx_crc32_checked", "gzpx_last_status",
@@ -137,6 +137,8 @@ class GzpxLib:
         L.gzpx_ctx_last_stage_ms.argtypes = [vp, ctypes.POINTER(ctypes.c_float)]
         L.gzpx_stage_name.restype = ctypes.c_char_p
         L.gzpx_stage_name.argtypes = [i32]
+        L.gzpx_ctx_stage_kernel.restype = ctypes.c_char_p
+        L.gzpx_ctx_stage_kernel.argtypes = [vp, i32]
         L.gzpx_debug_tokens.restype = i32
         L.gzpx_debug_tokens.argtypes = [vp, sz, vp, sz, psz, vp, psz]
         L.gzpx_debug_set_flags.restype = i32
@@ -366,7 +368,12 @@ class Context:
     def last_stage_ms(self):
         ms = (ctypes.c_float * N_STAGES)()
         self.lib.check(self.lib.L.gzpx_ctx_last_stage_ms(self.h, ms))
-        return {self.lib.L.gzpx_stage_name(i).decode(): float(ms[i]) for i in range(N_STAGES)}
+        out = {}
+        for i in range(N_STAGES):
+            name = self.lib.L.gzpx_ctx_stage_kernel(self.h, i).decode()
+            if name != "-":
+                out[name] = float(ms[i])
+        return out
 
     def debug_set_flags(self, flags):
         self.lib.check(self.lib.L.gzpx_debug_set_flags(self.h, flags))

@@ -393,9 +393,29 @@ int check_slab_args(const gzpx_ctx *ctx, const void *in, size_t in_len, int mode
 
 // Enqueue one slab (ctx->mu held).  host_in / host_out non-null: a host-buffer job that goes
 // through the slot's staging buffers; otherwise d_in / d_out are the caller's device buffers.
+int submit_enqueue(gzpx_ctx *ctx, const uint8_t *host_in, const uint8_t *d_in, size_t in_len, int mode,
+                   uint8_t *host_out, uint8_t *d_out, size_t out_cap, hipStream_t after, bool block_for_slot,
+                   std::unique_lock<std::mutex> &lk, uint64_t *ticket);
+
+// A submit that fails may already have put copies and kernels on the streams (the slot stays free):
+// nothing of them may still be running when the caller gets its buffers back or the next submit reuses
+// the slot's staging.
 int submit_locked(gzpx_ctx *ctx, const uint8_t *host_in, const uint8_t *d_in, size_t in_len, int mode,
                   uint8_t *host_out, uint8_t *d_out, size_t out_cap, hipStream_t after, bool block_for_slot,
                   std::unique_lock<std::mutex> &lk, uint64_t *ticket) {
+    const int rc = submit_enqueue(ctx, host_in, d_in, in_len, mode, host_out, d_out, out_cap, after, block_for_slot,
+                                  lk, ticket);
+    if (rc != GZPX_OK && rc != GZPX_ERR_BUSY && rc != GZPX_ERR_INVALID_ARG) {
+        (void)hipStreamSynchronize(ctx->s_h2d);
+        (void)hipStreamSynchronize(ctx->stream);
+        (void)hipStreamSynchronize(ctx->s_side);
+    }
+    return rc;
+}
+
+int submit_enqueue(gzpx_ctx *ctx, const uint8_t *host_in, const uint8_t *d_in, size_t in_len, int mode,
+                   uint8_t *host_out, uint8_t *d_out, size_t out_cap, hipStream_t after, bool block_for_slot,
+                   std::unique_lock<std::mutex> &lk, uint64_t *ticket) {
     if (ctx->crc_only) return GZPX_ERR_INVALID_ARG;
     const size_t caller_cap = out_cap;  // (host jobs: out_cap becomes the staging buffer's below)
     int si = -1;
@@ -537,12 +557,13 @@ void release_slot(gzpx_ctx *ctx, Slot &sl) {
 }
 
 // Complete a ticket: wait for its kernels, copy the stream out (host jobs), report.
-int wait_ticket(gzpx_ctx *ctx, uint64_t ticket, size_t host_out_cap, size_t *out_len, uint32_t *block_sizes,
-                size_t max_blocks, size_t *n_blocks) {
+int wait_ticket(gzpx_ctx *ctx, uint64_t ticket, size_t *out_len, uint32_t *block_sizes, size_t max_blocks,
+                size_t *n_blocks) {
     Slot *slp = nullptr;
     int rc = claim_ticket(ctx, ticket, &slp);
     if (rc != GZPX_OK) return rc;
     Slot &sl = *slp;
+    const size_t host_out_cap = sl.host_out_cap;  // (the slot is ours from the claim on: no other thread writes it)
     Completion c = kernels_done(ctx, sl);
     rc = c.rc;
     if (rc == GZPX_OK && sl.host_out && c.produced > host_out_cap) rc = GZPX_ERR_INSUFFICIENT_SPACE;
@@ -724,7 +745,7 @@ int gzpx_compress_slab_wait(gzpx_ctx *ctx, uint64_t ticket, size_t *out_len, uin
     if (!ctx) return GZPX_ERR_INVALID_ARG;
     const int si = (int)(ticket & 0xFF);
     if (si >= kSlots) return GZPX_ERR_INVALID_ARG;
-    return wait_ticket(ctx, ticket, ctx->slots[si].host_out_cap, out_len, block_sizes, max_blocks, n_blocks);
+    return wait_ticket(ctx, ticket, out_len, block_sizes, max_blocks, n_blocks);
 }
 
 int gzpx_compress_slab_event(gzpx_ctx *ctx, uint64_t ticket, void **hip_event) {
@@ -753,7 +774,7 @@ int gzpx_compress_slab_device(gzpx_ctx *ctx, const void *d_in, size_t in_len, in
                            (hipStream_t)hip_stream, true, lk, &ticket);
     }
     if (rc != GZPX_OK) return rc;
-    return wait_ticket(ctx, ticket, 0, out_len, block_sizes, max_blocks, n_blocks);
+    return wait_ticket(ctx, ticket, out_len, block_sizes, max_blocks, n_blocks);
 }
 
 int gzpx_compress_slab(gzpx_ctx *ctx, const uint8_t *in, size_t in_len, int mode, uint8_t *out,
@@ -770,7 +791,7 @@ int gzpx_compress_slab(gzpx_ctx *ctx, const uint8_t *in, size_t in_len, int mode
         rc = submit_locked(ctx, in, nullptr, in_len, mode, out, nullptr, out_cap, nullptr, true, lk, &ticket);
     }
     if (rc != GZPX_OK) return rc;
-    return wait_ticket(ctx, ticket, out_cap, out_len, block_sizes, max_blocks, n_blocks);
+    return wait_ticket(ctx, ticket, out_len, block_sizes, max_blocks, n_blocks);
 }
 
 int gzpx_encode_block(gzpx_ctx *ctx, const uint8_t *in, size_t n, int is_last, uint8_t *out,
@@ -1478,6 +1499,17 @@ const char *gzpx_stage_name(int stage) {
     static const char *names[GZPX_N_STAGES] = {"k_init_meta", "k_candidates", "k_match", "k_parse", "k_hist",
                                                "k_huffman",   "k_crc32",      "k_scan",  "k_emit"};
     return (stage >= 0 && stage < GZPX_N_STAGES) ? names[stage] : "?";
+}
+
+const char *gzpx_ctx_stage_kernel(const gzpx_ctx *ctx, int stage) {
+    // the kernels behind stages 2 and 3 depend on the level (and, at level 1, on the block size)
+    if (ctx && stage == 2) {
+        const Config &c = ctx->dcfg;
+        if (c.level <= 1) return (c.block_size <= kTile && !(c.debug & 2u)) ? "k_mparse" : "k_match";
+        return c.lazy ? "k_match_hc+k_parse_lazy" : "k_match_hc+k_parse_hc";
+    }
+    if (ctx && stage == 3 && ctx->dcfg.level > 1) return "-";
+    return gzpx_stage_name(stage);
 }
 
 int gzpx_debug_tokens(gzpx_ctx *ctx, size_t block, uint32_t *tokens, size_t max_tokens,

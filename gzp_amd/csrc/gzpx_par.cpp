@@ -342,11 +342,13 @@ void ParCompress::finish() {
 void ParCompress::complete(InFlight &f) {
     const size_t n = f.job->input.len, bs = cfg_.buffer_size;
     const size_t nb = n == 0 ? 1 : (n + bs - 1) / bs;
+    bool waited = false;
     try {
         Done d;
         d.block_sizes.resize(nb);
         d.in_len = n;
         size_t out_len = 0, blk = 0;
+        waited = true;
         const int rc = gzpx_compress_slab_wait(ctx_, f.ticket, &out_len, d.block_sizes.data(), nb, &blk);
         give_buffer(f.job->input);
         f.job->input = Pinned();
@@ -358,6 +360,9 @@ void ParCompress::complete(InFlight &f) {
         d.out = f.out;
         f.job->result.set_value(std::move(d));
     } catch (...) {
+        // (an exception before the wait -- bad_alloc -- must not leave the ticket's slot taken: every
+        // later submit would find the context busy)
+        if (!waited) (void)gzpx_compress_slab_wait(ctx_, f.ticket, nullptr, nullptr, 0, nullptr);
         f.job->result.set_exception(std::current_exception());
     }
 }

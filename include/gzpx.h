@@ -290,6 +290,10 @@ int gzpx_synth_ascii_device(void *d_out, uint64_t stream_offset, uint64_t n, uin
 int gzpx_ctx_set_profiling(gzpx_ctx *ctx, int on);
 int gzpx_ctx_last_stage_ms(const gzpx_ctx *ctx, float ms[GZPX_N_STAGES]);
 const char *gzpx_stage_name(int stage);
+/* the kernel(s) behind a stage for THIS context: stage 2 is k_mparse (level 1, blocks <= 64 KiB: match
+ * on demand; k_match / k_parse then only see the blocks it hands back), k_match (level 1, larger
+ * blocks), k_match_hc + k_parse_hc (levels 2-4) or k_match_hc + k_parse_lazy (levels 5-9) */
+const char *gzpx_ctx_stage_kernel(const gzpx_ctx *ctx, int stage);
 
 /* ---- test hooks: intermediate products of the last slab call (device -> host copies) ---- */
 int gzpx_debug_tokens(gzpx_ctx *ctx, size_t block, uint32_t *tokens, size_t max_tokens,

@@ -28,6 +28,15 @@ def test_header_symbols_exported(built_lib):
     assert set(_native.EXPORTS) <= declared
 
 
+def test_release_build_has_no_experiment_hooks(built_lib):
+    """The measurement-only switches (-DGZPX_EXPERIMENT: parts of kernels skipped, cycle counters)
+    live in a second library that tools/exp_*.py build; the product library must not carry them."""
+    L = ctypes.CDLL(built_lib)
+    assert not hasattr(L, "gzpx_exp_cycles")
+    blob = open(built_lib, "rb").read()
+    assert b"g_exp_cycles" not in blob
+
+
 def test_no_cpu_fallback_without_device(built_lib):
     import torch
     if torch.cuda.is_available():

@@ -40,5 +40,5 @@ for level in (3, 6):
             if it:
                 for k, v in ctx.last_stage_ms().items():
                     acc[k] = acc.get(k, 0.0) + v / 2
-        print("level %d %-18s match+parse %.2f ms" % (level, name, acc["k_match"]), flush=True)
+        print("level %d %-18s match+parse %.2f ms" % (level, name, acc["k_match_hc+k_parse_lazy" if level >= 5 else "k_match_hc+k_parse_hc"]), flush=True)
     ctx.close()

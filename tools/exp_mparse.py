@@ -43,4 +43,4 @@ for name, flags in [("baseline", 0), ("no gather", 1 << 13), ("no token build", 
     lib.L.gzpx_exp_cycles(cyc, 1)
     c = [x / 5 / nb for x in cyc]
     print("%-16s k_mparse %.3f ms | per block: stage %.0f  first walk %.0f  later rounds %.0f  settle %.0f  scan+build %.0f cycles; "
-          "%.2f barrier rounds, %.1f re-walks" % (name, acc["k_match"], c[0], c[1], c[2], c[3], c[4], c[5], c[6]), flush=True)
+          "%.2f barrier rounds, %.1f re-walks" % (name, acc["k_mparse"], c[0], c[1], c[2], c[3], c[4], c[5], c[6]), flush=True)

@@ -71,8 +71,9 @@ doc = {
 }
 doc["round"] = tag
 doc["pipeline_total_bytes"] = int(sum(v for k, v in doc["hbm_bytes_per_launch"].items()
-                                      if k in ("k_init_meta", "k_candidates", "k_candidates_safe", "k_match", "k_parse", "k_hist",
-                                               "k_huffman", "k_crc32", "k_scan", "k_emit")))
+                                      if k in ("k_init_meta", "k_candidates", "k_candidates_safe", "k_mparse", "k_match", "k_parse",
+                                               "k_hist", "k_huffman", "k_crc32", "k_scan", "k_emit")))
+doc["hbm_bytes_per_launch"]["pipeline"] = doc["pipeline_total_bytes"]  # every kernel of one level-1 step
 with open(os.path.join(P, "pmc_traffic.json"), "w") as f:
     json.dump(doc, f, indent=1)
 print(json.dumps(doc["hbm_bytes_per_launch"], indent=1))
