@@ -202,6 +202,14 @@ __device__ __forceinline__ void offset_slot(uint32_t off, uint32_t &slot, uint32
 
 __device__ __forceinline__ uint32_t hdr_len_of(uint32_t format) { return format == 0 ? 18u : 20u; }
 
+// RFC 1951's order of the code length code lengths (16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13,
+// 2, 14, 1, 15), five bits each in two constants: a table indexed by a lane or a loop counter would be an
+// array in scratch memory.  i < 19.
+__device__ __forceinline__ uint32_t precode_order(uint32_t i) {
+    const uint64_t lo = 0x22caa324e804a30ull, hi = 0x3c2e1346cull;
+    return i < 12u ? (uint32_t)(lo >> (5u * i)) & 31u : (uint32_t)(hi >> (5u * (i - 12u))) & 31u;
+}
+
 // ------------------------------------------------------------------------------------------
 // k_init_meta: cut the slab into blocks the way ParCompress::write / flush_last do
 // (src/par/compress.rs:415-416, :333-341): full `block_size` cuts, the remainder (possibly a
@@ -1773,7 +1781,10 @@ __device__ __forceinline__ unsigned long long mask_after_kth(unsigned long long 
     return ~((kth << 1) - 1);
 }
 
-__global__ __launch_bounds__(kMpThreads, 8) void k_parse_hc(
+#ifndef GZPX_PHC_WAVES
+#define GZPX_PHC_WAVES 8
+#endif
+__global__ __launch_bounds__(kMpThreads, GZPX_PHC_WAVES) void k_parse_hc(
     Config cfg, const uint8_t *__restrict__ slab, BlockMeta *__restrict__ meta_all,
     SubMeta *__restrict__ sub_all, HcState *__restrict__ hc_all, const uint8_t *__restrict__ len8_all,
     const uint32_t *__restrict__ mbits_all, const uint16_t *__restrict__ val_all,
@@ -2581,13 +2592,17 @@ static_assert(kHdrWords <= kNumLitlen, "header bits fit region A");
 // 0.66 ms: with six waves per SIMD the kernel is bound by instructions issued, not by the latency of
 // lane 0's LDS reads, and the register queues cost more instructions per node.)
 __device__ __forceinline__ uint32_t reg5_get(const uint32_t (&r)[5], uint32_t k) {
-    const uint32_t j = k >> 6;
-    uint32_t v = r[0];
-    v = j == 1 ? r[1] : v;
-    v = j == 2 ? r[2] : v;
-    v = j == 3 ? r[3] : v;
-    v = j == 4 ? r[4] : v;
-    return rdlane(v, k & 63u);
+    // (k is wave-uniform.  Selecting the REGISTER first and reading the lane after it invites the
+    // compiler to turn the selects into an indexed load of an array in scratch memory; five lane
+    // reads and scalar selects stay in registers.)
+    const uint32_t j = k >> 6, l = k & 63u;
+    uint32_t v = rdlane(r[0], l);
+    const uint32_t v1 = rdlane(r[1], l), v2 = rdlane(r[2], l), v3 = rdlane(r[3], l), v4 = rdlane(r[4], l);
+    v = j == 1 ? v1 : v;
+    v = j == 2 ? v2 : v;
+    v = j == 3 ? v3 : v;
+    v = j == 4 ? v4 : v;
+    return v;
 }
 
 // Builds lens[] / cw[] for `num_syms` symbols from h.freq[].  All 64 lanes must call.
@@ -2760,9 +2775,10 @@ __device__ void make_code(HuffLds &h, uint32_t num_syms, uint32_t max_len, uint3
     }
     wave_sync();
     // canonical codewords: next_code[len] + (# lower symbols of the same length), bit-reversed
-    uint32_t next_code[16];
+    uint32_t next_code[16];  // (wave-uniform; every loop over it unrolled, so it stays in registers)
     next_code[0] = 0;
     next_code[1] = 0;
+#pragma unroll
     for (uint32_t l = 2; l <= 15; l++)
         next_code[l] = l <= max_len ? (next_code[l - 1] + h.len_counts[l - 1]) << 1 : 0;
     const uint64_t lane_below = (1ull << lane) - 1ull;
@@ -2770,6 +2786,7 @@ __device__ void make_code(HuffLds &h, uint32_t num_syms, uint32_t max_len, uint3
         const uint32_t s = base + lane;
         const uint32_t myl = s < num_syms ? lens[s] : 0;
         uint32_t code = 0;
+#pragma unroll
         for (uint32_t l = 1; l <= 15; l++) {
             const uint64_t m = __ballot(myl == l);
             if (myl == l) code = next_code[l] + (uint32_t)__popcll(m & lane_below);
@@ -2795,7 +2812,10 @@ __device__ __forceinline__ void hdr_put(uint32_t *hdr, uint32_t &bitpos, uint32_
     bitpos += nbits;
 }
 
-__global__ __launch_bounds__(64, 6) void k_huffman(Config cfg, BlockMeta *__restrict__ meta_all,
+#ifndef GZPX_HUFF_WAVES
+#define GZPX_HUFF_WAVES 6
+#endif
+__global__ __launch_bounds__(64, GZPX_HUFF_WAVES) void k_huffman(Config cfg, BlockMeta *__restrict__ meta_all,
                                                 SubMeta *__restrict__ sub_all,
                                                 const uint32_t *__restrict__ hist_all,
                                                 uint32_t *__restrict__ codes_all,
@@ -2954,10 +2974,9 @@ __global__ __launch_bounds__(64, 6) void k_huffman(Config cfg, BlockMeta *__rest
         make_code(h, 19, 7, cfg.compat, h.plens, h.pcw, lane);
         uint32_t num_explicit;
         {
-            const uint32_t perm[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
             uint32_t ne = 4;
             for (uint32_t i = 0; i < 19; i++)
-                if (h.plens[perm[i]]) ne = i + 1 > ne ? i + 1 : ne;
+                if (h.plens[precode_order(i)]) ne = i + 1 > ne ? i + 1 : ne;
             num_explicit = ne;
         }
 
@@ -3012,11 +3031,10 @@ __global__ __launch_bounds__(64, 6) void k_huffman(Config cfg, BlockMeta *__rest
                 // BFINAL, BTYPE, HLIT, HDIST, HCLEN (17 bits), the explicit precode lengths (3 bits
                 // each, one per lane), then the items: codeword + extra bits, placed by a running
                 // prefix sum of their bit counts and OR-ed into the header words
-                const uint32_t perm[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
                 if (lane == 0)
                     atomicOr(&h.hdr[0], is_final | (2u << 1) | ((num_litlen - 257) << 3) | ((num_offset - 1) << 8) |
                                             ((num_explicit - 4) << 13));
-                if (lane < num_explicit) hdr_or_bits(h.hdr, 17 + 3 * lane, h.plens[perm[lane < 19 ? lane : 0]], 3);
+                if (lane < num_explicit) hdr_or_bits(h.hdr, 17 + 3 * lane, h.plens[precode_order(lane < 19 ? lane : 0)], 3);
                 uint32_t bp = 17 + 3 * num_explicit;
                 for (uint32_t base = 0; base < num_items; base += 64) {
                     const uint32_t i = base + lane;
@@ -3631,6 +3649,11 @@ __device__ __forceinline__ uint32_t inflate_entry(uint32_t sym, uint32_t cl) {
 // Build the decode tables of one code from lens[0 .. nsyms): counts, canonical first codes, symbols
 // in canonical order, and the direct-lookup table for codes of <= fast_bits bits.  All 64 lanes
 // call it.  Returns false for an over-subscribed code.
+// (Not inlined on purpose, and cnt / fst / off indexed by a lane's own code length -- 544 bytes of
+// scratch per lane in a part of the kernel that runs once per DEFLATE sub-block.  Measured in round 3:
+// with the tables in registers / LDS and the function inlined the kernel has no scratch and 64 VGPRs,
+// but the register allocator then spills 130 SGPRs inside the decode loop: 8.35 -> 9.08 ms on the
+// bench stream; padded back to five waves per SIMD 9.08; not inlined but without the arrays 10.6.)
 template <int KIND>
 __device__ bool inflate_build(const uint8_t *lens, uint32_t nsyms, uint32_t fast_bits, uint32_t *fast,
                               uint16_t *sorted, uint32_t *count, uint32_t *first, uint32_t *offs,
