@@ -230,6 +230,15 @@ class Env:
             dt = float(t.item())
         return dt
 
+    def all_ranks(self, x):
+        """One float from every rank, as a list on every rank."""
+        if self.world == 1:
+            return [float(x)]
+        t = self.torch.tensor([float(x)], dtype=self.torch.float64, device=self.dev)
+        out = [self.torch.zeros_like(t) for _ in range(self.world)]
+        self.dist.all_gather(out, t)
+        return [float(o.item()) for o in out]
+
     def close(self):
         if self.world > 1:
             self.dist.barrier()
@@ -724,10 +733,12 @@ def main():
     # two output buffers: with N > 1 the write-out of one step's shard (asynchronous) runs while the
     # next step compresses into the other buffer, the way ParCompress's slabs overlap
     d_outs = [torch.empty(cap, dtype=torch.uint8, device=env.dev) for _ in range(2 if world > 1 else 1)]
-    gathered = torch.empty(cap * world, dtype=torch.uint8, device=env.dev) \
-        if (world > 1 and rank == 0 and args.writeout == "rccl") else None
+    # N > 1: BOTH in-order write-outs are timed in this one run, back to back -- first the one --writeout
+    # names (default rccl: north_star's ordered gather; it is the line's `value`), then the other.
+    modes = [None] if world == 1 else [args.writeout, "offsets" if args.writeout == "rccl" else "rccl"]
+    gathered = torch.empty(cap * world, dtype=torch.uint8, device=env.dev) if (world > 1 and rank == 0) else None
     host_out = None
-    if world > 1 and args.writeout == "offsets" and not env.emulate:
+    if world > 1 and not env.emulate:
         host_out = [torch.empty(cap, dtype=torch.uint8).pin_memory() for _ in range(2)]
         copy_stream = torch.cuda.Stream()
     nb = ctx.n_blocks(n)
@@ -735,7 +746,14 @@ def main():
     ctx.set_profiling(True)
     if args.debug_flags:
         ctx.debug_set_flags(args.debug_flags)
-    state = {"i": 0, "pending": None, "offsets": None}
+    state = {"i": 0, "pending": None, "offsets": None, "writeout": modes[0], "wait_s": 0.0}
+
+    def wait_pending():
+        if state["pending"] is not None:
+            t = time.perf_counter()
+            state["pending"].wait()
+            state["wait_s"] += time.perf_counter() - t  # host time spent waiting for a shard to leave
+            state["pending"] = None
 
     def step():
         k = state["i"] % len(d_outs)
@@ -744,9 +762,8 @@ def main():
         out_len, _ = ctx.compress_slab_device(d_in.data_ptr(), n, buf.data_ptr(), cap, mode,
                                               None, block_sizes)
         if world > 1:
-            if state["pending"] is not None:  # the previous shard has left (it travelled while this
-                state["pending"].wait()       # step compressed); its buffers are free again
-            if args.writeout == "rccl":
+            wait_pending()  # the previous shard has left (it travelled while this step compressed)
+            if state["writeout"] == "rccl":
                 # in-order write-out: ordered variable-size gather of the shards to rank 0 (RCCL),
                 # started now and completed while the next step compresses
                 state["pending"] = shard.ordered_gather_start(buf[:out_len], dst=0, out=gathered)
@@ -764,26 +781,34 @@ def main():
                     state["pending"] = shard.EventHandle(ev)
         return out_len
 
-    def drain():
-        if state["pending"] is not None:
-            state["pending"].wait()
-            state["pending"] = None
+    def timed_region(writeout):
+        """W warm-up steps, then exactly K timed steps between barriers; max over ranks."""
+        state["writeout"] = writeout
+        acc = {}
+        for _ in range(args.warmup):
+            step()
+        wait_pending()
+        state["wait_s"] = 0.0
+        env.sync()
+        t0 = time.perf_counter()
+        out_len = 0
+        for _ in range(args.steps):
+            out_len = step()
+            for k, v in ctx.last_stage_ms().items():
+                acc[k] = acc.get(k, 0.0) + v
+        wait_pending()  # the last write-out belongs to the timed region
+        env.sync()
+        mine = time.perf_counter() - t0
+        per_rank = env.all_ranks(mine / args.steps * 1e3)
+        waits = env.all_ranks(state["wait_s"] / args.steps * 1e3)
+        return {"dt": max(per_rank) * args.steps / 1e3 if world > 1 else mine, "out_len": out_len, "stage_acc": acc,
+                "rank_ms_per_step": [round(x, 3) for x in per_rank], "rank_writeout_wait_ms": [round(x, 3) for x in waits]}
 
-    stage_acc = {}
-    for _ in range(args.warmup):
-        step()
-    drain()
-
-    env.sync()
-    t0 = time.perf_counter()
-    out_len = 0
-    for _ in range(args.steps):
-        out_len = step()
-        for k, v in ctx.last_stage_ms().items():
-            stage_acc[k] = stage_acc.get(k, 0.0) + v
-    drain()  # the last write-out belongs to the timed region
-    env.sync()
-    dt = env.max_over_ranks(time.perf_counter() - t0)
+    regions = {}
+    for wmode in modes:
+        regions[wmode] = timed_region(wmode)
+    head = regions[modes[0]]
+    dt, out_len, stage_acc = head["dt"], head["out_len"], head["stage_acc"]
 
     ms_per_step = dt / args.steps * 1e3
     total_mib = total / 2**20
@@ -857,6 +882,12 @@ def main():
                 "stage_ms": {k: round(v, 3) for k, v in stage_ms.items()},
             },
         }
+        if world > 1:
+            res["writeouts"] = {
+                m: {"MiBps": round(total_mib / (r["dt"] / args.steps), 1), "ms_per_step": round(r["dt"] / args.steps * 1e3, 3),
+                    "rank_ms_per_step": r["rank_ms_per_step"], "rank_writeout_wait_ms": r["rank_writeout_wait_ms"]}
+                for m, r in regions.items()}
+            res["writeouts"]["value_is"] = modes[0]
         if world == 1 and not args.no_extras:
             ctx.set_profiling(False)
             try:

@@ -56,6 +56,7 @@ EXPORTS = [
     "gzpx_pard_last_error", "gzpx_host_alloc", "gzpx_host_free", "gzpx_dctx_last_inflate_ms",
     "gzpx_debug_inflate", "gzpx_synth_fastq_device", "gzpx_synth_ascii_device",
     "gzpx_multi_create", "gzpx_multi_destroy", "gzpx_multi_devices", "gzpx_multi_compress_slab",
+    "gzpx_multi_shard", "gzpx_multi_compress_slab_device",
 ]
 
 
@@ -229,6 +230,10 @@ class GzpxLib:
         L.gzpx_multi_devices.argtypes = [vp]
         L.gzpx_multi_compress_slab.restype = i32
         L.gzpx_multi_compress_slab.argtypes = [vp, vp, sz, i32, vp, sz, psz, vp, sz, psz]
+        L.gzpx_multi_shard.restype = i32
+        L.gzpx_multi_shard.argtypes = [vp, sz, sz, psz, psz]
+        L.gzpx_multi_compress_slab_device.restype = i32
+        L.gzpx_multi_compress_slab_device.argtypes = [vp, ctypes.POINTER(vp), sz, i32, sz, vp, sz, psz, vp, sz, psz]
         L.gzpx_synth_ascii_device.restype = i32
         L.gzpx_synth_ascii_device.argtypes = [vp, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint64, vp]
         L.gzpx_pard_create.restype = i32
@@ -459,6 +464,29 @@ class MultiContext:
         self.lib.check(rc, nb.value if rc == ERR_BLOCK_SIZE_EXCEEDED else None)
         res = out[:out_len.value].tobytes()
         return (res, sizes[:nb.value].copy()) if return_block_sizes else res
+
+    def shard(self, in_len, g):
+        """(offset, length) of the block range device g takes of a slab of in_len bytes."""
+        off, n = ctypes.c_size_t(0), ctypes.c_size_t(0)
+        self.lib.check(self.lib.L.gzpx_multi_shard(self.h, in_len, g, ctypes.byref(off), ctypes.byref(n)))
+        return off.value, n.value
+
+    def compress_slab_device(self, d_in_ptrs, in_len, d_out_ptr, out_cap, mode=SLAB_LAST, root=0):
+        """Every range already on its own device (d_in_ptrs[g]); the shards are gathered device to device
+        into d_out_ptr on devices[root].  Returns (out_len, block_sizes)."""
+        ptrs = (ctypes.c_void_p * len(d_in_ptrs))(*[ctypes.c_void_p(int(p) if p else None) for p in d_in_ptrs])
+        nb_max = 1 if in_len == 0 else -(-in_len // self.buffer_size)
+        sizes = np.zeros(nb_max, dtype=np.uint32)
+        out_len = ctypes.c_size_t(0)
+        nb = ctypes.c_size_t(0)
+        rc = self.lib.L.gzpx_multi_compress_slab_device(self.h, ptrs, in_len, int(mode), root, d_out_ptr, out_cap,
+                                                        ctypes.byref(out_len), sizes.ctypes.data, nb_max, ctypes.byref(nb))
+        self.lib.check(rc, nb.value if rc == ERR_BLOCK_SIZE_EXCEEDED else None)
+        return out_len.value, sizes[:nb.value].copy()
+
+    def slab_bound(self, n):
+        nb_max = 1 if n == 0 else -(-n // self.buffer_size)
+        return nb_max * (self.buffer_size + max(128, self.buffer_size // 10) + 28) + 128
 
     def close(self):
         if getattr(self, "h", None):

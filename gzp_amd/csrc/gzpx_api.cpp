@@ -824,7 +824,30 @@ struct gzpx_multi {
     std::vector<gzpx_ctx *> ctxs;
     size_t buffer_size = 0;
     std::mutex mu;
+    // device-resident form: every device's own output staging (its shard before the gather)
+    std::vector<uint8_t *> d_stage;
+    std::vector<size_t> d_stage_cap;
 };
+
+namespace {
+// the block range of device g of G when a slab of in_len bytes is cut (contiguous, balanced to one block)
+struct MultiPart {
+    uint64_t first = 0, nb = 0;
+    size_t lo = 0, n = 0;
+};
+MultiPart multi_part(size_t in_len, size_t bs, size_t G, size_t g) {
+    const uint64_t total_nb = in_len == 0 ? 1 : (in_len + bs - 1) / bs;
+    MultiPart p;
+    for (size_t k = 0; k <= g; k++) {
+        p.first += p.nb;
+        p.nb = total_nb / G + (k < total_nb % G ? 1 : 0);
+    }
+    p.lo = (size_t)(p.first * bs < in_len ? p.first * bs : in_len);
+    const size_t hi = (size_t)((p.first + p.nb) * bs < in_len ? (p.first + p.nb) * bs : in_len);
+    p.n = hi - p.lo;
+    return p;
+}
+}  // namespace
 
 int gzpx_multi_create(const gzpx_config *cfg, const int *devices, size_t n_devices, gzpx_multi **out) {
     if (!cfg || !devices || !n_devices || !out) return GZPX_ERR_INVALID_ARG;
@@ -845,14 +868,141 @@ int gzpx_multi_create(const gzpx_config *cfg, const int *devices, size_t n_devic
         }
         m->ctxs.push_back(ctx);
     }
+    // device-to-device copies of the gather: direct over xGMI where the devices can reach each other
+    for (size_t a = 0; a < n_devices; a++)
+        for (size_t b = 0; b < n_devices; b++) {
+            int can = 0;
+            if (devices[a] != devices[b] && hipDeviceCanAccessPeer(&can, devices[a], devices[b]) == hipSuccess && can &&
+                hipSetDevice(devices[a]) == hipSuccess)
+                (void)hipDeviceEnablePeerAccess(devices[b], 0);  // (already enabled: an error we ignore)
+        }
+    (void)hipGetLastError();
     *out = m;
     return GZPX_OK;
 }
 
 void gzpx_multi_destroy(gzpx_multi *m) {
     if (!m) return;
+    for (size_t g = 0; g < m->d_stage.size(); g++)
+        if (m->d_stage[g] && g < m->ctxs.size() && hipSetDevice(m->ctxs[g]->cfg.device) == hipSuccess)
+            (void)hipFree(m->d_stage[g]);
     for (gzpx_ctx *c : m->ctxs) gzpx_ctx_destroy(c);
     delete m;
+}
+
+int gzpx_multi_shard(const gzpx_multi *m, size_t in_len, size_t g, size_t *offset, size_t *len) {
+    if (!m || g >= m->ctxs.size() || !offset || !len) return GZPX_ERR_INVALID_ARG;
+    const MultiPart p = multi_part(in_len, m->buffer_size, m->ctxs.size(), g);
+    *offset = p.lo;
+    *len = p.n;
+    return GZPX_OK;
+}
+
+// The device-resident form: north_star's write-out.  Range g of the slab already lives on device g
+// (d_in[g]); every device compresses its range into its own staging buffer, the host learns the shard
+// sizes (a 16-byte record per device) and each shard then travels ONCE, device to device, into its
+// stream offset of `d_out` on devices[root] -- hipMemcpyPeerAsync on the owning device's copy stream,
+// all peers at once (every peer has its own xGMI link to the root); the root's own shard is a local
+// copy.  No payload byte touches host memory.  In-order property: src/par/compress.rs:305-310.
+int gzpx_multi_compress_slab_device(gzpx_multi *m, const void *const *d_in, size_t in_len, int mode, size_t root,
+                                    void *d_out, size_t out_cap, size_t *out_len, uint32_t *block_sizes,
+                                    size_t max_blocks, size_t *n_blocks) {
+    if (!m || !out_len || m->ctxs.empty() || !d_in || !d_out || root >= m->ctxs.size()) return GZPX_ERR_INVALID_ARG;
+    if (mode != GZPX_SLAB_FULL_BLOCKS && mode != GZPX_SLAB_LAST && mode != GZPX_SLAB_FLUSH) return GZPX_ERR_INVALID_ARG;
+    const size_t bs = m->buffer_size, G = m->ctxs.size();
+    if (mode == GZPX_SLAB_FULL_BLOCKS && (in_len == 0 || in_len % bs != 0)) return GZPX_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> guard(m->mu);
+    const uint64_t total_nb = in_len == 0 ? 1 : (in_len + bs - 1) / bs;
+    if (block_sizes && max_blocks < total_nb) return GZPX_ERR_INVALID_ARG;
+    struct Part {
+        MultiPart r;
+        uint64_t ticket = 0;
+        Slot *slot = nullptr;
+        Completion c;
+        bool submitted = false;
+    };
+    std::vector<Part> parts(G);
+    m->d_stage.resize(G, nullptr);
+    m->d_stage_cap.resize(G, 0);
+    int rc = GZPX_OK;
+    // 1. every device: the kernels of its range, output into its own staging (devices work concurrently)
+    for (size_t g = 0; g < G && rc == GZPX_OK; g++) {
+        Part &p = parts[g];
+        p.r = multi_part(in_len, bs, G, g);
+        if (p.r.nb == 0) continue;
+        if (p.r.n && !d_in[g]) {
+            rc = GZPX_ERR_INVALID_ARG;
+            break;
+        }
+        const bool owns_end = p.r.first + p.r.nb == total_nb;
+        gzpx_ctx *ctx = m->ctxs[g];
+        std::unique_lock<std::mutex> lk(ctx->mu);
+        if (hipSetDevice(ctx->cfg.device) != hipSuccess) {
+            rc = GZPX_ERR_DEVICE;
+            break;
+        }
+        const size_t need = gzpx_slab_bound(ctx, p.r.n);
+        if (need > m->d_stage_cap[g]) {
+            if (m->d_stage[g]) (void)hipFree(m->d_stage[g]);
+            m->d_stage[g] = nullptr;
+            m->d_stage_cap[g] = 0;
+            if (hipMalloc((void **)&m->d_stage[g], need + need / 8 + 4096) != hipSuccess) {
+                rc = GZPX_ERR_DEVICE;
+                break;
+            }
+            m->d_stage_cap[g] = need + need / 8 + 4096;
+        }
+        rc = submit_locked(ctx, nullptr, (const uint8_t *)d_in[g], p.r.n, owns_end ? mode : GZPX_SLAB_FULL_BLOCKS, nullptr,
+                           m->d_stage[g], m->d_stage_cap[g], nullptr, true, lk, &p.ticket);
+        p.submitted = rc == GZPX_OK;
+    }
+    // 2. shard sizes -> stream offsets
+    size_t fail_block = (size_t)total_nb;
+    for (size_t g = 0; g < G; g++) {
+        Part &p = parts[g];
+        if (!p.submitted) continue;
+        if (claim_ticket(m->ctxs[g], p.ticket, &p.slot) != GZPX_OK) {
+            if (rc == GZPX_OK) rc = GZPX_ERR_DEVICE;
+            p.submitted = false;
+            continue;
+        }
+        p.c = kernels_done(m->ctxs[g], *p.slot);
+        if (p.c.rc != GZPX_OK && rc == GZPX_OK) {  // the first failing block in stream order
+            rc = p.c.rc;
+            fail_block = (size_t)p.r.first + p.c.blocks_done;
+        }
+    }
+    size_t total = 0;
+    std::vector<size_t> offs(G, 0);
+    for (size_t g = 0; g < G; g++) {
+        offs[g] = total;
+        if (parts[g].submitted) total += parts[g].c.produced;
+    }
+    if (rc == GZPX_OK && total > out_cap) rc = GZPX_ERR_INSUFFICIENT_SPACE;
+    // 3. the ordered gather: every shard straight into its place on the root device, all at once
+    const int root_dev = m->ctxs[root]->cfg.device;
+    for (size_t g = 0; g < G && rc == GZPX_OK; g++) {
+        Part &p = parts[g];
+        if (!p.submitted || !p.c.produced) continue;
+        gzpx_ctx *ctx = m->ctxs[g];
+        if (hipSetDevice(ctx->cfg.device) != hipSuccess ||
+            hipMemcpyPeerAsync((uint8_t *)d_out + offs[g], root_dev, m->d_stage[g], ctx->cfg.device, p.c.produced,
+                               ctx->s_d2h) != hipSuccess ||
+            hipEventRecord(p.slot->ev_d2h, ctx->s_d2h) != hipSuccess)
+            rc = GZPX_ERR_DEVICE;
+    }
+    for (size_t g = 0; g < G; g++) {
+        Part &p = parts[g];
+        if (!p.submitted) continue;
+        const int r2 = finish_copy_out(m->ctxs[g], *p.slot, p.c.produced);
+        if (rc == GZPX_OK) rc = r2;
+        if (rc == GZPX_OK && block_sizes)
+            memcpy(block_sizes + p.r.first, p.slot->h_sizes, (size_t)p.r.nb * sizeof(uint32_t));
+        release_slot(m->ctxs[g], *p.slot);
+    }
+    *out_len = rc == GZPX_OK ? total : 0;
+    if (n_blocks) *n_blocks = rc == GZPX_OK ? (size_t)total_nb : fail_block;
+    return rc;
 }
 
 size_t gzpx_multi_devices(const gzpx_multi *m) { return m ? m->ctxs.size() : 0; }

@@ -154,6 +154,19 @@ int gzpx_multi_compress_slab(gzpx_multi *m, const uint8_t *in, size_t in_len, in
                              size_t out_cap, size_t *out_len, uint32_t *block_sizes, size_t max_blocks,
                              size_t *n_blocks);
 
+/* The same with every range already resident on its own device -- north_star's "shard of the input slab
+ * across 8 GPUs with a gather of compressed blocks over xGMI for in-order write-out": d_in[g] is a device
+ * pointer ON devices[g] to range g of the slab (gzpx_multi_shard tells offset and length of range g for a
+ * slab of in_len bytes), every device compresses its range into its own staging, and each shard is then
+ * copied once, device to device (hipMemcpyPeerAsync, all peers at once), into its stream offset of d_out on
+ * devices[root].  No payload passes through host memory; only the 16-byte result records and the
+ * per-block sizes do.  Byte for byte the stream of gzpx_compress_slab.  Replaces the writer thread's
+ * in-order collection, src/par/compress.rs:305-310. */
+int gzpx_multi_shard(const gzpx_multi *m, size_t in_len, size_t g, size_t *offset, size_t *len);
+int gzpx_multi_compress_slab_device(gzpx_multi *m, const void *const *d_in, size_t in_len, int mode, size_t root,
+                                    void *d_out, size_t out_cap, size_t *out_len, uint32_t *block_sizes,
+                                    size_t max_blocks, size_t *n_blocks);
+
 /* FormatSpec::encode: one framed block (is_last => BGZF_EOF appended for BGZF). */
 int gzpx_encode_block(gzpx_ctx *ctx, const uint8_t *in, size_t n, int is_last, uint8_t *out,
                       size_t out_cap, size_t *out_len);

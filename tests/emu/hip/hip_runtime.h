@@ -253,6 +253,11 @@ hipError_t hipHostMalloc(void **p, size_t n, unsigned flags = 0);
 hipError_t hipHostFree(void *p);
 hipError_t hipMemcpy(void *d, const void *s, size_t n, hipMemcpyKind k);
 hipError_t hipMemcpyAsync(void *d, const void *s, size_t n, hipMemcpyKind k, hipStream_t st = 0);
+static inline hipError_t hipMemcpyPeerAsync(void *d, int, const void *s, int, size_t n, hipStream_t st = 0) {
+    return hipMemcpyAsync(d, s, n, hipMemcpyDeviceToDevice, st);
+}
+static inline hipError_t hipDeviceCanAccessPeer(int *can, int, int) { *can = 0; return hipSuccess; }
+static inline hipError_t hipDeviceEnablePeerAccess(int, unsigned) { return hipSuccess; }
 hipError_t hipMemset(void *d, int v, size_t n);
 hipError_t hipMemsetAsync(void *d, int v, size_t n, hipStream_t st = 0);
 hipError_t hipStreamCreate(hipStream_t *s);

@@ -29,6 +29,12 @@ def test_two_ranks_self_launch_ordered_gather():
     for k in ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "higher_is_better", "vs_baseline", "dtype",
               "data", "roofline"):
         assert k in d
+    # one run tells the whole story: both in-order write-outs timed back to back, per-rank times in the line
+    w = d["writeouts"]
+    assert w["value_is"] == "rccl" and set(w) == {"rccl", "offsets", "value_is"}
+    for m in ("rccl", "offsets"):
+        assert len(w[m]["rank_ms_per_step"]) == 2 and len(w[m]["rank_writeout_wait_ms"]) == 2 and w[m]["MiBps"] > 0
+    assert abs(w["rccl"]["ms_per_step"] - d["ms_per_step"]) < 1e-6
 
 
 def test_config4_workload_two_ranks():

@@ -1,0 +1,41 @@
+"""The lines the driver's runs produce, checked on the GPU box by launching bench.py the way the driver
+does (a subprocess from a bare shell): the default headline line with its self-proving keys, and
+configs[3]'s workload (`--workload fastq`) on a 4 GiB share of the stream."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+
+
+def _bench(*args, timeout=900):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + list(args), capture_output=True, text=True,
+                       timeout=timeout, env=env, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_headline_line_proves_itself():
+    d = _bench("--steps", "3", "--warmup", "1", "--no-extras", "--no-cpu-baseline")
+    c, r = d["config"], d["roofline"]
+    assert d["metric"].startswith("BGZF compress MiB/s at level 1") and d["unit"] == "MiB/s" and d["n_gpus"] == 1
+    assert c["verified_bit_exact_full"] is True and c["verified_bit_exact_sample"] is True  # all 8,835 blocks vs libdeflate's
+    assert c["blocks"] == 8835 and c["blocks_handed_back_to_dense_kernels"] == 0
+    assert r["kernel"] in r["stage_ms"] and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-4
+    assert 0 < r["pipeline_frac"] < r["frac"] and 0 < r["hbm_read_frac"] < r["pipeline_frac"]
+    assert c["box_libdeflate"] in (None, "1.10-like", "1.24-like", "unknown")
+
+
+def test_config4_fastq_share_of_the_stream():
+    d = _bench("--workload", "fastq", "--stream-bytes", str(4 << 30), "--steps", "1", "--warmup", "1", "--no-cpu-baseline")
+    c = d["config"]
+    assert d["n_gpus"] == 1 and d["scaling"] == "strong" and d["value"] > 0
+    assert c["gpu_inflate_crc_roundtrip_ok"] is True
+    assert c["gzip_t_prefix_suffix_rc"] in ([0, 0], None)

@@ -5,6 +5,7 @@ for the GPU runs.  The oracle is only the checker."""
 import ctypes
 import gzip
 import io
+import os
 import struct
 
 import numpy as np
@@ -78,12 +79,65 @@ def multi_device(lib, oracle, scale=1):
         with _native.Context(level=1, buffer_size=BS, lib=lib, max_slab_bytes=max(a.size, BS)) as c:
             want, wsizes = c.compress_slab(a, mode, return_block_sizes=True)
         assert got == want and list(sizes) == list(wsizes), (ndev, nblk, extra, mode)
+        # ... and to the oracle's stream (the product default is the 1.24 rule)
+        if mode == _native.SLAB_LAST:
+            assert got == oracle.compress_stream(a, oracle.FMT_BGZF, 1, oracle.COMPAT_1_24, BS), (ndev, nblk, extra, mode)
+    # the device-resident form: every range on "its" device, shards gathered device to device into the
+    # root's buffer (one GPU here: the peers are the same device, the copy path and the offsets are real)
+    multi_device_resident(lib, oracle, scale)
     # BlockSizeExceeded in the second device's range is reported with its stream-order index
     a = np.concatenate([synth.make("text", 2 * 65536, 1), synth.uniform_random(65536, 2), synth.make("text", 65536, 3)])
     with _native.MultiContext([0, 0], level=1, buffer_size=65536, lib=lib, max_slab_bytes=a.size) as m:
         with pytest.raises(_native.GzpxError) as e:
             m.compress_slab(a, _native.SLAB_LAST)
     assert e.value.code == _native.ERR_BLOCK_SIZE_EXCEEDED and e.value.block == 2
+
+
+def multi_device_resident(lib, oracle, scale=1):
+    """gzpx_multi_compress_slab_device against the oracle: ranges handed over as device pointers (host
+    arrays under the emulator, torch tensors on the GPU), output gathered in stream order on the root."""
+    on_gpu = "emu" not in os.path.basename(lib.path) and _has_cuda()
+    for ndev, nblk, extra, mode, root in ((3, 7, 123, _native.SLAB_LAST, 0), (2, 5, 0, _native.SLAB_FULL_BLOCKS, 1),
+                                          (4, 2, 17, _native.SLAB_LAST, 2), (3, 0, 0, _native.SLAB_LAST, 0)):
+        a = synth.make("text", nblk * BS * scale + extra, 11 + nblk)
+        with _native.MultiContext([0] * ndev, level=1, buffer_size=BS, lib=lib, max_slab_bytes=max(a.size, BS)) as m:
+            shards, keep = [], []
+            for g in range(ndev):
+                off, n = m.shard(a.size, g)
+                part = np.ascontiguousarray(a[off:off + n])
+                if on_gpu:
+                    import torch
+                    t = torch.from_numpy(part.copy()).cuda() if n else None
+                    keep.append(t)
+                    shards.append(t.data_ptr() if n else None)
+                else:
+                    keep.append(part)
+                    shards.append(part.ctypes.data if n else None)
+            cap = m.slab_bound(a.size)
+            if on_gpu:
+                import torch
+                d_out = torch.zeros(cap, dtype=torch.uint8, device="cuda")
+                torch.cuda.synchronize()
+                n_out, sizes = m.compress_slab_device(shards, a.size, d_out.data_ptr(), cap, mode, root)
+                got = d_out[:n_out].cpu().numpy().tobytes()
+            else:
+                out = np.zeros(cap, dtype=np.uint8)
+                n_out, sizes = m.compress_slab_device(shards, a.size, out.ctypes.data, cap, mode, root)
+                got = out[:n_out].tobytes()
+        want, wsizes = oracle.compress_stream(a, oracle.FMT_BGZF, 1, oracle.COMPAT_1_24, BS, return_block_sizes=True)
+        if mode == _native.SLAB_LAST:
+            assert got == want and list(sizes) == list(wsizes), (ndev, nblk, extra, root)
+        else:  # full blocks, no EOF marker: the oracle's stream minus its tail
+            assert got == want[:len(got)] and len(got) == len(want) - 28 and len(sizes) == nblk * scale
+            assert list(sizes[:-1]) == list(wsizes[:len(sizes) - 1]) and int(sizes[-1]) == int(wsizes[len(sizes) - 1]) - 28
+
+
+def _has_cuda():
+    try:
+        import torch
+        return torch.cuda.is_available()
+    except Exception:
+        return False
 
 
 def reserve_commit(lib, oracle, scale=1):
