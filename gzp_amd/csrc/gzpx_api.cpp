@@ -835,9 +835,9 @@ struct MultiPart {
     uint64_t first = 0, nb = 0;
     size_t lo = 0, n = 0;
 };
-MultiPart multi_part(size_t in_len, size_t bs, size_t G, size_t g) {
+void multi_part_of(size_t in_len, size_t bs, size_t G, size_t g, MultiPart &p) {
     const uint64_t total_nb = in_len == 0 ? 1 : (in_len + bs - 1) / bs;
-    MultiPart p;
+    p = MultiPart();
     for (size_t k = 0; k <= g; k++) {
         p.first += p.nb;
         p.nb = total_nb / G + (k < total_nb % G ? 1 : 0);
@@ -845,7 +845,6 @@ MultiPart multi_part(size_t in_len, size_t bs, size_t G, size_t g) {
     p.lo = (size_t)(p.first * bs < in_len ? p.first * bs : in_len);
     const size_t hi = (size_t)((p.first + p.nb) * bs < in_len ? (p.first + p.nb) * bs : in_len);
     p.n = hi - p.lo;
-    return p;
 }
 }  // namespace
 
@@ -892,7 +891,8 @@ void gzpx_multi_destroy(gzpx_multi *m) {
 
 int gzpx_multi_shard(const gzpx_multi *m, size_t in_len, size_t g, size_t *offset, size_t *len) {
     if (!m || g >= m->ctxs.size() || !offset || !len) return GZPX_ERR_INVALID_ARG;
-    const MultiPart p = multi_part(in_len, m->buffer_size, m->ctxs.size(), g);
+    MultiPart p;
+    multi_part_of(in_len, m->buffer_size, m->ctxs.size(), g, p);
     *offset = p.lo;
     *len = p.n;
     return GZPX_OK;
@@ -928,7 +928,7 @@ int gzpx_multi_compress_slab_device(gzpx_multi *m, const void *const *d_in, size
     // 1. every device: the kernels of its range, output into its own staging (devices work concurrently)
     for (size_t g = 0; g < G && rc == GZPX_OK; g++) {
         Part &p = parts[g];
-        p.r = multi_part(in_len, bs, G, g);
+        multi_part_of(in_len, bs, G, g, p.r);
         if (p.r.nb == 0) continue;
         if (p.r.n && !d_in[g]) {
             rc = GZPX_ERR_INVALID_ARG;
