@@ -3243,15 +3243,109 @@ __device__ uint32_t crc32_workgroup(CrcLdsT<T> &l, const uint8_t *__restrict__ i
     return total;
 }
 
+// CRC-32 of in[0..n) by a 256-thread workgroup whose threads read their bytes straight from global
+// memory: thread t owns ONE contiguous 256-byte segment per 64 KiB chunk (segments aligned to the end of
+// the input, so only the first is short), runs slice-by-4 over it out of registers -- sixteen 16-byte
+// loads, the byte alignment taken out with v_alignbyte -- and the 256 partial CRCs are combined by the
+// GF(2) log-tree once per chunk.  Against crc32_workgroup<256> (64-byte segments staged in LDS, a tree
+// per 16 KiB): a BGZF block needs one tree instead of four to five (the tree was more than half of that
+// routine's instructions), no staging traffic through LDS, and 5 KiB of LDS instead of 21.
+struct CrcDirectLds {
+    uint32_t table[4][256];
+    uint32_t part[kCrcSmall];
+};
+
+__device__ uint32_t crc32_direct(CrcDirectLds &l, const uint8_t *__restrict__ in, uint32_t n, const CrcConsts &cc,
+                                 uint32_t tid) {
+    constexpr uint32_t T = kCrcSmall, kSegB = 256, kChunk = T * kSegB;  // 64 KiB per chunk
+    for (uint32_t i = tid; i < 256; i += T) {
+        uint32_t c = i;
+        for (int k = 0; k < 8; k++) c = (c >> 1) ^ (0xEDB88320u & (0u - (c & 1u)));
+        l.table[0][i] = c;
+    }
+    __syncthreads();
+    for (uint32_t i = tid; i < 256; i += T) {
+        const uint32_t t0 = l.table[0][i];
+        const uint32_t t1 = (t0 >> 8) ^ l.table[0][t0 & 0xFFu];
+        const uint32_t t2 = (t1 >> 8) ^ l.table[0][t1 & 0xFFu];
+        const uint32_t t3 = (t2 >> 8) ^ l.table[0][t2 & 0xFFu];
+        l.table[1][i] = t1;
+        l.table[2][i] = t2;
+        l.table[3][i] = t3;
+    }
+    uint32_t total = 0;
+    const uint32_t first_len = n ? ((n - 1) % kChunk) + 1 : 0;
+    for (uint32_t cb = 0; cb < n || cb == 0; cb += (cb == 0 ? first_len : kChunk)) {
+        const uint32_t clen = n == 0 ? 0 : (cb == 0 ? first_len : kChunk);
+        __syncthreads();  // tables ready / part[] of the previous chunk consumed
+        const int32_t seg_end_i = (int32_t)clen - (int32_t)kSegB * (int32_t)(T - 1 - tid);
+        uint32_t crc = 0;
+        if (seg_end_i > 0) {
+            const uint32_t sb = seg_end_i > (int32_t)kSegB ? (uint32_t)seg_end_i - kSegB : 0u;
+            const uint32_t len = (uint32_t)seg_end_i - sb;
+            const uint8_t *p = in + cb + sb;
+            uint32_t c = 0xFFFFFFFFu;
+            if (len == kSegB) {
+                const uint32_t mis = (uint32_t)((uintptr_t)p & 3u);
+                const uint32_t *q = (const uint32_t *)(p - mis);
+                // the input's very last dword pair: nothing behind the input may be read
+                const bool at_end = cb + (uint32_t)seg_end_i == n && mis == 0;
+                uint32_t carry = q[0];
+                for (uint32_t g = 0; g < 16; g++) {
+                    dword4 v;
+                    if (g == 15 && at_end) {
+                        v.x = q[61];
+                        v.y = q[62];
+                        v.z = q[63];
+                        v.w = 0;
+                    } else {
+                        v = *(const dword4 *)(q + 1 + 4 * g);
+                    }
+                    const uint32_t w[4] = {__builtin_amdgcn_alignbyte(v.x, carry, mis), __builtin_amdgcn_alignbyte(v.y, v.x, mis),
+                                           __builtin_amdgcn_alignbyte(v.z, v.y, mis), __builtin_amdgcn_alignbyte(v.w, v.z, mis)};
+                    carry = v.w;
+#pragma unroll
+                    for (uint32_t k = 0; k < 4; k++) {
+                        c ^= w[k];
+                        c = l.table[3][c & 0xFFu] ^ l.table[2][(c >> 8) & 0xFFu] ^ l.table[1][(c >> 16) & 0xFFu] ^
+                            l.table[0][c >> 24];
+                    }
+                }
+            } else {  // the short first segment of the input (one thread per input)
+                for (uint32_t i = 0; i < len; i++) c = (c >> 8) ^ l.table[0][(c ^ p[i]) & 0xFFu];
+            }
+            crc = ~c;
+        }
+        l.part[tid] = crc;
+        __syncthreads();
+        // log-tree over the 256 parts: x^(8 * 256 * 2^level) = pow64[level + 2]; a level's pairs are
+        // handled by the LOWEST threads, so that it keeps only as many waves busy as it has work for
+        for (uint32_t level = 0; level < 8; level++) {
+            const uint32_t stride = 1u << level;
+            const uint32_t left = 2 * stride * tid;
+            uint32_t merged = 0;
+            const bool act = left < T;
+            if (act) merged = gf2_multmodp(cc.pow64[level + 2], l.part[left]) ^ l.part[left + stride];
+            __syncthreads();
+            if (act) l.part[left] = merged;
+            __syncthreads();
+        }
+        // crc(A || chunk) = crc(A) * x^(8 * chunk) + crc(chunk); the first chunk has no A
+        total = cb == 0 ? l.part[0] : (gf2_multmodp(cc.pow_tile, total) ^ l.part[0]);
+        if (n == 0) break;
+    }
+    return total;
+}
+
 // The compressor's CRC kernel needs nothing but the input, so it runs on a low-priority SIDE STREAM
 // beside k_hist / k_huffman (gzpx_api.cpp, enqueue_batch): small workgroups (256 threads, 21 KiB of
 // LDS) that slip in between k_huffman's one-wave workgroups.  (The 1024-thread routine of k_dcrc32
 // in the same place: the join waits 0.24 ms for it, step 4.86 -> 5.00 ms.)
 __global__ __launch_bounds__(kCrcSmall) void k_crc32(Config cfg, const uint8_t *__restrict__ slab,
                                                      BlockMeta *__restrict__ meta_all, CrcConsts cc) {
-    __shared__ CrcLdsT<kCrcSmall> l;
+    __shared__ CrcDirectLds l;
     const uint32_t b = blockIdx.x;
-    const uint32_t total = crc32_workgroup<kCrcSmall>(l, slab + (uint64_t)b * cfg.block_size, meta_all[b].n, cc, threadIdx.x);
+    const uint32_t total = crc32_direct(l, slab + (uint64_t)b * cfg.block_size, meta_all[b].n, cc, threadIdx.x);
     if (threadIdx.x == 0) meta_all[b].crc = total;
 }
 

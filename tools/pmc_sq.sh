@@ -1,11 +1,11 @@
 #!/bin/bash
 # SQ counters of the level-1 kernels (two passes of <= 8 SQ counters; counters only with --kernel-trace)
-#   tools/pmc_sq.sh <outdir-under-gpurun_out>
+#   tools/pmc_sq.sh <outdir-under-gpurun_out> ["<extra bench args>"]
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/${1:-pmc_sq}
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-B="python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras"
+B="python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras $2"
 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS -d $O/a -o a --output-format csv -- $B > $O/a.log 2>&1
 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_SCA SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR -d $O/b -o b --output-format csv -- $B > $O/b.log 2>&1
 python3 - <<PY
