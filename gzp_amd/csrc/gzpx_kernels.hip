@@ -1190,6 +1190,21 @@ __global__ __launch_bounds__(kMpThreads, 4) void k_mparse(
     auto exp_lap = [](uint32_t) {};
 #endif
 
+    // d0 of a pass: 64 bytes per thread (the per-block stride is padded: whole uint4s are readable),
+    // requested a pass ahead -- the first pass's together with the block's bytes, the second's while the
+    // first is walked -- so that the workgroup, alone on its CU, waits for HBM once per block
+    uint4 d0v0, d0v1, d0v2, d0v3;
+#define GZPX_D0_REQUEST(hb_)                                                        \
+    do {                                                                            \
+        const uint32_t he_ = (hb_) + kMhHalf < n ? (hb_) + kMhHalf : n;             \
+        const uint4 *src_ = (const uint4 *)(cand + (hb_));                          \
+        const uint32_t nq_ = (he_ - (hb_) + 7) / 8;                                 \
+        d0v0 = src_[tid < nq_ ? tid : nq_ - 1];                                     \
+        d0v1 = src_[tid + kMpThreads < nq_ ? tid + kMpThreads : nq_ - 1];           \
+        d0v2 = src_[tid + 2 * kMpThreads < nq_ ? tid + 2 * kMpThreads : nq_ - 1];   \
+        d0v3 = src_[tid + 3 * kMpThreads < nq_ ? tid + 3 * kMpThreads : nq_ - 1];   \
+    } while (0)
+    GZPX_D0_REQUEST(0u);
     {   // stage the block (n <= kTile): 16 bytes per load, four loads per thread in flight
         const uint32_t *src = (const uint32_t *)(in - mis);
         const uint32_t ndw = (mis + n + 3) >> 2;
@@ -1230,18 +1245,13 @@ __global__ __launch_bounds__(kMpThreads, 4) void k_mparse(
     for (uint32_t hb = 0; hb < n; hb += kMhHalf) {
         const uint32_t he = hb + kMhHalf < n ? hb + kMhHalf : n;  // this pass: positions [hb, he)
         __syncthreads();  // the previous pass is done with d0_w / seg_exit
-        {   // d0 of the pass: 64 bytes per thread (the per-block stride is padded: whole uint4s are readable)
-            const uint4 *src = (const uint4 *)(cand + hb);
+        {
             uint4 *dst = (uint4 *)d0_w;
-            const uint32_t nq = (he - hb + 7) / 8;
-            uint4 v[4];
-#pragma unroll
-            for (uint32_t k = 0; k < 4; k++) {
-                const uint32_t q = tid + k * kMpThreads;
-                v[k] = src[q < nq ? q : nq - 1];
-            }
-#pragma unroll
-            for (uint32_t k = 0; k < 4; k++) dst[tid + k * kMpThreads] = v[k];
+            dst[tid] = d0v0;
+            dst[tid + kMpThreads] = d0v1;
+            dst[tid + 2 * kMpThreads] = d0v2;
+            dst[tid + 3 * kMpThreads] = d0v3;
+            if (he < n) GZPX_D0_REQUEST(he);  // (uniform) the next pass's d0 travels while this pass is walked
         }
         __syncthreads();
         exp_lap(0);
@@ -1436,6 +1446,7 @@ __global__ __launch_bounds__(kMpThreads, 4) void k_mparse(
         entry_carry = exit_pos;
         exp_lap(4);
     }
+#undef GZPX_D0_REQUEST
     if (tid == 0) {
         sub[cur_sub].tok_begin = sub_start_tok;
         sub[cur_sub].tok_end = tok_carry;
