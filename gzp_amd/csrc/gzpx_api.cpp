@@ -99,7 +99,6 @@ struct gzpx_ctx {
     hipEvent_t ev_meta = nullptr, ev_crc = nullptr;    // fork / join of the side stream
     hipEvent_t ev_crc_t0 = nullptr, ev_crc_t1 = nullptr;  // timing of k_crc32 when profiling
     hipEvent_t ev_dep = nullptr;  // "the caller's stream got this far" (device jobs)
-    hipEvent_t ev_round[2] = {nullptr, nullptr};  // levels 2-4: end of a match/parse round
     hipEvent_t prof_ev[2 * 64] = {nullptr};  // measurement mode: begin / end of launch groups
     int prof_stage[64] = {0};
     int prof_n = 0;
@@ -109,7 +108,6 @@ struct gzpx_ctx {
     uint64_t next_gen = 1;
     BlockMeta *h_meta = nullptr;  // pinned; CRC-only contexts and the debug hooks
     SubMeta *h_sub = nullptr;     // pinned, max_sub entries (debug hooks)
-    uint32_t *h_pending = nullptr;  // pinned
     bool profiling = false;
     bool crc_only = false;
     float stage_ms[GZPX_N_STAGES] = {0};
@@ -156,7 +154,6 @@ int alloc_scratch(gzpx_ctx *ctx) {
     const Config &c = ctx->dcfg;
     Scratch &s = ctx->scratch;
     HIP_TRY(hipMalloc((void **)&s.meta, nb * sizeof(BlockMeta)));
-    HIP_TRY(hipHostMalloc((void **)&ctx->h_pending, 64, hipHostMallocDefault));
     if (ctx->crc_only) {  // gzpx_crc32's private context: k_init_meta + k_crc32 only
         HIP_TRY(hipHostMalloc((void **)&ctx->h_meta, nb * sizeof(BlockMeta), hipHostMallocDefault));
         return GZPX_OK;
@@ -222,7 +219,6 @@ void free_scratch(gzpx_ctx *ctx) {
     if (s.out_off) (void)hipFree(s.out_off);
     if (s.sizes) (void)hipFree(s.sizes);
     if (ctx->h_meta) (void)hipHostFree(ctx->h_meta);
-    if (ctx->h_pending) (void)hipHostFree(ctx->h_pending);
     for (Slot &sl : ctx->slots) free_slot(sl);
     s = Scratch{};
 }
@@ -277,20 +273,10 @@ int enqueue_batch(gzpx_ctx *ctx, const uint8_t *d_in, size_t in_len, uint32_t nb
         if (c.lazy) {  // levels 5-9: every match variant once, then the serial-per-block lazy parse
             launch_lazy(c, d_in, nb, s, stream);
         } else {
-            // levels 2-4: match + parse rounds until no block needs its tail redone with another
-            // min_len (one round unless should_end_block splits a block into unlike halves).  Round
-            // r + 1 is enqueued before round r's "blocks left" word is looked at, so the device never
-            // idles while the host decides; a round with nothing left costs two empty launches.
-            uint32_t *pend = ctx->h_pending;  // [round & 1]
-            for (uint32_t round = 0;; round++) {
-                launch_hc_round(c, d_in, nb, s, round == 0, stream);
-                HIP_TRY(hipMemcpyAsync(&pend[round & 1], s.pending, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
-                HIP_TRY(hipEventRecord(ctx->ev_round[round & 1], stream));
-                if (round == 0) continue;
-                HIP_TRY(hipEventSynchronize(ctx->ev_round[(round - 1) & 1]));
-                if (pend[(round - 1) & 1] == 0) break;  // (the round just enqueued finds every block done)
-                if (round > c.max_sub + 3) return GZPX_ERR_DEVICE;  // cannot happen: one sub-block per round
-            }
+            // levels 2-4: every match once, then the greedy parse; a block whose new sub-block needs
+            // another min_len parses on inside k_parse_hc, so nothing is read back and submit returns
+            // without waiting for the device (round 2 ran these rounds from the host, a word per round)
+            launch_hc(c, d_in, nb, s, stream);
         }
         pp.end(t, stream);
     }
@@ -669,9 +655,7 @@ int ctx_create(const gzpx_config *cfg, bool crc_only, gzpx_ctx **out) {
         hipEventCreateWithFlags(&ctx->ev_meta, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_crc, hipEventDisableTiming) != hipSuccess ||
         hipEventCreate(&ctx->ev_crc_t0) != hipSuccess || hipEventCreate(&ctx->ev_crc_t1) != hipSuccess ||
-        hipEventCreateWithFlags(&ctx->ev_dep, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&ctx->ev_round[0], hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&ctx->ev_round[1], hipEventDisableTiming) != hipSuccess)
+        hipEventCreateWithFlags(&ctx->ev_dep, hipEventDisableTiming) != hipSuccess)
         rc = GZPX_ERR_DEVICE;
     if (rc == GZPX_OK) rc = alloc_scratch(ctx);
     if (rc == GZPX_OK) {
@@ -706,8 +690,6 @@ void gzpx_ctx_destroy(gzpx_ctx *ctx) {
         (void)hipStreamSynchronize(ctx->s_side);
         (void)hipStreamDestroy(ctx->s_side);
     }
-    for (hipEvent_t e : ctx->ev_round)
-        if (e) (void)hipEventDestroy(e);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     if (ctx->s_h2d) (void)hipStreamDestroy(ctx->s_h2d);
     if (ctx->s_d2h) (void)hipStreamDestroy(ctx->s_d2h);

@@ -126,8 +126,7 @@ void launch_match(const Config &cfg, const uint8_t *slab, uint64_t slab_len, uin
                   const Scratch &s, hipStream_t stream);
 void launch_parse(const Config &cfg, const uint8_t *slab, uint64_t slab_len, uint32_t nb,
                   const Scratch &s, hipStream_t stream);
-void launch_hc_round(const Config &cfg, const uint8_t *slab, uint32_t nb, const Scratch &s, int first,
-                     hipStream_t stream);
+void launch_hc(const Config &cfg, const uint8_t *slab, uint32_t nb, const Scratch &s, hipStream_t stream);
 void launch_lazy(const Config &cfg, const uint8_t *slab, uint32_t nb, const Scratch &s, hipStream_t stream);
 void launch_hist(const Config &cfg, uint32_t nb, const Scratch &s, hipStream_t stream);
 void launch_huffman(const Config &cfg, uint32_t nb, const Scratch &s, hipStream_t stream);

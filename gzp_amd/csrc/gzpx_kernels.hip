@@ -1774,9 +1774,9 @@ __global__ __launch_bounds__(1024) void k_match_hc(Config cfg, const uint8_t *__
 //     block's so far (do_end_block_check).
 // The class counts per 512-token bin are gathered in parallel and all checks of a tile evaluated side
 // by side from their prefix sums.  When the sub-block that follows a boundary needs a different
-// min_len, the "long enough" filter of the matches from there on was the wrong one: the state is
-// saved, `pending` is bumped and the host runs another k_parse_hc round for this block (k_match_hc's
-// results stand: they do not depend on min_len).
+// min_len, the "long enough" filter of the matches from there on was the wrong one: the workgroup
+// parses the block again from there (another "round" of its own loop; k_match_hc's results stand:
+// they do not depend on min_len).
 // ------------------------------------------------------------------------------------------
 constexpr uint32_t kHpTile = 32768;  // (a BGZF block is two full tiles; ~50 KiB of LDS: three workgroups per CU.  48 KiB tiles: +0.3 ms per 550 MiB)
 constexpr uint32_t kHpGroups = kHpTile / 64;  // 512 groups / walk segments of 64 positions
@@ -1831,19 +1831,27 @@ __global__ __launch_bounds__(kMpThreads, GZPX_PHC_WAVES) void k_parse_hc(
     const unsigned long long *mbits_g = (const unsigned long long *)(mbits_all + (uint64_t)b * (cfg.stride / 32));
     uint32_t *tok = tok_all + (uint64_t)b * cfg.stride;
 
+    // A "round" parses from r_resume with r_min_len until the block ends or a new sub-block needs
+    // another minimum match length; the block then parses on from there in its next round.  Rounds
+    // are a loop of THIS workgroup (blocks owe each other nothing), so one launch finishes every block
+    // and the host reads nothing back.
+    uint32_t r_resume = st->resume_pos, r_tok = st->tok_carry, r_mat = st->mat_carry, r_sub = st->cur_sub;
+    uint32_t r_min_len = st->min_len;
+    const unsigned long long lane_below = (1ull << lane) - 1ull;
+    for (;;) {
     // state (uniform across the workgroup)
-    uint32_t entry_carry = st->resume_pos;
-    uint32_t tok_carry = st->tok_carry, mat_carry = st->mat_carry;
-    uint32_t cur_sub = st->cur_sub;
-    uint32_t sub_start = st->resume_pos, sub_start_tok = tok_carry, sub_start_mat = mat_carry;
+    uint32_t entry_carry = r_resume;
+    uint32_t tok_carry = r_tok, mat_carry = r_mat;
+    uint32_t cur_sub = r_sub;
+    uint32_t sub_start = r_resume, sub_start_tok = tok_carry, sub_start_mat = mat_carry;
     uint32_t sub_limit = hc_sub_limit_of(sub_start, n);
-    uint32_t min_len = st->min_len;
+    uint32_t min_len = r_min_len;
+    __syncthreads();  // the previous round is done with the LDS state
     if (min_len == 0) {  // first round: the sub-block that starts the block (calculate_min_match_len)
         min_len = hc_calc_min_len(cfg, in, 0, n, used, tid, kMpThreads);
         __syncthreads();
         if (tid == 0) st->min_len = min_len;
     }
-    const unsigned long long lane_below = (1ull << lane) - 1ull;
     if (tid == 0) {
         s_next_check = kNoCheckYet;
         s_num_obs = 0;
@@ -2214,16 +2222,13 @@ __global__ __launch_bounds__(kMpThreads, GZPX_PHC_WAVES) void k_parse_hc(
             if (new_min_len != min_len) {
                 // the "long enough" filter of the matches from bp on was another sub-block's: parse
                 // again from there (k_match_hc's results stand, they do not depend on min_len)
-                if (tid == 0) {
-                    st->min_len = new_min_len;
-                    st->resume_pos = bp;
-                    st->tok_carry = bti;
-                    st->mat_carry = bm;
-                    st->cur_sub = cur_sub;
-                    st->rounds++;
-                    atomicAdd(pending, 1u);
-                }
-                return;
+                r_min_len = new_min_len;
+                r_resume = bp;
+                r_tok = bti;
+                r_mat = bm;
+                r_sub = cur_sub;
+                if (tid == 0) st->rounds++;  // (diagnostics)
+                goto next_round;
             }
             build = false;
         }
@@ -2240,6 +2245,9 @@ __global__ __launch_bounds__(kMpThreads, GZPX_PHC_WAVES) void k_parse_hc(
         meta->ntok = tok_carry;
         meta->nsub = cur_sub + 1;
         st->done = 1;
+    }
+    return;
+next_round:;
     }
 }
 
@@ -4573,17 +4581,13 @@ void launch_parse(const Config &cfg, const uint8_t *slab, uint64_t, uint32_t nb,
                        fused ? (const uint32_t *)s.redo : (const uint32_t *)nullptr);
 }
 
-void launch_hc_round(const Config &cfg, const uint8_t *slab, uint32_t nb, const Scratch &s, int first,
-                     hipStream_t stream) {
-    if (first) {
-        hipLaunchKernelGGL(k_hc_init, dim3((nb + 255) / 256), dim3(256), 0, stream, nb, s.hc, s.pending);
-        // (once: the match of a position does not depend on the sub-block's min_len, see k_match_hc)
-        hipLaunchKernelGGL(k_match_hc, dim3(nb), dim3(1024), 0, stream, cfg, slab, (const BlockMeta *)s.meta, s.hc,
-                           (const uint16_t *)s.cand, (const uint16_t *)s.d4, s.len8, s.which, s.alt,
-                           (uint8_t *)nullptr, (uint16_t *)nullptr);
-    } else {
-        (void)hipMemsetAsync(s.pending, 0, sizeof(uint32_t), stream);
-    }
+// levels 2-4: every match once (it does not depend on a sub-block's min_len, see k_match_hc), then the
+// greedy parse, whose re-parse rounds are a loop inside k_parse_hc: nothing comes back to the host
+void launch_hc(const Config &cfg, const uint8_t *slab, uint32_t nb, const Scratch &s, hipStream_t stream) {
+    hipLaunchKernelGGL(k_hc_init, dim3((nb + 255) / 256), dim3(256), 0, stream, nb, s.hc, s.pending);
+    hipLaunchKernelGGL(k_match_hc, dim3(nb), dim3(1024), 0, stream, cfg, slab, (const BlockMeta *)s.meta, s.hc,
+                       (const uint16_t *)s.cand, (const uint16_t *)s.d4, s.len8, s.which, s.alt,
+                       (uint8_t *)nullptr, (uint16_t *)nullptr);
     hipLaunchKernelGGL(k_parse_hc, dim3(nb), dim3(kMpThreads), 0, stream, cfg, slab, s.meta, s.sub, s.hc,
                        (const uint8_t *)s.len8, (const uint32_t *)s.which, (const uint16_t *)s.alt, s.tok,
                        s.pending);
