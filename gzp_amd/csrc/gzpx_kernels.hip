@@ -1795,6 +1795,7 @@ __device__ __forceinline__ unsigned long long mask_after_kth(unsigned long long 
 #ifndef GZPX_PHC_WAVES
 #define GZPX_PHC_WAVES 8
 #endif
+template <bool LOOP>
 __global__ __launch_bounds__(kMpThreads, GZPX_PHC_WAVES) void k_parse_hc(
     Config cfg, const uint8_t *__restrict__ slab, BlockMeta *__restrict__ meta_all,
     SubMeta *__restrict__ sub_all, HcState *__restrict__ hc_all, const uint8_t *__restrict__ len8_all,
@@ -1831,22 +1832,24 @@ __global__ __launch_bounds__(kMpThreads, GZPX_PHC_WAVES) void k_parse_hc(
     const unsigned long long *mbits_g = (const unsigned long long *)(mbits_all + (uint64_t)b * (cfg.stride / 32));
     uint32_t *tok = tok_all + (uint64_t)b * cfg.stride;
 
-    // A "round" parses from r_resume with r_min_len until the block ends or a new sub-block needs
-    // another minimum match length; the block then parses on from there in its next round.  Rounds
-    // are a loop of THIS workgroup (blocks owe each other nothing), so one launch finishes every block
-    // and the host reads nothing back.
-    uint32_t r_resume = st->resume_pos, r_tok = st->tok_carry, r_mat = st->mat_carry, r_sub = st->cur_sub;
-    uint32_t r_min_len = st->min_len;
+    // A "round" parses from HcState.resume_pos with HcState.min_len until the block ends or a new
+    // sub-block needs another minimum match length; the block then parses on from there in its next
+    // round.  LOOP = false: one round per launch (the state is saved, the kernel returns).  LOOP = true:
+    // the rounds are a loop of THIS workgroup (blocks owe each other nothing) until the block is done.
+    // The host enqueues two single rounds and one looping launch and reads nothing back: nearly every
+    // block is done after one round, the looping form -- which costs this kernel 20 more spilled VGPRs --
+    // only ever sees the few that need a third.
     const unsigned long long lane_below = (1ull << lane) - 1ull;
     for (;;) {
-    // state (uniform across the workgroup)
-    uint32_t entry_carry = r_resume;
-    uint32_t tok_carry = r_tok, mat_carry = r_mat;
-    uint32_t cur_sub = r_sub;
-    uint32_t sub_start = r_resume, sub_start_tok = tok_carry, sub_start_mat = mat_carry;
+    // state (uniform across the workgroup; in the looping form written by thread 0 a round ago)
+    auto ld = [](const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+    uint32_t entry_carry = ld(&st->resume_pos);
+    uint32_t tok_carry = ld(&st->tok_carry), mat_carry = ld(&st->mat_carry);
+    uint32_t cur_sub = ld(&st->cur_sub);
+    uint32_t sub_start = entry_carry, sub_start_tok = tok_carry, sub_start_mat = mat_carry;
     uint32_t sub_limit = hc_sub_limit_of(sub_start, n);
-    uint32_t min_len = r_min_len;
-    __syncthreads();  // the previous round is done with the LDS state
+    uint32_t min_len = ld(&st->min_len);
+    if (LOOP) __syncthreads();  // the previous round is done with the LDS state
     if (min_len == 0) {  // first round: the sub-block that starts the block (calculate_min_match_len)
         min_len = hc_calc_min_len(cfg, in, 0, n, used, tid, kMpThreads);
         __syncthreads();
@@ -2222,12 +2225,17 @@ __global__ __launch_bounds__(kMpThreads, GZPX_PHC_WAVES) void k_parse_hc(
             if (new_min_len != min_len) {
                 // the "long enough" filter of the matches from bp on was another sub-block's: parse
                 // again from there (k_match_hc's results stand, they do not depend on min_len)
-                r_min_len = new_min_len;
-                r_resume = bp;
-                r_tok = bti;
-                r_mat = bm;
-                r_sub = cur_sub;
-                if (tid == 0) st->rounds++;  // (diagnostics)
+                if (tid == 0) {
+                    st->min_len = new_min_len;
+                    st->resume_pos = bp;
+                    st->tok_carry = bti;
+                    st->mat_carry = bm;
+                    st->cur_sub = cur_sub;
+                    st->rounds++;
+                    if (LOOP) __threadfence();
+                }
+                if (!LOOP) return;
+                __syncthreads();
                 goto next_round;
             }
             build = false;
@@ -4582,13 +4590,18 @@ void launch_parse(const Config &cfg, const uint8_t *slab, uint64_t, uint32_t nb,
 }
 
 // levels 2-4: every match once (it does not depend on a sub-block's min_len, see k_match_hc), then the
-// greedy parse, whose re-parse rounds are a loop inside k_parse_hc: nothing comes back to the host
+// greedy parse with its re-parse rounds: nothing comes back to the host
 void launch_hc(const Config &cfg, const uint8_t *slab, uint32_t nb, const Scratch &s, hipStream_t stream) {
     hipLaunchKernelGGL(k_hc_init, dim3((nb + 255) / 256), dim3(256), 0, stream, nb, s.hc, s.pending);
     hipLaunchKernelGGL(k_match_hc, dim3(nb), dim3(1024), 0, stream, cfg, slab, (const BlockMeta *)s.meta, s.hc,
                        (const uint16_t *)s.cand, (const uint16_t *)s.d4, s.len8, s.which, s.alt,
                        (uint8_t *)nullptr, (uint16_t *)nullptr);
-    hipLaunchKernelGGL(k_parse_hc, dim3(nb), dim3(kMpThreads), 0, stream, cfg, slab, s.meta, s.sub, s.hc,
+    // two single rounds (the second finds nearly every block done), then the looping form for the rest
+    for (int r = 0; r < 2; r++)
+        hipLaunchKernelGGL(k_parse_hc<false>, dim3(nb), dim3(kMpThreads), 0, stream, cfg, slab, s.meta, s.sub, s.hc,
+                           (const uint8_t *)s.len8, (const uint32_t *)s.which, (const uint16_t *)s.alt, s.tok,
+                           s.pending);
+    hipLaunchKernelGGL(k_parse_hc<true>, dim3(nb), dim3(kMpThreads), 0, stream, cfg, slab, s.meta, s.sub, s.hc,
                        (const uint8_t *)s.len8, (const uint32_t *)s.which, (const uint16_t *)s.alt, s.tok,
                        s.pending);
 }

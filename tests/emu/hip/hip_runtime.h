@@ -78,6 +78,8 @@ void yield_now();  // let the other fibers run (spin-wait loops)
 
 // ---------------------------------------------------------------- barriers / collectives
 static inline void __syncthreads() { emu::sync_threads(); }
+static inline void __threadfence() {}        // (fibers are cooperative: program order is memory order)
+static inline void __threadfence_block() {}
 static inline int __syncthreads_or(int p) { return emu::sync_threads_or(p); }
 static inline int __syncthreads_count(int p) { return emu::sync_threads_count(p); }
 static inline unsigned long long __ballot(int p) { return emu::wave_ballot(p); }
