@@ -632,6 +632,17 @@ def run_config(args, env, fmt, level, bs, kind, n, label):
         d_back = torch.empty(n + 64, dtype=torch.uint8, device=env.dev)
         got = d.decompress_device(d_out.data_ptr(), used, offs, sizes, d_back.data_ptr(), n + 64)
         ok = got == n and bool(torch.equal(d_back[:n], d_in[:n]))
+        # ... and the ParDecompress side on THIS stream (configs[2]'s 1 MiB members leave the one-wave-
+        # per-member kernel 4,096 members for 5,120 wave slots): two timed inflations of the output
+        env.sync()
+        t1 = time.perf_counter()
+        kms = 0.0
+        for _ in range(2):
+            d.decompress_device(d_out.data_ptr(), used, offs, sizes, d_back.data_ptr(), n + 64)
+            kms += d.last_inflate_ms() / 2
+        env.sync()
+        inflate_leg = {"MiBps": round(n / 2**20 / ((time.perf_counter() - t1) / 2), 1), "k_inflate_ms": round(kms, 3),
+                       "members": int(offs.size)}
         d.close()
         dom = max(acc, key=acc.get)
         achieved = (n + out_len) / (max(acc[dom], 1e-9) * 1e-3) / 1e9
@@ -642,7 +653,8 @@ def run_config(args, env, fmt, level, bs, kind, n, label):
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": label, "slab_bytes": n, "block_size": bs, "level": level,
                        "format": "bgzf" if fmt == _native.FORMAT_BGZF else "mgzip", "ratio": round(out_len / n, 4),
-                       "gpu_inflate_crc_roundtrip_ok": bool(ok), "device": ctx.device_name()},
+                       "gpu_inflate_crc_roundtrip_ok": bool(ok), "inflate_of_output": inflate_leg,
+                       "device": ctx.device_name()},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
                          "stage_ms": {k: round(v, 3) for k, v in acc.items()}}}))

@@ -59,6 +59,11 @@ try:  # the ParDecompress workload: keep its own kernels only
             write[k] = wi.get(k, 0.0)
 except FileNotFoundError:
     pass
+# Kernels whose loads are NOT a wide coalesced stream count 1:1.  k_crc32 (round 3): every lane reads its own
+# 256-byte segment with 16-byte loads.  Three variants of it, raw FETCH_SIZE per launch for a 576.7 MB slab:
+# 16 bytes per lane and step 1133 MB, 64 bytes 604 MB, 128 bytes 559 MB -- the count converges on the slab
+# size itself (it must read every byte once), so the x1.996 of the streaming kernels does not apply.
+uncorrected = {"k_crc32"}
 doc = {
     "source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), bench.py slab "
               "(compress workload; k_d*/k_inflate from --workload inflate)",
@@ -67,7 +72,10 @@ doc = {
     "fetch_calibration": "k_candidates reads the %d-byte slab exactly once" % slab_bytes,
     "raw_fetch_kib": fetch,
     "raw_write_kib": write,
-    "hbm_bytes_per_launch": {k: int(fetch.get(k, 0) * 1024 * cal + write.get(k, 0) * 1024) for k in fetch},
+    "fetch_uncorrected": sorted(uncorrected),
+    "fetch_uncorrected_why": "lane-strided 16-byte loads count 1:1 (three variants of k_crc32 converge on the slab size)",
+    "hbm_bytes_per_launch": {k: int(fetch.get(k, 0) * 1024 * (1.0 if k in uncorrected else cal) + write.get(k, 0) * 1024)
+                             for k in fetch},
 }
 doc["round"] = tag
 doc["pipeline_total_bytes"] = int(sum(v for k, v in doc["hbm_bytes_per_launch"].items()
