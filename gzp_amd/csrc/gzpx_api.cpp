@@ -240,8 +240,7 @@ struct ProfPairs {
     }
 };
 
-// One batch of blocks through the pipeline, enqueued on `stream`.  Nothing here waits for the
-// device at level 0/1 and 5-9; the match/parse rounds of levels 2-4 read one word back per round.
+// One batch of blocks through the pipeline, enqueued on `stream`.  Nothing here waits for the device.
 // `prev` / `result`: the batch before this one of the same slab (device, may be null) and this
 // batch's own record; output offsets continue from prev->total.
 int enqueue_batch(gzpx_ctx *ctx, const uint8_t *d_in, size_t in_len, uint32_t nb, int is_last,

@@ -104,8 +104,10 @@ int gzpx_compress_slab(gzpx_ctx *ctx, const uint8_t *in, size_t in_len, int mode
                        size_t *n_blocks);
 
 /* Same, with the slab and the output already resident in DEVICE memory (d_in, d_out are device
- * pointers).  hip_stream (a hipStream_t, may be NULL): the slab is read only after everything
- * enqueued on that stream so far has completed.  Synchronous with respect to the host on return. */
+ * pointers).  hip_stream (a hipStream_t; NULL = the legacy default stream, which is also PyTorch's
+ * current stream unless told otherwise): the slab is read only after everything enqueued on that stream
+ * so far has completed -- the context's own streams are non-blocking, so the dependency is always made
+ * explicit with an event, also for NULL.  Synchronous with respect to the host on return. */
 int gzpx_compress_slab_device(gzpx_ctx *ctx, const void *d_in, size_t in_len, int mode,
                               void *d_out, size_t out_cap, size_t *out_len, uint32_t *block_sizes,
                               size_t max_blocks, size_t *n_blocks, void *hip_stream);
@@ -117,8 +119,7 @@ int gzpx_compress_slab_device(gzpx_ctx *ctx, const void *d_in, size_t in_len, in
  *
  *   gzpx_compress_slab_submit   enqueues the copy-in of `in` (page-locked memory makes it a DMA
  *                               transfer: gzpx_host_alloc) and every kernel of the slab, and returns
- *                               without waiting for the device at levels 0/1 and 5-9 (the match/parse rounds
- *                               of levels 2-4 read one word back per round).  GZPX_ERR_BUSY when all
+ *                               without waiting for the device, at every level.  GZPX_ERR_BUSY when all
  *                               slots are taken.  `in` and `out` must stay valid until the wait.
  *   gzpx_compress_slab_wait     blocks until that slab's kernels are done, copies exactly the
  *                               produced bytes to `out`, reports like gzpx_compress_slab, frees the slot.
