@@ -216,8 +216,10 @@ __device__ __forceinline__ uint32_t precode_order(uint32_t i) {
 // full block, possibly empty when the slab is empty) last.
 // ------------------------------------------------------------------------------------------
 __global__ void k_init_meta(Config cfg, uint64_t slab_len, uint32_t nb, uint32_t is_last,
-                            BlockMeta *meta) {
+                            BlockMeta *meta, uint32_t *cand_any, uint32_t *redo) {
     const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b == 0 && cand_any) *cand_any = 0;  // "some block of this batch failed k_candidates' order check"
+    if (b == 0 && redo) redo[0] = 0;        // level 1: nothing handed back to the dense kernels yet
     if (b >= nb) return;
     const uint64_t begin = (uint64_t)b * cfg.block_size;
     uint64_t len = slab_len > begin ? slab_len - begin : 0;
@@ -307,7 +309,8 @@ template <int MODE>
 __global__ __launch_bounds__(64 * kCandWaves) void k_candidates(Config cfg,
                                                                  const uint8_t *__restrict__ slab,
                                                                  BlockMeta *__restrict__ meta,
-                                                                 uint16_t *__restrict__ cand_all) {
+                                                                 uint16_t *__restrict__ cand_all,
+                                                                 uint32_t *__restrict__ cand_any) {
     __shared__ uint32_t tab[kBuckets + 64];  // 128 KiB + one spare word per lane for lanes without a bucket
     __shared__ uint32_t turn;               // index of the iteration whose atomics may go next
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
@@ -387,7 +390,10 @@ __global__ __launch_bounds__(64 * kCandWaves) void k_candidates(Config cfg,
             if (MODE < 2 || mine[k] || (MODE == 2 && p + 5 > n)) cand[p] = (uint16_t)d0;
         }
     }
-    if (__ballot(bad) && lane == 0) atomicOr(&meta[b].cand_redo, 1u << MODE);
+    if (__ballot(bad) && lane == 0) {
+        atomicOr(&meta[b].cand_redo, 1u << MODE);
+        atomicOr(cand_any, 1u);
+    }
 }
 
 // Order-independent restatement used for blocks flagged by k_candidates (expected: never):
@@ -425,9 +431,12 @@ template <int MODE>
 __global__ __launch_bounds__(64) void k_candidates_safe(Config cfg, const uint8_t *__restrict__ slab,
                                                         BlockMeta *__restrict__ meta, uint32_t nb,
                                                         uint32_t force,
-                                                        uint16_t *__restrict__ cand_all) {
+                                                        uint16_t *__restrict__ cand_all,
+                                                        const uint32_t *__restrict__ cand_any) {
     __shared__ uint32_t tab[kBuckets];
     const uint32_t lane = threadIdx.x;
+    // (expected: no block of the batch is flagged -- one word says so, instead of a look at every block)
+    if (!force && __hip_atomic_load(cand_any, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) return;
     for (uint32_t b = blockIdx.x; b < nb; b += gridDim.x) {
         const uint32_t n = meta[b].n;
         if (n <= cfg.passthrough || !(force || (meta[b].cand_redo >> MODE) & 1u)) continue;  // wave-uniform
@@ -4531,30 +4540,31 @@ __global__ __launch_bounds__(kCrcThreads, 8) void k_dcrc32(const uint8_t *__rest
 void launch_init_meta(const Config &cfg, uint64_t slab_len, uint32_t nb, int is_last,
                       const Scratch &s, hipStream_t stream) {
     hipLaunchKernelGGL(k_init_meta, dim3((nb + 255) / 256), dim3(256), 0, stream, cfg, slab_len, nb,
-                       (uint32_t)(is_last ? 1 : 0), s.meta);
+                       (uint32_t)(is_last ? 1 : 0), s.meta, s.cand_any, s.redo);
 }
 
 template <int MODE>
 static void launch_candidates_mode(const Config &cfg, const uint8_t *slab, uint32_t nb, BlockMeta *meta,
-                                   uint16_t *out, hipStream_t stream) {
+                                   uint16_t *out, uint32_t *cand_any, hipStream_t stream) {
     const uint32_t force_safe = cfg.debug & 1u;  // diagnostics: exercise the fallback on every block
     if (!force_safe)
-        hipLaunchKernelGGL(k_candidates<MODE>, dim3(nb), dim3(64 * kCandWaves), 0, stream, cfg, slab, meta, out);
+        hipLaunchKernelGGL(k_candidates<MODE>, dim3(nb), dim3(64 * kCandWaves), 0, stream, cfg, slab, meta, out,
+                           cand_any);
     // blocks flagged by the order check (none expected) are redone order-independently
     const uint32_t grid = force_safe ? nb : (nb < 256u ? nb : 256u);
     hipLaunchKernelGGL(k_candidates_safe<MODE>, dim3(grid), dim3(64), 0, stream, cfg, slab, meta, nb,
-                       force_safe, out);
+                       force_safe, out, (const uint32_t *)cand_any);
 }
 
 void launch_candidates(const Config &cfg, const uint8_t *slab, uint64_t, uint32_t nb, const Scratch &s,
                        hipStream_t stream) {
     if (cfg.level == 0) return;  // stored blocks only: no matchfinding
     if (cfg.level == 1) {
-        launch_candidates_mode<0>(cfg, slab, nb, s.meta, s.cand, stream);
+        launch_candidates_mode<0>(cfg, slab, nb, s.meta, s.cand, s.cand_any, stream);
     } else {  // hc_matchfinder: hash3 predecessor in cand, hash4 chain links in d4
-        launch_candidates_mode<1>(cfg, slab, nb, s.meta, s.cand, stream);
-        launch_candidates_mode<2>(cfg, slab, nb, s.meta, s.d4, stream);
-        launch_candidates_mode<3>(cfg, slab, nb, s.meta, s.d4, stream);
+        launch_candidates_mode<1>(cfg, slab, nb, s.meta, s.cand, s.cand_any, stream);
+        launch_candidates_mode<2>(cfg, slab, nb, s.meta, s.d4, s.cand_any, stream);
+        launch_candidates_mode<3>(cfg, slab, nb, s.meta, s.d4, s.cand_any, stream);
     }
 }
 
@@ -4581,8 +4591,7 @@ extern "C" int gzpx_exp_cycles(unsigned long long out[8], int reset) {
 void launch_match(const Config &cfg, const uint8_t *slab, uint64_t, uint32_t nb, const Scratch &s,
                   hipStream_t stream) {
     const bool fused = level1_fused(cfg);
-    if (fused) {
-        (void)hipMemsetAsync(s.redo, 0, sizeof(uint32_t), stream);
+    if (fused) {  // (k_init_meta has emptied the redo list)
         hipLaunchKernelGGL(k_mparse, dim3(nb), dim3(kMpThreads), 0, stream, cfg, slab, s.meta, s.sub,
                            (const uint16_t *)s.cand, s.tok, s.redo);
     }
