@@ -1093,7 +1093,7 @@ __global__ __launch_bounds__(kMpThreads, 8) void k_parse(
 // (long runs: every 258-byte match shifts the phase of the segments behind it) is handed back to
 // the dense kernels through the `redo` list -- the cooperative run logic lives there.
 // ------------------------------------------------------------------------------------------
-constexpr uint32_t kMpMaxRounds = 10;
+constexpr uint32_t kMpMaxRounds = 24;
 constexpr uint32_t kMhHalf = 32768;  // positions per pass (their d0: 64 KiB of LDS)
 constexpr uint32_t kMhSeg = kMhHalf / kMpThreads;  // 32 positions per walk segment = one 32-bit mask
 #ifdef GZPX_EXPERIMENT
@@ -1312,10 +1312,14 @@ __global__ __launch_bounds__(kMpThreads, 4) void k_mparse(
         // one that also tells whether any entry moved.
         uint32_t cur = 0;
         seg_exit[tid] = my_exit;
-        __syncthreads();
+        // Long runs show at once: their matches fly over whole segments, entries then settle by one
+        // segment per round and the block would go to the dense kernels after kMpMaxRounds wasted
+        // rounds.  One in eight segments left by a match that overshoots it by two segments or more:
+        // hand the block over now (text: none; DNA / FASTQ / low-entropy binary: a few per block).
+        const uint32_t n_over = (uint32_t)__syncthreads_count(active && my_exit >= seg_end + 2u * kMhSeg);
         exp_lap(1);
-        bool settled = true;
-        for (uint32_t round = 0;; round++) {
+        bool settled = n_over * 8u <= (he - hb + kMhSeg - 1u) / kMhSeg;
+        for (uint32_t round = 0; settled; round++) {
             uint32_t new_entry = entry;
             if (active && tid > 0) new_entry = seg_exit[cur * kMpThreads + tid - 1];
             const bool changed = new_entry != entry;
