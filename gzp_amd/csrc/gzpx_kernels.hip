@@ -132,13 +132,12 @@ __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t *w
     __syncthreads();  // protect wsum from the previous use
     if (lane == 63) wsum[wave] = inc;
     __syncthreads();
-    uint32_t base = 0, tot = 0;
-    for (unsigned w = 0; w < NW; w++) {
-        const uint32_t s = wsum[w];
-        if (w < wave) base += s;
-        tot += s;
-    }
-    *total = tot;
+    // the wave totals: one LDS read per lane and a second DPP scan (NW <= 64) instead of NW reads and
+    // 2 NW additions in every lane
+    const uint32_t mine = lane < NW ? wsum[lane] : 0u;
+    const uint32_t winc = wave_incl_add(mine);
+    *total = rdlane(winc, NW - 1);
+    const uint32_t base = wave ? rdlane(winc, wave - 1) : 0u;
     return base + inc - v;
 }
 
@@ -1360,26 +1359,18 @@ __global__ __launch_bounds__(kMpThreads, 4) void k_mparse(
         uint32_t tile_tok, tile_mat, my_pre;
         {
             const uint32_t vt = (uint32_t)__popc(marks), vm = (uint32_t)__popc(mbits);
-            const uint32_t it = wave_incl_add(vt), im = wave_incl_add(vm);
-            if (lane == 63) {
-                wsum_t[wave] = it;
-                wsum_m[wave] = im;
-            }
+            // tokens <= 32768 fit 17 bits, matches <= 8192 fit 15 bits: one scan for both
+            const uint32_t v = vt | (vm << 17);
+            const uint32_t inc = wave_incl_add(v);
+            if (lane == 63) wsum_t[wave] = inc;
             __syncthreads();
-            uint32_t bt = 0, bm = 0, tt = 0, tm = 0;
-            for (uint32_t w = 0; w < kMpWaves; w++) {
-                const uint32_t st = wsum_t[w], sm = wsum_m[w];
-                if (w < wave) {
-                    bt += st;
-                    bm += sm;
-                }
-                tt += st;
-                tm += sm;
-            }
-            tile_tok = uniform(tt);
-            tile_mat = uniform(tm);
-            // exclusive prefixes: tokens <= 32768 fit 17 bits, matches <= 8192 fit 15 bits
-            my_pre = (bt + it - vt) | ((bm + im - vm) << 17);
+            // the wave totals: one LDS read per lane and a second DPP scan instead of 16 reads in every lane
+            const uint32_t winc = wave_incl_add(lane < kMpWaves ? wsum_t[lane] : 0u);
+            const uint32_t tot = rdlane(winc, kMpWaves - 1);
+            const uint32_t base = wave ? rdlane(winc, wave - 1) : 0u;
+            tile_tok = tot & 0x1FFFFu;
+            tile_mat = tot >> 17;
+            my_pre = base + inc - v;  // exclusive prefixes: tokens | matches << 17
         }
 
         // ---- phase 3a: sub-block boundaries.  A new DEFLATE sub-block starts at the first token that
