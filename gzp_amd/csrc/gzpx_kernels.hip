@@ -3640,16 +3640,12 @@ __global__ __launch_bounds__(kEmitThreads, 8) void k_emit(Config cfg, const uint
                         length_slot(len, ls, le, lv);
                         offset_slot(off, os, oe, ov);
                         const uint32_t lc = codes[257 + ls], oc = codes[kNumLitlen + os];
-                        uint64_t v = lc & 0xFFFFu;
-                        uint32_t nb = lc >> 16;
-                        v |= (uint64_t)lv << nb;
-                        nb += le;
-                        v |= (uint64_t)(oc & 0xFFFFu) << nb;
-                        nb += oc >> 16;
-                        v |= (uint64_t)ov << nb;
-                        nb += oe;
-                        bits[j] = v;
-                        nbits[j] = nb;
+                        // length codeword + extra bits (<= 20 bits) and offset codeword + extra bits (<= 28)
+                        // are put together in 32-bit arithmetic, then joined by ONE 64-bit shift
+                        const uint32_t lpart = (lc & 0xFFFFu) | (lv << (lc >> 16)), lbits = (lc >> 16) + le;
+                        const uint32_t opart = (oc & 0xFFFFu) | (ov << (oc >> 16)), obits = (oc >> 16) + oe;
+                        bits[j] = (uint64_t)lpart | ((uint64_t)opart << lbits);
+                        nbits[j] = lbits + obits;
                     } else {
                         const uint32_t lc = codes[t];
                         bits[j] = lc & 0xFFFFu;
