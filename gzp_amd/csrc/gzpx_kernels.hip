@@ -17,21 +17,27 @@
 // of data-parallel stages, each a kernel over all blocks of a slab:
 //   k_candidates   16 waves / block : LDS-resident 128 KiB bucket table, ordered atomicMax chain,
 //                                     1024 positions per ticket turn
-//   k_match        1024 thr / block : block input in LDS; both candidates of every position
-//                                     extended by one lockstep loop; run groups for long runs
-//   k_parse        1024 thr / block : per-position match lengths in LDS; the greedy parse as a
-//                                     speculative walk over 64-position segments, then the
+//   k_mparse       1024 thr / block : (blocks <= 64 KiB) match on demand: the block's bytes and half
+//                                     its candidate distances in LDS; the greedy parse as a
+//                                     speculative walk over 32-position segments that searches only
+//                                     where it lands; every lane writes its own tokens
+//   k_match        1024 thr / block : (larger blocks, and blocks k_mparse hands back) block input in LDS;
+//                                     both candidates of EVERY position extended by one lockstep
+//                                     loop; run groups for long runs
+//   k_parse        1024 thr / block : (same blocks) per-position match lengths in LDS; the greedy parse
+//                                     as a speculative walk over 64-position segments, then the
 //                                     position-parallel token build
 //   k_hist         256 thr  / block : symbol frequencies per DEFLATE sub-block
 //   k_huffman      one wave / block : libdeflate's length-limited Huffman construction, header
 //                                     RLE, exact cost comparison (dynamic / static / stored)
-//   k_crc32        256 thr  / block : per-segment CRC + GF(2) combine tree (side stream)
+//   k_crc32        256 thr  / block : 256-byte segments straight from global memory, slice-by-4, one GF(2)
+//                                     combine tree per 64 KiB (side stream)
 //   k_scan         one workgroup    : exclusive scan of framed sizes -> output offsets
 //   k_emit         1024 thr / block : bit-exact bitstream assembly in LDS, coalesced write-out
 // Levels 2-4 swap k_match / k_parse for k_match_hc / k_parse_hc (hc_matchfinder chains, block
 // splitting), levels 5-9 for k_match_hc / k_parse_lazy (the lazy and lazy2 parsers); ParDecompress
 // is k_dinit / k_dscan / k_inflate / k_dcrc32.
-// Integer/byte work only: no MFMA; LDS, the texture path and instruction issue are what matter.
+// Integer/byte work only: no MFMA; the path is bound by instruction issue, then LDS.
 #include <hip/hip_runtime.h>
 #include <type_traits>
 #include <cstring>
@@ -1088,9 +1094,11 @@ __global__ __launch_bounds__(kMpThreads, 8) void k_parse(
 //            it: match ranks are known from the scan, every lane names its own candidate), then
 //            every lane writes the tokens of its own segment: length = distance to the next token
 //            start, distance = d0 or d0 + d0[p - d0] out of LDS again, literals from the LDS window.
-// Nothing but tokens goes to HBM.  A block whose entries have not settled after kMpMaxRounds rounds
-// (long runs: every 258-byte match shifts the phase of the segments behind it) is handed back to
-// the dense kernels through the `redo` list -- the cooperative run logic lives there.
+// Nothing but tokens goes to HBM.  Long runs (every 258-byte match shifts the phase of the segments
+// behind it, entries settle by one segment per round) are handed back to the dense kernels through the
+// `redo` list -- the cooperative run logic lives there: at once when a pass's first walk shows them (one
+// segment in eight left by a match that overshoots it by two segments or more), or when the entries have
+// not settled after kMpMaxRounds rounds.
 // ------------------------------------------------------------------------------------------
 constexpr uint32_t kMpMaxRounds = 24;
 constexpr uint32_t kMhHalf = 32768;  // positions per pass (their d0: 64 KiB of LDS)
