@@ -884,6 +884,8 @@ def main():
                 "frac": round(achieved / HBM_PEAK_GBS, 5),
                 "traffic": traffic,
                 "traffic_ratio": round(traffic / alg_bytes, 2) if traffic else None,  # this kernel's HBM bytes / the path's algorithmic bytes
+                # what the kernel really moves over its own duration, as a fraction of the peak (it is issue-bound)
+                "own_traffic_frac": round(traffic / (max(stage_ms[dom], 1e-9) * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if traffic else None,
                 "traffic_pipeline": traffic_all,
                 "traffic_ratio_pipeline": round(traffic_all / alg_bytes, 2) if traffic_all else None,
                 "traffic_source": "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes of "
