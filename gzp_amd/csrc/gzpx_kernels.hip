@@ -3497,6 +3497,7 @@ __global__ __launch_bounds__(kEmitThreads, 8) void k_emit(Config cfg, const uint
     __shared__ uint32_t stage[kStageWords];
     __shared__ uint32_t codes[kCodeWords];
     __shared__ uint32_t wsum[kEmitThreads / 64];
+    __shared__ uint8_t lslot[256];  // length - 3 -> DEFLATE length slot | extra-bit count << 5 (one LDS read instead of ~10 VALU)
     const uint32_t tid = threadIdx.x;
     const uint32_t b = blockIdx.x;
     const BlockMeta *meta = meta_all + b;
@@ -3516,6 +3517,11 @@ __global__ __launch_bounds__(kEmitThreads, 8) void k_emit(Config cfg, const uint
     uint32_t win_base = 0;  // aligned coordinate of stage[0] (multiple of 4)
 
     for (uint32_t i = tid; i < kStageWords; i += kEmitThreads) stage[i] = 0;
+    if (tid < 256) {
+        uint32_t ls, le, lv;
+        length_slot(tid + 3, ls, le, lv);
+        lslot[tid] = (uint8_t)(ls | (le << 5));
+    }
     __syncthreads();
 
     // ---- gzip member header (src/bgzf.rs:274-303 / src/mgzip.rs:246-275)
@@ -3644,8 +3650,9 @@ __global__ __launch_bounds__(kEmitThreads, 8) void k_emit(Config cfg, const uint
                     const uint32_t t = tcur[j];
                     if (t & kTokMatch) {
                         const uint32_t len = t & 0x1FFu, off = (t >> 9) & 0xFFFFu;
-                        uint32_t ls, le, lv, os, oe, ov;
-                        length_slot(len, ls, le, lv);
+                        uint32_t os, oe, ov;
+                        const uint32_t lt = lslot[len - 3u];
+                        const uint32_t ls = lt & 31u, le = lt >> 5, lv = (len - 3u) & ((1u << le) - 1u);
                         offset_slot(off, os, oe, ov);
                         const uint32_t lc = codes[257 + ls], oc = codes[kNumLitlen + os];
                         // length codeword + extra bits (<= 20 bits) and offset codeword + extra bits (<= 28)
