@@ -2528,11 +2528,18 @@ __global__ void k_hc_init(uint32_t nb, HcState *hc, uint32_t *pending) {
 // k_hist: litlen / offset symbol frequencies of every DEFLATE sub-block (deflate_choose_literal /
 // deflate_choose_match tallies), from the token stream.  256 threads per block, LDS atomics.
 // ------------------------------------------------------------------------------------------
+constexpr uint32_t kHistCopies = 8;                 // (a power of two)
+constexpr uint32_t kHistPad = kHistStride + 1;      // copies a word apart in the banks
+
 __global__ __launch_bounds__(256) void k_hist(Config cfg, const BlockMeta *__restrict__ meta_all,
                                               const SubMeta *__restrict__ sub_all,
                                               const uint32_t *__restrict__ tok_all,
                                               uint32_t *__restrict__ hist_all) {
-    __shared__ uint32_t hist[kHistStride];
+    // Text has a few very hot symbols (the space, 'e', the first offset slots): with one histogram the
+    // lanes of an atomic instruction pile up on their words and the LDS applies them one by one (PMC:
+    // three quarters of this kernel's LDS cycles were bank conflicts).  Eight copies, picked by the
+    // lane, staggered by one bank; summed when the sub-block is written out.
+    __shared__ uint32_t hist[kHistCopies * kHistPad];
     const uint32_t tid = threadIdx.x;
     const uint32_t b = blockIdx.x;
     const BlockMeta *meta = meta_all + b;
@@ -2540,8 +2547,9 @@ __global__ __launch_bounds__(256) void k_hist(Config cfg, const BlockMeta *__res
     const SubMeta *sub = sub_all + (uint64_t)b * cfg.max_sub;
     const uint32_t *tok = tok_all + (uint64_t)b * cfg.stride;
     const uint32_t nsub = meta->nsub;
+    uint32_t *mine = hist + (tid & (kHistCopies - 1u)) * kHistPad;
     for (uint32_t s = 0; s < nsub; s++) {
-        for (uint32_t i = tid; i < kHistStride; i += 256) hist[i] = 0;
+        for (uint32_t i = tid; i < kHistCopies * kHistPad; i += 256) hist[i] = 0;
         __syncthreads();
         const uint32_t t_end = sub[s].tok_end;
         for (uint32_t t0 = sub[s].tok_begin + tid; t0 < t_end; t0 += 4 * 256) {
@@ -2556,16 +2564,21 @@ __global__ __launch_bounds__(256) void k_hist(Config cfg, const BlockMeta *__res
                     uint32_t ls, le, lv, os, oe, ov;
                     length_slot(t & 0x1FFu, ls, le, lv);
                     offset_slot((t >> 9) & 0xFFFFu, os, oe, ov);
-                    atomicAdd(&hist[257 + ls], 1u);
-                    atomicAdd(&hist[kNumLitlen + os], 1u);
+                    atomicAdd(&mine[257 + ls], 1u);
+                    atomicAdd(&mine[kNumLitlen + os], 1u);
                 } else {
-                    atomicAdd(&hist[t], 1u);
+                    atomicAdd(&mine[t], 1u);
                 }
             }
         }
         __syncthreads();
         uint32_t *out = hist_all + ((uint64_t)b * cfg.max_sub + s) * kHistStride;
-        for (uint32_t i = tid; i < kHistStride; i += 256) out[i] = hist[i];
+        for (uint32_t i = tid; i < kHistStride; i += 256) {
+            uint32_t sum = 0;
+#pragma unroll
+            for (uint32_t c = 0; c < kHistCopies; c++) sum += hist[c * kHistPad + i];
+            out[i] = sum;
+        }
         __syncthreads();
     }
 }
