@@ -1104,6 +1104,8 @@ constexpr uint32_t kMpMaxRounds = 24;
 constexpr uint32_t kMhHalf = 32768;  // positions per pass (their d0: 64 KiB of LDS)
 constexpr uint32_t kMhSeg = kMhHalf / kMpThreads;  // 32 positions per walk segment = one 32-bit mask
 #ifdef GZPX_EXPERIMENT
+// k_huffman: setup, litlen code, offset code, precode RLE, precode code, costs, header + tables (rows as below)
+__device__ unsigned long long g_exp_huff[1024 * 8];
 // k_mparse: stage, first walk, later rounds, settle, build, barrier rounds, re-walks (x 1024 rows, a
 // block adds to row blockIdx & 1023: same-address atomics serialise at the L2)
 __device__ unsigned long long g_exp_cycles[1024 * 8];
@@ -2658,8 +2660,13 @@ __device__ __forceinline__ uint32_t reg5_get(const uint32_t (&r)[5], uint32_t k)
 }
 
 // Builds lens[] / cw[] for `num_syms` symbols from h.freq[].  All 64 lanes must call.
-__device__ void make_code(HuffLds &h, uint32_t num_syms, uint32_t max_len, uint32_t compat,
-                          uint8_t *lens, uint32_t *cw, uint32_t lane) {
+// NCH = 64-symbol chunks of the alphabet (5 for litlen, 1 for the offset code and the precode), MAXL = the
+// code's length limit: the per-chunk and per-length loops below are unrolled to exactly what the alphabet
+// needs -- written for the litlen code alone they made the 30-symbol offset code cost 62 % of the
+// 286-symbol one (k_huffman's phases, tools/exp_huffman.py).
+template <uint32_t NCH, uint32_t MAXL>
+__device__ void make_code(HuffLds &h, uint32_t num_syms, uint32_t compat, uint8_t *lens, uint32_t *cw, uint32_t lane) {
+    constexpr uint32_t max_len = MAXL;
     // keys + used count
     uint32_t used = 0;
     for (uint32_t base = 0; base < num_syms; base += 64) {
@@ -2751,9 +2758,9 @@ __device__ void make_code(HuffLds &h, uint32_t num_syms, uint32_t max_len, uint3
     // follow from how many internal nodes sit at each depth, otherwise the sequential clamp runs.
     {
         const uint32_t last = used - 1, root = last - 1;
-        uint32_t par[5], dep[5];
+        uint32_t par[NCH], dep[NCH];
 #pragma unroll
-        for (uint32_t k = 0; k < 5; k++) {
+        for (uint32_t k = 0; k < NCH; k++) {
             const uint32_t node = lane + 64 * k;
             par[k] = node < root ? h.parent[node] : 0xFFFFu;
             dep[k] = node == root ? 0u : 0xFFu;
@@ -2763,7 +2770,7 @@ __device__ void make_code(HuffLds &h, uint32_t num_syms, uint32_t max_len, uint3
         for (;;) {
             bool changed = false;
 #pragma unroll
-            for (uint32_t k = 0; k < 5; k++) {
+            for (uint32_t k = 0; k < NCH; k++) {
                 if (par[k] != 0xFFFFu && dep[k] == 0xFFu) {
                     const uint32_t pd = h.depth[par[k]];
                     if (pd != 0xFFu) {
@@ -2774,14 +2781,14 @@ __device__ void make_code(HuffLds &h, uint32_t num_syms, uint32_t max_len, uint3
             }
             wave_sync();
 #pragma unroll
-            for (uint32_t k = 0; k < 5; k++)
+            for (uint32_t k = 0; k < NCH; k++)
                 if (par[k] != 0xFFFFu && dep[k] != 0xFFu) h.depth[lane + 64 * k] = (uint8_t)dep[k];
             wave_sync();
             if (!__ballot(changed)) break;
         }
         uint32_t deepest = 0;
 #pragma unroll
-        for (uint32_t k = 0; k < 5; k++)
+        for (uint32_t k = 0; k < NCH; k++)
             if (par[k] != 0xFFFFu && dep[k] > deepest) deepest = dep[k];
         const bool clamp = __ballot(deepest >= max_len) != 0;  // an internal node at depth >= max_len
         if (!clamp) {
@@ -2790,7 +2797,7 @@ __device__ void make_code(HuffLds &h, uint32_t num_syms, uint32_t max_len, uint3
             for (uint32_t l = 1; l <= max_len; l++) {
                 uint32_t c = 0;
 #pragma unroll
-                for (uint32_t k = 0; k < 5; k++) c += (uint32_t)__popcll(__ballot(par[k] != 0xFFFFu && dep[k] == l));
+                for (uint32_t k = 0; k < NCH; k++) c += (uint32_t)__popcll(__ballot(par[k] != 0xFFFFu && dep[k] == l));
                 if (lane == 0) h.len_counts[l] = (l == 1 ? 2u : 0u) + 2u * prev - c;
                 prev = c;
             }
@@ -2831,15 +2838,14 @@ __device__ void make_code(HuffLds &h, uint32_t num_syms, uint32_t max_len, uint3
     next_code[0] = 0;
     next_code[1] = 0;
 #pragma unroll
-    for (uint32_t l = 2; l <= 15; l++)
-        next_code[l] = l <= max_len ? (next_code[l - 1] + h.len_counts[l - 1]) << 1 : 0;
+    for (uint32_t l = 2; l <= MAXL; l++) next_code[l] = (next_code[l - 1] + h.len_counts[l - 1]) << 1;
     const uint64_t lane_below = (1ull << lane) - 1ull;
     for (uint32_t base = 0; base < num_syms; base += 64) {
         const uint32_t s = base + lane;
         const uint32_t myl = s < num_syms ? lens[s] : 0;
         uint32_t code = 0;
 #pragma unroll
-        for (uint32_t l = 1; l <= 15; l++) {
+        for (uint32_t l = 1; l <= MAXL; l++) {
             const uint64_t m = __ballot(myl == l);
             if (myl == l) code = next_code[l] + (uint32_t)__popcll(m & lane_below);
             next_code[l] += (uint32_t)__popcll(m);
@@ -2913,6 +2919,17 @@ __global__ __launch_bounds__(64, GZPX_HUFF_WAVES) void k_huffman(Config cfg, Blo
         const uint32_t block_length = sub[s].byte_len;
         const uint32_t is_final = sub[s].is_final;
 
+#ifdef GZPX_EXPERIMENT
+        unsigned long long hx_t = __builtin_readcyclecounter();
+#define GZPX_HLAP(slot)                                                                               \
+    do {                                                                                              \
+        const unsigned long long t_ = __builtin_readcyclecounter();                                   \
+        if (lane == 0) atomicAdd(&g_exp_huff[(b & 1023u) * 8u + (slot)], t_ - hx_t);                  \
+        hx_t = t_;                                                                                    \
+    } while (0)
+#else
+#define GZPX_HLAP(slot) ((void)0)
+#endif
         // ---- litlen code (EOB tallied once), offset code
         // per-lane copies of the frequencies for the cost sums (make_code reuses freq[]'s storage)
         uint32_t lfreq[5];
@@ -2922,11 +2939,14 @@ __global__ __launch_bounds__(64, GZPX_HUFF_WAVES) void k_huffman(Config cfg, Blo
             if (i < kNumLitlen) h.freq[i] = lfreq[k];
         }
         wave_sync();
-        make_code(h, kNumLitlen, 14, cfg.compat, h.lens, h.lcw, lane);
+        GZPX_HLAP(0);
+        make_code<5, 14>(h, kNumLitlen, cfg.compat, h.lens, h.lcw, lane);
+        GZPX_HLAP(1);
         const uint32_t ofreq = lane < kNumOffset ? hist[kNumLitlen + lane] : 0;
         if (lane < kNumOffset) h.freq[lane] = ofreq;
         wave_sync();
-        make_code(h, kNumOffset, 15, cfg.compat, h.olens, h.ocw, lane);
+        make_code<1, 15>(h, kNumOffset, cfg.compat, h.olens, h.ocw, lane);
+        GZPX_HLAP(2);
         wave_sync();
 
         // ---- deflate_precompute_huffman_header
@@ -3023,7 +3043,9 @@ __global__ __launch_bounds__(64, GZPX_HUFF_WAVES) void k_huffman(Config cfg, Blo
         wave_sync();
         if (lane < 32) h.freq[lane] = lane < 19 ? pf : 0;
         wave_sync();
-        make_code(h, 19, 7, cfg.compat, h.plens, h.pcw, lane);
+        GZPX_HLAP(3);
+        make_code<1, 7>(h, 19, cfg.compat, h.plens, h.pcw, lane);
+        GZPX_HLAP(4);
         uint32_t num_explicit;
         {
             uint32_t ne = 4;
@@ -3075,6 +3097,7 @@ __global__ __launch_bounds__(64, GZPX_HUFF_WAVES) void k_huffman(Config cfg, Blo
             type = kStored;
         }
 
+        GZPX_HLAP(5);
         // ---- header bit string + code tables for k_emit
         for (uint32_t i = lane; i < kHdrWords; i += 64) h.hdr[i] = 0;
         wave_sync();
@@ -3162,7 +3185,9 @@ __global__ __launch_bounds__(64, GZPX_HUFF_WAVES) void k_huffman(Config cfg, Blo
         }
         bitpos += sub_bits;
         wave_sync();
+        GZPX_HLAP(6);
     }
+#undef GZPX_HLAP
     if (lane == 0) {
         const uint32_t c = (bitpos + 7u) >> 3;
         meta->payload_bytes = c;
@@ -4593,6 +4618,19 @@ void launch_candidates(const Config &cfg, const uint8_t *slab, uint64_t, uint32_
 bool level1_fused(const Config &cfg) { return cfg.block_size <= kTile && !(cfg.debug & 2u); }
 
 #ifdef GZPX_EXPERIMENT
+extern "C" int gzpx_exp_huff(unsigned long long out[8], int reset) {
+    static unsigned long long rows[1024 * 8];
+    if (hipMemcpyFromSymbol(rows, HIP_SYMBOL(g_exp_huff), sizeof(rows)) != hipSuccess) return -1;
+    for (int k = 0; k < 8; k++) out[k] = 0;
+    for (int r = 0; r < 1024; r++)
+        for (int k = 0; k < 8; k++) out[k] += rows[r * 8 + k];
+    if (reset) {
+        memset(rows, 0, sizeof(rows));
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_exp_huff), rows, sizeof(rows)) != hipSuccess) return -1;
+    }
+    return 0;
+}
+
 extern "C" int gzpx_exp_cycles(unsigned long long out[8], int reset) {
     static unsigned long long rows[1024 * 8];
     if (hipMemcpyFromSymbol(rows, HIP_SYMBOL(g_exp_cycles), sizeof(rows)) != hipSuccess) return -1;
