@@ -166,9 +166,8 @@ int alloc_scratch(gzpx_ctx *ctx) {
     HIP_TRY(hipMalloc((void **)&s.which, nb * (size_t)(c.stride / 32) * 4));
     HIP_TRY(hipMalloc((void **)&s.alt, nb * (size_t)c.stride * sizeof(uint16_t)));
     HIP_TRY(hipMalloc((void **)&s.tok, nb * (size_t)c.stride * 4));
-    HIP_TRY(hipMalloc((void **)&s.redo, (nb + 2) * sizeof(uint32_t)));
-    HIP_TRY(hipMemset(s.redo, 0, (nb + 2) * sizeof(uint32_t)));
-    s.cand_any = s.redo + nb + 1;
+    HIP_TRY(hipMalloc((void **)&s.redo, (nb + 1) * sizeof(uint32_t)));
+    HIP_TRY(hipMemset(s.redo, 0, (nb + 1) * sizeof(uint32_t)));
     if (c.level >= 2) {  // hc_matchfinder levels: hash4 chain links + per-block parse state
         HIP_TRY(hipMalloc((void **)&s.d4, nb * (size_t)c.stride * sizeof(uint16_t)));
         HIP_TRY(hipMalloc((void **)&s.hc, nb * sizeof(HcState)));
@@ -272,11 +271,9 @@ int enqueue_batch(gzpx_ctx *ctx, const uint8_t *d_in, size_t in_len, uint32_t nb
     const Scratch &s = ctx->scratch;
     ProfPairs pp{ctx, ctx->profiling};
     ctx->prof_n = 0;
-    int t = pp.begin(0, stream);
-    launch_init_meta(c, in_len, nb, is_last, s, stream);
-    pp.end(t, stream);
-    t = pp.begin(1, stream);
-    launch_candidates(c, d_in, in_len, nb, s, stream);
+    // (the slab is cut into blocks -- BlockMeta -- by the first k_candidates launch; level 0: k_init_meta)
+    int t = pp.begin(c.level == 0 ? 0 : 1, stream);
+    launch_candidates(c, d_in, in_len, nb, is_last, s, stream);
     pp.end(t, stream);
     if (c.level <= 1) {  // (at level 0 every block is a passthrough block: the kernels return at once)
         // (Tried in round 3: the batch cut into 2..8 block ranges, k_hist / k_huffman of range k on a

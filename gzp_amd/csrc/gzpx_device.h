@@ -49,7 +49,6 @@ struct BlockMeta {
     uint32_t framed_bytes;   // header + c + footer (+ EOF)
     uint32_t crc;
     uint32_t status;
-    uint32_t cand_redo;        // k_candidates' LDS-order check failed: redo with k_candidates_safe
 };
 
 // What the host needs back from one batch (written by k_scan): 16 bytes instead of every BlockMeta.
@@ -84,7 +83,7 @@ struct Config {
     uint32_t compat;      // 0: libdeflate >= 1.1x Huffman rule, 1: libdeflate 1.10
     uint32_t block_size;  // buffer_size of the reference's builder
     uint32_t xfl;         // gzip XFL byte derived from level (src/bgzf.rs:278-284)
-    uint32_t debug;       // diagnostics only: bit 0 = force k_candidates_safe on every block, bit 1 =
+    uint32_t debug;       // diagnostics only: bit 0 = k_candidates' order-independent fallback on every block, bit 1 =
                           // level 1 through the dense k_match / k_parse pair instead of k_mparse, bit 2 =
                           // k_mparse hands every block back (exercises the redo list)
     uint32_t stride;      // per-block stride (positions) of cand / len8 / alt / tok: >= block_size + 1024
@@ -110,7 +109,6 @@ struct Scratch {
     uint32_t *pending;    // [1]                 levels 2-4: blocks that need another round
     uint32_t *tok;        // [nb][stride]        worst case one token per byte
     uint32_t *redo;       // [1 + nb]            level 1: blocks k_mparse hands back to k_match / k_parse
-    uint32_t *cand_any;   // [1]                 some block failed k_candidates' order check (k_candidates_safe has work)
     uint32_t *hist;       // [nb][max_sub][kHistStride]
     uint32_t *codes;      // [nb][max_sub][kCodeWords]
     uint32_t *hdr;        // [nb][max_sub][kHdrWords]
@@ -121,8 +119,8 @@ struct Scratch {
 // Host-side launchers (gzpx_kernels.hip).  All asynchronous on `stream`.
 void launch_init_meta(const Config &cfg, uint64_t slab_len, uint32_t nb, int is_last,
                       const Scratch &s, hipStream_t stream);
-void launch_candidates(const Config &cfg, const uint8_t *slab, uint64_t slab_len, uint32_t nb,
-                       const Scratch &s, hipStream_t stream);
+void launch_candidates(const Config &cfg, const uint8_t *slab, uint64_t slab_len, uint32_t nb, int is_last,
+                       const Scratch &s, hipStream_t stream);  // (fills BlockMeta too: k_init_meta's work)
 void launch_match(const Config &cfg, const uint8_t *slab, uint64_t slab_len, uint32_t nb,
                   const Scratch &s, hipStream_t stream);
 void launch_parse(const Config &cfg, const uint8_t *slab, uint64_t slab_len, uint32_t nb,

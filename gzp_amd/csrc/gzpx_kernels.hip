@@ -220,12 +220,8 @@ __device__ __forceinline__ uint32_t precode_order(uint32_t i) {
 // (src/par/compress.rs:415-416, :333-341): full `block_size` cuts, the remainder (possibly a
 // full block, possibly empty when the slab is empty) last.
 // ------------------------------------------------------------------------------------------
-__global__ void k_init_meta(Config cfg, uint64_t slab_len, uint32_t nb, uint32_t is_last,
-                            BlockMeta *meta, uint32_t *cand_any, uint32_t *redo) {
-    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b == 0 && cand_any) *cand_any = 0;  // "some block of this batch failed k_candidates' order check"
-    if (b == 0 && redo) redo[0] = 0;        // level 1: nothing handed back to the dense kernels yet
-    if (b >= nb) return;
+__device__ __forceinline__ BlockMeta block_meta_of(const Config &cfg, uint64_t slab_len, uint32_t nb, uint32_t is_last,
+                                                   uint32_t b) {
     const uint64_t begin = (uint64_t)b * cfg.block_size;
     uint64_t len = slab_len > begin ? slab_len - begin : 0;
     if (len > cfg.block_size) len = cfg.block_size;
@@ -238,8 +234,17 @@ __global__ void k_init_meta(Config cfg, uint64_t slab_len, uint32_t nb, uint32_t
     m.framed_bytes = 0;
     m.crc = 0;
     m.status = kStatusOk;
-    m.cand_redo = 0;
-    meta[b] = m;
+    return m;
+}
+
+// (Level 0 and the decompressor's CRC pass only: at levels >= 1 the first k_candidates launch of a batch
+// does this for its own block -- one launch and one dependent load at the head of every workgroup less.)
+__global__ void k_init_meta(Config cfg, uint64_t slab_len, uint32_t nb, uint32_t is_last,
+                            BlockMeta *meta, uint32_t *redo) {
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b == 0 && redo) redo[0] = 0;        // level 1: nothing handed back to the dense kernels yet
+    if (b >= nb) return;
+    meta[b] = block_meta_of(cfg, slab_len, nb, is_last, b);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -261,8 +266,8 @@ __global__ void k_init_meta(Config cfg, uint64_t slab_len, uint32_t nb, uint32_t
 // (kCandSteps * 64 positions) of atomics are kept in flight per iteration; sixteen waves (four per
 // SIMD) take turns at the table so that only the atomic phase is serial.  The ordering
 // assumption is CHECKED, never trusted: a lane that is handed a predecessor >= its own position
-// flags the block, and k_candidates_safe (ballot match-any, order-independent) redoes flagged
-// blocks.
+// flags the block, and one wave of the workgroup then redoes it in the same table with
+// cand_block_safe (ballot match-any, order-independent) before the kernel ends.
 // Output: cand[p] = d0 (u16, 0 = no live predecessor).
 // ------------------------------------------------------------------------------------------
 constexpr uint32_t kBuckets = 1u << 15;
@@ -310,17 +315,81 @@ __device__ __forceinline__ bool cand_bucket(uint32_t v, uint32_t p, uint32_t &h)
     }
 }
 
+// Order-independent restatement for a block whose order check failed in k_candidates (expected: never):
+// lanes of a step that share a bucket are linked in position order with a 15-round ballot
+// match-any; the last lane of each group rewrites the bucket (position mod 65536, with a dead
+// marker 0x8000 behind that is refreshed every 32768 positions).
+template <int MODE>
+__device__ __forceinline__ void cand_step_safe(uint32_t *tab, uint32_t mis, uint32_t base,
+                                               uint32_t lane, uint32_t n, uint2 raw,
+                                               uint16_t *__restrict__ cand) {
+    const uint32_t p = base + lane;
+    uint32_t h = 0;
+    const bool owns = cand_bucket<MODE>(__builtin_amdgcn_alignbyte(raw.y, raw.x, (p + mis) & 3u), p, h);
+    const bool valid = owns && p + 5 <= n;  // positions the matchfinder hashes (REQUIRED_NBYTES = 5)
+    if (!valid) h = 0;
+    uint32_t c0 = tab[h];
+    uint64_t same = __ballot(valid);
+    for (int bit = 0; bit < 15; bit++) {
+        const bool one = (h >> bit) & 1u;
+        const uint64_t m = __ballot(one);
+        same &= one ? m : ~m;
+    }
+    const uint64_t below = same & ((1ull << lane) - 1ull);
+    const bool is_last_of_group = ((same >> lane) >> 1) == 0;
+    if (below) c0 = (base + 63u - (uint32_t)__clzll((long long)below)) & 0xFFFFu;
+    wave_sync();  // every lane has read its bucket before any lane rewrites one
+    if (valid && is_last_of_group) tab[h] = p & 0xFFFFu;
+    wave_sync();
+    uint32_t d0 = (p - c0) & 0xFFFFu;
+    if (d0 > 32767u) d0 = 0;
+    if (MODE < 2 || valid || (MODE == 2 && p + 5 > n)) cand[p] = (uint16_t)(valid ? d0 : 0u);
+}
+
+// One wave redoes the block in `tab` (the workgroup's table, free again): k_candidates' fallback.
+template <int MODE>
+__device__ void cand_block_safe(uint32_t *tab, const uint32_t *in32, uint32_t mis, uint32_t wmax, uint32_t n,
+                                uint32_t lane, uint16_t *__restrict__ cand) {
+    for (uint32_t i = lane; i < kBuckets; i += 64) tab[i] = 0x8000u;
+    wave_sync();
+    for (uint32_t base = 0; base < n; base += 64) {
+        if (base != 0 && (base & 32767u) == 0) {
+            // sweep: entries farther than 32767 behind `base` become "dead for the next
+            // 32768 positions" (the analogue of libdeflate's window slide)
+            const uint32_t dead = (base + 0x8000u) & 0xFFFFu;
+            for (uint32_t i = lane; i < kBuckets; i += 64) {
+                const uint32_t e = tab[i];
+                const uint32_t a = (base - e) & 0xFFFFu;
+                if (a == 0 || a > 32767u) tab[i] = dead;
+            }
+            wave_sync();
+        }
+        cand_step_safe<MODE>(tab, mis, base, lane, n, cand_fetch(in32, mis, base + lane, wmax), cand);
+    }
+}
+
 template <int MODE>
 __global__ __launch_bounds__(64 * kCandWaves) void k_candidates(Config cfg,
                                                                  const uint8_t *__restrict__ slab,
                                                                  BlockMeta *__restrict__ meta,
                                                                  uint16_t *__restrict__ cand_all,
-                                                                 uint32_t *__restrict__ cand_any) {
+                                                                 uint64_t slab_len, uint32_t nb, uint32_t is_last,
+                                                                 uint32_t *__restrict__ redo) {
     __shared__ uint32_t tab[kBuckets + 64];  // 128 KiB + one spare word per lane for lanes without a bucket
     __shared__ uint32_t turn;               // index of the iteration whose atomics may go next
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint32_t b = blockIdx.x;
-    const uint32_t n = meta[b].n;
+    uint32_t n;
+    if (MODE <= 1) {  // the first launch of a batch (hash4 / hash3 pass): cut the slab, k_init_meta's rules
+        const BlockMeta m = block_meta_of(cfg, slab_len, nb, is_last, b);
+        n = m.n;
+        if (tid == 0) {
+            meta[b] = m;
+            if (b == 0) redo[0] = 0;  // level 1: nothing handed back to the dense kernels yet
+        }
+    } else {
+        n = meta[b].n;
+    }
     if (n <= cfg.passthrough) return;  // stored-only path, no matchfinding (uniform)
     const uint8_t *in = slab + (uint64_t)b * cfg.block_size;
     const uint32_t mis = (uint32_t)((uintptr_t)in & 3u);
@@ -343,8 +412,9 @@ __global__ __launch_bounds__(64 * kCandWaves) void k_candidates(Config cfg,
     for (uint32_t k = 0; k < kCandSteps; k++)
         ring[k] = cand_fetch(in32, mis, wave * kIterPos + k * 64 + lane, wmax);
 
-    bool bad = false;
-    for (uint32_t it = wave; it < n_iters; it += kCandWaves) {
+    const bool force_safe = (cfg.debug & 1u) != 0;  // diagnostics: the fallback on every block, instead of the fast form
+    bool bad = force_safe;
+    for (uint32_t it = wave; it < n_iters && !force_safe; it += kCandWaves) {
         const uint32_t base0 = it * kIterPos;
         // The serial phase must be nothing but the atomics: a lone wave issues about one dependent
         // instruction per ten cycles, so every instruction inside the turn costs every wave.
@@ -395,79 +465,9 @@ __global__ __launch_bounds__(64 * kCandWaves) void k_candidates(Config cfg,
             if (MODE < 2 || mine[k] || (MODE == 2 && p + 5 > n)) cand[p] = (uint16_t)d0;
         }
     }
-    if (__ballot(bad) && lane == 0) {
-        atomicOr(&meta[b].cand_redo, 1u << MODE);
-        atomicOr(cand_any, 1u);
-    }
-}
-
-// Order-independent restatement used for blocks flagged by k_candidates (expected: never):
-// lanes of a step that share a bucket are linked in position order with a 15-round ballot
-// match-any; the last lane of each group rewrites the bucket (position mod 65536, with a dead
-// marker 0x8000 behind that is refreshed every 32768 positions).
-template <int MODE>
-__device__ __forceinline__ void cand_step_safe(uint32_t *tab, uint32_t mis, uint32_t base,
-                                               uint32_t lane, uint32_t n, uint2 raw,
-                                               uint16_t *__restrict__ cand) {
-    const uint32_t p = base + lane;
-    uint32_t h = 0;
-    const bool owns = cand_bucket<MODE>(__builtin_amdgcn_alignbyte(raw.y, raw.x, (p + mis) & 3u), p, h);
-    const bool valid = owns && p + 5 <= n;  // positions the matchfinder hashes (REQUIRED_NBYTES = 5)
-    if (!valid) h = 0;
-    uint32_t c0 = tab[h];
-    uint64_t same = __ballot(valid);
-    for (int bit = 0; bit < 15; bit++) {
-        const bool one = (h >> bit) & 1u;
-        const uint64_t m = __ballot(one);
-        same &= one ? m : ~m;
-    }
-    const uint64_t below = same & ((1ull << lane) - 1ull);
-    const bool is_last_of_group = ((same >> lane) >> 1) == 0;
-    if (below) c0 = (base + 63u - (uint32_t)__clzll((long long)below)) & 0xFFFFu;
-    wave_sync();  // every lane has read its bucket before any lane rewrites one
-    if (valid && is_last_of_group) tab[h] = p & 0xFFFFu;
-    wave_sync();
-    uint32_t d0 = (p - c0) & 0xFFFFu;
-    if (d0 > 32767u) d0 = 0;
-    if (MODE < 2 || valid || (MODE == 2 && p + 5 > n)) cand[p] = (uint16_t)(valid ? d0 : 0u);
-}
-
-template <int MODE>
-__global__ __launch_bounds__(64) void k_candidates_safe(Config cfg, const uint8_t *__restrict__ slab,
-                                                        BlockMeta *__restrict__ meta, uint32_t nb,
-                                                        uint32_t force,
-                                                        uint16_t *__restrict__ cand_all,
-                                                        const uint32_t *__restrict__ cand_any) {
-    __shared__ uint32_t tab[kBuckets];
-    const uint32_t lane = threadIdx.x;
-    // (expected: no block of the batch is flagged -- one word says so, instead of a look at every block)
-    if (!force && __hip_atomic_load(cand_any, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) return;
-    for (uint32_t b = blockIdx.x; b < nb; b += gridDim.x) {
-        const uint32_t n = meta[b].n;
-        if (n <= cfg.passthrough || !(force || (meta[b].cand_redo >> MODE) & 1u)) continue;  // wave-uniform
-        const uint8_t *in = slab + (uint64_t)b * cfg.block_size;
-        const uint32_t mis = (uint32_t)((uintptr_t)in & 3u);
-        const uint32_t *in32 = (const uint32_t *)(in - mis);
-        const uint32_t wmax = (mis + n - 1) >> 2;
-        uint16_t *cand = cand_all + (uint64_t)b * cfg.stride;
-        wave_sync();
-        for (uint32_t i = lane; i < kBuckets; i += 64) tab[i] = 0x8000u;
-        wave_sync();
-        for (uint32_t base = 0; base < n; base += 64) {
-            if (base != 0 && (base & 32767u) == 0) {
-                // sweep: entries farther than 32767 behind `base` become "dead for the next
-                // 32768 positions" (the analogue of libdeflate's window slide)
-                const uint32_t dead = (base + 0x8000u) & 0xFFFFu;
-                for (uint32_t i = lane; i < kBuckets; i += 64) {
-                    const uint32_t e = tab[i];
-                    const uint32_t a = (base - e) & 0xFFFFu;
-                    if (a == 0 || a > 32767u) tab[i] = dead;
-                }
-                wave_sync();
-            }
-            cand_step_safe<MODE>(tab, mis, base, lane, n, cand_fetch(in32, mis, base + lane, wmax), cand);
-        }
-    }
+    // (expected: never) the order check failed somewhere in the block: one wave redoes it, order-independently,
+    // in the same table -- in this launch, so that no second kernel has to look for flagged blocks
+    if (__syncthreads_or(bad) && wave == 0) cand_block_safe<MODE>(tab, in32, mis, wmax, n, lane, cand);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -2974,68 +2974,75 @@ __global__ __launch_bounds__(64, GZPX_HUFF_WAVES) void k_huffman(Config cfg, Blo
         wave_sync();
         uint32_t num_items;
         {
-            // deflate_compute_precode_items: RLE of the concatenated code lengths, wave-uniform: the
-            // lengths sit in registers, a run's end is the first lane of a ballot, items and precode
-            // frequencies are written by lane 0
+            // deflate_compute_precode_items: run-length coding of the concatenated code lengths, one
+            // POSITION per lane (five per lane: <= 316 lengths) instead of a walk over the ~150 runs.
+            // libdeflate's loops cut a run of zeros into pieces of 138 from its start (symbol 18 while
+            // >= 11 are left, symbol 17 for 3..10, literal zeros for 1..2) and a run of >= 4 equal
+            // non-zero lengths into one literal plus pieces of 6 (symbol 16 while >= 3 are left,
+            // literals for the rest) -- so whether an item starts at a position, and which, follows
+            // from the position's offset in its run and the run's length.  Run starts come from
+            // ballots; items land in position order by their rank among the item starts.
             const uint32_t num_lens = num_litlen + num_offset;
             uint32_t lr[5];
+            unsigned long long sm[5];  // run starts per chunk of 64 positions (uniform)
 #pragma unroll
             for (uint32_t k = 0; k < 5; k++) {
                 const uint32_t idx = lane + 64 * k;
-                lr[k] = idx < num_lens ? (uint32_t)h.lens[idx] : 0xFFu;  // (no length: ends every run)
+                // (no length behind the last one: position num_lens "starts a run", which ends the last real one)
+                lr[k] = idx < num_lens ? (uint32_t)h.lens[idx] : 0xFFu;
             }
-            uint32_t ni = 0, run_start = 0;
-            auto emit = [&](uint32_t item, uint32_t sym) {
-                if (lane == 0) {
-                    h.items[ni] = (uint16_t)item;
-                    atomicAdd(&h.pfreq[sym], 1u);
-                }
-                ni++;
-            };
-            do {
-                const uint32_t len = reg5_get(lr, run_start);
-                uint32_t run_end = num_lens, extra;
-                for (uint32_t j = run_start >> 6; j < 5; j++) {  // first length after run_start that differs
-                    uint32_t v = lr[0];
-                    v = j == 1 ? lr[1] : v;
-                    v = j == 2 ? lr[2] : v;
-                    v = j == 3 ? lr[3] : v;
-                    v = j == 4 ? lr[4] : v;
-                    unsigned long long ne = __ballot(v != len);
-                    if (j == (run_start >> 6)) ne &= ~0ull << (run_start & 63u);  // (bit run_start itself is 0)
-                    if (ne) {
-                        run_end = 64 * j + (uint32_t)__ffsll((long long)ne) - 1;
-                        break;
+#pragma unroll
+            for (uint32_t k = 0; k < 5; k++) {
+                uint32_t prev = (uint32_t)__shfl_up((int)lr[k], 1);
+                const uint32_t carry = k ? rdlane(lr[k ? k - 1 : 0], 63) : 0x100u;  // (position 0 starts a run)
+                if (lane == 0) prev = carry;
+                sm[k] = __ballot(lr[k] != prev);
+            }
+            uint32_t ni = 0;
+#pragma unroll
+            for (uint32_t k = 0; k < 5; k++) {
+                if (64 * k >= num_lens) break;  // (uniform)
+                uint32_t before = 0, after = num_lens;  // the nearest run start in the chunks before / behind this one
+#pragma unroll
+                for (uint32_t j = 0; j < 5; j++)
+                    if (j < k && sm[j]) before = 64 * j + 63u - (uint32_t)__clzll((long long)sm[j]);
+#pragma unroll
+                for (uint32_t j = 4; j >= 1; j--)
+                    if (j > k && sm[j]) after = 64 * j + (uint32_t)__ffsll((long long)sm[j]) - 1u;
+                const uint32_t idx = lane + 64 * k;
+                const unsigned long long upto = lane == 63 ? ~0ull : (2ull << lane) - 1ull;  // bits <= lane
+                const unsigned long long lo = sm[k] & upto, hi = sm[k] & ~upto;
+                const uint32_t rs = lo ? 64 * k + 63u - (uint32_t)__clzll((long long)lo) : before;
+                const uint32_t re = hi ? 64 * k + (uint32_t)__ffsll((long long)hi) - 1u : after;
+                const uint32_t L = re - rs, t = idx - rs, v = lr[k];
+                bool is = idx < num_lens;
+                uint32_t item = v;
+                if (v == 0) {
+                    const uint32_t tb = t >= 276u ? 276u : t >= 138u ? 138u : 0u;
+                    const uint32_t rb = L - tb;
+                    if (rb >= 11u) {
+                        is = is && t == tb;
+                        item = 18u | ((rb - 11u > 0x7Fu ? 0x7Fu : rb - 11u) << 5);
+                    } else if (rb >= 3u) {
+                        is = is && t == tb;
+                        item = 17u | ((rb - 3u) << 5);
+                    }
+                } else if (L >= 4u && t != 0u) {
+                    const uint32_t u = t - 1u;
+                    const uint32_t ub = 6u * ((u * 10923u) >> 16);  // (u / 6, u < 316)
+                    const uint32_t rb = L - 1u - ub;
+                    if (rb >= 3u) {
+                        is = is && u == ub;
+                        item = 16u | ((rb - 3u > 3u ? 3u : rb - 3u) << 5);
                     }
                 }
-                if (len == 0) {
-                    while (run_end - run_start >= 11) {
-                        extra = run_end - run_start - 11;
-                        if (extra > 0x7F) extra = 0x7F;
-                        emit(18 | (extra << 5), 18);
-                        run_start += 11 + extra;
-                    }
-                    if (run_end - run_start >= 3) {
-                        extra = run_end - run_start - 3;
-                        if (extra > 0x7) extra = 0x7;
-                        emit(17 | (extra << 5), 17);
-                        run_start += 3 + extra;
-                    }
-                } else if (run_end - run_start >= 4) {
-                    emit(len, len);
-                    run_start++;
-                    do {
-                        extra = run_end - run_start - 3;
-                        if (extra > 0x3) extra = 0x3;
-                        emit(16 | (extra << 5), 16);
-                        run_start += 3 + extra;
-                    } while (run_end - run_start >= 3);
+                const unsigned long long im = __ballot(is);
+                if (is) {
+                    h.items[ni + (uint32_t)__popcll(im & (upto >> 1))] = (uint16_t)item;
+                    atomicAdd(&h.pfreq[item & 31u], 1u);
                 }
-                while (run_start != run_end) {
-                    emit(len, len);
-                    run_start++;
-                }
-            } while (run_start != num_lens);
+                ni += (uint32_t)__popcll(im);
+            }
             num_items = ni;
         }
         wave_sync();
@@ -3442,39 +3449,58 @@ __global__ __launch_bounds__(kCrcSmall) void k_crc32(Config cfg, const uint8_t *
 // k_scan: exclusive scan of the framed block sizes -> byte offset of every block in the output
 // stream (the in-order property of the reference's writer loop, src/par/compress.rs:305-310).
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_scan(uint32_t nb, const BlockMeta *__restrict__ meta,
-                                              uint64_t *__restrict__ out_off, uint32_t *__restrict__ sizes,
-                                              const SlabResult *__restrict__ prev,
-                                              SlabResult *__restrict__ result) {
-    __shared__ uint64_t wsum[4];
-    __shared__ uint64_t carry_s;
+// (One workgroup: the kernel is a chain of memory round trips, not work.  Every thread owns a run of
+// consecutive blocks, so the loads of a pass are independent and in flight together: two passes of
+// ceil(nb / 1024) loads per thread around ONE workgroup scan -- the 550 MiB slab's 8,815 blocks in
+// 0.034 -> 0.0xx ms; it was 35 scans of 256 blocks, each waiting for its own loads.)
+constexpr uint32_t kScanThreads = 1024;
+__global__ __launch_bounds__(kScanThreads) void k_scan(uint32_t nb, const BlockMeta *__restrict__ meta,
+                                                       uint64_t *__restrict__ out_off, uint32_t *__restrict__ sizes,
+                                                       const SlabResult *__restrict__ prev,
+                                                       SlabResult *__restrict__ result) {
+    __shared__ uint64_t wsum[kScanThreads / 64];
     __shared__ uint32_t fail_s;
-    const uint32_t tid = threadIdx.x;
-    if (tid == 0) {
-        carry_s = prev ? prev->total : 0;  // a slab of several batches: offsets run on
-        fail_s = 0xFFFFFFFFu;
-    }
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    if (tid == 0) fail_s = 0xFFFFFFFFu;
     __syncthreads();
-    for (uint32_t base = 0; base < nb; base += 256) {
-        const uint32_t i = base + tid;
-        const uint32_t v = i < nb ? meta[i].framed_bytes : 0;
-        if (i < nb) {
-            sizes[i] = v;
-            if (meta[i].status != kStatusOk) atomicMin(&fail_s, i);
-        }
-        uint64_t total;
-        const uint64_t ex = block_exclusive_scan256((uint64_t)v, wsum, &total);
-        const uint64_t carry = carry_s;
-        if (i < nb) out_off[i] = carry + ex;
-        __syncthreads();
-        if (tid == 0) carry_s = carry + total;
-        __syncthreads();
+    const uint32_t per = (nb + kScanThreads - 1) / kScanThreads;
+    const uint32_t i0 = tid * per < nb ? tid * per : nb, i1 = i0 + per < nb ? i0 + per : nb;
+    uint64_t mine = 0;
+    uint32_t bad = 0xFFFFFFFFu;
+#pragma unroll 8
+    for (uint32_t i = i0; i < i1; i++) {
+        mine += meta[i].framed_bytes;
+        if (meta[i].status != kStatusOk && bad == 0xFFFFFFFFu) bad = i;
+    }
+    if (bad != 0xFFFFFFFFu) atomicMin(&fail_s, bad);
+    uint64_t inc = mine;
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint64_t t = __shfl_up(inc, d);
+        if (lane >= (unsigned)d) inc += t;
+    }
+    if (lane == 63) wsum[wave] = inc;
+    __syncthreads();
+    uint64_t run = prev ? prev->total : 0;  // a slab of several batches: offsets run on
+    uint64_t total = run;
+    for (uint32_t w = 0; w < kScanThreads / 64; w++) {
+        const uint64_t v = wsum[w];
+        if (w < wave) run += v;
+        total += v;
+    }
+    run += inc - mine;
+#pragma unroll 8
+    for (uint32_t i = i0; i < i1; i++) {
+        const uint32_t v = meta[i].framed_bytes;
+        sizes[i] = v;
+        out_off[i] = run;
+        run += v;
     }
     if (tid == 0) {
-        out_off[nb] = carry_s;
-        result->total = carry_s;
-        result->fail_block = fail_s;
-        result->fail_status = fail_s != 0xFFFFFFFFu ? meta[fail_s].status : kStatusOk;
+        const uint32_t f = fail_s;
+        out_off[nb] = total;
+        result->total = total;
+        result->fail_block = f;
+        result->fail_status = f != 0xFFFFFFFFu ? meta[f].status : kStatusOk;
     }
 }
 
@@ -4584,31 +4610,30 @@ __global__ __launch_bounds__(kCrcThreads, 8) void k_dcrc32(const uint8_t *__rest
 void launch_init_meta(const Config &cfg, uint64_t slab_len, uint32_t nb, int is_last,
                       const Scratch &s, hipStream_t stream) {
     hipLaunchKernelGGL(k_init_meta, dim3((nb + 255) / 256), dim3(256), 0, stream, cfg, slab_len, nb,
-                       (uint32_t)(is_last ? 1 : 0), s.meta, s.cand_any, s.redo);
+                       (uint32_t)(is_last ? 1 : 0), s.meta, s.redo);
 }
 
 template <int MODE>
-static void launch_candidates_mode(const Config &cfg, const uint8_t *slab, uint32_t nb, BlockMeta *meta,
-                                   uint16_t *out, uint32_t *cand_any, hipStream_t stream) {
-    const uint32_t force_safe = cfg.debug & 1u;  // diagnostics: exercise the fallback on every block
-    if (!force_safe)
-        hipLaunchKernelGGL(k_candidates<MODE>, dim3(nb), dim3(64 * kCandWaves), 0, stream, cfg, slab, meta, out,
-                           cand_any);
-    // blocks flagged by the order check (none expected) are redone order-independently
-    const uint32_t grid = force_safe ? nb : (nb < 256u ? nb : 256u);
-    hipLaunchKernelGGL(k_candidates_safe<MODE>, dim3(grid), dim3(64), 0, stream, cfg, slab, meta, nb,
-                       force_safe, out, (const uint32_t *)cand_any);
+static void launch_candidates_mode(const Config &cfg, const uint8_t *slab, uint64_t slab_len, uint32_t nb,
+                                   int is_last, const Scratch &s, uint16_t *out, hipStream_t stream) {
+    hipLaunchKernelGGL(k_candidates<MODE>, dim3(nb), dim3(64 * kCandWaves), 0, stream, cfg, slab, s.meta, out,
+                       slab_len, nb, (uint32_t)(is_last ? 1 : 0), s.redo);
 }
 
-void launch_candidates(const Config &cfg, const uint8_t *slab, uint64_t, uint32_t nb, const Scratch &s,
-                       hipStream_t stream) {
-    if (cfg.level == 0) return;  // stored blocks only: no matchfinding
+// Levels >= 1: the first launch also fills BlockMeta (k_init_meta's work); level 0 has no matchfinding and
+// goes through launch_init_meta alone.
+void launch_candidates(const Config &cfg, const uint8_t *slab, uint64_t slab_len, uint32_t nb, int is_last,
+                       const Scratch &s, hipStream_t stream) {
+    if (cfg.level == 0) {  // stored blocks only
+        launch_init_meta(cfg, slab_len, nb, is_last, s, stream);
+        return;
+    }
     if (cfg.level == 1) {
-        launch_candidates_mode<0>(cfg, slab, nb, s.meta, s.cand, s.cand_any, stream);
+        launch_candidates_mode<0>(cfg, slab, slab_len, nb, is_last, s, s.cand, stream);
     } else {  // hc_matchfinder: hash3 predecessor in cand, hash4 chain links in d4
-        launch_candidates_mode<1>(cfg, slab, nb, s.meta, s.cand, s.cand_any, stream);
-        launch_candidates_mode<2>(cfg, slab, nb, s.meta, s.d4, s.cand_any, stream);
-        launch_candidates_mode<3>(cfg, slab, nb, s.meta, s.d4, s.cand_any, stream);
+        launch_candidates_mode<1>(cfg, slab, slab_len, nb, is_last, s, s.cand, stream);
+        launch_candidates_mode<2>(cfg, slab, slab_len, nb, is_last, s, s.d4, stream);
+        launch_candidates_mode<3>(cfg, slab, slab_len, nb, is_last, s, s.d4, stream);
     }
 }
 
@@ -4715,7 +4740,7 @@ void launch_crc32(const Config &cfg, const uint8_t *slab, uint64_t, uint32_t nb,
 }
 
 void launch_scan(uint32_t nb, const Scratch &s, const SlabResult *prev, SlabResult *result, hipStream_t stream) {
-    hipLaunchKernelGGL(k_scan, dim3(1), dim3(256), 0, stream, nb, (const BlockMeta *)s.meta,
+    hipLaunchKernelGGL(k_scan, dim3(1), dim3(kScanThreads), 0, stream, nb, (const BlockMeta *)s.meta,
                        s.out_off, s.sizes, prev, result);
 }
 

@@ -313,8 +313,8 @@ const char *gzpx_ctx_stage_kernel(const gzpx_ctx *ctx, int stage);
 int gzpx_debug_tokens(gzpx_ctx *ctx, size_t block, uint32_t *tokens, size_t max_tokens,
                       size_t *n_tokens, uint32_t *sub_first_token, size_t *n_sub);
 
-/* Diagnostics switches (0 in production): bit 0 = run the order-independent candidate kernel
- * (k_candidates_safe) on every block instead of the atomic-chain kernel; bit 1 = level 1 through the
+/* Diagnostics switches (0 in production): bit 0 = k_candidates takes its order-independent
+ * fallback (cand_block_safe) on every block instead of the atomic-chain form; bit 1 = level 1 through the
  * dense k_match / k_parse pair instead of the match-on-demand kernel k_mparse; bit 2 = k_mparse
  * hands every block back to the dense pair (exercises the redo list). */
 int gzpx_debug_set_flags(gzpx_ctx *ctx, uint32_t flags);

@@ -150,7 +150,7 @@ def test_builder_validation(emu_lib):
 
 
 def test_order_independent_candidate_kernel(emu_lib, oracle):
-    """k_candidates_safe (the fallback for a failed LDS-order check) forced on every block."""
+    """k_candidates' order-independent fallback (for a failed LDS-order check) forced on every block."""
     with _native.Context(level=1, compat=_native.COMPAT_1_10, lib=emu_lib, max_slab_bytes=3 * 65280) as c:
         c.debug_set_flags(1)
         for cls in ("text", "zeros", "period2", "repeats", "random"):

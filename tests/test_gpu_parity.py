@@ -125,7 +125,7 @@ def test_device_resident_slab_and_properties(hip_lib, oracle):
 
 
 def test_order_independent_candidate_kernel(hip_lib, oracle):
-    """k_candidates_safe (the fallback for a failed LDS-order check) forced on every block, and
+    """k_candidates' order-independent fallback (for a failed LDS-order check) forced on every block, and
     the fast kernel never needing it on this hardware."""
     with _native.Context(level=1, compat=_native.COMPAT_1_10, lib=hip_lib, max_slab_bytes=3 * 65280) as c:
         c.debug_set_flags(1)

@@ -79,7 +79,7 @@ doc = {
 }
 doc["round"] = tag
 doc["pipeline_total_bytes"] = int(sum(v for k, v in doc["hbm_bytes_per_launch"].items()
-                                      if k in ("k_init_meta", "k_candidates", "k_candidates_safe", "k_mparse", "k_match", "k_parse",
+                                      if k in ("k_init_meta", "k_candidates", "k_mparse", "k_match", "k_parse",
                                                "k_hist", "k_huffman", "k_crc32", "k_scan", "k_emit")))
 doc["hbm_bytes_per_launch"]["pipeline"] = doc["pipeline_total_bytes"]  # every kernel of one level-1 step
 with open(os.path.join(P, "pmc_traffic.json"), "w") as f:
