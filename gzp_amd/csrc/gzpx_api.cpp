@@ -658,6 +658,7 @@ int ctx_create(const gzpx_config *cfg, bool crc_only, gzpx_ctx **out) {
     if (hipGetDeviceProperties(&prop, cfg->device) == hipSuccess) {
         snprintf(ctx->devname, sizeof(ctx->devname), "%s (%s, %d CUs)", prop.name, prop.gcnArchName,
                  prop.multiProcessorCount);
+        ctx->dcfg.n_cu = prop.multiProcessorCount > 0 ? (uint32_t)prop.multiProcessorCount : 0u;
     }
     const uint64_t want = blocks_of(ctx, cfg->max_slab_bytes ? cfg->max_slab_bytes : 1);
     ctx->batch_blocks = (uint32_t)(want < kMaxBatchBlocks ? want : kMaxBatchBlocks);

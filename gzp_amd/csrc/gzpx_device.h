@@ -92,6 +92,7 @@ struct Config {
     uint32_t hc_depth;    // levels 2-9: max_search_depth
     uint32_t hc_nice;     // levels 2-9: nice_match_length
     uint32_t lazy;        // 0: greedy parser (levels 2-4), 1: lazy (5-7), 2: lazy2 (8-9)
+    uint32_t n_cu;        // compute units of the device (persistent kernels launch one workgroup per CU)
 };
 
 // Device scratch for one batch of blocks.

@@ -368,6 +368,14 @@ __device__ void cand_block_safe(uint32_t *tab, const uint32_t *in32, uint32_t mi
     }
 }
 
+// One workgroup per CU walks the blocks blockIdx.x, + gridDim.x, ... WITHOUT ever clearing the table or
+// meeting at a barrier: a block's positions are filed as vbase + p + 1 with vbase growing by n + 32768 from
+// block to block, so whatever an earlier block left in a bucket is farther than the window behind every
+// position of this one and fails the liveness test like any other stale entry; and the turn counter runs on
+// through the blocks, so a wave that has done its last turn of a block goes straight on to its first turn
+// of the next (its input already prefetched) while slower waves still finish the old one.  (One workgroup
+// per block: every block paid for 128 KiB of LDS zeroing, the first loads' round trip, the wait for its
+// slowest wave and the dispatch of the next workgroup -- 0.64 -> 0.xx ms on the 550 MiB slab.)
 template <int MODE>
 __global__ __launch_bounds__(64 * kCandWaves) void k_candidates(Config cfg,
                                                                  const uint8_t *__restrict__ slab,
@@ -376,46 +384,69 @@ __global__ __launch_bounds__(64 * kCandWaves) void k_candidates(Config cfg,
                                                                  uint64_t slab_len, uint32_t nb, uint32_t is_last,
                                                                  uint32_t *__restrict__ redo) {
     __shared__ uint32_t tab[kBuckets + 64];  // 128 KiB + one spare word per lane for lanes without a bucket
-    __shared__ uint32_t turn;               // index of the iteration whose atomics may go next
+    __shared__ uint32_t turn;               // index of the iteration (counted through the blocks) whose atomics may go next
+    __shared__ uint32_t bad_any;            // some wave saw the order check fail
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    const uint32_t b = blockIdx.x;
-    uint32_t n;
+    constexpr uint32_t kIterPos = 64 * kCandSteps;
+    auto block_len = [&](uint32_t blk) -> uint32_t {  // k_init_meta's cut
+        const uint64_t begin = (uint64_t)blk * cfg.block_size;
+        const uint64_t len = slab_len > begin ? slab_len - begin : 0;
+        return (uint32_t)(len > cfg.block_size ? cfg.block_size : len);
+    };
     if (MODE <= 1) {  // the first launch of a batch (hash4 / hash3 pass): cut the slab, k_init_meta's rules
-        const BlockMeta m = block_meta_of(cfg, slab_len, nb, is_last, b);
-        n = m.n;
-        if (tid == 0) {
-            meta[b] = m;
-            if (b == 0) redo[0] = 0;  // level 1: nothing handed back to the dense kernels yet
-        }
-    } else {
-        n = meta[b].n;
+        for (uint32_t blk = blockIdx.x + tid * gridDim.x; blk < nb; blk += 64 * kCandWaves * gridDim.x)
+            meta[blk] = block_meta_of(cfg, slab_len, nb, is_last, blk);
+        if (blockIdx.x == 0 && tid == 0) redo[0] = 0;  // level 1: nothing handed back to the dense kernels yet
     }
-    if (n <= cfg.passthrough) return;  // stored-only path, no matchfinding (uniform)
-    const uint8_t *in = slab + (uint64_t)b * cfg.block_size;
-    const uint32_t mis = (uint32_t)((uintptr_t)in & 3u);
-    const uint32_t *in32 = (const uint32_t *)(in - mis);
-    const uint32_t wmax = (mis + n - 1) >> 2;  // last dword holding a byte of this block
-    uint16_t *cand = cand_all + (uint64_t)b * cfg.stride;
-
     for (uint32_t i = tid; i < kBuckets + 64; i += 64 * kCandWaves) tab[i] = 0;
-    if (tid == 0) turn = 0;
+    if (tid == 0) {
+        turn = 0;
+        bad_any = 0;
+    }
     __syncthreads();
 
     // The table is one LDS array, so the atomics of iteration i+1 must reach it after those of
     // iteration i -- but hashing / input prefetch before and distance / store work after are
-    // independent.  Wave w owns iterations w, w+16, ...; a ticket in LDS (`turn`) serialises only
-    // the atomic phase, so fifteen waves hash, prefetch and store while one is at the table.
-    constexpr uint32_t kIterPos = 64 * kCandSteps;
-    const uint32_t n_iters = (n + kIterPos - 1) / kIterPos;
-    uint2 ring[kCandSteps];
-#pragma unroll
-    for (uint32_t k = 0; k < kCandSteps; k++)
-        ring[k] = cand_fetch(in32, mis, wave * kIterPos + k * 64 + lane, wmax);
-
+    // independent.  Wave w owns iterations w, w+16, ... of every block; a ticket in LDS (`turn`)
+    // serialises only the atomic phase, so fifteen waves hash, prefetch and store while one is at the table.
+    //
+    // A wave's cursor: block b (its geometry), iteration `it` of that block, and the block's bases
+    // (vbase for positions, ibase for turns -- the same in every wave: they depend on the block lengths only).
+    struct Cursor {
+        uint32_t b, it, n, n_iters, vbase, ibase;
+    };
+    // the first block at or behind `c.b` (in this workgroup's sequence) in which this wave owns an iteration;
+    // false = none left.  Blocks of at most cfg.passthrough bytes have no matchfinding and take no turns.
+    auto settle = [&](Cursor &c) -> bool {
+        for (;;) {
+            if (c.b >= nb) return false;
+            c.n = block_len(c.b);
+            c.n_iters = c.n > cfg.passthrough ? (c.n + kIterPos - 1) / kIterPos : 0u;
+            if (c.it < c.n_iters) return true;
+            if (c.n_iters) {
+                c.vbase += c.n + 32768u;
+                c.ibase += c.n_iters;
+            }
+            c.b += gridDim.x;
+            c.it = wave;
+        }
+    };
     const bool force_safe = (cfg.debug & 1u) != 0;  // diagnostics: the fallback on every block, instead of the fast form
-    bool bad = force_safe;
-    for (uint32_t it = wave; it < n_iters && !force_safe; it += kCandWaves) {
-        const uint32_t base0 = it * kIterPos;
+    Cursor cur{blockIdx.x, wave, 0, 0, 32768u, 0};  // (vbase starts a window's length up: an empty bucket, 0, reads as dead too)
+    bool live = !force_safe && settle(cur);
+    bool bad = false;
+    uint2 ring[kCandSteps];
+    if (live) {
+        const uint8_t *in = slab + (uint64_t)cur.b * cfg.block_size;
+        const uint32_t mis = (uint32_t)((uintptr_t)in & 3u);
+#pragma unroll
+        for (uint32_t k = 0; k < kCandSteps; k++)
+            ring[k] = cand_fetch((const uint32_t *)(in - mis), mis, cur.it * kIterPos + k * 64 + lane, (mis + cur.n - 1) >> 2);
+    }
+    while (live) {  // (wave-uniform)
+        const uint32_t n = cur.n, base0 = cur.it * kIterPos, vbase = cur.vbase, my_turn = cur.ibase + cur.it;
+        const uint32_t mis = (uint32_t)((uintptr_t)(slab + (uint64_t)cur.b * cfg.block_size) & 3u);
+        uint16_t *cand = cand_all + (uint64_t)cur.b * cfg.stride;
         // The serial phase must be nothing but the atomics: a lone wave issues about one dependent
         // instruction per ten cycles, so every instruction inside the turn costs every wave.
         // LDS byte address and value of every step are therefore finished (and pinned in registers)
@@ -433,15 +464,23 @@ __global__ __launch_bounds__(64 * kCandWaves) void k_candidates(Config cfg,
             // atomic hit the same address, which the LDS serialises (hash4 passes 1.43 / 1.25 ms against
             // 1.00 ms for the hash3 pass)
             addr[k] = 4u * (mine[k] ? hk : kBuckets + lane);
-            val[k] = mine[k] ? p + 1 : 0u;
+            val[k] = mine[k] ? vbase + p + 1 : 0u;
             GZPX_PIN_VGPR(addr[k]);
             GZPX_PIN_VGPR(val[k]);
         }
+        // this wave's next iteration: of this block, or the first it owns in a later one
+        Cursor nxt = cur;
+        nxt.it += kCandWaves;
+        const bool more = settle(nxt);
+        if (more) {
+            const uint8_t *in = slab + (uint64_t)nxt.b * cfg.block_size;
+            const uint32_t nmis = (uint32_t)((uintptr_t)in & 3u);
 #pragma unroll
-        for (uint32_t k = 0; k < kCandSteps; k++)  // this wave's next iteration
-            ring[k] = cand_fetch(in32, mis, base0 + (kCandWaves * kCandSteps + k) * 64 + lane, wmax);
+            for (uint32_t k = 0; k < kCandSteps; k++)
+                ring[k] = cand_fetch((const uint32_t *)(in - nmis), nmis, nxt.it * kIterPos + k * 64 + lane, (nmis + nxt.n - 1) >> 2);
+        }
         wave_sync();
-        while (__hip_atomic_load(&turn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != it)
+        while (__hip_atomic_load(&turn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != my_turn)
             __builtin_amdgcn_s_sleep(1);
         // newest position per bucket; the return value is the predecessor
 #pragma unroll
@@ -453,21 +492,35 @@ __global__ __launch_bounds__(64 * kCandWaves) void k_candidates(Config cfg,
         for (uint32_t k = 0; k < kCandSteps; k++) seen |= old[k];
         bad |= seen > 0x7FFFFFFFu;  // (never) -- orders the ticket store after the atomics' return
         wave_sync();
-        if (lane == 0) __hip_atomic_store(&turn, it + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (lane == 0) __hip_atomic_store(&turn, my_turn + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 #pragma unroll
         for (uint32_t k = 0; k < kCandSteps; k++) {
             const uint32_t p = base0 + k * 64 + lane;
-            bad |= old[k] > p;  // handed a predecessor that is not earlier: LDS order assumption broken
-            uint32_t d0 = old[k] ? p + 1 - old[k] : 0;
+            bad |= old[k] > vbase + p;  // handed a predecessor that is not earlier: LDS order assumption broken
+            uint32_t d0 = vbase + p + 1 - old[k];  // (an empty bucket, or an earlier block's entry: > 32767)
             if (d0 > 32767u) d0 = 0;  // farther than the window: dead
             // p < cfg.stride (padded by >= one iteration).  The two hash4 passes own disjoint
             // positions; positions that are never hashed are zeroed by the first of them.
             if (MODE < 2 || mine[k] || (MODE == 2 && p + 5 > n)) cand[p] = (uint16_t)d0;
         }
+        cur = nxt;
+        live = more;
     }
-    // (expected: never) the order check failed somewhere in the block: one wave redoes it, order-independently,
-    // in the same table -- in this launch, so that no second kernel has to look for flagged blocks
-    if (__syncthreads_or(bad) && wave == 0) cand_block_safe<MODE>(tab, in32, mis, wmax, n, lane, cand);
+    // (expected: never) the order check failed somewhere: one wave redoes this workgroup's blocks,
+    // order-independently, in the same table -- in this launch, so that no second kernel has to look for them
+    if (__ballot(bad) && lane == 0) atomicOr(&bad_any, 1u);
+    __syncthreads();
+    if ((bad_any || force_safe) && wave == 0) {
+        for (uint32_t b = blockIdx.x; b < nb; b += gridDim.x) {
+            const uint32_t n = block_len(b);
+            if (n <= cfg.passthrough) continue;
+            const uint8_t *in = slab + (uint64_t)b * cfg.block_size;
+            const uint32_t mis = (uint32_t)((uintptr_t)in & 3u);
+            cand_block_safe<MODE>(tab, (const uint32_t *)(in - mis), mis, (mis + n - 1) >> 2, n, lane,
+                                  cand_all + (uint64_t)b * cfg.stride);
+            wave_sync();
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1177,7 +1230,7 @@ __device__ __forceinline__ uint32_t l1_search(const uint32_t *in_w, const uint16
 __global__ __launch_bounds__(kMpThreads, 4) void k_mparse(
     Config cfg, const uint8_t *__restrict__ slab, BlockMeta *__restrict__ meta_all,
     SubMeta *__restrict__ sub_all, const uint16_t *__restrict__ cand_all, uint32_t *__restrict__ tok_all,
-    uint32_t *__restrict__ redo) {
+    uint32_t *__restrict__ redo, uint64_t slab_len, uint32_t nb) {
     __shared__ uint32_t in_w[kInWords];        // the block's bytes (+ lead misalignment, + pad)
     __shared__ uint32_t d0_w[kMhHalf / 2];     // d0 (u16) of the positions of the current pass
     __shared__ uint32_t seg_exit[2 * kMpThreads];  // where the walk of segment s leaves it (two copies, see the rounds)
@@ -1187,15 +1240,74 @@ __global__ __launch_bounds__(kMpThreads, 4) void k_mparse(
     const uint16_t *d0_h = (const uint16_t *)d0_w;
 
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    const uint32_t b = blockIdx.x;
+    // One workgroup per CU (the LDS is its alone), walking the blocks blockIdx.x, + gridDim.x, ...: while it
+    // parses a block, the NEXT block's bytes and first-pass d0 are already on their way into registers, so
+    // the CU waits for HBM once per launch instead of once per block (17 k of a block's 142 k cycles were
+    // that wait when every block was a workgroup of its own).
+    auto block_len = [&](uint32_t blk) -> uint32_t {  // k_init_meta's cut
+        const uint64_t begin = (uint64_t)blk * cfg.block_size;
+        const uint64_t len = slab_len > begin ? slab_len - begin : 0;
+        return (uint32_t)(len > cfg.block_size ? cfg.block_size : len);
+    };
+    // d0 of a pass: 64 bytes per thread (the per-block stride is padded: whole uint4s are readable)
+    uint4 d0v0, d0v1, d0v2, d0v3;
+#define GZPX_D0_REQUEST(cand_, hb_, n_)                                              \
+    do {                                                                            \
+        const uint32_t he_ = (hb_) + kMhHalf < (n_) ? (hb_) + kMhHalf : (n_);       \
+        const uint4 *src_ = (const uint4 *)((cand_) + (hb_));                       \
+        const uint32_t nq_ = (he_ - (hb_) + 7) / 8;                                 \
+        d0v0 = src_[tid < nq_ ? tid : nq_ - 1];                                     \
+        d0v1 = src_[tid + kMpThreads < nq_ ? tid + kMpThreads : nq_ - 1];           \
+        d0v2 = src_[tid + 2 * kMpThreads < nq_ ? tid + 2 * kMpThreads : nq_ - 1];   \
+        d0v3 = src_[tid + 3 * kMpThreads < nq_ ? tid + 3 * kMpThreads : nq_ - 1];   \
+    } while (0)
+    // a block's bytes (n <= kTile): four 16-byte loads per thread + one dword of tail for three threads
+    uint4 bv0, bv1, bv2, bv3;
+    uint32_t bvt = 0;
+    auto load16 = [](const dword4 *p4) -> uint4 {  // (a 16-byte load of a 4-byte-aligned address)
+        const dword4 t = *p4;
+        return make_uint4(t.x, t.y, t.z, t.w);
+    };
+#define GZPX_BLOCK_REQUEST(blk_, n_)                                                 \
+    do {                                                                            \
+        const uint8_t *in_ = slab + (uint64_t)(blk_) * cfg.block_size;              \
+        const uint32_t mis_ = (uint32_t)((uintptr_t)in_ & 3u);                      \
+        const uint32_t *src_ = (const uint32_t *)(in_ - mis_);                      \
+        const uint32_t ndw_ = (mis_ + (n_) + 3) >> 2, nq_ = ndw_ >> 2;              \
+        const dword4 *src4_ = (const dword4 *)src_;                                 \
+        const uint32_t last_ = nq_ - 1; /* (n > passthrough >= 15: nq_ >= 1) */      \
+        bv0 = load16(src4_ + (tid < nq_ ? tid : last_));                            \
+        bv1 = load16(src4_ + (tid + kMpThreads < nq_ ? tid + kMpThreads : last_));  \
+        bv2 = load16(src4_ + (tid + 2 * kMpThreads < nq_ ? tid + 2 * kMpThreads : last_)); \
+        bv3 = load16(src4_ + (tid + 3 * kMpThreads < nq_ ? tid + 3 * kMpThreads : last_)); \
+        bvt = src_[4 * nq_ + tid < ndw_ ? 4 * nq_ + tid : ndw_ - 1];                \
+    } while (0)
+    static_assert(((3 + kTile + 3) >> 4) <= 4 * kMpThreads, "a block is four uint4 per thread (+ tail dwords)");
+
+    uint32_t b = blockIdx.x;
+    if (b >= nb) return;
+    bool staged;  // (uniform) block b's bytes and first-pass d0 have been requested
+    {
+        const uint32_t n0 = block_len(b);
+        staged = n0 > cfg.passthrough;
+        if (staged) {
+            GZPX_D0_REQUEST(cand_all + (uint64_t)b * cfg.stride, 0u, n0);
+            GZPX_BLOCK_REQUEST(b, n0);
+        }
+    }
+  for (;;) {
+    const uint32_t next_b = b + gridDim.x;
+    const uint32_t next_n = next_b < nb ? block_len(next_b) : 0u;
+    const bool next_staged = next_n > cfg.passthrough;  // (uniform; implies next_b < nb)
+    bool next_d0_requested = false;
     BlockMeta *meta = meta_all + b;
     SubMeta *sub = sub_all + (uint64_t)b * cfg.max_sub;
-    const uint32_t n = meta->n;
-    if (n <= cfg.passthrough) return;  // uniform for the workgroup
+    const uint32_t n = block_len(b);
     const uint8_t *in = slab + (uint64_t)b * cfg.block_size;
     const uint16_t *cand = cand_all + (uint64_t)b * cfg.stride;
     uint32_t *tok = tok_all + (uint64_t)b * cfg.stride;
     const uint32_t mis = (uint32_t)((uintptr_t)in & 3u);
+  if (staged) {  // (else: n <= cfg.passthrough, a stored-only block: nothing to parse)
 #ifdef GZPX_EXPERIMENT
     // measurement builds: cycles per phase, summed over the blocks of a launch (thread 0's clock)
     unsigned long long exp_t = __builtin_readcyclecounter();
@@ -1207,52 +1319,20 @@ __global__ __launch_bounds__(kMpThreads, 4) void k_mparse(
 #else
     auto exp_lap = [](uint32_t) {};
 #endif
-
-    // d0 of a pass: 64 bytes per thread (the per-block stride is padded: whole uint4s are readable),
-    // requested a pass ahead -- the first pass's together with the block's bytes, the second's while the
-    // first is walked -- so that the workgroup, alone on its CU, waits for HBM once per block
-    uint4 d0v0, d0v1, d0v2, d0v3;
-#define GZPX_D0_REQUEST(hb_)                                                        \
-    do {                                                                            \
-        const uint32_t he_ = (hb_) + kMhHalf < n ? (hb_) + kMhHalf : n;             \
-        const uint4 *src_ = (const uint4 *)(cand + (hb_));                          \
-        const uint32_t nq_ = (he_ - (hb_) + 7) / 8;                                 \
-        d0v0 = src_[tid < nq_ ? tid : nq_ - 1];                                     \
-        d0v1 = src_[tid + kMpThreads < nq_ ? tid + kMpThreads : nq_ - 1];           \
-        d0v2 = src_[tid + 2 * kMpThreads < nq_ ? tid + 2 * kMpThreads : nq_ - 1];   \
-        d0v3 = src_[tid + 3 * kMpThreads < nq_ ? tid + 3 * kMpThreads : nq_ - 1];   \
-    } while (0)
-    GZPX_D0_REQUEST(0u);
-    {   // stage the block (n <= kTile): 16 bytes per load, four loads per thread in flight
-        const uint32_t *src = (const uint32_t *)(in - mis);
+    __syncthreads();  // the previous block is done with in_w
+    {   // the block's bytes: registers -> LDS
         const uint32_t ndw = (mis + n + 3) >> 2;
-        const dword4 *src4 = (const dword4 *)src;
-        dword4 *dst4 = (dword4 *)in_w;
+        uint4 *dst4 = (uint4 *)in_w;
         const uint32_t nq = ndw >> 2;
-        for (uint32_t q0 = 0; q0 < nq; q0 += 4 * kMpThreads) {
-            dword4 v[4];
-#pragma unroll
-            for (uint32_t k = 0; k < 4; k++) {
-                const uint32_t q = q0 + tid + k * kMpThreads;
-                v[k] = src4[q < nq ? q : nq - 1];
-            }
-#pragma unroll
-            for (uint32_t k = 0; k < 4; k++) {
-                GZPX_PIN_VGPR(v[k].x);
-                GZPX_PIN_VGPR(v[k].y);
-                GZPX_PIN_VGPR(v[k].z);
-                GZPX_PIN_VGPR(v[k].w);
-            }
-#pragma unroll
-            for (uint32_t k = 0; k < 4; k++) {
-                const uint32_t q = q0 + tid + k * kMpThreads;
-                if (q < nq) dst4[q] = v[k];
-            }
-        }
-        for (uint32_t i = 4 * nq + tid; i < ndw; i += kMpThreads) in_w[i] = src[i];
+        if (tid < nq) dst4[tid] = bv0;
+        if (tid + kMpThreads < nq) dst4[tid + kMpThreads] = bv1;
+        if (tid + 2 * kMpThreads < nq) dst4[tid + 2 * kMpThreads] = bv2;
+        if (tid + 3 * kMpThreads < nq) dst4[tid + 3 * kMpThreads] = bv3;
+        if (4 * nq + tid < ndw) in_w[4 * nq + tid] = bvt;
         for (uint32_t i = ndw + tid; i < ndw + 3 && i < kInWords; i += kMpThreads) in_w[i] = 0;
         if (tid == 0) bnd = ~0ull;
     }
+    if (next_staged) GZPX_BLOCK_REQUEST(next_b, next_n);  // (uniform) travels while this block is parsed
 
     // state carried from pass to pass (uniform across the workgroup)
     uint32_t entry_carry = 0;  // where the parse enters the next pass
@@ -1260,16 +1340,23 @@ __global__ __launch_bounds__(kMpThreads, 4) void k_mparse(
     uint32_t cur_sub = 0, sub_start = 0, sub_start_tok = 0, sub_start_mat = 0;
     const uint8_t *in_b = (const uint8_t *)in_w + mis;
 
+    bool handed_back = false;
     for (uint32_t hb = 0; hb < n; hb += kMhHalf) {
         const uint32_t he = hb + kMhHalf < n ? hb + kMhHalf : n;  // this pass: positions [hb, he)
-        __syncthreads();  // the previous pass is done with d0_w / seg_exit
+        if (hb) __syncthreads();  // the previous pass is done with d0_w / seg_exit
         {
             uint4 *dst = (uint4 *)d0_w;
             dst[tid] = d0v0;
             dst[tid + kMpThreads] = d0v1;
             dst[tid + 2 * kMpThreads] = d0v2;
             dst[tid + 3 * kMpThreads] = d0v3;
-            if (he < n) GZPX_D0_REQUEST(he);  // (uniform) the next pass's d0 travels while this pass is walked
+            // (uniform) the next pass's d0 -- this block's, or the next block's first -- travels while this pass is walked
+            if (he < n) {
+                GZPX_D0_REQUEST(cand, he, n);
+            } else if (next_staged) {
+                GZPX_D0_REQUEST(cand_all + (uint64_t)next_b * cfg.stride, 0u, next_n);
+                next_d0_requested = true;
+            }
         }
         __syncthreads();
         exp_lap(0);
@@ -1355,7 +1442,8 @@ __global__ __launch_bounds__(kMpThreads, 4) void k_mparse(
         }
         if (!settled || (cfg.debug & 4u)) {  // uniform: the dense kernels take this block (debug bit 2: every block)
             if (tid == 0) redo[1u + atomicAdd(&redo[0], 1u)] = b;
-            return;
+            handed_back = true;
+            break;
         }
         const uint32_t n_seg = (he - hb + kMhSeg - 1) / kMhSeg;
         const uint32_t exit_pos = uniform(seg_exit[cur * kMpThreads + n_seg - 1]);  // where the parse leaves this pass
@@ -1460,8 +1548,7 @@ __global__ __launch_bounds__(kMpThreads, 4) void k_mparse(
         entry_carry = exit_pos;
         exp_lap(4);
     }
-#undef GZPX_D0_REQUEST
-    if (tid == 0) {
+    if (tid == 0 && !handed_back) {
         sub[cur_sub].tok_begin = sub_start_tok;
         sub[cur_sub].tok_end = tok_carry;
         sub[cur_sub].byte_begin = sub_start;
@@ -1470,6 +1557,15 @@ __global__ __launch_bounds__(kMpThreads, 4) void k_mparse(
         meta->ntok = tok_carry;
         meta->nsub = cur_sub + 1;
     }
+  }  // staged
+    if (next_b >= nb) break;
+    // (a block handed back in its first pass, or one of a single pass: the next block's d0 is not on its way yet)
+    if (next_staged && !next_d0_requested) GZPX_D0_REQUEST(cand_all + (uint64_t)next_b * cfg.stride, 0u, next_n);
+    b = next_b;
+    staged = next_staged;
+  }
+#undef GZPX_D0_REQUEST
+#undef GZPX_BLOCK_REQUEST
 }
 
 // ------------------------------------------------------------------------------------------
@@ -4616,8 +4712,12 @@ void launch_init_meta(const Config &cfg, uint64_t slab_len, uint32_t nb, int is_
 template <int MODE>
 static void launch_candidates_mode(const Config &cfg, const uint8_t *slab, uint64_t slab_len, uint32_t nb,
                                    int is_last, const Scratch &s, uint16_t *out, hipStream_t stream) {
-    hipLaunchKernelGGL(k_candidates<MODE>, dim3(nb), dim3(64 * kCandWaves), 0, stream, cfg, slab, s.meta, out,
-                       slab_len, nb, (uint32_t)(is_last ? 1 : 0), s.redo);
+    // one workgroup per CU (more only if a workgroup's positions, counted on through its blocks, could pass 2^30)
+    uint64_t wgs = cfg.n_cu ? cfg.n_cu : 256u;
+    const uint64_t span = slab_len + (uint64_t)nb * 32768u;
+    if (span / wgs >= (1ull << 30)) wgs = span / (1ull << 30) + 1;
+    hipLaunchKernelGGL(k_candidates<MODE>, dim3((uint32_t)(nb < wgs ? nb : wgs)), dim3(64 * kCandWaves), 0, stream, cfg,
+                       slab, s.meta, out, slab_len, nb, (uint32_t)(is_last ? 1 : 0), s.redo);
 }
 
 // Levels >= 1: the first launch also fills BlockMeta (k_init_meta's work); level 0 has no matchfinding and
@@ -4670,12 +4770,13 @@ extern "C" int gzpx_exp_cycles(unsigned long long out[8], int reset) {
 }
 #endif
 
-void launch_match(const Config &cfg, const uint8_t *slab, uint64_t, uint32_t nb, const Scratch &s,
+void launch_match(const Config &cfg, const uint8_t *slab, uint64_t slab_len, uint32_t nb, const Scratch &s,
                   hipStream_t stream) {
     const bool fused = level1_fused(cfg);
     if (fused) {  // (k_init_meta has emptied the redo list)
-        hipLaunchKernelGGL(k_mparse, dim3(nb), dim3(kMpThreads), 0, stream, cfg, slab, s.meta, s.sub,
-                           (const uint16_t *)s.cand, s.tok, s.redo);
+        const uint32_t wgs = cfg.n_cu ? cfg.n_cu : 256u;  // one per CU, each walking its share of the blocks
+        hipLaunchKernelGGL(k_mparse, dim3(nb < wgs ? nb : wgs), dim3(kMpThreads), 0, stream, cfg, slab, s.meta, s.sub,
+                           (const uint16_t *)s.cand, s.tok, s.redo, slab_len, nb);
     }
     const uint32_t grid = fused ? (nb < 512u ? nb : 512u) : nb;
     hipLaunchKernelGGL(k_match, dim3(grid), dim3(kMpThreads), 0, stream, cfg, slab, s.meta,

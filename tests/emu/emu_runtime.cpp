@@ -359,7 +359,7 @@ hipError_t hipGetDeviceProperties(hipDeviceProp_t *p, int) {
     memset(p, 0, sizeof(*p));
     snprintf(p->name, sizeof(p->name), "gzpx CPU SIMT emulator");
     snprintf(p->gcnArchName, sizeof(p->gcnArchName), "emu");
-    p->multiProcessorCount = 1;
+    p->multiProcessorCount = 3;  // (persistent kernels: three workgroups share the blocks)
     return hipSuccess;
 }
 const char *hipGetErrorString(hipError_t e) { return e == hipSuccess ? "hipSuccess" : "hipError(emu)"; }
