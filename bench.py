@@ -755,7 +755,9 @@ def main():
         copy_stream = torch.cuda.Stream()
     nb = ctx.n_blocks(n)
     block_sizes = np.zeros(nb, dtype=np.uint32)
-    ctx.set_profiling(True)
+    # the timed region carries HIP events around the dominant kernel only (two markers per step; its duration is
+    # the roofline figure); the other stages are timed in a few steps of their own behind it
+    ctx.set_profiling(2)
     if args.debug_flags:
         ctx.debug_set_flags(args.debug_flags)
     state = {"i": 0, "pending": None, "offsets": None, "writeout": modes[0], "wait_s": 0.0}
@@ -821,6 +823,18 @@ def main():
         regions[wmode] = timed_region(wmode)
     head = regions[modes[0]]
     dt, out_len, stage_acc = head["dt"], head["out_len"], head["stage_acc"]
+    # every stage, outside the timed region (thirteen event markers per step cost the step 0.03 ms)
+    ctx.set_profiling(1)
+    state["writeout"] = modes[0]
+    other_steps = min(3, args.steps)
+    stage_other = {}
+    for _ in range(other_steps):
+        step()
+        for k, v in ctx.last_stage_ms().items():
+            stage_other[k] = stage_other.get(k, 0.0) + v / other_steps
+    wait_pending()
+    env.sync()
+    ctx.set_profiling(2)
 
     ms_per_step = dt / args.steps * 1e3
     total_mib = total / 2**20
@@ -834,8 +848,12 @@ def main():
         full_ok, stream_sha = (None, hashlib.sha256(out_host).hexdigest())
         if world == 1 and not env.emulate:
             full_ok, stream_sha = check_full_stream("config2_text_550MiB_bgzf_l1", n, 20250927, out_host, block_sizes)
-        stage_ms = {k: v / args.steps for k, v in stage_acc.items()}
+        live = {k: v / args.steps for k, v in stage_acc.items() if v > 0}  # the timed region's own events: the dominant kernel
+        stage_ms = dict(stage_other)
+        stage_ms.update(live)
         dom = max(stage_ms, key=stage_ms.get)
+        if dom not in live:  # (not expected: the match stage dominates at every level)
+            live = {dom: stage_other[dom]}
         alg_bytes = n + out_len  # 1 B read + r B written per input byte
         achieved = alg_bytes / (max(stage_ms[dom], 1e-9) * 1e-3) / 1e9
         traffic = pmc_traffic(dom)
@@ -894,6 +912,8 @@ def main():
                 "pipeline_frac": round(alg_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
                 "hbm_read_frac": round(n / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),  # input bytes only (north_star's wording)
                 "stage_ms": {k: round(v, 3) for k, v in stage_ms.items()},
+                "stage_ms_source": "%s: HIP events inside the timed region (%d steps); the other stages: %d steps behind it"
+                                   % (dom, args.steps, other_steps),
             },
         }
         if world > 1:

@@ -109,7 +109,7 @@ struct gzpx_ctx {
     uint64_t next_gen = 1;
     BlockMeta *h_meta = nullptr;  // pinned; CRC-only contexts and the debug hooks
     SubMeta *h_sub = nullptr;     // pinned, max_sub entries (debug hooks)
-    bool profiling = false;
+    int profiling = 0;  // 0 off, 1 every stage, 2 the dominant stage only (two markers per batch instead of thirteen)
     bool crc_only = false;
     float stage_ms[GZPX_N_STAGES] = {0};
     uint32_t last_nb = 0;
@@ -237,6 +237,7 @@ struct ProfPairs {
     hipStream_t last_st = nullptr;  // ... on this stream, with nothing enqueued behind it yet
     int begin(int stage, hipStream_t st) {
         if (!on || ctx->prof_n >= kProfPairs || used + 2 > 2 * kProfPairs) return -1;
+        if (ctx->profiling == 2 && stage != 2) return -1;
         const int i = ctx->prof_n++;
         ctx->prof_stage[i] = stage;
         if (last_ev >= 0 && last_st == st) {
@@ -269,12 +270,33 @@ int enqueue_batch(gzpx_ctx *ctx, const uint8_t *d_in, size_t in_len, uint32_t nb
                   SlabResult *result) {
     const Config &c = ctx->dcfg;
     const Scratch &s = ctx->scratch;
-    ProfPairs pp{ctx, ctx->profiling};
+    ProfPairs pp{ctx, ctx->profiling != 0};
     ctx->prof_n = 0;
+    // fork: the CRC of every block on the low-priority side stream, beside the match kernels.  Where it
+    // runs is a question of whom it takes issue slots from (per 550 MiB step, round 3): beside k_mparse
+    // that kernel goes from 2.01 to 2.07 ms and k_hist + k_huffman, alone now, from 0.41 to 0.33 -- 3.50
+    // against 3.53 ms; forked behind k_mparse (in front of the dense pair) 3.56.  (Round 2, beside the
+    // one-workgroup-per-block k_candidates: that kernel slowed down by the CRC's time.)
+    auto fork_crc = [&]() -> int {
+        HIP_TRY(hipEventRecord(ctx->ev_meta, stream));
+        HIP_TRY(hipStreamWaitEvent(ctx->s_side, ctx->ev_meta, 0));
+        pp.touch(stream);
+        const int tc = pp.begin(6, ctx->s_side);
+        launch_crc32(c, d_in, in_len, nb, s, ctx->crc_consts, ctx->s_side);
+        pp.end(tc, ctx->s_side);
+        HIP_TRY(hipEventRecord(ctx->ev_crc, ctx->s_side));
+        return GZPX_OK;
+    };
+    // (Config.debug bits 8-9, experiments: 1 = fork behind all match / parse kernels, 2 = behind the first of them)
+    const uint32_t fork_sel = (c.debug >> 8) & 3u, fork_at = fork_sel == 0 ? 1u : fork_sel == 1 ? 0u : 2u;
     // (the slab is cut into blocks -- BlockMeta -- by the first k_candidates launch; level 0: k_init_meta)
     int t = pp.begin(c.level == 0 ? 0 : 1, stream);
     launch_candidates(c, d_in, in_len, nb, is_last, s, stream);
     pp.end(t, stream);
+    if (fork_at == 1) {
+        const int rc = fork_crc();
+        if (rc != GZPX_OK) return rc;
+    }
     if (c.level <= 1) {  // (at level 0 every block is a passthrough block: the kernels return at once)
         // (Tried in round 3: the batch cut into 2..8 block ranges, k_hist / k_huffman of range k on a
         // side stream beside the matching of range k + 1.  4.27 -> 4.83 / 5.90 / 7.44 ms per step: the
@@ -283,6 +305,10 @@ int enqueue_batch(gzpx_ctx *ctx, const uint8_t *d_in, size_t in_len, uint32_t nb
         t = pp.begin(2, stream);
         launch_match(c, d_in, in_len, nb, s, stream);  // k_mparse, and k_match over the blocks it handed back
         pp.end(t, stream);
+        if (fork_at == 2) {
+            const int rc = fork_crc();
+            if (rc != GZPX_OK) return rc;
+        }
         t = pp.begin(3, stream);
         launch_parse(c, d_in, in_len, nb, s, stream);
         pp.end(t, stream);
@@ -298,29 +324,22 @@ int enqueue_batch(gzpx_ctx *ctx, const uint8_t *d_in, size_t in_len, uint32_t nb
         }
         pp.end(t, stream);
     }
-    {
-        // fork: the CRC of every block on the low-priority side stream, beside k_hist and k_huffman --
-        // k_huffman is a chain of dependent LDS reads on one lane per block and leaves the CUs' issue
-        // slots and HBM idle.  (Measured alternatives, round 2: beside k_candidates that kernel slows
-        // down by the CRC's time -- both live on LDS operations; in front of k_parse 5.34 ms, here 5.32.)
-        HIP_TRY(hipEventRecord(ctx->ev_meta, stream));
-        HIP_TRY(hipStreamWaitEvent(ctx->s_side, ctx->ev_meta, 0));
-        const int tc = pp.begin(6, ctx->s_side);
-        launch_crc32(c, d_in, in_len, nb, s, ctx->crc_consts, ctx->s_side);
-        pp.end(tc, ctx->s_side);
-        HIP_TRY(hipEventRecord(ctx->ev_crc, ctx->s_side));
-        t = pp.begin(4, stream);
-        launch_hist(c, nb, s, stream);
-        pp.end(t, stream);
-        t = pp.begin(5, stream);
-        launch_huffman(c, nb, s, stream);
-        pp.end(t, stream);
+    if (fork_at == 0 || (fork_at == 2 && c.level > 1)) {
+        const int rc = fork_crc();
+        if (rc != GZPX_OK) return rc;
     }
-    HIP_TRY(hipStreamWaitEvent(stream, ctx->ev_crc, 0));  // join: k_emit writes the CRCs into the footers
-    pp.touch(stream);  // (the wait for the side stream is nobody's stage time)
+    t = pp.begin(4, stream);
+    launch_hist(c, nb, s, stream);
+    pp.end(t, stream);
+    t = pp.begin(5, stream);
+    launch_huffman(c, nb, s, stream);
+    pp.end(t, stream);
     t = pp.begin(7, stream);
     launch_scan(nb, s, prev, result, stream);
     pp.end(t, stream);
+    // join behind k_scan (which does not read the CRCs): k_emit writes them into the footers
+    HIP_TRY(hipStreamWaitEvent(stream, ctx->ev_crc, 0));
+    pp.touch(stream);  // (the wait for the side stream is nobody's stage time)
     t = pp.begin(8, stream);
     launch_emit(c, d_in, in_len, nb, s, d_out, out_cap, stream);
     pp.end(t, stream);
@@ -1637,7 +1656,7 @@ void gzpx_free_decompressor(gzpx_decompressor *d) {
 // ---------------------------------------------------------------- measurement / debug hooks
 int gzpx_ctx_set_profiling(gzpx_ctx *ctx, int on) {
     if (!ctx) return GZPX_ERR_INVALID_ARG;
-    ctx->profiling = on != 0;
+    ctx->profiling = on == 2 ? 2 : on != 0 ? 1 : 0;
     return GZPX_OK;
 }
 

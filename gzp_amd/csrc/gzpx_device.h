@@ -85,7 +85,8 @@ struct Config {
     uint32_t xfl;         // gzip XFL byte derived from level (src/bgzf.rs:278-284)
     uint32_t debug;       // diagnostics only: bit 0 = k_candidates' order-independent fallback on every block, bit 1 =
                           // level 1 through the dense k_match / k_parse pair instead of k_mparse, bit 2 =
-                          // k_mparse hands every block back (exercises the redo list)
+                          // k_mparse hands every block back (exercises the redo list); bits 8-9 (host side,
+                          // experiments): where the CRC kernel is forked onto the side stream
     uint32_t stride;      // per-block stride (positions) of cand / len8 / alt / tok: >= block_size + 1024
     uint32_t max_sub;     // per-block capacity of sub / hist / codes / hdr (sub-blocks >= 32768 bytes)
     uint32_t passthrough; // n <= 55 - 4*level is emitted as stored blocks only (deflate_compress_none)

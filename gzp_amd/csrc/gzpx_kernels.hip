@@ -1234,7 +1234,7 @@ __global__ __launch_bounds__(kMpThreads, 4) void k_mparse(
     __shared__ uint32_t in_w[kInWords];        // the block's bytes (+ lead misalignment, + pad)
     __shared__ uint32_t d0_w[kMhHalf / 2];     // d0 (u16) of the positions of the current pass
     __shared__ uint32_t seg_exit[2 * kMpThreads];  // where the walk of segment s leaves it (two copies, see the rounds)
-    __shared__ uint32_t wsum_t[kMpWaves], wsum_m[kMpWaves];
+    __shared__ uint32_t wsum_t[kMpWaves];
     __shared__ unsigned long long bnd;  // (position << 32 | token index) of the sub-block boundary
     __shared__ uint32_t bnd_mat;        // matches before that boundary
     const uint16_t *d0_h = (const uint16_t *)d0_w;
@@ -3646,20 +3646,16 @@ __device__ __forceinline__ void stage_flush(const uint32_t *stage, uint8_t *dst_
     }
 }
 
-__global__ __launch_bounds__(kEmitThreads, 8) void k_emit(Config cfg, const uint8_t *__restrict__ slab,
-                                              const BlockMeta *__restrict__ meta_all,
-                                              const SubMeta *__restrict__ sub_all,
-                                              const uint32_t *__restrict__ tok_all,
-                                              const uint32_t *__restrict__ codes_all,
-                                              const uint32_t *__restrict__ hdr_all,
-                                              const uint64_t *__restrict__ out_off,
-                                              uint8_t *__restrict__ out, uint64_t out_cap) {
-    __shared__ uint32_t stage[kStageWords];
-    __shared__ uint32_t codes[kCodeWords];
-    __shared__ uint32_t wsum[kEmitThreads / 64];
-    __shared__ uint8_t lslot[256];  // length - 3 -> DEFLATE length slot | extra-bit count << 5 (one LDS read instead of ~10 VALU)
+__device__ __forceinline__ void emit_block(const Config &cfg, const uint8_t *__restrict__ slab,
+                                           const BlockMeta *__restrict__ meta_all,
+                                           const SubMeta *__restrict__ sub_all,
+                                           const uint32_t *__restrict__ tok_all,
+                                           const uint32_t *__restrict__ codes_all,
+                                           const uint32_t *__restrict__ hdr_all,
+                                           const uint64_t *__restrict__ out_off,
+                                           uint8_t *__restrict__ out, uint64_t out_cap, const uint32_t b,
+                                           uint32_t *stage, uint32_t *codes, uint32_t *wsum, const uint8_t *lslot) {
     const uint32_t tid = threadIdx.x;
-    const uint32_t b = blockIdx.x;
     const BlockMeta *meta = meta_all + b;
     const SubMeta *sub = sub_all + (uint64_t)b * cfg.max_sub;
     const uint32_t n = meta->n;
@@ -3677,11 +3673,6 @@ __global__ __launch_bounds__(kEmitThreads, 8) void k_emit(Config cfg, const uint
     uint32_t win_base = 0;  // aligned coordinate of stage[0] (multiple of 4)
 
     for (uint32_t i = tid; i < kStageWords; i += kEmitThreads) stage[i] = 0;
-    if (tid < 256) {
-        uint32_t ls, le, lv;
-        length_slot(tid + 3, ls, le, lv);
-        lslot[tid] = (uint8_t)(ls | (le << 5));
-    }
     __syncthreads();
 
     // ---- gzip member header (src/bgzf.rs:274-303 / src/mgzip.rs:246-275)
@@ -3874,6 +3865,33 @@ __global__ __launch_bounds__(kEmitThreads, 8) void k_emit(Config cfg, const uint
     }
     __syncthreads();
     stage_flush(stage, dst_aligned, win_base, end_byte, lead, end_byte, tid);
+}
+
+// (One workgroup per block.  Measured in round 3: two or four persistent workgroups per CU walking the blocks
+// blockIdx.x, + gridDim.x, ... 0.383 -> 0.423 / 0.411 ms -- blocks differ in cost and the dispatcher balances
+// them better than a fixed stride; the loop below is what is left of that and runs once.)
+__global__ __launch_bounds__(kEmitThreads, 8) void k_emit(Config cfg, const uint8_t *__restrict__ slab,
+                                              const BlockMeta *__restrict__ meta_all,
+                                              const SubMeta *__restrict__ sub_all,
+                                              const uint32_t *__restrict__ tok_all,
+                                              const uint32_t *__restrict__ codes_all,
+                                              const uint32_t *__restrict__ hdr_all,
+                                              const uint64_t *__restrict__ out_off,
+                                              uint8_t *__restrict__ out, uint64_t out_cap, uint32_t nb) {
+    __shared__ uint32_t stage[kStageWords];
+    __shared__ uint32_t codes[kCodeWords];
+    __shared__ uint32_t wsum[kEmitThreads / 64];
+    __shared__ uint8_t lslot[256];  // length - 3 -> DEFLATE length slot | extra-bit count << 5 (one LDS read instead of ~10 VALU)
+    if (threadIdx.x < 256) {
+        uint32_t ls, le, lv;
+        length_slot(threadIdx.x + 3, ls, le, lv);
+        lslot[threadIdx.x] = (uint8_t)(ls | (le << 5));
+    }
+    for (uint32_t b = blockIdx.x; b < nb; b += gridDim.x) {
+        __syncthreads();  // the previous block is done with the stage
+        emit_block(cfg, slab, meta_all, sub_all, tok_all, codes_all, hdr_all, out_off, out, out_cap, b, stage, codes, wsum,
+                   lslot);
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -4849,7 +4867,7 @@ void launch_emit(const Config &cfg, const uint8_t *slab, uint64_t, uint32_t nb, 
                  uint8_t *out, uint64_t out_cap, hipStream_t stream) {
     hipLaunchKernelGGL(k_emit, dim3(nb), dim3(kEmitThreads), 0, stream, cfg, slab, (const BlockMeta *)s.meta,
                        (const SubMeta *)s.sub, (const uint32_t *)s.tok, (const uint32_t *)s.codes,
-                       (const uint32_t *)s.hdr, (const uint64_t *)s.out_off, out, out_cap);
+                       (const uint32_t *)s.hdr, (const uint64_t *)s.out_off, out, out_cap, nb);
 }
 
 void launch_inflate(uint32_t hdr_len, const uint8_t *d_in, const uint64_t *d_offsets, const uint32_t *d_sizes,

@@ -301,6 +301,8 @@ int gzpx_synth_ascii_device(void *d_out, uint64_t stream_offset, uint64_t n, uin
 /* ---- measurement hooks (HIP events on the launching stream; bench.py roofline leg) ---- */
 #define GZPX_N_STAGES 9
 /* stage order: init_meta, candidates, match, parse, hist, huffman, crc32, scan, emit */
+/* on: 0 off, 1 HIP events around every stage, 2 around the dominant stage (2: match) only -- two markers in the
+ * stream instead of thirteen, for a timed region that wants the kernel's duration without paying for the rest */
 int gzpx_ctx_set_profiling(gzpx_ctx *ctx, int on);
 int gzpx_ctx_last_stage_ms(const gzpx_ctx *ctx, float ms[GZPX_N_STAGES]);
 const char *gzpx_stage_name(int stage);
