@@ -276,7 +276,9 @@ constexpr uint32_t kCandSteps = 16;  // steps per iteration; also the depth of t
 // aligned dword pair covering in[p .. p+3] (in32 = the block's bytes rounded down to a dword
 // boundary, mis = bytes skipped by that rounding).  Unconditional (index clamped to the block's
 // last dword) so that the number of loads in flight is static and the compiler can wait with
-// exact vmcnt values instead of vmcnt(0).
+// exact vmcnt values instead of vmcnt(0).  (Tried: ONE 8-byte load of the 4-byte-aligned pair -- a hashed
+// position never starts in the block's last dword, so one clamp would do -- four VALU less per 64
+// positions, and k_candidates 0.56 -> 0.68 ms: under-aligned dwordx2 loads are the slower way.)
 __device__ __forceinline__ uint2 cand_fetch(const uint32_t *__restrict__ in32, uint32_t mis,
                                             uint32_t p, uint32_t wmax) {
     const uint32_t w = (p + mis) >> 2;  // bytes p..p+4 lie inside dwords w, w+1
