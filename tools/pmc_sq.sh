@@ -13,10 +13,11 @@ import csv, glob, collections
 for tag in ("a","b"):
     fs = glob.glob("$O/%s/**/*counter_collection.csv" % tag, recursive=True)
     if not fs: print(tag, "no counter file"); continue
-    acc = collections.defaultdict(lambda: collections.defaultdict(float)); cnt = collections.Counter()
+    acc = collections.defaultdict(lambda: collections.defaultdict(float)); disp = collections.defaultdict(set)
     for row in csv.DictReader(open(fs[0])):
-        k = row["Kernel_Name"].split("(")[0][:40]
-        acc[k][row["Counter_Name"]] += float(row["Counter_Value"])
-    for k, d in acc.items():
-        if "gzpx" in k: print(tag, k, {c: "%.3g" % v for c, v in d.items()})
+        k = row["Kernel_Name"].split("(")[0].replace("void ", "").replace("gzpx::", "")[:32]
+        acc[k][row["Counter_Name"].replace("SQ_", "")] += float(row["Counter_Value"])
+        disp[k].add(row["Dispatch_Id"])
+    for k, d in acc.items():  # per launch (the run holds len(disp[k]) launches of the kernel)
+        print("%-28s launches=%-3d " % (k, len(disp[k])) + "  ".join("%s=%.3g" % (c, v / len(disp[k])) for c, v in sorted(d.items())))
 PY
