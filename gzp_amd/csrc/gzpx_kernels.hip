@@ -15,12 +15,14 @@
 // the input ("the two most recent earlier positions with the same 15-bit hash, within 32767
 // bytes") and do not depend on the parse.  That turns the sequential compressor into a pipeline
 // of data-parallel stages, each a kernel over all blocks of a slab:
-//   k_candidates   16 waves / block : LDS-resident 128 KiB bucket table, ordered atomicMax chain,
-//                                     1024 positions per ticket turn
-//   k_mparse       1024 thr / block : (blocks <= 64 KiB) match on demand: the block's bytes and half
-//                                     its candidate distances in LDS; the greedy parse as a
-//                                     speculative walk over 32-position segments that searches only
-//                                     where it lands; every lane writes its own tokens
+//   k_candidates   16 waves / CU    : (persistent: a workgroup walks its share of the blocks) LDS-resident
+//                                     128 KiB bucket table that is never cleared, ordered atomicMax chain,
+//                                     1024 positions per ticket turn, no barrier between blocks
+//   k_mparse       1024 thr / CU    : (blocks <= 64 KiB; persistent) match on demand: the block's bytes and
+//                                     half its candidate distances in LDS, the next block's on their way in
+//                                     registers; the greedy parse as a speculative walk over 32-position
+//                                     segments that searches only where it lands; every lane writes its
+//                                     own tokens
 //   k_match        1024 thr / block : (larger blocks, and blocks k_mparse hands back) block input in LDS;
 //                                     both candidates of EVERY position extended by one lockstep
 //                                     loop; run groups for long runs
@@ -31,7 +33,7 @@
 //   k_huffman      one wave / block : libdeflate's length-limited Huffman construction, header
 //                                     RLE, exact cost comparison (dynamic / static / stored)
 //   k_crc32        256 thr  / block : 256-byte segments straight from global memory, slice-by-4, one GF(2)
-//                                     combine tree per 64 KiB (side stream)
+//                                     combine tree per 64 KiB (side stream, beside the match kernels)
 //   k_scan         one workgroup    : exclusive scan of framed sizes -> output offsets
 //   k_emit         1024 thr / block : bit-exact bitstream assembly in LDS, coalesced write-out
 // Levels 2-4 swap k_match / k_parse for k_match_hc / k_parse_hc (hc_matchfinder chains, block
