@@ -17,6 +17,7 @@
 
 #include <stdlib.h>
 #include <string.h>
+#include <math.h>
 
 /* ------------------------------------------------------------------ CRC-32 */
 
@@ -1143,6 +1144,600 @@ static int compress_lazy(const uint8_t *in, size_t n, unsigned nice_match_length
 
 /* ------------------------------------------------------------------ entry points */
 
+/* ------------------------------------------------------------------------------------------
+ * Levels 10-12: deflate_compress_near_optimal (libdeflate v1.10), restated: bt_matchfinder (hash3
+ * 2-way + hash4 -> binary trees of the window's positions), every position's matches cached, block
+ * splitting on the observation statistics with a rewind to the previous check, then per block an
+ * iterated minimum-cost path over the cached matches (costs from default tables blended with the
+ * previous block's, then from the Huffman codes of the previous pass).
+ * The three default-cost tables are libdeflate's default_litlen_costs[]: int(-log2((1 - p) / max(j, 1))
+ * * BIT_COST) for match probabilities p = 0.25 / 0.5 / 0.75 -- the same bytes sit in the v1.10 binary's
+ * read-only data (tests/test_oracle_near_optimal.py compares them when the library is there).
+ * ------------------------------------------------------------------------------------------ */
+#define BT_HASH3_ORDER 16
+#define BT_HASH3_WAYS 2
+#define BT_HASH4_ORDER 16
+#define BT_REQUIRED_NBYTES 5
+#define MATCH_CACHE_LENGTH (SOFT_MAX_BLOCK_LENGTH * 5)
+#define MAX_MATCHES_PER_POS (MAX_MATCH_LEN - MIN_MATCH_LEN + 1)
+#define NO_MAX_BLOCK_LENGTH (SOFT_MAX_BLOCK_LENGTH + MIN_BLOCK_LENGTH - 1)
+#define BIT_COST 16
+#define LITERAL_NOSTAT_BITS 13
+#define LENGTH_NOSTAT_BITS 13
+#define OFFSET_NOSTAT_BITS 10
+#define OPTIMUM_OFFSET_SHIFT 9
+#define OPTIMUM_LEN_MASK ((1u << OPTIMUM_OFFSET_SHIFT) - 1)
+
+struct bt_mf {
+    int16_t hash3_tab[1u << BT_HASH3_ORDER][BT_HASH3_WAYS];
+    int16_t hash4_tab[1u << BT_HASH4_ORDER];
+    int16_t child_tab[2 * WINDOW_SIZE];
+};
+
+struct lz_match {
+    uint16_t length;
+    uint16_t offset;
+};
+
+struct optimum_node {
+    uint32_t cost_to_end;
+    uint32_t item; /* literal: (byte << 9) | 1; match: (offset << 9) | length */
+};
+
+struct no_costs {
+    uint32_t literal[256];
+    uint32_t length[MAX_MATCH_LEN + 1];
+    uint32_t offset_slot[30];
+};
+
+struct no_state {
+    struct bt_mf mf;
+    struct lz_match match_cache[MATCH_CACHE_LENGTH + MAX_MATCHES_PER_POS + MAX_MATCH_LEN - 1];
+    struct optimum_node optimum_nodes[NO_MAX_BLOCK_LENGTH + 1];
+    struct no_costs costs;
+    struct split_stats split;
+    uint32_t new_match_len_freqs[MAX_MATCH_LEN + 1];
+    uint32_t match_len_freqs[MAX_MATCH_LEN + 1];
+    uint32_t prev_observations[NUM_OBSERVATION_TYPES];
+    uint32_t prev_num_observations;
+    uint32_t tokens[NO_MAX_BLOCK_LENGTH + 1];
+    unsigned max_search_depth, nice_match_length, num_optim_passes;
+    int compat;
+};
+
+static __thread struct no_state *tl_no;
+
+/* default_litlen_costs[i].used_lits_to_lit_cost[j] / .len_sym_cost (scripts/gen_default_litlen_costs.py) */
+static uint8_t no_default_lit_cost[3][257];
+static uint8_t no_default_len_sym_cost[3];
+static int no_tables_ready;
+
+void gzpx_oracle_default_litlen_costs(uint8_t lit[3][257], uint8_t len_sym[3])
+{
+    static const double probs[3] = {0.25, 0.5, 0.75};
+    for (int i = 0; i < 3; i++) {
+        for (int j = 0; j <= 256; j++)
+            lit[i][j] = (uint8_t)(int)(-log2((1.0 - probs[i]) / (double)(j ? j : 1)) * BIT_COST);
+        len_sym[i] = (uint8_t)(int)(-log2(probs[i] / 29.0) * BIT_COST);
+    }
+}
+
+static inline int16_t *bt_left(struct bt_mf *mf, int32_t node) { return &mf->child_tab[2 * (node & (WINDOW_SIZE - 1))]; }
+static inline int16_t *bt_right(struct bt_mf *mf, int32_t node) { return &mf->child_tab[2 * (node & (WINDOW_SIZE - 1)) + 1]; }
+
+static void bt_init(struct bt_mf *mf)
+{
+    int16_t *t = (int16_t *)mf;
+    for (size_t i = 0; i < sizeof(*mf) / sizeof(int16_t); i++)
+        t[i] = -WINDOW_SIZE;
+}
+
+static void bt_slide(struct bt_mf *mf)
+{
+    int16_t *t = (int16_t *)mf;
+    for (size_t i = 0; i < sizeof(*mf) / sizeof(int16_t); i++)
+        t[i] = (int16_t)(t[i] >= 0 ? t[i] - WINDOW_SIZE : -WINDOW_SIZE);
+}
+
+static uint32_t le24(const uint8_t *p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16); }
+
+/* bt_matchfinder_advance_one_byte: record_matches = get_matches, else skip_byte */
+static struct lz_match *bt_advance(struct bt_mf *mf, const uint8_t *in_base, ptrdiff_t cur_pos, uint32_t max_len,
+                                   uint32_t nice_len, uint32_t max_search_depth, uint32_t next_hashes[2],
+                                   struct lz_match *lz_matchptr, int record_matches)
+{
+    const uint8_t *in_next = in_base + cur_pos;
+    uint32_t depth_remaining = max_search_depth;
+    const int32_t cutoff = (int32_t)cur_pos - WINDOW_SIZE;
+    uint32_t next_hashseq, hash3, hash4;
+    int32_t cur_node, cur_node_2;
+    const uint8_t *matchptr;
+    int16_t *pending_lt_ptr, *pending_gt_ptr;
+    uint32_t best_lt_len, best_gt_len, len, best_len = 3;
+
+    next_hashseq = le32(in_next + 1);
+    hash3 = next_hashes[0];
+    hash4 = next_hashes[1];
+    next_hashes[0] = lz_hash(next_hashseq & 0xFFFFFF, BT_HASH3_ORDER);
+    next_hashes[1] = lz_hash(next_hashseq, BT_HASH4_ORDER);
+
+    cur_node = mf->hash3_tab[hash3][0];
+    mf->hash3_tab[hash3][0] = (int16_t)cur_pos;
+    cur_node_2 = mf->hash3_tab[hash3][1];
+    mf->hash3_tab[hash3][1] = (int16_t)cur_node;
+    if (record_matches && cur_node > cutoff) {
+        uint32_t seq3 = le24(in_next);
+        if (seq3 == le24(&in_base[cur_node])) {
+            lz_matchptr->length = 3;
+            lz_matchptr->offset = (uint16_t)(in_next - &in_base[cur_node]);
+            lz_matchptr++;
+        } else if (cur_node_2 > cutoff && seq3 == le24(&in_base[cur_node_2])) {
+            lz_matchptr->length = 3;
+            lz_matchptr->offset = (uint16_t)(in_next - &in_base[cur_node_2]);
+            lz_matchptr++;
+        }
+    }
+
+    cur_node = mf->hash4_tab[hash4];
+    mf->hash4_tab[hash4] = (int16_t)cur_pos;
+
+    pending_lt_ptr = bt_left(mf, (int32_t)cur_pos);
+    pending_gt_ptr = bt_right(mf, (int32_t)cur_pos);
+
+    if (cur_node <= cutoff) {
+        *pending_lt_ptr = -WINDOW_SIZE;
+        *pending_gt_ptr = -WINDOW_SIZE;
+        return lz_matchptr;
+    }
+
+    best_lt_len = 0;
+    best_gt_len = 0;
+    len = 0;
+
+    for (;;) {
+        matchptr = &in_base[cur_node];
+        if (matchptr[len] == in_next[len]) {
+            len = lz_extend(in_next, matchptr, len + 1, max_len);
+            if (!record_matches || len > best_len) {
+                if (record_matches) {
+                    best_len = len;
+                    lz_matchptr->length = (uint16_t)len;
+                    lz_matchptr->offset = (uint16_t)(in_next - matchptr);
+                    lz_matchptr++;
+                }
+                if (len >= nice_len) {
+                    *pending_lt_ptr = *bt_left(mf, cur_node);
+                    *pending_gt_ptr = *bt_right(mf, cur_node);
+                    return lz_matchptr;
+                }
+            }
+        }
+        if (matchptr[len] < in_next[len]) {
+            *pending_lt_ptr = (int16_t)cur_node;
+            pending_lt_ptr = bt_right(mf, cur_node);
+            cur_node = *pending_lt_ptr;
+            best_lt_len = len;
+            if (best_gt_len < len)
+                len = best_gt_len;
+        } else {
+            *pending_gt_ptr = (int16_t)cur_node;
+            pending_gt_ptr = bt_left(mf, cur_node);
+            cur_node = *pending_gt_ptr;
+            best_gt_len = len;
+            if (best_lt_len < len)
+                len = best_lt_len;
+        }
+        if (cur_node <= cutoff || !--depth_remaining) {
+            *pending_lt_ptr = -WINDOW_SIZE;
+            *pending_gt_ptr = -WINDOW_SIZE;
+            return lz_matchptr;
+        }
+    }
+}
+
+static void no_init_stats(struct no_state *c)
+{
+    memset(&c->split, 0, sizeof(c->split));
+    memset(c->new_match_len_freqs, 0, sizeof(c->new_match_len_freqs));
+    memset(c->match_len_freqs, 0, sizeof(c->match_len_freqs));
+}
+
+static void no_merge_stats(struct no_state *c)
+{
+    for (int i = 0; i < NUM_OBSERVATION_TYPES; i++) {
+        c->split.num_observations += c->split.new_observations[i];
+        c->split.observations[i] += c->split.new_observations[i];
+        c->split.new_observations[i] = 0;
+    }
+    c->split.num_new_observations = 0;
+    for (unsigned i = 0; i <= MAX_MATCH_LEN; i++) {
+        c->match_len_freqs[i] += c->new_match_len_freqs[i];
+        c->new_match_len_freqs[i] = 0;
+    }
+}
+
+static void no_save_stats(struct no_state *c)
+{
+    for (int i = 0; i < NUM_OBSERVATION_TYPES; i++)
+        c->prev_observations[i] = c->split.observations[i];
+    c->prev_num_observations = c->split.num_observations;
+}
+
+static void no_clear_old_stats(struct no_state *c)
+{
+    for (int i = 0; i < NUM_OBSERVATION_TYPES; i++)
+        c->split.observations[i] = 0;
+    c->split.num_observations = 0;
+    memset(c->match_len_freqs, 0, sizeof(c->match_len_freqs));
+}
+
+/* deflate_choose_default_litlen_costs */
+static void no_choose_default_litlen_costs(struct no_state *c, const uint8_t *block_begin, uint32_t block_length,
+                                           uint32_t *lit_cost, uint32_t *len_sym_cost)
+{
+    uint32_t litfreq[256];
+    unsigned num_used_literals = 0;
+    uint32_t literal_freq = block_length, match_freq = 0, cutoff, i;
+    memset(litfreq, 0, sizeof(litfreq));
+    cutoff = literal_freq >> 11; /* ignore literals used very rarely */
+    for (i = 0; i < block_length; i++)
+        litfreq[block_begin[i]]++;
+    for (i = 0; i < 256; i++)
+        if (litfreq[i] > cutoff)
+            num_used_literals++;
+    if (num_used_literals == 0)
+        num_used_literals = 1;
+    /* the match frequency of a greedy parse, with the min_len heuristic of the greedy / lazy parsers */
+    i = choose_min_match_len(num_used_literals, c->max_search_depth);
+    for (; i <= MAX_MATCH_LEN; i++) {
+        match_freq += c->match_len_freqs[i];
+        literal_freq -= i * c->match_len_freqs[i];
+    }
+    if ((int32_t)literal_freq < 0)
+        literal_freq = 0;
+    if (match_freq > literal_freq)
+        i = 2; /* many matches */
+    else if (match_freq * 4 > literal_freq)
+        i = 1; /* neutral */
+    else
+        i = 0; /* few matches */
+    *lit_cost = no_default_lit_cost[i][num_used_literals];
+    *len_sym_cost = no_default_len_sym_cost[i];
+}
+
+static uint32_t no_default_length_cost(unsigned len, uint32_t len_sym_cost)
+{
+    return len_sym_cost + extra_length_bits[length_slot(len)] * BIT_COST;
+}
+
+static uint32_t no_default_offset_slot_cost(unsigned slot)
+{
+    /* int(-log2(1/30) * BIT_COST): all 30 offset symbols equally probable */
+    const uint32_t offset_sym_cost = 4 * BIT_COST + (907 * BIT_COST) / 1000;
+    return offset_sym_cost + extra_offset_bits[slot] * BIT_COST;
+}
+
+static void no_set_default_costs(struct no_state *c, uint32_t lit_cost, uint32_t len_sym_cost)
+{
+    unsigned i;
+    for (i = 0; i < 256; i++)
+        c->costs.literal[i] = lit_cost;
+    for (i = MIN_MATCH_LEN; i <= MAX_MATCH_LEN; i++)
+        c->costs.length[i] = no_default_length_cost(i, len_sym_cost);
+    for (i = 0; i < 30; i++)
+        c->costs.offset_slot[i] = no_default_offset_slot_cost(i);
+}
+
+static void no_adjust_cost(uint32_t *cost_p, uint32_t default_cost, int change_amount)
+{
+    if (change_amount == 0) /* block is very similar to the previous one: prefer the previous costs */
+        *cost_p = (default_cost + 3 * *cost_p) / 4;
+    else if (change_amount == 1)
+        *cost_p = (default_cost + *cost_p) / 2;
+    else if (change_amount == 2)
+        *cost_p = (5 * default_cost + 3 * *cost_p) / 8;
+    else /* block differs greatly from the previous one: prefer the default costs */
+        *cost_p = (3 * default_cost + *cost_p) / 4;
+}
+
+static void no_adjust_costs(struct no_state *c, uint32_t lit_cost, uint32_t len_sym_cost)
+{
+    uint64_t total_delta = 0, cutoff;
+    int change_amount;
+    unsigned i;
+    for (i = 0; i < NUM_OBSERVATION_TYPES; i++) {
+        uint64_t prev = (uint64_t)c->prev_observations[i] * c->split.num_observations;
+        uint64_t cur = (uint64_t)c->split.observations[i] * c->prev_num_observations;
+        total_delta += prev > cur ? prev - cur : cur - prev;
+    }
+    cutoff = ((uint64_t)c->prev_num_observations * c->split.num_observations * 200) / 512;
+    if (4 * total_delta > 9 * cutoff)
+        change_amount = 3;
+    else if (2 * total_delta > 3 * cutoff)
+        change_amount = 2;
+    else if (2 * total_delta > cutoff)
+        change_amount = 1;
+    else
+        change_amount = 0;
+    for (i = 0; i < 256; i++)
+        no_adjust_cost(&c->costs.literal[i], lit_cost, change_amount);
+    for (i = MIN_MATCH_LEN; i <= MAX_MATCH_LEN; i++)
+        no_adjust_cost(&c->costs.length[i], no_default_length_cost(i, len_sym_cost), change_amount);
+    for (i = 0; i < 30; i++)
+        no_adjust_cost(&c->costs.offset_slot[i], no_default_offset_slot_cost(i), change_amount);
+}
+
+static void no_set_costs_from_codes(struct no_state *c, const uint8_t *litlen_lens, const uint8_t *offset_lens)
+{
+    unsigned i;
+    for (i = 0; i < 256; i++)
+        c->costs.literal[i] = (litlen_lens[i] ? litlen_lens[i] : LITERAL_NOSTAT_BITS) * BIT_COST;
+    for (i = MIN_MATCH_LEN; i <= MAX_MATCH_LEN; i++) {
+        unsigned slot = length_slot(i), sym = FIRST_LEN_SYM + slot;
+        uint32_t bits = litlen_lens[sym] ? litlen_lens[sym] : LENGTH_NOSTAT_BITS;
+        c->costs.length[i] = (bits + extra_length_bits[slot]) * BIT_COST;
+    }
+    for (i = 0; i < 30; i++) {
+        uint32_t bits = offset_lens[i] ? offset_lens[i] : OFFSET_NOSTAT_BITS;
+        c->costs.offset_slot[i] = (bits + extra_offset_bits[i]) * BIT_COST;
+    }
+}
+
+/* deflate_find_min_cost_path + deflate_tally_item_list: `cache_ptr` = the end of the block's cache entries */
+static void no_find_min_cost_path(struct no_state *c, uint32_t block_length, const struct lz_match *cache_ptr,
+                                  struct freqs *fr)
+{
+    struct optimum_node *end_node = &c->optimum_nodes[block_length];
+    struct optimum_node *cur_node = end_node;
+    cur_node->cost_to_end = 0;
+    do {
+        unsigned num_matches, literal;
+        uint32_t best_cost_to_end;
+        cur_node--;
+        cache_ptr--;
+        num_matches = cache_ptr->length;
+        literal = cache_ptr->offset;
+        /* it is always possible to choose a literal */
+        best_cost_to_end = c->costs.literal[literal] + (cur_node + 1)->cost_to_end;
+        cur_node->item = ((uint32_t)literal << OPTIMUM_OFFSET_SHIFT) | 1;
+        if (num_matches) {
+            /* every length from 3 to the longest match found here, each with the smallest offset that has it */
+            const struct lz_match *match = cache_ptr - num_matches;
+            unsigned len = MIN_MATCH_LEN;
+            do {
+                unsigned offset = match->offset;
+                uint32_t offset_cost = c->costs.offset_slot[offset_slot(offset)];
+                do {
+                    uint32_t cost_to_end = offset_cost + c->costs.length[len] + (cur_node + len)->cost_to_end;
+                    if (cost_to_end < best_cost_to_end) {
+                        best_cost_to_end = cost_to_end;
+                        cur_node->item = ((uint32_t)offset << OPTIMUM_OFFSET_SHIFT) | len;
+                    }
+                } while (++len <= match->length);
+            } while (++match != cache_ptr);
+            cache_ptr -= num_matches;
+        }
+        cur_node->cost_to_end = best_cost_to_end;
+    } while (cur_node != &c->optimum_nodes[0]);
+
+    memset(fr, 0, sizeof(*fr));
+    for (uint32_t pos = 0; pos < block_length;) {
+        uint32_t item = c->optimum_nodes[pos].item;
+        unsigned length = item & OPTIMUM_LEN_MASK, offset = item >> OPTIMUM_OFFSET_SHIFT;
+        if (length == 1) {
+            fr->litlen[offset]++;
+        } else {
+            fr->litlen[FIRST_LEN_SYM + length_slot(length)]++;
+            fr->offset[offset_slot(offset)]++;
+        }
+        pos += length;
+    }
+}
+
+/* deflate_optimize_block, then the block goes to the sink as tokens (deflate_flush_block on the item list) */
+static void no_optimize_and_flush(struct no_state *c, const uint8_t *block_begin, uint32_t block_length,
+                                  const struct lz_match *cache_ptr, int is_first_block, int is_final_block,
+                                  block_sink_fn sink, void *ctx)
+{
+    unsigned num_passes_remaining = c->num_optim_passes;
+    uint32_t i, lit_cost, len_sym_cost;
+    struct freqs fr;
+    size_t nt = 0;
+
+    /* the block really ends at block_length, even if matches reach beyond it */
+    for (i = block_length;
+         i <= (block_length - 1 + MAX_MATCH_LEN < NO_MAX_BLOCK_LENGTH ? block_length - 1 + MAX_MATCH_LEN : NO_MAX_BLOCK_LENGTH);
+         i++)
+        c->optimum_nodes[i].cost_to_end = 0x80000000u;
+
+    no_choose_default_litlen_costs(c, block_begin, block_length, &lit_cost, &len_sym_cost);
+    if (is_first_block)
+        no_set_default_costs(c, lit_cost, len_sym_cost);
+    else
+        no_adjust_costs(c, lit_cost, len_sym_cost);
+
+    do {
+        /* a pass: the minimum-cost path under the current costs, the Huffman codes of what it uses (with the
+         * end-of-block symbol tallied), and the costs those codes imply -- after the LAST pass as well: they are
+         * what the next block blends its default costs with.  (Both details pinned on the v1.10 binary: without
+         * the end-of-block symbol 141 of 165 single-block cases match it, with it all; with the costs left at
+         * those of the last pass 106 of 132 two-block cases, updated 132.) */
+        uint8_t litlen_lens[NUM_LITLEN_SYMS], offset_lens[NUM_OFFSET_SYMS];
+        uint32_t litlen_cw[NUM_LITLEN_SYMS], offset_cw[NUM_OFFSET_SYMS];
+        no_find_min_cost_path(c, block_length, cache_ptr, &fr);
+        fr.litlen[END_OF_BLOCK]++;
+        gzpx_oracle_make_huffman_code(NUM_LITLEN_SYMS, MAX_LITLEN_CODEWORD_LEN, c->compat, fr.litlen, litlen_lens, litlen_cw);
+        gzpx_oracle_make_huffman_code(NUM_OFFSET_SYMS, MAX_OFFSET_CODEWORD_LEN, c->compat, fr.offset, offset_lens, offset_cw);
+        no_set_costs_from_codes(c, litlen_lens, offset_lens);
+        fr.litlen[END_OF_BLOCK]--; /* (flush_block tallies it itself) */
+    } while (--num_passes_remaining);
+
+    for (uint32_t pos = 0; pos < block_length;) {
+        uint32_t item = c->optimum_nodes[pos].item;
+        unsigned length = item & OPTIMUM_LEN_MASK, offset = item >> OPTIMUM_OFFSET_SHIFT;
+        c->tokens[nt++] = length == 1 ? offset : (TOKEN_MATCH | (offset << 9) | length);
+        pos += length;
+    }
+    sink(ctx, block_begin, block_length, c->tokens, nt, &fr, is_final_block);
+}
+
+static int compress_near_optimal(const uint8_t *in, size_t n, unsigned nice_match_length, unsigned max_search_depth,
+                                 unsigned num_optim_passes, int compat, block_sink_fn sink, void *ctx)
+{
+    struct no_state *c;
+    const uint8_t *in_next = in, *in_block_begin = in, *in_end = in + n, *in_cur_base = in, *in_next_slide;
+    unsigned max_len = MAX_MATCH_LEN;
+    unsigned nice_len = nice_match_length < max_len ? nice_match_length : max_len;
+    struct lz_match *cache_ptr;
+    uint32_t next_hashes[2] = {0, 0};
+
+    if (!slot_tabs_ready)
+        init_slot_tabs();
+    if (!no_tables_ready) {
+        gzpx_oracle_default_litlen_costs(no_default_lit_cost, no_default_len_sym_cost);
+        no_tables_ready = 1;
+    }
+    if (!tl_no)
+        tl_no = (struct no_state *)malloc(sizeof(*tl_no));
+    c = tl_no;
+    if (!c)
+        return -1;
+    c->max_search_depth = max_search_depth;
+    c->nice_match_length = nice_match_length;
+    c->num_optim_passes = num_optim_passes;
+    c->compat = compat;
+    memset(c->prev_observations, 0, sizeof(c->prev_observations));
+    c->prev_num_observations = 0;
+    cache_ptr = c->match_cache;
+    in_next_slide = in_next + ((size_t)(in_end - in_next) < WINDOW_SIZE ? (size_t)(in_end - in_next) : WINDOW_SIZE);
+
+    bt_init(&c->mf);
+    no_init_stats(c);
+
+    do {
+        /* starting a new DEFLATE block */
+        const uint8_t *in_max_block_end =
+            ((size_t)(in_end - in_block_begin) < SOFT_MAX_BLOCK_LENGTH + MIN_BLOCK_LENGTH)
+                ? in_end
+                : in_block_begin + SOFT_MAX_BLOCK_LENGTH;
+        const uint8_t *prev_end_block_check = NULL;
+        int change_detected = 0;
+        const uint8_t *next_observation = in_next;
+        unsigned min_len = calculate_min_match_len(in_block_begin, (size_t)(in_max_block_end - in_block_begin),
+                                                   max_search_depth, compat);
+
+        for (;;) {
+            struct lz_match *matches;
+            unsigned best_len;
+            size_t remaining = (size_t)(in_end - in_next);
+
+            if (in_next == in_next_slide) {
+                bt_slide(&c->mf);
+                in_cur_base = in_next;
+                in_next_slide = in_next + (remaining < WINDOW_SIZE ? remaining : WINDOW_SIZE);
+            }
+            matches = cache_ptr;
+            best_len = 0;
+            if (remaining < MAX_MATCH_LEN) {
+                max_len = (unsigned)remaining;
+                if (nice_len > max_len)
+                    nice_len = max_len;
+            }
+            if (max_len >= BT_REQUIRED_NBYTES) {
+                cache_ptr = bt_advance(&c->mf, in_cur_base, in_next - in_cur_base, max_len, nice_len, max_search_depth,
+                                       next_hashes, matches, 1);
+                if (cache_ptr > matches)
+                    best_len = cache_ptr[-1].length;
+            }
+            if (in_next >= next_observation) {
+                if (best_len >= min_len) {
+                    c->split.new_observations[NUM_LITERAL_OBSERVATION_TYPES + (best_len >= 9)]++;
+                    c->split.num_new_observations++;
+                    next_observation = in_next + best_len;
+                    c->new_match_len_freqs[best_len]++;
+                } else {
+                    uint8_t lit = *in_next;
+                    c->split.new_observations[((lit >> 5) & 0x6) | (lit & 1)]++;
+                    c->split.num_new_observations++;
+                    next_observation = in_next + 1;
+                }
+            }
+            cache_ptr->length = (uint16_t)(cache_ptr - matches);
+            cache_ptr->offset = *in_next;
+            in_next++;
+            cache_ptr++;
+
+            /* a very long match: no matches are cached for the bytes it covers */
+            if (best_len >= MIN_MATCH_LEN && best_len >= nice_len) {
+                --best_len;
+                do {
+                    remaining = (size_t)(in_end - in_next);
+                    if (in_next == in_next_slide) {
+                        bt_slide(&c->mf);
+                        in_cur_base = in_next;
+                        in_next_slide = in_next + (remaining < WINDOW_SIZE ? remaining : WINDOW_SIZE);
+                    }
+                    if (remaining < MAX_MATCH_LEN) {
+                        max_len = (unsigned)remaining;
+                        if (nice_len > max_len)
+                            nice_len = max_len;
+                    }
+                    if (max_len >= BT_REQUIRED_NBYTES)
+                        bt_advance(&c->mf, in_cur_base, in_next - in_cur_base, max_len, nice_len, max_search_depth,
+                                   next_hashes, NULL, 0);
+                    cache_ptr->length = 0;
+                    cache_ptr->offset = *in_next;
+                    in_next++;
+                    cache_ptr++;
+                } while (--best_len);
+            }
+            if (in_next >= in_max_block_end)
+                break;
+            if (cache_ptr >= &c->match_cache[MATCH_CACHE_LENGTH])
+                break;
+            if (!(c->split.num_new_observations >= NUM_OBSERVATIONS_PER_BLOCK_CHECK &&
+                  (size_t)(in_next - in_block_begin) >= MIN_BLOCK_LENGTH && (size_t)(in_end - in_next) >= MIN_BLOCK_LENGTH))
+                continue;
+            if (do_end_block_check(&c->split, (uint32_t)(in_next - in_block_begin))) {
+                change_detected = 1;
+                break;
+            }
+            no_merge_stats(c);
+            prev_end_block_check = in_next;
+        }
+
+        if (change_detected && prev_end_block_check != NULL) {
+            /* a recent chunk differs from the rest of the block: rewind to just before it */
+            struct lz_match *orig_cache_ptr = cache_ptr;
+            const uint8_t *in_block_end = prev_end_block_check;
+            uint32_t block_length = (uint32_t)(in_block_end - in_block_begin);
+            uint32_t num_bytes_to_rewind = (uint32_t)(in_next - in_block_end);
+            size_t cache_len_rewound;
+            do {
+                cache_ptr--;
+                cache_ptr -= cache_ptr->length;
+            } while (--num_bytes_to_rewind);
+            cache_len_rewound = (size_t)(orig_cache_ptr - cache_ptr);
+            no_optimize_and_flush(c, in_block_begin, block_length, cache_ptr, in_block_begin == in, 0, sink, ctx);
+            memmove(c->match_cache, cache_ptr, cache_len_rewound * sizeof(*cache_ptr));
+            cache_ptr = &c->match_cache[cache_len_rewound];
+            no_save_stats(c);
+            no_clear_old_stats(c);
+            in_block_begin = in_block_end;
+        } else {
+            uint32_t block_length = (uint32_t)(in_next - in_block_begin);
+            no_merge_stats(c);
+            no_optimize_and_flush(c, in_block_begin, block_length, cache_ptr, in_block_begin == in, in_next == in_end,
+                                  sink, ctx);
+            cache_ptr = &c->match_cache[0];
+            no_save_stats(c);
+            no_init_stats(c);
+            in_block_begin = in_next;
+        }
+    } while (in_next != in_end);
+    return 0;
+}
+
 struct emit_ctx {
     struct bitwriter w;
     int compat;
@@ -1172,8 +1767,8 @@ size_t gzpx_oracle_deflate_compress(int level, int compat, const uint8_t *in, si
     c.w.out = out;
     c.w.cap = cap;
     c.compat = compat;
-    if (level < 0 || level > 9)
-        return 0; /* levels 10..12 (near-optimal parser): not restated */
+    if (level < 0 || level > 12)
+        return 0;
     /* A.0: very short inputs (and level 0) are emitted as stored blocks only */
     if (level == 0 || n <= (size_t)(55 - 4 * level)) {
         write_stored(&c.w, in, n, 1);
@@ -1185,6 +1780,13 @@ size_t gzpx_oracle_deflate_compress(int level, int compat, const uint8_t *in, si
         /* level 2: depth 6 nice 10; level 3: depth 12 nice 14; level 4: depth 16 nice 30 */
         static const unsigned depth[5] = {0, 0, 6, 12, 16}, nice[5] = {0, 0, 10, 14, 30};
         if (compress_greedy(in, n, nice[level], depth[level], compat, emit_sink, &c) != 0)
+            return 0;
+        bw_align(&c.w);
+    } else if (level >= 10) {
+        /* levels 10-12: near-optimal parsing (max_search_depth / nice_match_length / num_optim_passes) */
+        static const unsigned depth[3] = {35, 70, 150}, nice[3] = {75, 150, 258}, passes[3] = {2, 3, 4};
+        if (compress_near_optimal(in, n, nice[level - 10], depth[level - 10], passes[level - 10], compat, emit_sink,
+                                  &c) != 0)
             return 0;
         bw_align(&c.w);
     } else {

@@ -47,6 +47,10 @@ size_t gzpx_oracle_deflate_bound(size_t n);
 size_t gzpx_oracle_deflate_compress(int level, int compat, const uint8_t *in, size_t n,
                                     uint8_t *out, size_t cap);
 
+/* libdeflate's default_litlen_costs[] (levels 10-12), computed: lit[i][j] for match probability 0.25 / 0.5 / 0.75 and
+ * j used literals, len_sym[i] the cost of a length symbol (the same bytes sit in the v1.10 binary's read-only data) */
+void gzpx_oracle_default_litlen_costs(uint8_t lit[3][257], uint8_t len_sym[3]);
+
 /*
  * One framed block: bgzf::compress / mgzip::compress (+ BGZF_EOF when is_last and fmt==BGZF).
  * Returns bytes written, 0 on "does not fit"; *err (optional) gets 0 ok, 1 insufficient space,

@@ -41,6 +41,13 @@ def golden_lazy():
 
 
 @pytest.fixture(scope="session")
+def golden_near_optimal():
+    import json
+    with open(os.path.join(ROOT, "tests", "golden", "l1012_vectors.json")) as f:
+        return json.load(f)
+
+
+@pytest.fixture(scope="session")
 def emu_lib():
     """The product sources compiled against the CPU SIMT emulator (kernel-logic checks only)."""
     sys.path.insert(0, os.path.join(ROOT, "tests", "emu"))

@@ -30,7 +30,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(HERE, "..", ".."))
 from gzp_amd import synth  # noqa: E402
 
-LD = ctypes.CDLL(os.environ.get("LIBDEFLATE_SO", "/lib/x86_64-linux-gnu/libdeflate.so.0"))
+LD_PATH = os.environ.get("LIBDEFLATE_SO", "/lib/x86_64-linux-gnu/libdeflate.so.0")
+LD = ctypes.CDLL(LD_PATH)
 LD.libdeflate_alloc_compressor.restype = ctypes.c_void_p
 LD.libdeflate_alloc_compressor.argtypes = [ctypes.c_int]
 LD.libdeflate_deflate_compress.restype = ctypes.c_size_t
@@ -161,7 +162,60 @@ def lazy_vectors():
     print("wrote %d raw, %d stream vectors for levels 5-9" % (len(raw), len(streams)))
 
 
+def near_optimal_vectors():
+    """Levels 10-12 (deflate_compress_near_optimal) -> l1012_vectors.json."""
+    raw = []
+    for level in (10, 11, 12):
+        edge = 55 - 4 * level  # deflate_compress_none up to here
+        for cls in synth.CLASSES:
+            for n in (0, edge, edge + 1, 300, 4096, 5000, 10001, 20000, 32769, 65280):
+                seed = 5000 + n
+                a = synth.make(cls, n, seed)
+                e = {"class": cls, "n": n, "seed": seed, "level": level}
+                e.update(entry(ld_deflate(a, level)))
+                raw.append(e)
+    # several DEFLATE blocks, the rewind to the previous split check, the 300,000-byte soft limit, window slides
+    for level, cls, n in [(10, "text", 1 << 20), (10, "fastq", 700000), (11, "mixed", 700000), (12, "ascii", 400000),
+                          (12, "text", 400000), (11, "dna", 305001), (10, "repeats", 400000), (12, "text", 304999),
+                          (11, "mixed", 131072), (12, "lowent", 200000)]:
+        a = synth.make(cls, n, 81)
+        e = {"class": cls, "n": n, "seed": 81, "level": level}
+        e.update(entry(ld_deflate(a, level)))
+        raw.append(e)
+    streams = []
+    for fmt, bs, level, cases in [
+        ("bgzf", 65280, 10, [("text", 0), ("text", 65280), ("text", 3 * 65280 + 1234), ("mixed", 300000),
+                             ("fastq", 200000), ("random", 70000)]),
+        ("bgzf", 65280, 11, [("text", 200000)]),
+        ("bgzf", 65280, 12, [("repeats", 200000), ("fastq", 150000)]),
+        ("mgzip", 1 << 20, 10, [("ascii", (1 << 20) + 7)]),
+        ("mgzip", 131072, 12, [("mixed", 500000)]),
+    ]:
+        for cls, n in cases:
+            a = synth.make(cls, n, 4545)
+            st, blk = frame_stream(a, level, fmt, bs)
+            e = {"fmt": fmt, "buffer_size": bs, "class": cls, "n": n, "seed": 4545, "level": level,
+                 "block_sizes": blk}
+            e.update(entry(st))
+            streams.append(e)
+    # libdeflate's default_litlen_costs[] as they sit in the binary's read-only data (found by their first bytes):
+    # three rows of 257 literal costs + the length-symbol cost
+    blob = open(LD_PATH, "rb").read()
+    at = blob.find(bytes([6, 6, 22, 32, 38, 43, 48, 51]))
+    tables = [list(blob[at + 258 * k: at + 258 * (k + 1)]) for k in range(3)] if at >= 0 else None
+    with open(os.path.join(HERE, "l1012_vectors.json"), "w") as f:
+        json.dump({"generator": "tests/golden/make_golden.py near_optimal",
+                   "libdeflate": "v1.10 binary (Ubuntu libdeflate0 1.10-2), compat=1.10",
+                   "default_litlen_costs": tables,
+                   "raw_deflate": raw, "streams": streams}, f, indent=0, separators=(",", ":"))
+        f.write("\n")
+    print("wrote %d raw, %d stream vectors for levels 10-12" % (len(raw), len(streams)))
+
+
 def main():
+    if sys.argv[1:] == ["near_optimal"]:
+        near_optimal_vectors()
+        return
     if sys.argv[1:] == ["lazy"]:
         return lazy_vectors()
     sizes = [0, 1, 51, 52, 53, 100, 300, 511, 512, 513, 1000, 4096, 5000, 32767, 32768, 32769, 32773,

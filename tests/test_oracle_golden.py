@@ -110,3 +110,34 @@ def test_levels_5_to_9_match_libdeflate_vectors(oracle, golden_lazy):
         out, sizes = oracle.compress_stream(a, fmt, e["level"], oracle.COMPAT_1_10, e["buffer_size"], True)
         assert hashlib.sha256(out).hexdigest() == e["sha256"], e
         assert list(sizes) == e["block_sizes"]
+
+
+def test_levels_10_to_12_match_libdeflate_vectors(oracle, golden_near_optimal):
+    """The near-optimal parser (deflate_compress_near_optimal: bt_matchfinder, match cache, block splitting with
+    rewind, iterated minimum-cost path) against the v1.10 binary's output."""
+    for e in golden_near_optimal["raw_deflate"]:
+        a = synth.make(e["class"], e["n"], e["seed"])
+        out = oracle.deflate_compress(a, e["level"], oracle.COMPAT_1_10)
+        assert hashlib.sha256(out).hexdigest() == e["sha256"], e
+        if e["n"] <= 70000:
+            assert zlib.decompress(out, -15) == a.tobytes()
+    for e in golden_near_optimal["streams"]:
+        a = synth.make(e["class"], e["n"], e["seed"])
+        fmt = oracle.FMT_BGZF if e["fmt"] == "bgzf" else oracle.FMT_MGZIP
+        out, sizes = oracle.compress_stream(a, fmt, e["level"], oracle.COMPAT_1_10, e["buffer_size"], True)
+        assert hashlib.sha256(out).hexdigest() == e["sha256"], e
+        assert list(sizes) == e["block_sizes"]
+
+
+def test_default_litlen_cost_tables_are_the_binarys(oracle, golden_near_optimal):
+    """libdeflate's default_litlen_costs[] (three rows of 257 literal costs + a length-symbol cost), as they sit in
+    the v1.10 binary's read-only data, are int(-log2((1 - p) / max(j, 1)) * 16) and int(-log2(p / 29) * 16)."""
+    import ctypes
+    tables = golden_near_optimal["default_litlen_costs"]
+    assert tables is not None and len(tables) == 3
+    lit = ((ctypes.c_uint8 * 257) * 3)()
+    ln = (ctypes.c_uint8 * 3)()
+    oracle.lib().gzpx_oracle_default_litlen_costs(lit, ln)
+    for k in range(3):
+        assert list(lit[k]) == tables[k][:257]
+        assert ln[k] == tables[k][257]
