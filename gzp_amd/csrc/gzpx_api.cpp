@@ -8,6 +8,7 @@
 #include <hip/hip_runtime.h>
 
 #include <condition_variable>
+#include <cmath>
 #include <mutex>
 #include <new>
 #include <string.h>
@@ -179,6 +180,34 @@ int alloc_scratch(gzpx_ctx *ctx) {
         HIP_TRY(hipMalloc((void **)&s.lz_len, nb * 2 * (size_t)c.stride));
         HIP_TRY(hipMalloc((void **)&s.lz_dist, nb * 2 * (size_t)c.stride * sizeof(uint16_t)));
     }
+    if (c.level >= 10) {
+        // levels 10-12: one lane per block in flight, each with its trees / cache / path nodes (gzpx_nearopt.hip);
+        // as many as half the free HBM holds, 96 GiB at most (a BGZF block: 7.5 MiB); the lanes walk the batch's blocks
+        const size_t per_lane = no_lane_bytes() + no_cache_bytes() + no_nodes_bytes(c.block_size);
+        size_t free_b = 0, total_b = 0, budget = (size_t)12 << 30;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b / 2 > budget)
+            budget = free_b / 2 < ((size_t)96 << 30) ? free_b / 2 : ((size_t)96 << 30);  // (288 GB of HBM: up to 96 GiB of it)
+        size_t lanes = budget / per_lane;
+        if (lanes > nb) lanes = nb;
+        if (lanes < 1) lanes = 1;
+        s.no_lanes = (uint32_t)lanes;
+        HIP_TRY(hipMalloc(&s.no_state, lanes * no_lane_bytes()));
+        HIP_TRY(hipMalloc((void **)&s.no_cache, lanes * no_cache_bytes()));
+        HIP_TRY(hipMalloc((void **)&s.no_nodes, lanes * no_nodes_bytes(c.block_size)));
+        // libdeflate's default_litlen_costs[]: int(-log2((1 - p) / max(j, 1)) * 16), int(-log2(p / 29) * 16)
+        uint8_t tables[3 * 258];
+        static const double probs[3] = {0.25, 0.5, 0.75};
+        for (int k = 0; k < 3; k++) {
+            for (int j = 0; j <= 256; j++) tables[258 * k + j] = (uint8_t)(int)(-std::log2((1.0 - probs[k]) / (double)(j ? j : 1)) * 16);
+            tables[258 * k + 257] = (uint8_t)(int)(-std::log2(probs[k] / 29.0) * 16);
+        }
+        uint8_t *d_tables = nullptr;
+        HIP_TRY(hipMalloc((void **)&d_tables, sizeof(tables)));
+        HIP_TRY(hipMemcpy(d_tables, tables, sizeof(tables), hipMemcpyHostToDevice));
+        launch_near_optimal_tables(s.no_state, s.no_lanes, d_tables, nullptr);
+        HIP_TRY(hipDeviceSynchronize());
+        (void)hipFree(d_tables);
+    }
     HIP_TRY(hipMalloc((void **)&s.hist, nb * (size_t)c.max_sub * kHistStride * 4));
     HIP_TRY(hipMalloc((void **)&s.codes, nb * (size_t)c.max_sub * kCodeWords * 4));
     HIP_TRY(hipMalloc((void **)&s.hdr, nb * (size_t)c.max_sub * kHdrWords * 4));
@@ -210,6 +239,9 @@ void free_scratch(gzpx_ctx *ctx) {
     if (s.cand) (void)hipFree(s.cand);
     if (s.tok) (void)hipFree(s.tok);
     if (s.redo) (void)hipFree(s.redo);
+    if (s.no_state) (void)hipFree(s.no_state);
+    if (s.no_cache) (void)hipFree(s.no_cache);
+    if (s.no_nodes) (void)hipFree(s.no_nodes);
     if (s.len8) (void)hipFree(s.len8);
     if (s.which) (void)hipFree(s.which);
     if (s.alt) (void)hipFree(s.alt);
@@ -326,7 +358,9 @@ int enqueue_batch(gzpx_ctx *ctx, const uint8_t *d_in, size_t in_len, uint32_t nb
         pp.end(t, stream);
     } else {
         t = pp.begin(2, stream);
-        if (c.lazy) {  // levels 5-9: every match variant once, then the serial-per-block lazy parse
+        if (c.level >= 10) {  // levels 10-12: the near-optimal parser, one lane per block (gzpx_nearopt.hip)
+            launch_near_optimal(c, d_in, nb, s, stream);
+        } else if (c.lazy) {  // levels 5-9: every match variant once, then the serial-per-block lazy parse
             launch_lazy(c, d_in, nb, s, stream);
         } else {
             // levels 2-4: every match once, then the greedy parse; a block whose new sub-block needs
@@ -662,7 +696,6 @@ int ctx_create(const gzpx_config *cfg, bool crc_only, gzpx_ctx **out) {
     if (cfg->level < 0 || cfg->level > 12) return GZPX_ERR_COMPRESSION_LEVEL;
     if (cfg->compat != GZPX_COMPAT_LIBDEFLATE_1_24 && cfg->compat != GZPX_COMPAT_LIBDEFLATE_1_10)
         return GZPX_ERR_INVALID_ARG;
-    if (cfg->level > 9) return GZPX_ERR_UNSUPPORTED;  // 10..12 (near-optimal parser): not built
     if (cfg->buffer_size > kMaxBlockSize) return GZPX_ERR_UNSUPPORTED;  // > 16 MiB blocks: not built
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return GZPX_ERR_NO_DEVICE;
@@ -689,11 +722,13 @@ int ctx_create(const gzpx_config *cfg, bool crc_only, gzpx_ctx **out) {
     ctx->dcfg.passthrough = cfg->level == 0 ? 0xFFFFFFFFu : (uint32_t)(55 - 4 * cfg->level);
     {
         // libdeflate_alloc_compressor: max_search_depth / nice_match_length of levels 2-9
-        static const uint32_t depth[10] = {0, 0, 6, 12, 16, 16, 35, 100, 300, 600};
-        static const uint32_t nice[10] = {0, 0, 10, 14, 30, 30, 65, 130, 258, 258};
+        // (levels 10-12, deflate_compress_near_optimal: + num_optim_passes 2 / 3 / 4)
+        static const uint32_t depth[13] = {0, 0, 6, 12, 16, 16, 35, 100, 300, 600, 35, 70, 150};
+        static const uint32_t nice[13] = {0, 0, 10, 14, 30, 30, 65, 130, 258, 258, 75, 150, 258};
         ctx->dcfg.hc_depth = depth[cfg->level];
         ctx->dcfg.hc_nice = nice[cfg->level];
-        ctx->dcfg.lazy = cfg->level >= 8 ? 2u : cfg->level >= 5 ? 1u : 0u;
+        ctx->dcfg.lazy = cfg->level >= 10 ? 0u : cfg->level >= 8 ? 2u : cfg->level >= 5 ? 1u : 0u;
+        ctx->dcfg.no_passes = cfg->level >= 10 ? (uint32_t)cfg->level - 8u : 0u;
     }
     for (unsigned l = 0; l < 10; l++) ctx->crc_consts.pow64[l] = x2k(9 + l);
     ctx->crc_consts.pow_tile = x2k(19);  // x^(8 * 65536) = x^(2^19)
@@ -1702,6 +1737,7 @@ const char *gzpx_ctx_stage_kernel(const gzpx_ctx *ctx, int stage) {
     if (ctx && stage == 2) {
         const Config &c = ctx->dcfg;
         if (c.level <= 1) return (c.block_size <= kTile && !(c.debug & 2u)) ? "k_mparse" : "k_match";
+        if (c.level >= 10) return "k_near_optimal";
         return c.lazy ? "k_match_hc+k_parse_lazy" : "k_match_hc+k_parse_hc";
     }
     if (ctx && stage == 3 && ctx->dcfg.level > 1) return "-";

@@ -27,6 +27,7 @@ enum SubType : uint32_t { kStored = 0, kStatic = 1, kDynamic = 2 };
 enum BlockStatus : uint32_t {
     kStatusOk = 0,
     kStatusBlockSizeExceeded = 2,  // BGZF payload >= 65536 (src/bgzf.rs:218-223)
+    kStatusInternal = 3,           // a capacity this implementation sizes was exceeded (reported as a device error)
 };
 
 struct SubMeta {
@@ -94,6 +95,7 @@ struct Config {
     uint32_t hc_nice;     // levels 2-9: nice_match_length
     uint32_t lazy;        // 0: greedy parser (levels 2-4), 1: lazy (5-7), 2: lazy2 (8-9)
     uint32_t n_cu;        // compute units of the device (persistent kernels launch one workgroup per CU)
+    uint32_t no_passes;   // levels 10-12: num_optim_passes (hc_depth / hc_nice hold max_search_depth / nice_match_length)
 };
 
 // Device scratch for one batch of blocks.
@@ -116,6 +118,11 @@ struct Scratch {
     uint32_t *hdr;        // [nb][max_sub][kHdrWords]
     uint64_t *out_off;    // [nb + 1] byte offset of each framed block in the output
     uint32_t *sizes;      // [nb]     framed size of each block (compact copy for the host / the index)
+    // levels 10-12 (gzpx_nearopt.hip): the state of the blocks in flight, one lane each
+    uint32_t no_lanes;    // how many
+    void *no_state;       // [no_lanes] NoLane: trees, hash tables, costs, frequencies, Huffman scratch
+    uint8_t *no_cache;    // [no_lanes] match cache (libdeflate's MATCH_CACHE_LENGTH entries + slack)
+    uint8_t *no_nodes;    // [no_lanes] minimum-cost path nodes of a DEFLATE block
 };
 
 // Host-side launchers (gzpx_kernels.hip).  All asynchronous on `stream`.
@@ -129,6 +136,12 @@ void launch_parse(const Config &cfg, const uint8_t *slab, uint64_t slab_len, uin
                   const Scratch &s, hipStream_t stream);
 void launch_hc(const Config &cfg, const uint8_t *slab, uint32_t nb, const Scratch &s, hipStream_t stream);
 void launch_lazy(const Config &cfg, const uint8_t *slab, uint32_t nb, const Scratch &s, hipStream_t stream);
+// levels 10-12 (gzpx_nearopt.hip)
+size_t no_lane_bytes();
+size_t no_cache_bytes();
+size_t no_nodes_bytes(uint32_t block_size);
+void launch_near_optimal_tables(void *lanes, uint32_t n_lanes, const uint8_t *d_tables, hipStream_t stream);
+void launch_near_optimal(const Config &cfg, const uint8_t *slab, uint32_t nb, const Scratch &s, hipStream_t stream);
 void launch_hist(const Config &cfg, uint32_t nb, const Scratch &s, hipStream_t stream);
 void launch_huffman(const Config &cfg, uint32_t nb, const Scratch &s, hipStream_t stream);
 void launch_crc32(const Config &cfg, const uint8_t *slab, uint64_t slab_len, uint32_t nb,

@@ -4746,7 +4746,7 @@ static void launch_candidates_mode(const Config &cfg, const uint8_t *slab, uint6
 // goes through launch_init_meta alone.
 void launch_candidates(const Config &cfg, const uint8_t *slab, uint64_t slab_len, uint32_t nb, int is_last,
                        const Scratch &s, hipStream_t stream) {
-    if (cfg.level == 0) {  // stored blocks only
+    if (cfg.level == 0 || cfg.level >= 10) {  // stored blocks only / bt_matchfinder (gzpx_nearopt.hip) keeps its own tables
         launch_init_meta(cfg, slab_len, nb, is_last, s, stream);
         return;
     }

@@ -281,6 +281,7 @@ hipError_t hipPeekAtLastError();
 hipError_t hipSetDevice(int d);
 hipError_t hipGetDevice(int *d);
 hipError_t hipGetDeviceCount(int *n);
+static inline hipError_t hipMemGetInfo(size_t *free_b, size_t *total_b) { *free_b = (size_t)1 << 30; *total_b = (size_t)1 << 30; return hipSuccess; }
 hipError_t hipGetDeviceProperties(hipDeviceProp_t *p, int d);
 const char *hipGetErrorString(hipError_t e);
 

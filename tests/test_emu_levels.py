@@ -114,3 +114,40 @@ def test_regression_50000_sequences_end_a_sub_block_between_literals(emu_lib, or
                          lib=emu_lib, max_slab_bytes=a.size) as c:
         got = c.compress_slab(a, True)
     assert got == oracle.compress_stream(a, oracle.FMT_MGZIP, 2, oracle.COMPAT_1_10, 1 << 20)
+
+
+# ---- levels 10-12: the near-optimal parser (k_near_optimal, one lane per block)
+
+def test_golden_raw_deflate_near_optimal_levels(emu_lib, golden_near_optimal):
+    comps = {L: _native.Compressor(L, _native.COMPAT_1_10, lib=emu_lib) for L in (10, 11, 12)}
+    for e in golden_near_optimal["raw_deflate"]:
+        if e["n"] > 140000 or (e["n"] > 11000 and e["class"] not in ("text", "fastq", "mixed", "repeats", "dna")):
+            continue  # the rest runs on the GPU (tests/test_gpu_levels.py)
+        a = synth.make(e["class"], e["n"], e["seed"])
+        assert hashlib.sha256(comps[e["level"]].deflate_compress(a)).hexdigest() == e["sha256"], e
+    for c in comps.values():
+        c.close()
+
+
+def test_golden_streams_near_optimal_levels(emu_lib, golden_near_optimal):
+    for e in golden_near_optimal["streams"]:
+        if e["n"] > 320000:
+            continue
+        a = synth.make(e["class"], e["n"], e["seed"])
+        fmt = _native.FORMAT_BGZF if e["fmt"] == "bgzf" else _native.FORMAT_MGZIP
+        with _native.Context(format=fmt, level=e["level"], buffer_size=e["buffer_size"],
+                             compat=_native.COMPAT_1_10, lib=emu_lib, max_slab_bytes=max(a.size, 1)) as c:
+            out, sizes = c.compress_slab(a, True, return_block_sizes=True)
+        assert hashlib.sha256(out).hexdigest() == e["sha256"], e
+        assert list(sizes) == e["block_sizes"]
+
+
+@pytest.mark.parametrize("level", [10, 12])
+def test_heterogeneous_blocks_vs_oracle_near_optimal(emu_lib, oracle, level):
+    """DEFLATE block splits with the rewind to the previous check, and blocks above the 300000-byte soft limit."""
+    for fmt, ofmt, bs, n in [(_native.FORMAT_BGZF, 0, 65280, 2 * 65280 + 99), (_native.FORMAT_MGZIP, 1, 330001, 400000)]:
+        a = hetero(n, 10 * level + bs % 7)
+        for compat in (_native.COMPAT_1_10, _native.COMPAT_1_24):
+            with _native.Context(format=fmt, level=level, buffer_size=bs, compat=compat, lib=emu_lib, max_slab_bytes=n) as c:
+                got = c.compress_slab(a, True)
+            assert got == oracle.compress_stream(a, ofmt, level, compat, bs), (level, fmt, bs, compat)

@@ -127,3 +127,39 @@ def test_largest_block_16mib(hip_lib, oracle, level):
     want, wsizes = oracle.compress_stream(a, oracle.FMT_MGZIP, level, oracle.COMPAT_1_24, bs, True)
     assert list(sizes) == list(wsizes)
     assert got == want
+
+
+# ---- levels 10-12
+
+def test_golden_vectors_near_optimal_levels(hip_lib, golden_near_optimal):
+    comps = {L: _native.Compressor(L, _native.COMPAT_1_10, lib=hip_lib) for L in (10, 11, 12)}
+    for e in golden_near_optimal["raw_deflate"]:
+        # (one whole-buffer call = one block = ONE lane of k_near_optimal: the large vectors take ten seconds and more
+        # each, so the GPU run keeps three of them -- the soft block limit, a window slide, a rewind -- and the oracle
+        # test covers all)
+        if e["n"] > 140000 and (e["level"], e["class"], e["n"]) not in ((11, "dna", 305001), (12, "text", 304999), (12, "lowent", 200000)):
+            continue
+        a = synth.make(e["class"], e["n"], e["seed"])
+        assert hashlib.sha256(comps[e["level"]].deflate_compress(a)).hexdigest() == e["sha256"], e
+    for c in comps.values():
+        c.close()
+    for e in golden_near_optimal["streams"]:
+        a = synth.make(e["class"], e["n"], e["seed"])
+        fmt = _native.FORMAT_BGZF if e["fmt"] == "bgzf" else _native.FORMAT_MGZIP
+        with _native.Context(format=fmt, level=e["level"], buffer_size=e["buffer_size"],
+                             compat=_native.COMPAT_1_10, lib=hip_lib, max_slab_bytes=max(a.size, 1)) as c:
+            out, sizes = c.compress_slab(a, True, return_block_sizes=True)
+        assert hashlib.sha256(out).hexdigest() == e["sha256"], e
+        assert list(sizes) == e["block_sizes"]
+
+
+@pytest.mark.parametrize("level", [10, 11, 12])
+def test_heterogeneous_blocks_vs_oracle_near_optimal(hip_lib, oracle, level):
+    for fmt, ofmt, bs, n in [(_native.FORMAT_BGZF, 0, 65280, 24 * 65280 + 99),
+                             (_native.FORMAT_MGZIP, 1, 330001, 2 * 330001 + 4321)]:
+        a = hetero(n, 10 * level + bs % 7)
+        with _native.Context(format=fmt, level=level, buffer_size=bs, compat=_native.COMPAT_1_10, lib=hip_lib,
+                             max_slab_bytes=n) as c:
+            got = c.compress_slab(a, True)
+        assert got == oracle.compress_stream(a, ofmt, level, oracle.COMPAT_1_10, bs), (level, fmt, bs)
+        assert gzip.decompress(got) == a.tobytes()

@@ -281,9 +281,9 @@ def builder_errors(lib):
     with pytest.raises(par.GzpError) as e:
         par.ParCompressBuilder(par.Bgzf, lib=lib).compression_level(13).from_writer(io.BytesIO())
     assert e.value.code == _native.ERR_COMPRESSION_LEVEL
-    with pytest.raises(par.GzpError) as e:
-        par.ParCompressBuilder(par.Bgzf, lib=lib).compression_level(11).from_writer(io.BytesIO())
-    assert e.value.code == _native.ERR_UNSUPPORTED  # valid in gzp, not built: never a CPU fallback
+    with pytest.raises(par.GzpError) as e:  # valid in gzp, not built (blocks above 16 MiB): never a CPU fallback
+        par.ParCompressBuilder(par.Mgzip, lib=lib).buffer_size((16 << 20) + 1).from_writer(io.BytesIO())
+    assert e.value.code == _native.ERR_UNSUPPORTED
     with pytest.raises(par.GzpError) as e:
         par.ParDecompressBuilder(par.Bgzf, lib=lib).num_threads(0)
     assert e.value.code == _native.ERR_NUM_THREADS
