@@ -84,10 +84,12 @@ def digest_stream(a, level, fmt, bs, tail):
 def main():
     out = []
     t0 = time.time()
-    only_levels = sys.argv[1:] == ["levels"]  # add / refresh the text slab at levels 3, 6, 9 only
+    only_levels = sys.argv[1:] in (["levels"], ["near_optimal"])  # add / refresh the text slab at levels 3, 6, 9 (or 10, 12) only
+    levels = (10, 12) if sys.argv[1:] == ["near_optimal"] else (3, 6, 9)
     if only_levels:
         with open(os.path.join(HERE, "fullsize.json")) as f:
-            out = [e for e in json.load(f)["streams"] if not e["name"].startswith("text_550MiB_bgzf_l")]
+            out = [e for e in json.load(f)["streams"]
+                   if e["name"] not in ["text_550MiB_bgzf_l%d" % lv for lv in levels]]
 
     def add(name, a, level, fmt, bs, tail, inp):
         e = {"name": name, "fmt": fmt, "level": level, "buffer_size": bs, "tail": tail, "input": inp,
@@ -103,7 +105,7 @@ def main():
         add("config2_text_550MiB_bgzf_l1", a, 1, "bgzf", 65280, True,
             {"kind": "text_slab", "n": 576_716_800, "seed": 20250927})
     # the same slab at gzp's default level and through the lazy / lazy2 parsers (best() = 9: XFL 2)
-    for level in (3, 6, 9):
+    for level in levels:  # (10, 12: the near-optimal parser -- python tests/golden/make_fullsize.py near_optimal)
         add("text_550MiB_bgzf_l%d" % level, a, level, "bgzf", 65280, True,
             {"kind": "text_slab", "n": 576_716_800, "seed": 20250927})
     if only_levels:

@@ -81,6 +81,13 @@ def test_text_550mib_levels_3_6_9_every_block(hip_lib, level):
     assert int(d_out[8]) == (2 if level == 9 else 0)  # XFL (src/bgzf.rs:278-284)
 
 
+def test_text_550mib_level_12_every_block(hip_lib):
+    """The bench slab through the near-optimal parser (k_near_optimal, 4 optimisation passes): all 8,835 blocks + EOF
+    against the v1.10 binary's stream."""
+    d_in, d_out, out_len, sizes = _run(GOLD["text_550MiB_bgzf_l12"], hip_lib, check_input=False)
+    assert int(d_out[8]) == 2  # XFL: best compression from level 9 on (src/bgzf.rs:278-284)
+
+
 @pytest.mark.parametrize("name", ["config3_ascii_1GiB_mgzip_l3", "config3_ascii_4GiB_mgzip_l3"])
 def test_config3_mgzip_level3_every_block(hip_lib, name):
     _run(GOLD[name], hip_lib)
