@@ -24,6 +24,7 @@
 // that levels 10-12 exist on the device path, bit-exact with libdeflate 1.10 (later versions
 // changed this parser: tests/golden/l1012_vectors.json is the v1.10 binary's output).
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include <cstring>
 
 #include "gzpx_device.h"
@@ -447,7 +448,10 @@ __device__ void no_optimize_block(NoLane &L, NoStats &st, NoNode *nodes, const u
 }  // namespace
 
 // One lane per block; a lane walks the blocks lane_id, + lanes in flight, ...
-__global__ __launch_bounds__(64) void k_near_optimal(Config cfg, const uint8_t *__restrict__ slab,
+#ifndef GZPX_NO_WAVES
+#define GZPX_NO_WAVES 1  // waves per SIMD the kernel is compiled for
+#endif
+__global__ __launch_bounds__(64, GZPX_NO_WAVES) void k_near_optimal(Config cfg, const uint8_t *__restrict__ slab,
                                                      BlockMeta *__restrict__ meta_all, SubMeta *__restrict__ sub_all,
                                                      uint32_t *__restrict__ tok_all, uint32_t nb, NoLane *lanes,
                                                      uint8_t *cache_all, uint8_t *nodes_all, size_t nodes_stride,
@@ -620,8 +624,17 @@ void launch_near_optimal_tables(void *lanes, uint32_t n_lanes, const uint8_t *d_
 
 void launch_near_optimal(const Config &cfg, const uint8_t *slab, uint32_t nb, const Scratch &s, hipStream_t stream) {
     const uint32_t n_lanes = s.no_lanes < nb ? s.no_lanes : nb;
-    hipLaunchKernelGGL(k_near_optimal, dim3((n_lanes + 63) / 64), dim3(64), 0, stream, cfg, slab, s.meta, s.sub, s.tok, nb,
-                       (NoLane *)s.no_state, s.no_cache, s.no_nodes, no_nodes_bytes(cfg.block_size), n_lanes);
+    // Blocks per wave: the lanes of a wave run different blocks, so the wave executes the union of their paths (tree
+    // walks of different depths, extension loops of different lengths).  The chip has far more wave slots than a slab
+    // has 64-block groups, so the blocks are spread over as many waves as there are slots -- 8,835 blocks = 9 per wave
+    // instead of 64: 91 -> 194 MiB/s at level 10 (16 per wave 149-169, 5 per wave -- a second round of waves -- 126).
+    const uint32_t slots = (cfg.n_cu ? cfg.n_cu : 256u) * 4u * GZPX_NO_WAVES;
+    uint32_t per_wave = (n_lanes + slots - 1) / slots;
+    if (const char *e = getenv("GZPX_NO_LANES_PER_WAVE")) per_wave = (uint32_t)atoi(e);  // (experiments)
+    if (per_wave < 1) per_wave = 1;
+    if (per_wave > 64) per_wave = 64;
+    hipLaunchKernelGGL(k_near_optimal, dim3((n_lanes + per_wave - 1) / per_wave), dim3(per_wave), 0, stream, cfg, slab, s.meta,
+                       s.sub, s.tok, nb, (NoLane *)s.no_state, s.no_cache, s.no_nodes, no_nodes_bytes(cfg.block_size), n_lanes);
 }
 
 }  // namespace gzpx
