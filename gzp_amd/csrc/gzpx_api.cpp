@@ -735,7 +735,7 @@ int ctx_create(const gzpx_config *cfg, bool crc_only, gzpx_ctx **out) {
     ctx->crc_consts.pow_small = x2k(17);  // x^(8 * 16384)
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, cfg->device) == hipSuccess) {
-        snprintf(ctx->devname, sizeof(ctx->devname), "%s (%s, %d CUs)", prop.name, prop.gcnArchName,
+        snprintf(ctx->devname, sizeof(ctx->devname), "%.150s (%.60s, %d CUs)", prop.name, prop.gcnArchName,
                  prop.multiProcessorCount);
         ctx->dcfg.n_cu = prop.multiProcessorCount > 0 ? (uint32_t)prop.multiProcessorCount : 0u;
     }

@@ -1,5 +1,5 @@
 // gzpx_kernels.hip -- hand-written HIP kernels (gfx950 / CDNA4) for gzp's per-block encode and
-// decode: libdeflate DEFLATE (levels 0-9) + CRC-32 + BGZF/Mgzip framing, and inflate with the
+// decode: libdeflate DEFLATE (levels 0-9; 10-12: gzpx_nearopt.hip) + CRC-32 + BGZF/Mgzip framing, and inflate with the
 // per-block CRC check; thousands of blocks per launch.
 //
 // What this replaces (reference file:line, relative to the gzp tree):
@@ -1929,7 +1929,7 @@ __global__ __launch_bounds__(kMpThreads, GZPX_PHC_WAVES) void k_parse_hc(
     __shared__ uint32_t first_evt;                  // first check that ends the sub-block or the checking
     __shared__ uint32_t chk_end[kHpMaxBins];        // end position of every check token
     __shared__ uint32_t split_pos;                  // where should_end_block ended the sub-block
-    __shared__ uint32_t s_next_check, s_num_obs, s_num_new, s_obs[10], s_new[10];
+    __shared__ uint32_t s_next_check, s_obs[10], s_new[10];
     __shared__ uint32_t used[8];
     const uint8_t *len8 = (const uint8_t *)len8_w;
     uint32_t *seg_exit = rank_pre;
@@ -1971,8 +1971,6 @@ __global__ __launch_bounds__(kMpThreads, GZPX_PHC_WAVES) void k_parse_hc(
     }
     if (tid == 0) {
         s_next_check = kNoCheckYet;
-        s_num_obs = 0;
-        s_num_new = 0;
         for (int k = 0; k < 10; k++) {
             s_obs[k] = 0;
             s_new[k] = 0;
@@ -2280,17 +2278,12 @@ __global__ __launch_bounds__(kMpThreads, GZPX_PHC_WAVES) void k_parse_hc(
                     // no split in this tile: the state after the last check (or at the point where
                     // checks stop for good -- what is carried then is never looked at again)
                     const uint32_t kk = fe != 0xFFFFFFFFu ? fe : n_checks;  // bins [0, kk) are merged
-                    uint32_t merged = 0, fresh = 0;
                     for (int c = 0; c < 10; c++) {
                         const uint32_t o = s_obs[c] + (kk > 0 ? s_new[c] : 0u) + cum[kk][c];
                         const uint32_t w = (kk < kHpMaxBins ? bins[kk][c] : 0u) + (kk == 0 ? s_new[c] : 0u);
                         s_obs[c] = o;
                         s_new[c] = w;
-                        merged += o;
-                        fresh += w;
                     }
-                    s_num_obs = merged;
-                    s_num_new = fresh;
                     s_next_check = fe != 0xFFFFFFFFu ? kNoMoreChecks : (nck0 < kNoMoreChecks ? nck0 + 512u * n_checks : nck0);
                 }
             }
@@ -2319,8 +2312,6 @@ __global__ __launch_bounds__(kMpThreads, GZPX_PHC_WAVES) void k_parse_hc(
                 sub[cur_sub].byte_len = bp - sub_start;
                 sub[cur_sub].is_final = 0;
                 s_next_check = kNoCheckYet;
-                s_num_obs = 0;
-                s_num_new = 0;
                 for (int k = 0; k < 10; k++) {
                     s_obs[k] = 0;
                     s_new[k] = 0;

@@ -43,7 +43,7 @@ extern "C" {
 #define GZPX_ERR_BLOCK_SIZE_EXCEEDED 5 /* GzpError::BlockSizeExceeded(c, 65536), src/bgzf.rs:218-223  */
 #define GZPX_ERR_DEVICE 6              /* HIP runtime error (the Io-like class)                       */
 #define GZPX_ERR_NO_DEVICE 7           /* no MI355X / HIP device: there is NO CPU fallback            */
-#define GZPX_ERR_UNSUPPORTED 8         /* valid in the reference, not built yet (levels 10-12, blocks > 16 MiB) */
+#define GZPX_ERR_UNSUPPORTED 8         /* valid in the reference, not built yet (blocks > 16 MiB) */
 #define GZPX_ERR_NUM_THREADS 9         /* GzpError::NumThreads(0), src/par/compress.rs:84-90          */
 #define GZPX_ERR_IO 10                 /* GzpError::Io: the wrapped writer failed                     */
 #define GZPX_ERR_CHANNEL 11            /* GzpError::ChannelSend/Receive: pipeline already closed      */
@@ -70,7 +70,9 @@ extern "C" {
 typedef struct gzpx_config {
     int device;                /* HIP device ordinal                                              */
     int format;                /* GZPX_FORMAT_*                                                   */
-    int level;                 /* flate2::Compression level (0..12 accepted by libdeflate; 0..9 built) */
+    int level;                 /* flate2::Compression level, 0..12 as libdeflate accepts (src/deflate.rs:596-599); 10..12: the near-optimal
+                                * parser as in libdeflate 1.10 -- later versions changed it, so at these levels the stream is valid
+                                * and pinned against 1.10, not claimed equal to 1.24's */
     int compat;                /* GZPX_COMPAT_*                                                   */
     size_t buffer_size;        /* ParCompressBuilder::buffer_size (65280 default for BGZF)        */
     size_t max_slab_bytes;     /* largest slab a single gzpx_compress_slab* call will be given    */

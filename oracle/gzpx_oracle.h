@@ -41,8 +41,10 @@ size_t gzpx_oracle_deflate_bound(size_t n);
 
 /*
  * Raw DEFLATE of in[0..n) at `level` (0 = stored only, 1 = "fastest" ht_matchfinder parse,
- * 2..4 = greedy hc_matchfinder parse).  Returns the number of bytes written to out, or 0 if
- * they do not fit in cap (libdeflate_deflate_compress semantics) or the level is unsupported.
+ * 2..4 = greedy hc_matchfinder parse, 5..9 = lazy / lazy2, 10..12 = the near-optimal parser as in
+ * libdeflate v1.10 -- later versions changed it: pinned for that version, tests/golden/l1012_vectors.json).
+ * Returns the number of bytes written to out, or 0 if they do not fit in cap
+ * (libdeflate_deflate_compress semantics) or the level is out of range.
  */
 size_t gzpx_oracle_deflate_compress(int level, int compat, const uint8_t *in, size_t n,
                                     uint8_t *out, size_t cap);
