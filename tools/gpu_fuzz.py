@@ -11,7 +11,7 @@ import numpy as np
 from gzp_amd import _native, synth
 
 
-def fuzz(lib, oracle, seed=12345, secs=None, max_cases=None, max_n=1_500_000, verbose=True, max_level=9):
+def fuzz(lib, oracle, seed=12345, secs=None, max_cases=None, max_n=1_500_000, verbose=True, max_level=9, min_level=0):
     """Returns (cases, failures); failures is a list of case tuples."""
     rng = np.random.default_rng(seed)
     classes = sorted(synth.CLASSES)
@@ -22,7 +22,7 @@ def fuzz(lib, oracle, seed=12345, secs=None, max_cases=None, max_n=1_500_000, ve
     dctx = {}
     while (t_end is None or time.time() < t_end) and (max_cases is None or cases < max_cases):
         cls = classes[rng.integers(len(classes))]
-        level = int(rng.integers(0, max_level + 1))
+        level = int(rng.integers(min_level, max_level + 1))
         fmt = int(rng.integers(0, 2))
         if fmt == 0:
             bs = int(rng.choice([65280, 65280, 32768 + int(rng.integers(0, 32000)), 40000]))

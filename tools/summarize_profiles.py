@@ -31,7 +31,7 @@ def find(dirname, suffix):
 
 
 shutil.copy(find("prof_%s" % tag, "kernel_stats.csv"), os.path.join(P, "%s_kernel_stats.csv" % tag))
-for extra in ("inflate", "bgzf3", "mgzip3", "bgzf6", "bgzf9"):  # ParDecompress; level-3 (hc) kernels; lazy parsers
+for extra in ("inflate", "bgzf3", "mgzip3", "bgzf6", "bgzf9", "bgzf12"):  # ParDecompress; level-3 (hc) kernels; lazy parsers
     try:
         shutil.copy(find("prof_%s_%s" % (tag, extra), "kernel_stats.csv"),
                     os.path.join(P, "%s_%s_kernel_stats.csv" % (tag, extra)))
