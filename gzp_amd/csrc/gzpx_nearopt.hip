@@ -60,6 +60,9 @@ struct NoMatch {
 struct NoNode {
     uint32_t cost_to_end, item;  // item: literal (byte << 9) | 1, match (offset << 9) | length
 };
+struct __attribute__((aligned(8))) NoKids {
+    int32_t x, y;  // a tree node's children: less-than side, greater-than side
+};
 
 }  // namespace
 
@@ -110,7 +113,17 @@ __device__ __forceinline__ uint32_t no_offset_slot(uint32_t off) {
     const uint32_t m = off - 1, hb = 31u - (uint32_t)__clz((int)m);
     return 2 * hb + ((m >> (hb - 1)) & 1u);
 }
+// lz_extend, four bytes per step (unaligned dword loads are fine in global memory; both pointers stay inside the block:
+// len + 4 <= max_len <= bytes left)
 __device__ uint32_t no_lz_extend(const uint8_t *a, const uint8_t *b, uint32_t len, uint32_t max_len) {
+    while (len + 4 <= max_len) {
+        uint32_t va, vb;
+        __builtin_memcpy(&va, a + len, 4);
+        __builtin_memcpy(&vb, b + len, 4);
+        const uint32_t x = va ^ vb;
+        if (x) return len + (((uint32_t)__ffs((int)x) - 1u) >> 3);
+        len += 4;
+    }
     while (len < max_len && a[len] == b[len]) len++;
     return len;
 }
@@ -176,6 +189,10 @@ __device__ NoMatch *no_bt_advance(NoLane &L, const uint8_t *in, uint32_t cur_pos
     for (;;) {
         const uint8_t *matchptr = in + cur_node;
         int32_t *node_children = &L.child[2 * ((uint32_t)cur_node & (kNoWindow - 1))];
+        // the node's two children are read NOW, beside its bytes (one round trip to HBM per node instead of two: the
+        // walk is a chain of dependent loads).  Nothing below writes this node's own slots before they are used: the
+        // pending pointers belong to nodes visited earlier, or to the position being inserted.
+        const NoKids kids = *(const NoKids *)node_children;
         if (matchptr[len] == in_next[len]) {
             len = no_lz_extend(in_next, matchptr, len + 1, max_len);
             if (!record || len > best_len) {
@@ -186,8 +203,8 @@ __device__ NoMatch *no_bt_advance(NoLane &L, const uint8_t *in, uint32_t cur_pos
                     mp++;
                 }
                 if (len >= nice_len) {
-                    *pending_lt = node_children[0];
-                    *pending_gt = node_children[1];
+                    *pending_lt = kids.x;
+                    *pending_gt = kids.y;
                     return mp;
                 }
             }
@@ -195,13 +212,13 @@ __device__ NoMatch *no_bt_advance(NoLane &L, const uint8_t *in, uint32_t cur_pos
         if (matchptr[len] < in_next[len]) {
             *pending_lt = cur_node;
             pending_lt = node_children + 1;
-            cur_node = *pending_lt;
+            cur_node = kids.y;
             best_lt_len = len;
             if (best_gt_len < len) len = best_gt_len;
         } else {
             *pending_gt = cur_node;
             pending_gt = node_children;
-            cur_node = *pending_gt;
+            cur_node = kids.x;
             best_gt_len = len;
             if (best_lt_len < len) len = best_lt_len;
         }
