@@ -281,6 +281,13 @@ def builder_errors(lib):
     with pytest.raises(par.GzpError) as e:
         par.ParCompressBuilder(par.Bgzf, lib=lib).compression_level(13).from_writer(io.BytesIO())
     assert e.value.code == _native.ERR_COMPRESSION_LEVEL
+    # every level CompressionLvl accepts (src/deflate.rs:596-599), the near-optimal ones included
+    a12 = synth.make("text", 70000, 12)
+    sink12 = io.BytesIO()
+    w12 = par.ParCompressBuilder(par.Bgzf, lib=lib).compression_level(12).from_writer(sink12)
+    w12.write_all(a12)
+    w12.finish()
+    assert gzip.decompress(sink12.getvalue()) == a12.tobytes()
     with pytest.raises(par.GzpError) as e:  # valid in gzp, not built (blocks above 16 MiB): never a CPU fallback
         par.ParCompressBuilder(par.Mgzip, lib=lib).buffer_size((16 << 20) + 1).from_writer(io.BytesIO())
     assert e.value.code == _native.ERR_UNSUPPORTED
