@@ -24,7 +24,6 @@
 // that levels 10-12 exist on the device path, bit-exact with libdeflate 1.10 (later versions
 // changed this parser: tests/golden/l1012_vectors.json is the v1.10 binary's output).
 #include <hip/hip_runtime.h>
-#include <cstdlib>
 #include <cstring>
 
 #include "gzpx_device.h"
@@ -647,7 +646,6 @@ void launch_near_optimal(const Config &cfg, const uint8_t *slab, uint32_t nb, co
     // instead of 64: 91 -> 194 MiB/s at level 10 (16 per wave 149-169, 5 per wave -- a second round of waves -- 126).
     const uint32_t slots = (cfg.n_cu ? cfg.n_cu : 256u) * 4u * GZPX_NO_WAVES;
     uint32_t per_wave = (n_lanes + slots - 1) / slots;
-    if (const char *e = getenv("GZPX_NO_LANES_PER_WAVE")) per_wave = (uint32_t)atoi(e);  // (experiments)
     if (per_wave < 1) per_wave = 1;
     if (per_wave > 64) per_wave = 64;
     hipLaunchKernelGGL(k_near_optimal, dim3((n_lanes + per_wave - 1) / per_wave), dim3(per_wave), 0, stream, cfg, slab, s.meta,
