@@ -1627,14 +1627,22 @@ __device__ uint32_t hc_calc_min_len(const Config &cfg, const uint8_t *in, uint32
     return short_scan ? 3u : hc_choose_min_len(num_used, cfg.hc_depth);
 }
 
-// lz_extend for k_match_hc: 16 bytes per round.  Every round of the loop waits for its LDS reads
-// before it knows whether there is another, and the wave pays for its longest lane, so a round
-// fetches five dwords per side at once and most matches end in the first (level 3: 22.3 -> 19.4 ms
-// of match + parse on 512 MiB of text).
-__device__ __forceinline__ uint32_t lds_extend16(const uint32_t *in_w, uint32_t a, uint32_t c, uint32_t max_len) {
-    uint32_t len = 4;  // (max_len >= 5 here)
+// lz_extend for the chain walk: bytes [0, start) of the two strings at LDS byte addresses a / c are known
+// to be equal; returns the length of their common prefix, at most max_len (start <= max_len).  The first round
+// compares four bytes -- most matches of the bench text end there -- and every later one sixteen (five
+// dwords per side at once: a round waits for its LDS reads before it knows whether there is another, and
+// the wave pays for its longest lane).  One exit per loop, no break: every extra way out of a divergent loop
+// costs scalar mask bookkeeping per round.
+__device__ __forceinline__ uint32_t lds_extend_from(const uint32_t *in_w, uint32_t a, uint32_t c, uint32_t start,
+                                                    uint32_t max_len) {
+    uint32_t len = start;
+    {
+        const uint32_t x = lds_le32(in_w, a + len) ^ lds_le32(in_w, c + len);
+        len += x ? ((uint32_t)(__ffs((int)x) - 1) >> 3) : 4u;
+        if (x != 0 || len >= max_len) return len < max_len ? len : max_len;
+    }
     bool more;
-    do {  // one exit, no break: every extra way out of a divergent loop costs scalar mask bookkeeping per round
+    do {
         const uint32_t aa = a + len, cc = c + len;
         const uint32_t *pa = in_w + (aa >> 2), *pc = in_w + (cc >> 2);
         const uint32_t a0 = pa[0], a1 = pa[1], a2 = pa[2], a3 = pa[3], a4 = pa[4];
@@ -1652,121 +1660,99 @@ __device__ __forceinline__ uint32_t lds_extend16(const uint32_t *in_w, uint32_t 
     return len < max_len ? len : max_len;
 }
 
+// A staged d4 link that says "no live predecessor" (k_candidates writes 0): any distance above 32767 ends
+// a walk, so the test for the end of the chain and the test for the window are one comparison.
+constexpr uint32_t kHcNoLink = 0x8000u;
+
 // hc_matchfinder_longest_match (started from best_len = 2) for the position at LDS byte address a /
-// link index li, as ONE loop with one chain node per iteration.  libdeflate's two loops ("first
-// node whose 4 bytes match", then "a node longer than best_len") differ only in the byte offset
-// of the pre-filter word -- 0 while best_len < 4, best_len - 3 after -- and every node costs one
-// unit of depth in both, so the lanes of a wave, which sit in different phases, share the loop
-// instead of waiting for each other's.
-//   Measured on the way (level 3 match + parse on 512 MiB of text): fewer LDS reads per node at the
-//   price of more arithmetic (a partial compare of the node's first aligned dword) 22.1 -> 24.0 ms;
-//   one exit per loop instead of breaks 22.3 -> 17.0 ms (the scalar mask bookkeeping of every extra
-//   way out was most of a node's cost); two positions per lane (hc_search_pair) about even on text,
-//   -9 % on configs[2]'s ASCII noise and at level 9, where the walk is mostly latency.
+// link index li: ONE loop with one chain node per iteration.  libdeflate's two loops ("first node whose
+// 4 bytes match", then "a node longer than best_len") differ only in the byte offset of the pre-filter
+// word -- 0 while best_len < 4, best_len - 3 after -- and every node costs one unit of depth in both, so
+// the lanes of a wave, which sit in different phases, share the loop instead of waiting for each other's.
+//   Round 4: the instructions of a node and of a hit are what bounds the kernel (VALU and SALU issue at four
+//   waves per SIMD; tools/exp_hc_bounds.py on the round-3 form: 11 more nodes 2.4 ms, the hits without their
+//   extension 4.7 ms, the extension 2.6 ms of 16.2), so both are cut to the bone:
+//   * a node is its link read, its pre-filter word and three additions -- `tot`, the distance to the node,
+//     is the only walk state, "chain over" / "window left" / "nice_len reached" are all `tot > 32767`;
+//   * a hit behind the first one (the pre-filter word at best_len - 3 and the first four bytes equal) with
+//     best_len <= 7 has bytes [0, best_len + 1) equal -- the two words overlap -- so it IS longer and its
+//     extension starts at best_len + 1, usually one four-byte round; only longer best_len (a gap between
+//     the two words) extends from 4 like lz_extend does.  Same result: a candidate only ever matters
+//     through `len > best_len`;
+//   * one position per lane (round 3 walked two together to have two LDS reads in flight: with a node down
+//     to a dozen instructions four waves per SIMD cover the read, and the flags that let two chains share
+//     a loop cost more than they hid).
 //   NV > 1 (the lazy parsers): the searches with depth >> 1 (and >> 2) visit the same nodes in the
 //   same order and just stop earlier, so their results are this search's best match at the moment
 //   the smaller budget runs out: one stretch of the walk per variant, shortest budget first (if the
 //   walk died before a budget ran out nothing changes any more, and that is the final match as well).
-//   Two positions per lane, walked together: a node is a dependent LDS read (link, then bytes), and one
-// workgroup per CU leaves four waves per SIMD to hide it -- so a lane keeps two independent chains in
-// flight and issues both nodes' reads before it looks at either.  Both chains spend the same depth
-// budget (one node per round while alive), so the depth counter stays one scalar.
 template <int NV>
-__device__ __forceinline__ void hc_search_pair(const uint32_t *in_w, const uint16_t *link, const uint32_t (&a)[2],
-                                               const uint32_t (&li)[2], const uint32_t (&d3v)[2],
-                                               const uint32_t (&max_len)[2], const uint32_t (&nice_len)[2],
-                                               const uint32_t depth0, uint32_t (&len_out)[2][NV],
-                                               uint32_t (&dist_out)[2][NV], const uint32_t dbg = 0) {
-    uint32_t best_len[2], best_dist[2], seq4[2], tot[2], off[2], mine[2];
-    bool alive[2];
-#pragma unroll
-    for (int c = 0; c < 2; c++) {
-        best_len[c] = 2;
-        best_dist[c] = 0;
-        off[c] = 0;
-        tot[c] = 0;
-        alive[c] = false;
-        seq4[c] = lds_le32(in_w, a[c]);
-        mine[c] = seq4[c];
-        if (d3v[c] != 0) {  // (an empty hash3 bucket ends the search before the hash4 chain is looked at)
-            if (((lds_le32(in_w, a[c] - d3v[c]) ^ seq4[c]) & 0xFFFFFFu) == 0) {
-                best_len[c] = 3;
-                best_dist[c] = d3v[c];
-            }
-            const uint32_t t = link[li[c]];  // distance to the chain's next node (0: none); alive while <= 32767
-            alive[c] = t != 0 && t <= 32767u;
-            tot[c] = alive[c] ? t : 0u;  // (a dead chain keeps reading its own position: inside the window)
+__device__ __forceinline__ void hc_search(const uint32_t *in_w, const uint16_t *link, const uint32_t a,
+                                          const uint32_t li, const uint32_t d3v, const uint32_t max_len,
+                                          const uint32_t nice_len, const uint32_t depth0, uint32_t (&len_out)[NV],
+                                          uint32_t (&dist_out)[NV], const uint32_t dbg = 0) {
+    const uint32_t seq4 = lds_le32(in_w, a);
+    uint32_t best_len = 2, best_dist = 0;
+    uint32_t aoff = a;     // a + best_len - 3 once a node of the chain has matched (pre-filter address), a before
+    uint32_t mine = seq4;  // the word at aoff
+    uint32_t tot = kHcNoLink;  // distance to the node looked at next; > 32767: the walk is over
+    if (d3v != 0) {  // (an empty hash3 bucket ends the search before the hash4 chain is looked at)
+        if (((lds_le32(in_w, a - d3v) ^ seq4) & 0xFFFFFFu) == 0) {
+            best_len = 3;
+            best_dist = d3v;
         }
+        tot = link[li];
     }
-    uint32_t depth = depth0;
+    uint32_t depth = depth0;  // (uniform: a round costs every lane that is still walking one unit)
 #pragma unroll
     for (int v = NV - 1; v >= 0; v--) {
         const uint32_t stop = v ? depth0 - (depth0 >> v) : 0u;
-        bool go = (alive[0] || alive[1]) && depth != stop;
-        while (go) {  // (one way out, flags instead of breaks: see lds_extend16)
-            uint32_t ca[2], nxt[2], w[2];
-#pragma unroll
-            for (int c = 0; c < 2; c++) {  // every read of this round
-                ca[c] = a[c] - tot[c];
-                nxt[c] = link[li[c] - tot[c]];
-                w[c] = lds_le32(in_w, ca[c] + off[c]);
-            }
-#pragma unroll
-            for (int c = 0; c < 2; c++) {
-                bool hit = alive[c] && w[c] == mine[c];  // (libdeflate's order: the selective word first)
+        bool go = tot <= 32767u && depth != stop;
+        while (go) {  // (one way out, a flag instead of breaks)
+            const uint32_t nxt = link[li - tot];
+            const uint32_t w = lds_le32(in_w, aoff - tot);
+            bool hit = w == mine;
 #ifdef GZPX_EXPERIMENT
-                if ((dbg >> 11) & 1u) hit = false;
+            if ((dbg >> 11) & 1u) hit = false;
 #endif
-                if (hit && off[c]) hit = lds_le32(in_w, ca[c]) == seq4[c];
+            uint32_t next_tot = tot + nxt;
+            if (hit) {
+                const uint32_t ca = a - tot;
+                uint32_t start = 4;
+                if (aoff != a) {  // behind the first hit: the first four bytes are a second test
+                    hit = lds_le32(in_w, ca) == seq4;
+                    start = best_len <= 7u ? best_len + 1u : 4u;
+                }
                 if (hit) {
 #ifdef GZPX_EXPERIMENT
-                    const uint32_t len = ((dbg >> 10) & 1u) ? (best_len[c] + 1 < max_len[c] ? best_len[c] + 1 : max_len[c])
-                                                            : lds_extend16(in_w, a[c], ca[c], max_len[c]);
+                    const uint32_t len = ((dbg >> 10) & 1u) ? (best_len + 1 < max_len ? best_len + 1 : max_len)
+                                                            : lds_extend_from(in_w, a, ca, start, max_len);
 #else
-                    const uint32_t len = lds_extend16(in_w, a[c], ca[c], max_len[c]);
+                    const uint32_t len = lds_extend_from(in_w, a, ca, start, max_len);
 #endif
-                    if (len > best_len[c]) {
-                        best_len[c] = len;
-                        best_dist[c] = tot[c];
-                        alive[c] = best_len[c] < nice_len[c];
-                        off[c] = best_len[c] - 3u;
-                        mine[c] = lds_le32(in_w, a[c] + off[c]);
+                    if (len > best_len) {
+                        best_len = len;
+                        best_dist = tot;
+                        aoff = a + len - 3u;
+                        mine = lds_le32(in_w, aoff);
+                        if (len >= nice_len) next_tot = kHcNoLink;
                     }
                 }
-                const uint32_t t = tot[c] + nxt[c];
-                alive[c] = alive[c] && nxt[c] != 0 && t <= 32767u;
-                tot[c] = alive[c] ? t : 0u;
             }
+            tot = next_tot;
             --depth;
-            go = (alive[0] || alive[1]) && depth != stop;
+            go = tot <= 32767u && depth != stop;
         }
-#pragma unroll
-        for (int c = 0; c < 2; c++) {
-            len_out[c][v] = best_len[c];
-            dist_out[c][v] = best_dist[c];
-        }
+        len_out[v] = best_len;
+        dist_out[v] = best_dist;
     }
 }
 
-// The two positions a lane searches together: p0 and p0 + 1024.  One past the tile, or with fewer
-// than 5 bytes left (hc_matchfinder_longest_match bails out), idles: d3v = 0, addresses of p0.
-__device__ __forceinline__ void hc_pair_setup(uint32_t p0, uint32_t tile_end, uint32_t n, uint32_t win_begin,
-                                              uint32_t mis, uint32_t nice_level, const uint16_t *d3,
-                                              uint32_t (&a)[2], uint32_t (&li)[2], uint32_t (&d3v)[2],
-                                              uint32_t (&max_len)[2], uint32_t (&nice_len)[2], bool (&ok)[2]) {
-#pragma unroll
-    for (int c = 0; c < 2; c++) {
-        const uint32_t p = p0 + 1024u * c;
-        ok[c] = p < tile_end && p + 5 <= n;
-        const uint32_t q = ok[c] ? p : p0;  // (p0 < tile_end <= n: inside the window)
-        const uint32_t rem = n - q;
-        max_len[c] = rem < 258u ? rem : 258u;
-        nice_len[c] = max_len[c] < nice_level ? max_len[c] : nice_level;
-        a[c] = q - win_begin + mis;
-        li[c] = q - win_begin;
-        d3v[c] = ok[c] ? d3[p] : 0u;
-    }
-}
+// One workgroup's LDS as ONE array, the window of input bytes first: the byte reads of the walk then
+// address LDS from 0 (an immediate offset, no addition per read) and the links sit within the 16-bit
+// offset field of ds_read_u16.
+constexpr uint32_t kHcLinkWords = (32768 + kHcTile) / 2;  // d4 of every position in the window (u16)
+constexpr uint32_t kHcLdsWords = kHcInWords + kHcLinkWords + kHcTile / 32;
 
 __global__ __launch_bounds__(1024) void k_match_hc(Config cfg, const uint8_t *__restrict__ slab,
                                                    const BlockMeta *__restrict__ meta_all,
@@ -1778,10 +1764,10 @@ __global__ __launch_bounds__(1024) void k_match_hc(Config cfg, const uint8_t *__
                                                    uint16_t *__restrict__ dist_all,
                                                    uint8_t *__restrict__ lz_len_all,
                                                    uint16_t *__restrict__ lz_dist_all) {
-    __shared__ uint32_t in_w[kHcInWords];                // 48 KiB window of the block's bytes
-    __shared__ uint32_t link_w[(32768 + kHcTile) / 2];  // d4 of every position in the window (u16)
-    __shared__ uint32_t mbits[kHcTile / 32];
-    __shared__ uint32_t used[8];
+    __shared__ uint32_t hc_lds[kHcLdsWords];
+    uint32_t *in_w = hc_lds;                     // 48 KiB window of the block's bytes
+    uint32_t *link_w = hc_lds + kHcInWords;      // d4 of every position in the window
+    uint32_t *mbits = link_w + kHcLinkWords;
     const uint16_t *link = (const uint16_t *)link_w;
     const uint32_t tid = threadIdx.x;
     const uint32_t b = blockIdx.x;
@@ -1802,7 +1788,6 @@ __global__ __launch_bounds__(1024) void k_match_hc(Config cfg, const uint8_t *__
     // applies `len >= min_len`; a sub-block with another min_len re-parses, it does not re-match.
     const uint32_t resume = st->resume_pos;
     const uint32_t min_len = 3;
-    (void)used;
     const uint32_t nice_level = cfg.hc_nice, depth = GZPX_EXP(cfg, 12) ? 1u : cfg.hc_depth;
 
     for (uint32_t tile_begin = resume / kHcTile * kHcTile; tile_begin < n; tile_begin += kHcTile) {
@@ -1818,60 +1803,60 @@ __global__ __launch_bounds__(1024) void k_match_hc(Config cfg, const uint8_t *__
             for (uint32_t i = ndw + tid; i < ndw + 3 && i < kHcInWords; i += 1024) in_w[i] = 0;
             // win_begin is a multiple of 16384 and the stride of 1024: dword-aligned u16 pairs
             const uint32_t *lsrc = (const uint32_t *)(d4 + win_begin);
-            for (uint32_t i = tid; i < (tile_end - win_begin + 1) / 2; i += 1024) link_w[i] = lsrc[i];
+            for (uint32_t i = tid; i < (tile_end - win_begin + 1) / 2; i += 1024) {
+                uint32_t v = lsrc[i];  // two links; 0 = none
+                if ((v & 0xFFFFu) == 0) v |= kHcNoLink;
+                if ((v >> 16) == 0) v |= kHcNoLink << 16;
+                link_w[i] = v;
+            }
             for (uint32_t i = tid; i < kHcTile / 32; i += 1024) mbits[i] = 0;
         }
+        // the hash3 distance of a lane's next position travels while it searches the current one
+        uint32_t d3_next = tile_begin + tid + 5 <= n && tile_begin + tid < tile_end ? d3[tile_begin + tid] : 0u;
         __syncthreads();
-        if (cfg.lazy) {
-            // Levels 5-9: the lazy parsers search a position up to three times -- where a decision
-            // starts (full depth), as the position after a match (half), as the one after that
-            // (lazy2: a quarter) -- from best_len = min_len - 1 or the current match's length - 1.
-            // By the argument above each is the min_len-3 search of that depth plus a filter, so all
-            // two / three are computed here for every position and k_parse_lazy picks.  No length-3
-            // distance rule: the parser applies its own (8192, first search only).
-            uint8_t *lzl = lz_len_all + (uint64_t)b * 2u * cfg.stride;
-            uint16_t *lzd = lz_dist_all + (uint64_t)b * 2u * cfg.stride;
-            for (uint32_t p0 = tile_begin + tid; p0 < tile_end; p0 += 2048) {
-                uint32_t a[2], li[2], d3v[2], max_len[2], nice_len[2], len[2][3], dst[2][3];
-                bool ok[2];
-                hc_pair_setup(p0, tile_end, n, win_begin, mis, nice_level, d3, a, li, d3v, max_len, nice_len, ok);
-                hc_search_pair<3>(in_w, link, a, li, d3v, max_len, nice_len, depth, len, dst, cfg.debug);
-#pragma unroll
-                for (int c = 0; c < 2; c++) {
-                    const uint32_t p = p0 + 1024u * c;
-                    if (p >= tile_end) continue;
-                    for (uint32_t v = 0; v <= cfg.lazy; v++) {
-                        const bool have = ok[c] && len[c][v] >= 3u;
-                        uint8_t *lo = v == 0 ? len8 : lzl + (uint64_t)(v - 1) * cfg.stride;
-                        uint16_t *dd = v == 0 ? dist : lzd + (uint64_t)(v - 1) * cfg.stride;
-                        lo[p] = (uint8_t)(have ? len[c][v] - 3u : 0u);
-                        dd[p] = (uint16_t)(have ? dst[c][v] : 0u);
-                    }
+        uint8_t *lzl = lz_len_all + (uint64_t)b * 2u * cfg.stride;
+        uint16_t *lzd = lz_dist_all + (uint64_t)b * 2u * cfg.stride;
+        for (uint32_t p = tile_begin + tid; p < tile_end; p += 1024) {
+            // with fewer than 5 bytes left hc_matchfinder_longest_match bails out: d3v = 0 idles the search
+            const uint32_t d3v = d3_next;
+            const uint32_t pn = p + 1024u;
+            d3_next = pn + 5 <= n && pn < tile_end ? d3[pn] : 0u;
+            const uint32_t rem = n - p;
+            const uint32_t max_len = rem < 258u ? rem : 258u;
+            const uint32_t nice_len = max_len < nice_level ? max_len : nice_level;
+            const uint32_t a = p - win_begin + mis, li = p - win_begin;
+            if (cfg.lazy) {  // (uniform)
+                // Levels 5-9: the lazy parsers search a position up to three times -- where a decision
+                // starts (full depth), as the position after a match (half), as the one after that
+                // (lazy2: a quarter) -- from best_len = min_len - 1 or the current match's length - 1.
+                // By the argument above each is the min_len-3 search of that depth plus a filter, so all
+                // two / three are computed here for every position and k_parse_lazy picks.  No length-3
+                // distance rule: the parser applies its own (8192, first search only).
+                uint32_t len[3], dst[3];
+                hc_search<3>(in_w, link, a, li, d3v, max_len, nice_len, depth, len, dst, cfg.debug);
+                for (uint32_t v = 0; v <= cfg.lazy; v++) {
+                    const bool have = len[v] >= 3u;
+                    uint8_t *lo = v == 0 ? len8 : lzl + (uint64_t)(v - 1) * cfg.stride;
+                    uint16_t *dd = v == 0 ? dist : lzd + (uint64_t)(v - 1) * cfg.stride;
+                    lo[p] = (uint8_t)(have ? len[v] - 3u : 0u);
+                    dd[p] = (uint16_t)(have ? dst[v] : 0u);
                 }
+                continue;
             }
-            continue;  // (uniform; the next tile's loads start behind a barrier)
-        }
-        for (uint32_t p0 = tile_begin + tid; p0 < tile_end; p0 += 2048) {
-            uint32_t a[2], li[2], d3v[2], max_len[2], nice_len[2], ln[2][1], ds[2][1];
-            bool ok[2];
-            hc_pair_setup(p0, tile_end, n, win_begin, mis, nice_level, d3, a, li, d3v, max_len, nice_len, ok);
-            hc_search_pair<1>(in_w, link, a, li, d3v, max_len, nice_len, depth, ln, ds, cfg.debug);
-#pragma unroll
-            for (int c = 0; c < 2; c++) {
-                const uint32_t p = p0 + 1024u * c;
-                if (p >= tile_end) continue;
-                const uint32_t len = ok[c] ? ln[c][0] : 0u, dst = ds[c][0];
-                // deflate_compress_greedy: a length-3 match is only worth it at a short distance
-                const bool take = len >= min_len && (len > 3 || dst <= 4096u);
-                len8[p] = (uint8_t)(take ? len - 3 : 0);
-                // val: the match distance, or the literal byte (what k_parse_hc's token needs either way)
-                dist[p] = (uint16_t)(take ? dst : lds_le32(in_w, p - win_begin + mis) & 0xFFu);
-                if (take) {
-                    const uint32_t r = p - tile_begin;
-                    atomicOr(&mbits[r >> 5], 1u << (r & 31u));
-                }
+            uint32_t ln[1], ds[1];
+            hc_search<1>(in_w, link, a, li, d3v, max_len, nice_len, depth, ln, ds, cfg.debug);
+            const uint32_t len = ln[0], dst = ds[0];
+            // deflate_compress_greedy: a length-3 match is only worth it at a short distance
+            const bool take = len >= min_len && (len > 3 || dst <= 4096u);
+            len8[p] = (uint8_t)(take ? len - 3 : 0);
+            // val: the match distance, or the literal byte (what k_parse_hc's token needs either way)
+            dist[p] = (uint16_t)(take ? dst : lds_le32(in_w, a) & 0xFFu);
+            if (take) {
+                const uint32_t r = p - tile_begin;
+                atomicOr(&mbits[r >> 5], 1u << (r & 31u));
             }
         }
+        if (cfg.lazy) continue;  // (uniform; the next tile's loads start behind a barrier)
         __syncthreads();
         for (uint32_t i = tid; i < (tile_end - tile_begin + 31) / 32; i += 1024)
             mbits_out[tile_begin / 32 + i] = mbits[i];
