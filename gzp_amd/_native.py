@@ -36,6 +36,7 @@ FORMAT_BGZF = 0
 FORMAT_MGZIP = 1
 COMPAT_1_24 = 0
 COMPAT_1_10 = 1
+STREAM_NONE = ctypes.c_void_p(-1).value  # GZPX_STREAM_NONE: the caller has synchronized, no stream dependency
 N_STAGES = 9
 
 EXPORTS = [
@@ -55,7 +56,7 @@ EXPORTS = [
     "gzpx_free_decompressor", "gzpx_pard_create", "gzpx_pard_read", "gzpx_pard_destroy",
     "gzpx_pard_last_error", "gzpx_host_alloc", "gzpx_host_free", "gzpx_dctx_last_inflate_ms",
     "gzpx_debug_inflate", "gzpx_synth_fastq_device", "gzpx_synth_ascii_device",
-    "gzpx_multi_create", "gzpx_multi_destroy", "gzpx_multi_devices", "gzpx_multi_compress_slab",
+    "gzpx_ctx_active_compat", "gzpx_multi_create", "gzpx_multi_destroy", "gzpx_multi_devices", "gzpx_multi_compress_slab",
     "gzpx_multi_shard", "gzpx_multi_compress_slab_device",
 ]
 
@@ -114,6 +115,8 @@ class GzpxLib:
         L.gzpx_ctx_destroy.argtypes = [vp]
         L.gzpx_slab_bound.restype = sz
         L.gzpx_slab_bound.argtypes = [vp, sz]
+        L.gzpx_ctx_active_compat.restype = i32
+        L.gzpx_ctx_active_compat.argtypes = [vp]
         L.gzpx_compress_slab.restype = i32
         L.gzpx_compress_slab.argtypes = [vp, vp, sz, i32, vp, sz, psz, vp, sz, psz]
         L.gzpx_compress_slab_device.restype = i32
@@ -313,6 +316,10 @@ class Context:
 
     def slab_bound(self, n):
         return int(self.lib.L.gzpx_slab_bound(self.h, n))
+
+    def active_compat(self):
+        """The GZPX_COMPAT_* rules the context really runs (levels 10-12: always the 1.10 ones)."""
+        return int(self.lib.L.gzpx_ctx_active_compat(self.h))
 
     def n_blocks(self, n):
         return 1 if n == 0 else -(-n // self.buffer_size)

@@ -184,16 +184,32 @@ int alloc_scratch(gzpx_ctx *ctx) {
         // levels 10-12: one lane per block in flight, each with its trees / cache / path nodes (gzpx_nearopt.hip);
         // as many as half the free HBM holds, 96 GiB at most (a BGZF block: 7.5 MiB); the lanes walk the batch's blocks
         const size_t per_lane = no_lane_bytes() + no_cache_bytes() + no_nodes_bytes(c.block_size);
+        // (never more than half of what is free right now; if an allocation still fails -- fragmentation, another
+        // context growing meanwhile -- the lane count is halved and tried again: fewer lanes are slower, not wrong)
         size_t free_b = 0, total_b = 0, budget = (size_t)12 << 30;
-        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b / 2 > budget)
-            budget = free_b / 2 < ((size_t)96 << 30) ? free_b / 2 : ((size_t)96 << 30);  // (288 GB of HBM: up to 96 GiB of it)
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+            if (free_b / 2 > budget) budget = free_b / 2 < ((size_t)96 << 30) ? free_b / 2 : ((size_t)96 << 30);  // (288 GB of HBM: up to 96 GiB of it)
+            if (free_b / 2 < budget) budget = free_b / 2;
+        }
         size_t lanes = budget / per_lane;
         if (lanes > nb) lanes = nb;
         if (lanes < 1) lanes = 1;
+        for (;;) {
+            const bool ok = hipMalloc(&s.no_state, lanes * no_lane_bytes()) == hipSuccess &&
+                            hipMalloc((void **)&s.no_cache, lanes * no_cache_bytes()) == hipSuccess &&
+                            hipMalloc((void **)&s.no_nodes, lanes * no_nodes_bytes(c.block_size)) == hipSuccess;
+            if (ok) break;
+            (void)hipGetLastError();
+            if (s.no_state) (void)hipFree(s.no_state);
+            if (s.no_cache) (void)hipFree(s.no_cache);
+            if (s.no_nodes) (void)hipFree(s.no_nodes);
+            s.no_state = nullptr;
+            s.no_cache = nullptr;
+            s.no_nodes = nullptr;
+            if (lanes == 1) return GZPX_ERR_DEVICE;
+            lanes = (lanes + 1) / 2;
+        }
         s.no_lanes = (uint32_t)lanes;
-        HIP_TRY(hipMalloc(&s.no_state, lanes * no_lane_bytes()));
-        HIP_TRY(hipMalloc((void **)&s.no_cache, lanes * no_cache_bytes()));
-        HIP_TRY(hipMalloc((void **)&s.no_nodes, lanes * no_nodes_bytes(c.block_size)));
         // libdeflate's default_litlen_costs[]: int(-log2((1 - p) / max(j, 1)) * 16), int(-log2(p / 29) * 16)
         uint8_t tables[3 * 258];
         static const double probs[3] = {0.25, 0.5, 0.75};
@@ -203,10 +219,13 @@ int alloc_scratch(gzpx_ctx *ctx) {
         }
         uint8_t *d_tables = nullptr;
         HIP_TRY(hipMalloc((void **)&d_tables, sizeof(tables)));
-        HIP_TRY(hipMemcpy(d_tables, tables, sizeof(tables), hipMemcpyHostToDevice));
-        launch_near_optimal_tables(s.no_state, s.no_lanes, d_tables, nullptr);
-        HIP_TRY(hipDeviceSynchronize());
-        (void)hipFree(d_tables);
+        hipError_t te = hipMemcpy(d_tables, tables, sizeof(tables), hipMemcpyHostToDevice);
+        if (te == hipSuccess) {
+            launch_near_optimal_tables(s.no_state, s.no_lanes, d_tables, nullptr);
+            te = hipDeviceSynchronize();
+        }
+        (void)hipFree(d_tables);  // (on every path)
+        HIP_TRY(te);
     }
     HIP_TRY(hipMalloc((void **)&s.hist, nb * (size_t)c.max_sub * kHistStride * 4));
     HIP_TRY(hipMalloc((void **)&s.codes, nb * (size_t)c.max_sub * kCodeWords * 4));
@@ -524,7 +543,7 @@ int submit_enqueue(gzpx_ctx *ctx, const uint8_t *host_in, const uint8_t *d_in, s
         d_in = sl.d_in;
         d_out = sl.d_out;
         out_cap = sl.d_out_cap;
-    } else if (after != stream) {  // the slab is ready once `after` has reached this point; NULL is the
+    } else if (after != stream && after != (hipStream_t)GZPX_STREAM_NONE) {  // the slab is ready once `after` has reached this point; NULL is the
         // legacy default stream (PyTorch's current stream unless told otherwise) -- the context's
         // streams are non-blocking, so nothing orders them behind it implicitly
         HIP_TRY(hipEventRecord(ctx->ev_dep, after));
@@ -708,7 +727,10 @@ int ctx_create(const gzpx_config *cfg, bool crc_only, gzpx_ctx **out) {
     ctx->crc_only = crc_only;
     ctx->dcfg.format = (uint32_t)cfg->format;
     ctx->dcfg.level = (uint32_t)cfg->level;
-    ctx->dcfg.compat = (uint32_t)cfg->compat;
+    // Levels 10-12 are libdeflate 1.10's near-optimal parser (1.24 changed it; there is nothing here to pin a port of
+    // the later parser on): the 1.10 rules go with it WHATEVER the caller asked for, so the stream is exactly the
+    // 1.10 binary's and never a hybrid of two versions.  gzpx_ctx_active_compat() tells which rules a context runs.
+    ctx->dcfg.compat = (uint32_t)(cfg->level >= 10 ? GZPX_COMPAT_LIBDEFLATE_1_10 : cfg->compat);
     ctx->dcfg.block_size = (uint32_t)cfg->buffer_size;
     ctx->dcfg.xfl = cfg->level >= 9 ? 2u : cfg->level <= 1 ? 4u : 0u;  // src/bgzf.rs:278-284
     ctx->dcfg.debug = 0;
@@ -794,6 +816,8 @@ void gzpx_ctx_destroy(gzpx_ctx *ctx) {
     if (ctx->s_d2h) (void)hipStreamDestroy(ctx->s_d2h);
     delete ctx;
 }
+
+int gzpx_ctx_active_compat(const gzpx_ctx *ctx) { return ctx ? (int)ctx->dcfg.compat : GZPX_ERR_INVALID_ARG; }
 
 size_t gzpx_slab_bound(const gzpx_ctx *ctx, size_t in_len) {
     if (!ctx) return 0;
@@ -1034,7 +1058,7 @@ int gzpx_multi_compress_slab_device(gzpx_multi *m, const void *const *d_in, size
             m->d_stage_cap[g] = need + need / 8 + 4096;
         }
         rc = submit_locked(ctx, nullptr, (const uint8_t *)d_in[g], p.r.n, owns_end ? mode : GZPX_SLAB_FULL_BLOCKS, nullptr,
-                           m->d_stage[g], m->d_stage_cap[g], nullptr, true, lk, &p.ticket);
+                           m->d_stage[g], m->d_stage_cap[g], (hipStream_t)GZPX_STREAM_NONE, true, lk, &p.ticket);  // (the caller's contract: the ranges are ready)
         p.submitted = rc == GZPX_OK;
     }
     // 2. shard sizes -> stream offsets
@@ -1380,10 +1404,32 @@ struct gzpx_dctx {
 
 namespace {
 
+int dsubmit_enqueue(gzpx_dctx *c, const uint8_t *host_in, const uint8_t *d_in, size_t in_len,
+                    const uint64_t *offsets, const uint32_t *sizes, size_t nb, uint8_t *host_out, uint8_t *d_out,
+                    size_t out_cap, hipStream_t after, bool block_for_slot, std::unique_lock<std::mutex> &lk,
+                    uint64_t *ticket);
+
+// As on the compress side (submit_locked): a submit that fails may already have put copies and kernels on the
+// streams -- the copy-in still reads the caller's `in`, the copy-out may still write the caller's `out` -- and
+// the slot stays free; nothing of them may still be running when the caller gets its buffers back.
 int dsubmit_locked(gzpx_dctx *c, const uint8_t *host_in, const uint8_t *d_in, size_t in_len,
                    const uint64_t *offsets, const uint32_t *sizes, size_t nb, uint8_t *host_out, uint8_t *d_out,
                    size_t out_cap, hipStream_t after, bool block_for_slot, std::unique_lock<std::mutex> &lk,
                    uint64_t *ticket) {
+    const int rc = dsubmit_enqueue(c, host_in, d_in, in_len, offsets, sizes, nb, host_out, d_out, out_cap, after,
+                                   block_for_slot, lk, ticket);
+    if (rc != GZPX_OK && rc != GZPX_ERR_BUSY && rc != GZPX_ERR_INVALID_ARG) {
+        (void)hipStreamSynchronize(c->s_h2d);
+        (void)hipStreamSynchronize(c->stream);
+        (void)hipStreamSynchronize(c->s_d2h);
+    }
+    return rc;
+}
+
+int dsubmit_enqueue(gzpx_dctx *c, const uint8_t *host_in, const uint8_t *d_in, size_t in_len,
+                    const uint64_t *offsets, const uint32_t *sizes, size_t nb, uint8_t *host_out, uint8_t *d_out,
+                    size_t out_cap, hipStream_t after, bool block_for_slot, std::unique_lock<std::mutex> &lk,
+                    uint64_t *ticket) {
     if (nb && (!offsets || !sizes || (!host_in && !d_in))) return GZPX_ERR_INVALID_ARG;
     if (nb > 0xFFFFFFFFull) return GZPX_ERR_INVALID_ARG;
     const uint32_t hdr_len = c->format == GZPX_FORMAT_BGZF ? 18 : 20;
@@ -1424,7 +1470,7 @@ int dsubmit_locked(gzpx_dctx *c, const uint8_t *host_in, const uint8_t *d_in, si
             HIP_TRY(hipMemcpyAsync(sl.d_in, host_in, in_len, hipMemcpyHostToDevice, c->s_h2d));
             d_in = sl.d_in;
             d_out = sl.d_out;
-        } else if (after != stream) {  // (NULL = the legacy default stream, as on the compress side)
+        } else if (after != stream && after != (hipStream_t)GZPX_STREAM_NONE) {  // (NULL = the legacy default stream, as on the compress side)
             HIP_TRY(hipEventRecord(c->ev_dep, after));
             HIP_TRY(hipStreamWaitEvent(stream, c->ev_dep, 0));
         }

@@ -1565,6 +1565,10 @@ __global__ __launch_bounds__(kMpThreads, 4) void k_mparse(
     if (next_b >= nb) break;
     // (a block handed back in its first pass, or one of a single pass: the next block's d0 is not on its way yet)
     if (next_staged && !next_d0_requested) GZPX_D0_REQUEST(cand_all + (uint64_t)next_b * cfg.stride, 0u, next_n);
+    // (a stored-only block -- n <= passthrough -- in front of a parsed one did not request its successor's bytes
+    // above; only the last block of a slab can be that short today, so this never fires, but the parse must not
+    // depend on how batches are cut)
+    if (next_staged && !staged) GZPX_BLOCK_REQUEST(next_b, next_n);
     b = next_b;
     staged = next_staged;
   }

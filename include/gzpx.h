@@ -71,8 +71,9 @@ typedef struct gzpx_config {
     int device;                /* HIP device ordinal                                              */
     int format;                /* GZPX_FORMAT_*                                                   */
     int level;                 /* flate2::Compression level, 0..12 as libdeflate accepts (src/deflate.rs:596-599); 10..12: the near-optimal
-                                * parser as in libdeflate 1.10 -- later versions changed it, so at these levels the stream is valid
-                                * and pinned against 1.10, not claimed equal to 1.24's */
+                                * parser as in libdeflate 1.10 -- later versions changed it, so at these levels `compat` is
+                                * ignored, the 1.10 rules apply throughout (gzpx_ctx_active_compat) and the stream equals the
+                                * 1.10 binary's, not 1.24's */
     int compat;                /* GZPX_COMPAT_*                                                   */
     size_t buffer_size;        /* ParCompressBuilder::buffer_size (65280 default for BGZF)        */
     size_t max_slab_bytes;     /* largest slab a single gzpx_compress_slab* call will be given    */
@@ -88,6 +89,11 @@ void gzpx_config_default(gzpx_config *cfg, int format);
  * allocates device scratch.  Fails with GZPX_ERR_NO_DEVICE when no GPU is present. */
 int gzpx_ctx_create(const gzpx_config *cfg, gzpx_ctx **out);
 void gzpx_ctx_destroy(gzpx_ctx *ctx);
+
+/* The GZPX_COMPAT_* rules this context really runs: cfg->compat at levels 0-9; at levels 10-12 always
+ * GZPX_COMPAT_LIBDEFLATE_1_10 -- the near-optimal parser built here is libdeflate 1.10's (the one binary there is to
+ * pin it on), so its stream is the 1.10 binary's bit for bit and never a mix of two versions' rules. */
+int gzpx_ctx_active_compat(const gzpx_ctx *ctx);
 
 /* Upper bound of the bytes gzpx_compress_slab* can produce for in_len input bytes. */
 size_t gzpx_slab_bound(const gzpx_ctx *ctx, size_t in_len);
@@ -105,11 +111,17 @@ int gzpx_compress_slab(gzpx_ctx *ctx, const uint8_t *in, size_t in_len, int mode
                        size_t out_cap, size_t *out_len, uint32_t *block_sizes, size_t max_blocks,
                        size_t *n_blocks);
 
+/* For the hip_stream / after_stream arguments below: "the caller has already synchronized -- no dependency":
+ * nothing is recorded on any stream (NULL, the legacy default stream, waits behind ALL blocking streams of the
+ * device and may not be recorded on while a stream capture is running). */
+#define GZPX_STREAM_NONE ((void *)(intptr_t)-1)
+
 /* Same, with the slab and the output already resident in DEVICE memory (d_in, d_out are device
  * pointers).  hip_stream (a hipStream_t; NULL = the legacy default stream, which is also PyTorch's
  * current stream unless told otherwise): the slab is read only after everything enqueued on that stream
  * so far has completed -- the context's own streams are non-blocking, so the dependency is always made
- * explicit with an event, also for NULL.  Synchronous with respect to the host on return. */
+ * explicit with an event, also for NULL; GZPX_STREAM_NONE: no dependency at all, the slab is ready now.
+ * Synchronous with respect to the host on return. */
 int gzpx_compress_slab_device(gzpx_ctx *ctx, const void *d_in, size_t in_len, int mode,
                               void *d_out, size_t out_cap, size_t *out_len, uint32_t *block_sizes,
                               size_t max_blocks, size_t *n_blocks, void *hip_stream);
@@ -164,7 +176,10 @@ int gzpx_multi_compress_slab(gzpx_multi *m, const uint8_t *in, size_t in_len, in
  * copied once, device to device (hipMemcpyPeerAsync, all peers at once), into its stream offset of d_out on
  * devices[root].  No payload passes through host memory; only the 16-byte result records and the
  * per-block sizes do.  Byte for byte the stream of gzpx_compress_slab.  Replaces the writer thread's
- * in-order collection, src/par/compress.rs:305-310. */
+ * in-order collection, src/par/compress.rs:305-310.
+ * Caller contract: the ranges d_in[g] are complete and d_out is IDLE on entry (no work of the caller still reads
+ * or writes it on any stream of devices[root]) -- the call orders its kernels and peer copies among themselves
+ * and returns when all of them are done, but takes no stream or event of the caller to wait behind. */
 int gzpx_multi_shard(const gzpx_multi *m, size_t in_len, size_t g, size_t *offset, size_t *len);
 int gzpx_multi_compress_slab_device(gzpx_multi *m, const void *const *d_in, size_t in_len, int mode, size_t root,
                                     void *d_out, size_t out_cap, size_t *out_len, uint32_t *block_sizes,

@@ -302,7 +302,14 @@ hipError_t hipMemcpy(void *d, const void *s, size_t n, hipMemcpyKind) {
     memmove(d, s, n);
     return hipSuccess;
 }
+// Failure injection for the error-path tests: the n-th asynchronous copy from now fails (0 = off).  The
+// stream-synchronise counter tells whether the library drained its streams behind the failure.
+static long inject_memcpy_async = 0;
+static long stream_syncs = 0;
+extern "C" void emu_fail_nth_memcpy_async(long nth) { inject_memcpy_async = nth; }
+extern "C" long emu_stream_sync_count() { return stream_syncs; }
 hipError_t hipMemcpyAsync(void *d, const void *s, size_t n, hipMemcpyKind, hipStream_t) {
+    if (inject_memcpy_async > 0 && --inject_memcpy_async == 0) return hipErrorUnknown;
     memmove(d, s, n);
     return hipSuccess;
 }
@@ -323,7 +330,10 @@ hipError_t hipStreamCreateWithFlags(hipStream_t *s, unsigned) {
     return hipSuccess;
 }
 hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }
-hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+hipError_t hipStreamSynchronize(hipStream_t) {
+    stream_syncs++;
+    return hipSuccess;
+}
 hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }
 hipError_t hipDeviceSynchronize() { return hipSuccess; }
 hipError_t hipEventCreate(hipEvent_t *e) {

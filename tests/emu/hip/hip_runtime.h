@@ -230,6 +230,7 @@ typedef int hipError_t;
 #define hipSuccess 0
 #define hipErrorInvalidValue 1
 #define hipErrorOutOfMemory 2
+#define hipErrorUnknown 999
 #define hipErrorNoDevice 100
 typedef struct emu_stream *hipStream_t;
 typedef struct emu_event {

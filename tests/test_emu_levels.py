@@ -147,7 +147,12 @@ def test_heterogeneous_blocks_vs_oracle_near_optimal(emu_lib, oracle, level):
     """DEFLATE block splits with the rewind to the previous check, and blocks above the 300000-byte soft limit."""
     for fmt, ofmt, bs, n in [(_native.FORMAT_BGZF, 0, 65280, 2 * 65280 + 99), (_native.FORMAT_MGZIP, 1, 330001, 400000)]:
         a = hetero(n, 10 * level + bs % 7)
+        # whatever the caller asks for, levels 10-12 run libdeflate 1.10's rules throughout (the parser is 1.10's):
+        # the stream is the 1.10 binary's, never a hybrid of two versions (ADVICE round 3)
         for compat in (_native.COMPAT_1_10, _native.COMPAT_1_24):
             with _native.Context(format=fmt, level=level, buffer_size=bs, compat=compat, lib=emu_lib, max_slab_bytes=n) as c:
+                assert c.active_compat() == _native.COMPAT_1_10
                 got = c.compress_slab(a, True)
-            assert got == oracle.compress_stream(a, ofmt, level, compat, bs), (level, fmt, bs, compat)
+            assert got == oracle.compress_stream(a, ofmt, level, oracle.COMPAT_1_10, bs), (level, fmt, bs, compat)
+    with _native.Context(format=_native.FORMAT_BGZF, level=9, compat=_native.COMPAT_1_24, lib=emu_lib, max_slab_bytes=100) as c:
+        assert c.active_compat() == _native.COMPAT_1_24  # levels 0-9: the caller's choice

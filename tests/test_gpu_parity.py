@@ -108,6 +108,11 @@ def test_device_resident_slab_and_properties(hip_lib, oracle):
         d_out.zero_()
         out_len2, _ = c.compress_slab_device(d_in.data_ptr(), n, d_out.data_ptr(), cap, True, None, sizes)
         assert out_len2 == out_len and np.array_equal(d_out[:out_len].cpu().numpy(), out)  # idempotent
+        # GZPX_STREAM_NONE: "already synchronized", nothing recorded on the legacy stream -- the same stream
+        d_out.zero_()
+        torch.cuda.synchronize()
+        out_len3, _ = c.compress_slab_device(d_in.data_ptr(), n, d_out.data_ptr(), cap, True, _native.STREAM_NONE, sizes)
+        assert out_len3 == out_len and np.array_equal(d_out[:out_len].cpu().numpy(), out)
     assert nblk == nb and int(sizes.sum()) == out_len
     assert gzip.decompress(out.tobytes()) == a.tobytes()
     offs = np.concatenate([[0], np.cumsum(sizes.astype(np.int64))])

@@ -93,21 +93,41 @@ def multi_device(lib, oracle, scale=1):
     assert e.value.code == _native.ERR_BLOCK_SIZE_EXCEEDED and e.value.block == 2
 
 
-def multi_device_resident(lib, oracle, scale=1):
+def multi_device_distinct(lib, oracle, n_physical, scale=4):
+    """The same calls with the ranges on DIFFERENT devices (a box with >= 2 GPUs): host-buffer form and
+    device-resident form; the stream must equal the single-device one whatever the device list."""
+    for ndev, nblk, extra, mode in ((n_physical, 9, 123, _native.SLAB_LAST), (2, 5, 0, _native.SLAB_FULL_BLOCKS),
+                                    (min(n_physical, 4) + 1, 6, 17, _native.SLAB_LAST)):
+        a = synth.make("mixed", nblk * BS * scale + extra, 5 + nblk)
+        devs = [g % n_physical for g in range(ndev)]
+        with _native.MultiContext(devs, level=1, buffer_size=BS, lib=lib, max_slab_bytes=max(a.size, BS)) as m:
+            got, sizes = m.compress_slab(a, mode, return_block_sizes=True)
+        with _native.Context(level=1, buffer_size=BS, lib=lib, max_slab_bytes=max(a.size, BS)) as c:
+            want, wsizes = c.compress_slab(a, mode, return_block_sizes=True)
+        assert got == want and list(sizes) == list(wsizes), (devs, nblk, extra, mode)
+        if mode == _native.SLAB_LAST:
+            assert got == oracle.compress_stream(a, oracle.FMT_BGZF, 1, oracle.COMPAT_1_24, BS), (devs, nblk, extra, mode)
+    multi_device_resident(lib, oracle, scale, n_physical=n_physical)
+
+
+def multi_device_resident(lib, oracle, scale=1, n_physical=1):
     """gzpx_multi_compress_slab_device against the oracle: ranges handed over as device pointers (host
-    arrays under the emulator, torch tensors on the GPU), output gathered in stream order on the root."""
+    arrays under the emulator, torch tensors on the GPU), output gathered in stream order on the root.
+    n_physical > 1 (a box with several GPUs): range g lives on device g % n_physical, so the peer-access
+    set-up and the device-to-device copies into the root's buffer cross real device boundaries."""
     on_gpu = "emu" not in os.path.basename(lib.path) and _has_cuda()
     for ndev, nblk, extra, mode, root in ((3, 7, 123, _native.SLAB_LAST, 0), (2, 5, 0, _native.SLAB_FULL_BLOCKS, 1),
                                           (4, 2, 17, _native.SLAB_LAST, 2), (3, 0, 0, _native.SLAB_LAST, 0)):
         a = synth.make("text", nblk * BS * scale + extra, 11 + nblk)
-        with _native.MultiContext([0] * ndev, level=1, buffer_size=BS, lib=lib, max_slab_bytes=max(a.size, BS)) as m:
+        devs = [g % n_physical for g in range(ndev)]
+        with _native.MultiContext(devs, level=1, buffer_size=BS, lib=lib, max_slab_bytes=max(a.size, BS)) as m:
             shards, keep = [], []
             for g in range(ndev):
                 off, n = m.shard(a.size, g)
                 part = np.ascontiguousarray(a[off:off + n])
                 if on_gpu:
                     import torch
-                    t = torch.from_numpy(part.copy()).cuda() if n else None
+                    t = torch.from_numpy(part.copy()).to("cuda:%d" % devs[g]) if n else None
                     keep.append(t)
                     shards.append(t.data_ptr() if n else None)
                 else:
@@ -116,8 +136,9 @@ def multi_device_resident(lib, oracle, scale=1):
             cap = m.slab_bound(a.size)
             if on_gpu:
                 import torch
-                d_out = torch.zeros(cap, dtype=torch.uint8, device="cuda")
-                torch.cuda.synchronize()
+                d_out = torch.zeros(cap, dtype=torch.uint8, device="cuda:%d" % devs[root])  # the root's buffer
+                for dv in set(devs):
+                    torch.cuda.synchronize(dv)
                 n_out, sizes = m.compress_slab_device(shards, a.size, d_out.data_ptr(), cap, mode, root)
                 got = d_out[:n_out].cpu().numpy().tobytes()
             else:
