@@ -40,13 +40,31 @@ FASTQ_STREAM = 32 << 30   # BASELINE configs[3]
 FASTQ_SEED = 20250927
 
 
-def pmc_traffic(kernel):
-    """HBM bytes per launch of `kernel` from the committed PMC passes (profiles/), if any."""
+def pmc_traffic(kernel, build_id=None):
+    """HBM bytes per launch of `kernel` from the committed PMC passes (profiles/pmc_traffic.json) -- only if they were
+    collected with THIS build of the library (the file records gzpx_build_id of the run that made it): counters of
+    another build's kernels are refused, the line then says `traffic: null` and why."""
     try:
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
-            return json.load(f)["hbm_bytes_per_launch"].get(kernel)
+            doc = json.load(f)
+        if build_id is not None and doc.get("build_id") != build_id:
+            return None
+        return doc["hbm_bytes_per_launch"].get(kernel)
     except Exception:
         return None
+
+
+def pmc_traffic_source(build_id):
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+            have = json.load(f).get("build_id")
+    except Exception:
+        return "no profiles/pmc_traffic.json"
+    if have != build_id:
+        return ("profiles/pmc_traffic.json was collected with build %s, this library is build %s: refused "
+                "(tools/pmc_traffic.sh + tools/summarize_profiles.py refresh it)" % (have, build_id))
+    return ("profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes of this same command with "
+            "this same build %s of the library; committed, not collected in this run)" % build_id)
 
 
 def golden_stream(name):
@@ -314,7 +332,7 @@ def run_inflate(args, env, emit=True, d_stream=None, comp_host=None, slab=None, 
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 5),
-                "traffic": pmc_traffic("k_inflate"),
+                "traffic": pmc_traffic("k_inflate", env.lib.build_id()),
                 "kernel_ms": round(kern_ms, 3),
             },
         }
@@ -934,8 +952,9 @@ def main():
             live = {dom: stage_other[dom]}
         alg_bytes = n + out_len  # 1 B read + r B written per input byte
         achieved = alg_bytes / (max(stage_ms[dom], 1e-9) * 1e-3) / 1e9
-        traffic = pmc_traffic(dom)
-        traffic_all = pmc_traffic("pipeline")
+        build_id = env.lib.build_id()
+        traffic = pmc_traffic(dom, build_id)
+        traffic_all = pmc_traffic("pipeline", build_id)
         res = {
             "metric": "BGZF compress MiB/s at level 1, 550 MiB text",
             "value": round(value, 1),
@@ -984,8 +1003,8 @@ def main():
                 "own_traffic_frac": round(traffic / (max(stage_ms[dom], 1e-9) * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if traffic else None,
                 "traffic_pipeline": traffic_all,
                 "traffic_ratio_pipeline": round(traffic_all / alg_bytes, 2) if traffic_all else None,
-                "traffic_source": "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes of "
-                                  "this same command; committed, not collected in this run)",
+                "traffic_source": pmc_traffic_source(build_id),
+                "library_build_id": build_id,
                 # the whole timed step (kernels, launch gaps, the side stream's join), not a sum of stages
                 "pipeline_frac": round(alg_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
                 "hbm_read_frac": round(n / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),  # input bytes only (north_star's wording)

@@ -56,7 +56,7 @@ EXPORTS = [
     "gzpx_free_decompressor", "gzpx_pard_create", "gzpx_pard_read", "gzpx_pard_destroy",
     "gzpx_pard_last_error", "gzpx_host_alloc", "gzpx_host_free", "gzpx_dctx_last_inflate_ms",
     "gzpx_debug_inflate", "gzpx_synth_fastq_device", "gzpx_synth_ascii_device",
-    "gzpx_ctx_active_compat", "gzpx_multi_create", "gzpx_multi_destroy", "gzpx_multi_devices", "gzpx_multi_compress_slab",
+    "gzpx_ctx_active_compat", "gzpx_build_id", "gzpx_multi_create", "gzpx_multi_destroy", "gzpx_multi_devices", "gzpx_multi_compress_slab",
     "gzpx_multi_shard", "gzpx_multi_compress_slab_device",
 ]
 
@@ -115,6 +115,8 @@ class GzpxLib:
         L.gzpx_ctx_destroy.argtypes = [vp]
         L.gzpx_slab_bound.restype = sz
         L.gzpx_slab_bound.argtypes = [vp, sz]
+        L.gzpx_build_id.restype = ctypes.c_char_p
+        L.gzpx_build_id.argtypes = []
         L.gzpx_ctx_active_compat.restype = i32
         L.gzpx_ctx_active_compat.argtypes = [vp]
         L.gzpx_compress_slab.restype = i32
@@ -247,6 +249,10 @@ class GzpxLib:
         L.gzpx_pard_destroy.argtypes = [vp]
         L.gzpx_pard_last_error.restype = ctypes.c_char_p
         L.gzpx_pard_last_error.argtypes = [vp]
+
+    def build_id(self):
+        """gzpx_build_id(): which sources this library was built from (gzp_amd/build.py: source_id())."""
+        return self.L.gzpx_build_id().decode()
 
     def strerror(self, code):
         return self.L.gzpx_strerror(code).decode()

@@ -17,6 +17,20 @@ def _hipcc():
     return "hipcc"
 
 
+def source_id():
+    """SHA-256 (16 hex digits) over the sources the library is built from, in a fixed order: the library carries it
+    (gzpx_build_id) and profiles/pmc_traffic.json records the one it was collected with, so that bench.py can tell a
+    committed traffic figure of another build from one of this build."""
+    import hashlib
+    h = hashlib.sha256()
+    names = sorted(os.listdir(CSRC))
+    for path in [os.path.join(CSRC, f) for f in names if f.endswith((".hip", ".cpp", ".h", ".hpp"))] + [os.path.join(INCLUDE, "gzpx.h")]:
+        h.update(os.path.basename(path).encode() + b"\0")
+        with open(path, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
 def build(force=False, verbose=False):
     srcs = [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
     deps = srcs + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".hpp"))]
@@ -26,7 +40,7 @@ def build(force=False, verbose=False):
         return LIB
     os.makedirs(LIB_DIR, exist_ok=True)
     cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-pthread",
-           "-I", INCLUDE] + srcs + ["-o", LIB]
+           "-DGZPX_BUILD_ID=\"%s\"" % source_id(), "-I", INCLUDE] + srcs + ["-o", LIB]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

@@ -1884,5 +1884,9 @@ const char *gzpx_strerror(int code) {
 
 const char *gzpx_device_name(const gzpx_ctx *ctx) { return ctx ? ctx->devname : ""; }
 const char *gzpx_version(void) { return "gzpx 0.1 (gfx950)"; }
+#ifndef GZPX_BUILD_ID
+#define GZPX_BUILD_ID "unknown"
+#endif
+const char *gzpx_build_id(void) { return GZPX_BUILD_ID; }
 
 }  // extern "C"

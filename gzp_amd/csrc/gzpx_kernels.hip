@@ -1637,14 +1637,31 @@ __device__ uint32_t hc_calc_min_len(const Config &cfg, const uint8_t *in, uint32
 // dwords per side at once: a round waits for its LDS reads before it knows whether there is another, and
 // the wave pays for its longest lane).  One exit per loop, no break: every extra way out of a divergent loop
 // costs scalar mask bookkeeping per round.
+#ifndef GZPX_EXT_FIRST
+#define GZPX_EXT_FIRST 8
+#endif
 __device__ __forceinline__ uint32_t lds_extend_from(const uint32_t *in_w, uint32_t a, uint32_t c, uint32_t start,
                                                     uint32_t max_len) {
     uint32_t len = start;
+#if GZPX_EXT_FIRST == 8
+    {   // eight bytes: three dwords per side
+        const uint32_t aa = a + len, cc = c + len;
+        const uint32_t *pa = in_w + (aa >> 2), *pc = in_w + (cc >> 2);
+        const uint32_t a0 = pa[0], a1 = pa[1], a2 = pa[2], c0 = pc[0], c1 = pc[1], c2 = pc[2];
+        const uint32_t sa = aa & 3u, sc = cc & 3u;
+        const uint32_t x0 = __builtin_amdgcn_alignbyte(a1, a0, sa) ^ __builtin_amdgcn_alignbyte(c1, c0, sc);
+        const uint32_t x1 = __builtin_amdgcn_alignbyte(a2, a1, sa) ^ __builtin_amdgcn_alignbyte(c2, c1, sc);
+        const uint32_t x = x0 ? x0 : x1;
+        len += (x0 ? 0u : 4u) + (x ? ((uint32_t)(__ffs((int)x) - 1) >> 3) : 4u);
+        if (x != 0 || len >= max_len) return len < max_len ? len : max_len;
+    }
+#else
     {
         const uint32_t x = lds_le32(in_w, a + len) ^ lds_le32(in_w, c + len);
         len += x ? ((uint32_t)(__ffs((int)x) - 1) >> 3) : 4u;
         if (x != 0 || len >= max_len) return len < max_len ? len : max_len;
     }
+#endif
     bool more;
     do {
         const uint32_t aa = a + len, cc = c + len;
@@ -1943,6 +1960,18 @@ __global__ __launch_bounds__(kMpThreads, GZPX_PHC_WAVES) void k_parse_hc(
     // block is done after one round, the looping form -- which costs this kernel 20 more spilled VGPRs --
     // only ever sees the few that need a third.
     const unsigned long long lane_below = (1ull << lane) - 1ull;
+#ifdef GZPX_EXPERIMENT
+    // measurement builds (tools/exp_parse_hc.py): cycles per phase, summed over the blocks of a launch (thread 0's
+    // clock): 0 stage, 1 min_len filter, 2 first walk, 3 walk rounds, 4 scan, 5 boundaries + checks, 6 token pass, 7 rounds
+    unsigned long long exp_t = __builtin_readcyclecounter();
+    auto exp_lap = [&](uint32_t slot) {
+        const unsigned long long t = __builtin_readcyclecounter();
+        if (tid == 0) atomicAdd(&g_exp_cycles[(b & 1023u) * 8u + slot], t - exp_t);
+        exp_t = t;
+    };
+#else
+    auto exp_lap = [](uint32_t) {};
+#endif
     for (;;) {
     // state (uniform across the workgroup; in the looping form written by thread 0 a round ago)
     auto ld = [](const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
@@ -1975,6 +2004,7 @@ __global__ __launch_bounds__(kMpThreads, GZPX_PHC_WAVES) void k_parse_hc(
             for (uint32_t i = tid; i < (tile_len + 3) / 4; i += kMpThreads) len8_w[i] = src[i];
         }
         __syncthreads();
+        exp_lap(0);
         if (tid < kHpGroups) {
             // k_match_hc's matches are those of min_len 3: keep the long enough ones.  (The bitmap
             // word of the tile's last group may carry bits of positions >= n: dropped.)
@@ -1994,6 +2024,7 @@ __global__ __launch_bounds__(kMpThreads, GZPX_PHC_WAVES) void k_parse_hc(
             tok_bits[tid] = 0;
         }
         __syncthreads();
+        exp_lap(1);
 
         // ---- greedy parse: speculative segment walk, as in k_parse: thread s owns the 64 positions of
         // segment s and walks them from an entry (first guess: its own start; thread 0 knows the
@@ -2026,7 +2057,11 @@ __global__ __launch_bounds__(kMpThreads, GZPX_PHC_WAVES) void k_parse_hc(
         const uint32_t seg_begin = tid * kPSeg;
         uint32_t entry = tid == 0 ? entry_carry - tile_begin : seg_begin;
         if (active) seg_exit[tid] = walk_seg(tid, entry);
+        exp_lap(2);
         for (uint32_t round = 0;; round++) {
+#ifdef GZPX_EXPERIMENT
+            if (tid == 0) atomicAdd(&g_exp_cycles[(b & 1023u) * 8u + 7u], 1ull);
+#endif
             __syncthreads();
             bool changed = false;
             uint32_t new_entry = entry;
@@ -2070,6 +2105,7 @@ __global__ __launch_bounds__(kMpThreads, GZPX_PHC_WAVES) void k_parse_hc(
         }
         const uint32_t exit_rel = uniform(seg_exit[n_seg - 1]);
         __syncthreads();  // seg_exit is rank_pre from here on
+        exp_lap(3);
 
         // ---- tokens / matches per 64-position group (one thread each, from the two bitmaps), then
         // one workgroup-wide scan
@@ -2100,6 +2136,7 @@ __global__ __launch_bounds__(kMpThreads, GZPX_PHC_WAVES) void k_parse_hc(
             if (tid < kHpGroups) rank_pre[tid] = my_pre;
         }
         __syncthreads();
+        exp_lap(4);
 
         // ---- per sub-block that starts or continues in this tile: where it ends, its tokens
         bool build = true;
@@ -2163,6 +2200,7 @@ __global__ __launch_bounds__(kMpThreads, GZPX_PHC_WAVES) void k_parse_hc(
             if (tid == 0 && s_next_check == kNoCheckYet && first_check != 0xFFFFFFFFu) s_next_check = first_check;
             __syncthreads();
             const uint32_t nc = s_next_check;  // token index of the first check from here, or a sentinel
+            exp_lap(5);
             // (2) one pass in position order, a wave per group: lane l takes position l (coalesced val
             // reads and token stores), ranks from the group's prefix + popcounts below the lane.  Builds
             // the tokens (first time through) and tallies the observation classes per 512-token bin
@@ -2209,6 +2247,7 @@ __global__ __launch_bounds__(kMpThreads, GZPX_PHC_WAVES) void k_parse_hc(
                 }
             }
             __syncthreads();
+            exp_lap(6);
             // The checks themselves.  do_end_block_check for check k needs the observations merged so
             // far (everything before bin k) and the new ones (bin k): both follow from prefix sums over
             // the bins as long as no earlier check ended the block -- and the first one that does ends
@@ -2337,6 +2376,7 @@ __global__ __launch_bounds__(kMpThreads, GZPX_PHC_WAVES) void k_parse_hc(
         tok_carry += tile_tok;
         mat_carry += tile_mat;
         entry_carry = tile_begin + exit_rel;
+        exp_lap(5);
     }
     if (tid == 0) {
         sub[cur_sub].tok_begin = sub_start_tok;

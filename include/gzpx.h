@@ -350,6 +350,9 @@ int gzpx_debug_inflate(gzpx_dctx *ctx, int enable, uint64_t sums[8]);
 const char *gzpx_strerror(int code);
 const char *gzpx_device_name(const gzpx_ctx *ctx);
 const char *gzpx_version(void);
+/* Identifies the sources this library was built from (gzp_amd/build.py: source_id()); "unknown" for builds made
+ * another way.  profiles/pmc_traffic.json carries the id of the build its counters were collected with. */
+const char *gzpx_build_id(void);
 
 #ifdef __cplusplus
 }

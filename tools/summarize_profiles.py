@@ -78,6 +78,10 @@ doc = {
                              for k in fetch},
 }
 doc["round"] = tag
+# which build of the library the counters belong to (bench.py refuses the file for any other build)
+sys.path.insert(0, ROOT)
+from gzp_amd import build as _gbuild
+doc["build_id"] = _gbuild.source_id()
 doc["pipeline_total_bytes"] = int(sum(v for k, v in doc["hbm_bytes_per_launch"].items()
                                       if k in ("k_init_meta", "k_candidates", "k_mparse", "k_match", "k_parse",
                                                "k_hist", "k_huffman", "k_crc32", "k_scan", "k_emit")))
