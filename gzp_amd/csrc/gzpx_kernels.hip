@@ -4540,6 +4540,24 @@ __global__ __launch_bounds__(64, GWIN ? GZPX_INF_WAVES : 1) void k_inflate(uint3
                     break;
                 }
                 if (o + tout - flushed > 32768u) flush(o & ~3u);
+                // A round whose symbols are all literals (nearly every round of an incompressible member: configs[2]'s
+                // printable noise is literals of 7-8 bits, ~15 per round) needs no owners, no window and no order:
+                // every marked lane stores its byte where the prefix sum put it.
+                bool any_match = false;
+#pragma unroll
+                for (uint32_t g = 0; g < kInfR; g++) any_match = any_match || (mine[g] && is_match[g]);
+                if (GWIN && __ballot(any_match) == 0) {
+#pragma unroll
+                    for (uint32_t g = 0; g < kInfR; g++)
+                        if (mine[g]) out[o + opos[g]] = (uint8_t)(le[g] >> 8);
+                    o += tout;
+                    if (DBG) dbg[3] += (uint32_t)(clock64() - t_out);
+                    if (!hit_stop) {
+                        bp += pos;
+                        continue;
+                    }
+                    tout = 0;  // (falls through to the one-symbol path below)
+                }
                 uint32_t carry = 0;
                 for (uint32_t pass = 0; pass < tout; pass += 64) {
                     // owner (position + 1) of every output byte of this pass: scatter the symbol
