@@ -839,8 +839,17 @@ def main():
     d_outs = [torch.empty(cap, dtype=torch.uint8, device=env.dev) for _ in range(2 if world > 1 else 1)]
     # N > 1: BOTH in-order write-outs are timed in this one run, back to back -- first the one --writeout
     # names (default rccl: north_star's ordered gather), then the other; the line's `value` is the faster one.
-    modes = [None] if world == 1 else [args.writeout, "offsets" if args.writeout == "rccl" else "rccl"]
+    modes = [None] if world == 1 else [args.writeout] + [m for m in ("rccl", "offsets") if m != args.writeout]
     gathered = torch.empty(cap * world, dtype=torch.uint8, device=env.dev) if (world > 1 and rank == 0) else None
+    # ... and a third one where the devices can map each other's memory: the writer's buffer IPC-mapped into every rank,
+    # every rank copies its shard to its stream offset itself (copy engines over xGMI: no RCCL kernel on any CU)
+    peer_win, peer_err = None, None
+    if world > 1 and not env.emulate:
+        try:
+            peer_win = shard.PeerWindow(cap * world, env.dev, dst=0)
+            modes.append("peer")
+        except Exception as e:  # (all ranks fail or succeed together: the handle broadcast is collective)
+            peer_err = repr(e)
     host_out = None
     if world > 1 and not env.emulate:
         host_out = [torch.empty(cap, dtype=torch.uint8).pin_memory() for _ in range(2)]
@@ -869,7 +878,9 @@ def main():
                                               None, block_sizes)
         if world > 1:
             wait_pending()  # the previous shard has left (it travelled while this step compressed)
-            if state["writeout"] == "rccl":
+            if state["writeout"] == "peer":
+                state["pending"] = peer_win.gather_start(buf[:out_len])
+            elif state["writeout"] == "rccl":
                 # in-order write-out: ordered variable-size gather of the shards to rank 0 (RCCL),
                 # started now and completed while the next step compresses
                 state["pending"] = shard.ordered_gather_start(buf[:out_len], dst=0, out=gathered)
@@ -980,7 +991,9 @@ def main():
                 "ratio": round(out_len / n, 4),
                 "parallelism": "block-shard x%d%s" % (
                     world, "" if world == 1 else
-                    (" + ordered RCCL gather" if best_mode == "rccl" else " + size all_gather, per-rank write-out")),
+                    (" + ordered RCCL gather" if best_mode == "rccl" else
+                     " + peer copies into the writer's IPC-mapped buffer" if best_mode == "peer" else
+                     " + size all_gather, per-rank write-out")),
                 "verified_bit_exact_sample": bool(ok),
                 "verified_bit_exact_full": full_ok,  # all blocks: SHA-256 of the stream and of the framed sizes == tests/golden/fullsize.json
                 "compat": "libdeflate >= 1.1x rule (the pinned 1.24); the golden digest is the v1.10 binary's, whose "
@@ -1019,6 +1032,8 @@ def main():
                     "rank_ms_per_step": r["rank_ms_per_step"], "rank_writeout_wait_ms": r["rank_writeout_wait_ms"]}
                 for m, r in regions.items()}
             res["writeouts"]["value_is"] = best_mode
+            if peer_err:
+                res["writeouts"]["peer_error"] = peer_err
             for m, r in regions.items():
                 res["value_" + m] = round(total_mib / (r["dt"] / args.steps), 1)
         if world == 1 and not args.no_extras:

@@ -131,3 +131,66 @@ class EventHandle:
     def wait(self):
         self._ev.synchronize()
         return None
+
+
+class PeerWindow:
+    """The writer rank's output buffer mapped into every rank of the node (device memory shared by an IPC handle,
+    set up ONCE): the third in-order write-out.  Each rank copies its compressed shard straight into its stream
+    offset of the window with an ordinary device-to-device copy on a stream of its own -- over xGMI that is a
+    copy-engine (SDMA) transfer, so the exchange takes no compute unit from the compression kernels of the next
+    slab, which an RCCL send/recv kernel does.  Same result as ordered_gather: the window holds the single-process
+    stream (the in-order property of src/par/compress.rs:305-310)."""
+
+    def __init__(self, capacity, device, dst=0, group=None):
+        import torch
+        import torch.distributed as dist
+        from torch.multiprocessing.reductions import reduce_tensor
+        self.group, self.dst = group, dst
+        self.rank = dist.get_rank(group)
+        self.world = dist.get_world_size(group)
+        self.buf = None
+        box = [None]
+        if self.rank == dst:
+            self.buf = torch.empty(int(capacity), dtype=torch.uint8, device=device)
+            box[0] = reduce_tensor(self.buf)  # (rebuild function, IPC handle + geometry): picklable
+        dist.broadcast_object_list(box, src=dst, group=group)
+        if self.rank != dst:
+            fn, args = box[0]
+            self.buf = fn(*args)  # the SAME memory, opened in this process
+        self.stream = torch.cuda.Stream(device=device)
+        self._sizes_on_cpu = dist.get_backend(group) == "gloo"  # (tests: control plane on gloo, payload on the GPU)
+        self._device = device
+
+    def gather_start(self, local):
+        """Copy `local` (1-D uint8 cuda tensor) to its offset of the window, asynchronously; the returned handle's
+        wait() completes the step on every rank and returns the stream on dst (a view of the window)."""
+        import torch
+        import torch.distributed as dist
+        n = torch.tensor([local.numel()], dtype=torch.int64, device="cpu" if self._sizes_on_cpu else self._device)
+        sizes = torch.zeros(self.world, dtype=torch.int64, device=n.device)
+        dist.all_gather_into_tensor(sizes, n, group=self.group) if not self._sizes_on_cpu else \
+            dist.all_gather(list(sizes.split(1)), n, group=self.group)
+        sz = [int(x) for x in sizes.tolist()]
+        off, total = sum(sz[:self.rank]), sum(sz)
+        if total > self.buf.numel():
+            raise ValueError("PeerWindow: the stream (%d bytes) does not fit the window (%d)" % (total, self.buf.numel()))
+        ev = None
+        if local.numel():
+            self.stream.wait_stream(torch.cuda.current_stream(self._device))
+            with torch.cuda.stream(self.stream):
+                self.buf[off:off + local.numel()].copy_(local, non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record(self.stream)
+        return _PeerHandle(self, ev, total)
+
+
+class _PeerHandle:
+    def __init__(self, win, ev, total):
+        self._w, self._ev, self._total = win, ev, total
+
+    def wait(self):
+        import torch.distributed as dist
+        if self._ev is not None:
+            self._ev.synchronize()  # my shard has landed
+        dist.barrier(group=self._w.group)  # ... and so has everybody's: the writer may read the window
+        return self._w.buf[:self._total] if self._w.rank == self._w.dst else None
