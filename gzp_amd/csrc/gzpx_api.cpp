@@ -169,8 +169,9 @@ int alloc_scratch(gzpx_ctx *ctx) {
     HIP_TRY(hipMalloc((void **)&s.which, nb * (size_t)(c.stride / 32) * 4));
     HIP_TRY(hipMalloc((void **)&s.alt, nb * (size_t)c.stride * sizeof(uint16_t)));
     HIP_TRY(hipMalloc((void **)&s.tok, nb * (size_t)c.stride * 4));
-    HIP_TRY(hipMalloc((void **)&s.redo, (nb + 1) * sizeof(uint32_t)));
-    HIP_TRY(hipMemset(s.redo, 0, (nb + 1) * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc((void **)&s.redo, (nb + 1 + 8) * sizeof(uint32_t)));
+    HIP_TRY(hipMemset(s.redo, 0, (nb + 1 + 8) * sizeof(uint32_t)));
+    s.claim = s.redo + nb + 1;
     if (c.level >= 2) {  // hc_matchfinder levels: hash4 chain links + per-block parse state
         HIP_TRY(hipMalloc((void **)&s.d4, nb * (size_t)c.stride * sizeof(uint16_t)));
         HIP_TRY(hipMalloc((void **)&s.hc, nb * sizeof(HcState)));

@@ -113,6 +113,7 @@ struct Scratch {
     uint32_t *pending;    // [1]                 levels 2-4: blocks that need another round
     uint32_t *tok;        // [nb][stride]        worst case one token per byte
     uint32_t *redo;       // [1 + nb]            level 1: blocks k_mparse hands back to k_match / k_parse
+    uint32_t *claim;      // [8]                 ticket counters of the persistent kernels that claim their blocks (behind redo's list)
     uint32_t *hist;       // [nb][max_sub][kHistStride]
     uint32_t *codes;      // [nb][max_sub][kCodeWords]
     uint32_t *hdr;        // [nb][max_sub][kHdrWords]

@@ -386,7 +386,7 @@ __global__ __launch_bounds__(64 * kCandWaves) void k_candidates(Config cfg,
                                                                  BlockMeta *__restrict__ meta,
                                                                  uint16_t *__restrict__ cand_all,
                                                                  uint64_t slab_len, uint32_t nb, uint32_t is_last,
-                                                                 uint32_t *__restrict__ redo) {
+                                                                 uint32_t *__restrict__ redo, uint32_t *__restrict__ claim) {
     __shared__ uint32_t tab[kBuckets + 64];  // 128 KiB + one spare word per lane for lanes without a bucket
     __shared__ uint32_t turn;               // index of the iteration (counted through the blocks) whose atomics may go next
     __shared__ uint32_t bad_any;            // some wave saw the order check fail
@@ -401,6 +401,7 @@ __global__ __launch_bounds__(64 * kCandWaves) void k_candidates(Config cfg,
         for (uint32_t blk = blockIdx.x + tid * gridDim.x; blk < nb; blk += 64 * kCandWaves * gridDim.x)
             meta[blk] = block_meta_of(cfg, slab_len, nb, is_last, blk);
         if (blockIdx.x == 0 && tid == 0) redo[0] = 0;  // level 1: nothing handed back to the dense kernels yet
+        if (blockIdx.x == 0 && tid < 8) claim[tid] = 0;  // the ticket counters of the kernels behind this one (k_mparse)
     }
     for (uint32_t i = tid; i < kBuckets + 64; i += 64 * kCandWaves) tab[i] = 0;
     if (tid == 0) {
@@ -1234,8 +1235,9 @@ __device__ __forceinline__ uint32_t l1_search(const uint32_t *in_w, const uint16
 __global__ __launch_bounds__(kMpThreads, 4) void k_mparse(
     Config cfg, const uint8_t *__restrict__ slab, BlockMeta *__restrict__ meta_all,
     SubMeta *__restrict__ sub_all, const uint16_t *__restrict__ cand_all, uint32_t *__restrict__ tok_all,
-    uint32_t *__restrict__ redo, uint64_t slab_len, uint32_t nb) {
+    uint32_t *__restrict__ redo, uint64_t slab_len, uint32_t nb, uint32_t *__restrict__ claim) {
     __shared__ uint32_t in_w[kInWords];        // the block's bytes (+ lead misalignment, + pad)
+    __shared__ uint32_t s_claimed;             // the block this workgroup takes after the next one
     __shared__ uint32_t d0_w[kMhHalf / 2];     // d0 (u16) of the positions of the current pass
     __shared__ uint32_t seg_exit[2 * kMpThreads];  // where the walk of segment s leaves it (two copies, see the rounds)
     __shared__ uint32_t wsum_t[kMpWaves];
@@ -1288,8 +1290,14 @@ __global__ __launch_bounds__(kMpThreads, 4) void k_mparse(
     } while (0)
     static_assert(((3 + kTile + 3) >> 4) <= 4 * kMpThreads, "a block is four uint4 per thread (+ tail dwords)");
 
+    // Blocks are CLAIMED, not strided over (round 4): a workgroup's first two blocks are blockIdx.x and blockIdx.x +
+    // gridDim.x, every later one comes from one global ticket counter -- the ticket for the block after the next is
+    // drawn while the current block is parsed, so its round trip is never waited for.  With the static stride
+    // (b += gridDim.x) 8,835 blocks over 256 CUs left 121 CUs idle for the last 35th of the launch, and a CU slowed
+    // by anything else on it (an RCCL channel, a heavier run of blocks) stretched the whole launch.
     uint32_t b = blockIdx.x;
     if (b >= nb) return;
+    uint32_t next_b = b + gridDim.x;
     bool staged;  // (uniform) block b's bytes and first-pass d0 have been requested
     {
         const uint32_t n0 = block_len(b);
@@ -1300,7 +1308,8 @@ __global__ __launch_bounds__(kMpThreads, 4) void k_mparse(
         }
     }
   for (;;) {
-    const uint32_t next_b = b + gridDim.x;
+    uint32_t my_ticket = 0;
+    if (tid == 0) my_ticket = atomicAdd(claim, 1u);  // (its value is looked at only at the end of this block)
     const uint32_t next_n = next_b < nb ? block_len(next_b) : 0u;
     const bool next_staged = next_n > cfg.passthrough;  // (uniform; implies next_b < nb)
     bool next_d0_requested = false;
@@ -1562,15 +1571,18 @@ __global__ __launch_bounds__(kMpThreads, 4) void k_mparse(
         meta->nsub = cur_sub + 1;
     }
   }  // staged
-    if (next_b >= nb) break;
+    if (tid == 0) s_claimed = 2u * gridDim.x + my_ticket;
+    if (next_b >= nb) break;  // (tickets only grow: nothing is left for this workgroup either)
     // (a block handed back in its first pass, or one of a single pass: the next block's d0 is not on its way yet)
     if (next_staged && !next_d0_requested) GZPX_D0_REQUEST(cand_all + (uint64_t)next_b * cfg.stride, 0u, next_n);
     // (a stored-only block -- n <= passthrough -- in front of a parsed one did not request its successor's bytes
     // above; only the last block of a slab can be that short today, so this never fires, but the parse must not
     // depend on how batches are cut)
     if (next_staged && !staged) GZPX_BLOCK_REQUEST(next_b, next_n);
+    __syncthreads();  // s_claimed is written; everybody is done with this block's LDS
     b = next_b;
     staged = next_staged;
+    next_b = s_claimed;
   }
 #undef GZPX_D0_REQUEST
 #undef GZPX_BLOCK_REQUEST
@@ -4777,7 +4789,7 @@ static void launch_candidates_mode(const Config &cfg, const uint8_t *slab, uint6
     const uint64_t span = slab_len + (uint64_t)nb * 32768u;
     if (span / wgs >= (1ull << 30)) wgs = span / (1ull << 30) + 1;
     hipLaunchKernelGGL(k_candidates<MODE>, dim3((uint32_t)(nb < wgs ? nb : wgs)), dim3(64 * kCandWaves), 0, stream, cfg,
-                       slab, s.meta, out, slab_len, nb, (uint32_t)(is_last ? 1 : 0), s.redo);
+                       slab, s.meta, out, slab_len, nb, (uint32_t)(is_last ? 1 : 0), s.redo, s.claim);
 }
 
 // Levels >= 1: the first launch also fills BlockMeta (k_init_meta's work); level 0 has no matchfinding and
@@ -4836,7 +4848,7 @@ void launch_match(const Config &cfg, const uint8_t *slab, uint64_t slab_len, uin
     if (fused) {  // (k_init_meta has emptied the redo list)
         const uint32_t wgs = cfg.n_cu ? cfg.n_cu : 256u;  // one per CU, each walking its share of the blocks
         hipLaunchKernelGGL(k_mparse, dim3(nb < wgs ? nb : wgs), dim3(kMpThreads), 0, stream, cfg, slab, s.meta, s.sub,
-                           (const uint16_t *)s.cand, s.tok, s.redo, slab_len, nb);
+                           (const uint16_t *)s.cand, s.tok, s.redo, slab_len, nb, s.claim + 0);
     }
     const uint32_t grid = fused ? (nb < 512u ? nb : 512u) : nb;
     hipLaunchKernelGGL(k_match, dim3(grid), dim3(kMpThreads), 0, stream, cfg, slab, s.meta,
