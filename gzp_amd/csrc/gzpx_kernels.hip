@@ -1936,6 +1936,7 @@ __global__ __launch_bounds__(kMpThreads, GZPX_PHC_WAVES) void k_parse_hc(
     __shared__ uint32_t len8_w[kHpTile / 4];
     __shared__ unsigned long long tok_bits[kHpGroups];  // 1 = a token starts here (tile-relative)
     __shared__ unsigned long long mb[kHpGroups];        // 1 = k_match_hc's match here is long enough for min_len
+    __shared__ unsigned long long mraw[kHpGroups];      // k_match_hc's own bits (min_len 3): the too-short matches are mraw & ~mb
     __shared__ uint32_t rank_pre[kHpGroups];            // walk: exit of segment s; then (tokens | matches << 17) before group s
     __shared__ uint32_t rescue[2];
     __shared__ uint32_t wsum_t[kMpWaves], wsum_m[kMpWaves];
@@ -2023,6 +2024,7 @@ __global__ __launch_bounds__(kMpThreads, GZPX_PHC_WAVES) void k_parse_hc(
             unsigned long long w = tid < ngroups ? mbits_g[tile_begin / 64 + tid] : 0ull;
             const uint32_t left = tile_len - (tid < ngroups ? tid * 64 : tile_len);
             if (left < 64) w &= (1ull << left) - 1ull;
+            mraw[tid] = w;
             if (min_len > 3 && !GZPX_EXP(cfg, 13)) {
                 unsigned long long t = w, keep = 0;
                 while (t) {
@@ -2219,11 +2221,18 @@ __global__ __launch_bounds__(kMpThreads, GZPX_PHC_WAVES) void k_parse_hc(
             // (bin 0 = up to and including the first check token).
             for (uint32_t g0 = wave; g0 < ngroups; g0 += 8 * kMpWaves) {
                 uint32_t vals[8], tis[8];
+                // (min_len > 3: a match k_match_hc found that is too short for this sub-block is a literal, and `val` holds
+                // its distance, not its byte.  Which positions those are is in LDS (mraw), and the bytes are requested HERE,
+                // beside the val loads: asked for where they are needed -- the bitmap word, then the byte -- they were two
+                // dependent trips to memory per group, sixteen per turn of this loop, and half of the kernel's time on text)
+                uint32_t inb[8];
 #pragma unroll
                 for (uint32_t k = 0; k < 8; k++) {
                     const uint32_t g = g0 + k * kMpWaves;
                     const uint32_t r = g * 64 + lane;
-                    vals[k] = (g < ngroups && r < tile_len) ? val[tile_begin + r] : 0u;
+                    const bool in_tile = g < ngroups && r < tile_len;
+                    vals[k] = in_tile ? val[tile_begin + r] : 0u;
+                    inb[k] = (min_len > 3 && in_tile) ? (uint32_t)in[tile_begin + r] : 0u;
                 }
                 __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): no load is pending behind a later store's data
 #pragma unroll
@@ -2239,7 +2248,7 @@ __global__ __launch_bounds__(kMpThreads, GZPX_PHC_WAVES) void k_parse_hc(
                     const uint32_t len = is_match ? (uint32_t)len8[r] + 3u : 1u;
                     uint32_t v = vals[k];
                     // a match too short for this sub-block's min_len is a literal: val holds its distance
-                    if (!is_match && min_len > 3 && ((mbits_g[(tile_begin >> 6) + g] >> lane) & 1ull)) v = in[p];
+                    if (!is_match && ((mraw[g] >> lane) & 1ull)) v = inb[k];
                     vals[k] = is_match ? (kTokMatch | (v << 9) | len) : v;
                     tis[k] = ti;
                     if (ti < stat_from || ti >= lim_tok || GZPX_EXP(cfg, 14)) continue;
