@@ -39,11 +39,20 @@ def build(force=False, verbose=False):
             and os.path.getmtime(LIB) >= max(os.path.getmtime(d) for d in deps)):
         return LIB
     os.makedirs(LIB_DIR, exist_ok=True)
-    cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-pthread",
-           "-DGZPX_BUILD_ID=\"%s\"" % source_id(), "-I", INCLUDE] + srcs + ["-o", LIB]
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.check_call(cmd)
+    # (one builder at a time, into a temporary name renamed when complete: concurrent importers never load half a file)
+    import fcntl
+    with open(LIB + ".lock", "w") as lk:
+        fcntl.flock(lk, fcntl.LOCK_EX)
+        if (not force and os.path.exists(LIB)
+                and os.path.getmtime(LIB) >= max(os.path.getmtime(d) for d in deps)):
+            return LIB
+        tmp = LIB + ".tmp.%d" % os.getpid()
+        cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-pthread",
+               "-DGZPX_BUILD_ID=\"%s\"" % source_id(), "-I", INCLUDE] + srcs + ["-o", tmp]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+        os.replace(tmp, LIB)
     return LIB
 
 

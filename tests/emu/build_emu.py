@@ -21,9 +21,19 @@ def build(force=False):
     if (not force and os.path.exists(OUT)
             and os.path.getmtime(OUT) >= max(os.path.getmtime(d) for d in deps if os.path.exists(d))):
         return OUT
-    cmd = ["g++", "-O2", "-g", "-std=c++17", "-fPIC", "-shared", "-pthread", "-Wall", "-Wno-unused-function", "-Wno-unknown-pragmas",
-           "-I", HERE, "-I", os.path.join(ROOT, "include"), "-x", "c++"] + srcs + ["-o", OUT]
-    subprocess.check_call(cmd)
+    # Several processes may want the library at once (the two ranks of `bench.py --emulate --gpus 2`): one builds, under a
+    # file lock and into a temporary name that is renamed when complete; the others wait and find it up to date.
+    import fcntl
+    with open(OUT + ".lock", "w") as lk:
+        fcntl.flock(lk, fcntl.LOCK_EX)
+        if (not force and os.path.exists(OUT)
+                and os.path.getmtime(OUT) >= max(os.path.getmtime(d) for d in deps if os.path.exists(d))):
+            return OUT
+        tmp = OUT + ".tmp.%d" % os.getpid()
+        cmd = ["g++", "-O2", "-g", "-std=c++17", "-fPIC", "-shared", "-pthread", "-Wall", "-Wno-unused-function", "-Wno-unknown-pragmas",
+               "-I", HERE, "-I", os.path.join(ROOT, "include"), "-x", "c++"] + srcs + ["-o", tmp]
+        subprocess.check_call(cmd)
+        os.replace(tmp, OUT)
     return OUT
 
 
