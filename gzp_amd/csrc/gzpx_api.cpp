@@ -9,6 +9,8 @@
 
 #include <condition_variable>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <mutex>
 #include <new>
 #include <string.h>
@@ -123,10 +125,14 @@ struct gzpx_ctx {
 
 namespace {
 
-#define HIP_TRY(expr)                          \
-    do {                                       \
-        hipError_t _e = (expr);                \
-        if (_e != hipSuccess) return GZPX_ERR_DEVICE; \
+// (GZPX_TRACE in the environment: the failing runtime call is named on stderr)
+#define HIP_TRY(expr)                                                                                   \
+    do {                                                                                                \
+        hipError_t _e = (expr);                                                                         \
+        if (_e != hipSuccess) {                                                                         \
+            if (getenv("GZPX_TRACE")) fprintf(stderr, "gzpx: %s:%d %s -> %s\n", __FILE__, __LINE__, #expr, hipGetErrorString(_e)); \
+            return GZPX_ERR_DEVICE;                                                                     \
+        }                                                                                               \
     } while (0)
 
 thread_local int t_last_status = GZPX_OK;  // libdeflate-shaped calls have no status channel
