@@ -33,3 +33,23 @@ def test_available_cores_is_sane():
     import bench
     n, note = bench.available_cores()
     assert n >= 1 and isinstance(note, str)
+
+
+def test_traffic_figures_are_only_taken_from_this_build_of_the_library():
+    """profiles/pmc_traffic.json records the gzpx_build_id it was collected with; bench.py uses its counters only for a
+    library of that very build (a kernel change must not leave a stale `roofline.traffic` in the line)."""
+    import json
+    import os
+
+    import bench
+    from gzp_amd import build
+    with open(os.path.join(bench.ROOT, "profiles", "pmc_traffic.json")) as f:
+        doc = json.load(f)
+    have = doc["build_id"]
+    assert isinstance(have, str) and len(have) == 16
+    assert bench.pmc_traffic("pipeline", have) == doc["hbm_bytes_per_launch"]["pipeline"]
+    assert bench.pmc_traffic("pipeline", "0123456789abcdef") is None
+    assert "refused" in bench.pmc_traffic_source("0123456789abcdef")
+    assert have in bench.pmc_traffic_source(have)
+    # the committed counters belong to the committed sources
+    assert have == build.source_id(), "kernel sources changed: re-collect profiles/pmc_traffic.json (tools/pmc_traffic_all.sh + tools/summarize_profiles.py)"
