@@ -149,14 +149,30 @@ class PeerWindow:
         self.rank = dist.get_rank(group)
         self.world = dist.get_world_size(group)
         self.buf = None
+        # Set-up is collective and must fail on EVERY rank or on none: the writer broadcasts its handle or its error, every
+        # rank says whether it could map the buffer, and all of them raise together if one could not (a box whose devices
+        # cannot map each other's memory then simply runs without this write-out).
         box = [None]
         if self.rank == dst:
-            self.buf = torch.empty(int(capacity), dtype=torch.uint8, device=device)
-            box[0] = reduce_tensor(self.buf)  # (rebuild function, IPC handle + geometry): picklable
+            try:
+                self.buf = torch.empty(int(capacity), dtype=torch.uint8, device=device)
+                box[0] = ("ok", reduce_tensor(self.buf))  # (rebuild function, IPC handle + geometry): picklable
+            except Exception as e:  # noqa: BLE001
+                box[0] = ("error", repr(e))
         dist.broadcast_object_list(box, src=dst, group=group)
-        if self.rank != dst:
-            fn, args = box[0]
-            self.buf = fn(*args)  # the SAME memory, opened in this process
+        ok, why = box[0][0] == "ok", None if box[0][0] == "ok" else box[0][1]
+        if ok and self.rank != dst:
+            try:
+                fn, args = box[0][1]
+                self.buf = fn(*args)  # the SAME memory, opened in this process
+            except Exception as e:  # noqa: BLE001
+                ok, why = False, repr(e)
+        votes = [None] * self.world
+        dist.all_gather_object(votes, (ok, why), group=group)
+        if not all(v[0] for v in votes):
+            self.buf = None
+            raise RuntimeError("PeerWindow: the writer's buffer cannot be mapped on every rank: %s"
+                               % "; ".join("rank %d: %s" % (r, v[1]) for r, v in enumerate(votes) if not v[0]))
         self.stream = torch.cuda.Stream(device=device)
         self._sizes_on_cpu = dist.get_backend(group) == "gloo"  # (tests: control plane on gloo, payload on the GPU)
         self._device = device
