@@ -1858,6 +1858,19 @@ __global__ __launch_bounds__(1024) void k_match_hc(Config cfg, const uint8_t *__
             const uint32_t max_len = rem < 258u ? rem : 258u;
             const uint32_t nice_len = max_len < nice_level ? max_len : nice_level;
             const uint32_t a = p - win_begin + mis, li = p - win_begin;
+#ifdef GZPX_EXPERIMENT
+            // measurement only (tools/exp_hc_sparse.py): search a pseudo-random share of the positions -- bits 16-22 of the
+            // debug word, in 128ths -- and report "no match" for the rest: what would a wave cost whose lanes search only
+            // where a token starts?  (the stream stays valid, it just is not libdeflate's)
+            if (((cfg.debug >> 16) & 127u) && !cfg.lazy) {
+                const uint32_t hsh = (p * 2654435761u + b * 40503u) >> 25;  // 0..127
+                if (hsh >= ((cfg.debug >> 16) & 127u)) {
+                    len8[p] = 0;
+                    dist[p] = (uint16_t)(lds_le32(in_w, a) & 0xFFu);
+                    continue;
+                }
+            }
+#endif
             if (cfg.lazy) {  // (uniform)
                 // Levels 5-9: the lazy parsers search a position up to three times -- where a decision
                 // starts (full depth), as the position after a match (half), as the one after that
