@@ -31,6 +31,24 @@ def test_headline_line_proves_itself():
     assert r["kernel"] in r["stage_ms"] and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-4
     assert 0 < r["pipeline_frac"] < r["frac"] and 0 < r["hbm_read_frac"] < r["pipeline_frac"]
     assert c["box_libdeflate"] in (None, "1.10-like", "1.24-like", "unknown")
+    # the traffic figure is this build's or none at all (profiles/pmc_traffic.json records the build it belongs to)
+    assert r["library_build_id"] and ((r["traffic"] is None) == ("refused" in r["traffic_source"] or "no profiles" in r["traffic_source"]))
+
+
+def test_default_line_carries_the_other_configurations():
+    """Everything the default `python bench.py` line promises beside the headline: the levels legs, configs[2] (Mgzip 1 MiB
+    blocks, level 3, 4 GiB of ASCII noise) with its digest and the inflation of its own stream, configs[4] (`inflate`),
+    the host-to-host legs and the CPU baseline -- every stream checked against the libdeflate-made digest inside the run."""
+    d = _bench("--steps", "3", "--warmup", "1", timeout=1500)
+    for lv in ("level_3", "level_6", "level_9"):
+        leg = d["levels"][lv]
+        assert leg["verified_bit_exact_full"] is True and leg["gpu_inflate_crc_roundtrip_ok"] is True and leg["MiBps"] > 0
+    assert d["levels"]["level_12"]["compat_in_force"] == "libdeflate 1.10"  # (whatever the context was asked for)
+    m = d["mgzip3"]
+    assert m["verified_bit_exact_full"] is True and m["gpu_inflate_crc_roundtrip_ok"] is True and m["blocks"] == 4096
+    assert m["inflate_of_output"]["MiBps"] > 0 and m["roofline"]["kernel"] in m["roofline"]["stage_ms"]
+    assert d["inflate"]["verified_round_trip"] is True and d["e2e"]["api_write_ok"] and d["e2e"]["device_pinned_ok"]
+    assert d["cpu_baseline"]["kind"] in ("reference", "port") and d["cpu_baseline"]["cores"] >= 1
 
 
 def test_config4_fastq_share_of_the_stream():
