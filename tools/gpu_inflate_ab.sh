@@ -10,7 +10,7 @@ for L in "$@"; do
 import json
 try:
     d = json.loads(open("$O/$T.inflate.json").read().strip().splitlines()[-1])
-    print("$T text stream: inflate", d["value"], "MiB/s", d["ms_per_step"], "ms", d["config"].get("verified_round_trip"))
+    print("$T text stream: inflate", d["value"], "MiB/s", d["ms_per_step"], "ms; k_inflate", d["roofline"].get("kernel_ms"), "ms", d["config"].get("verified_round_trip"))
 except Exception as e:
     print("$T inflate FAILED", e, open("$O/$T.inflate.err").read()[-300:])
 try:
