@@ -2444,10 +2444,20 @@ next_round:;
 // observations, 5000 bytes either side) or min_len is due for recalculate_min_match_len.
 //   A decision's chain looks at most kLzReach positions ahead: each step raises 4*len - bsr(off),
 //   which lives in [-2, 1032], by >= 3 per position it advances, so <= 345 positions and 2 of
-//   lookahead.  Windows only start where that much of the LDS tile is left.
+//   lookahead.  Nearly every chain is a step or two, so a window starts wherever kLzNear positions of the
+//   LDS tile are left behind it; a lane whose chain runs off the tile says so, and if the walk reaches
+//   that lane the window is cut in front of it and the tile reloaded there (a tile that starts at a window
+//   holds the longest chain of every lane: kLzSpan >= 64 + kLzReach + 3).
 // ------------------------------------------------------------------------------------------
-constexpr uint32_t kLzSpan = 1024;  // positions per LDS tile
+#ifndef GZPX_LZ_SPAN
+#define GZPX_LZ_SPAN 512
+#endif
+constexpr uint32_t kLzSpan = GZPX_LZ_SPAN;  // positions per LDS tile
 constexpr uint32_t kLzReach = 352;
+constexpr uint32_t kLzNear = 16;
+constexpr uint32_t kLzStep = kLzSpan - 64 - kLzNear;           // the grid of tile starts
+constexpr uint32_t kLzInRegs = (kLzSpan / 4 + 2 + 63) / 64;  // dwords of input bytes per lane and tile
+static_assert(kLzSpan >= 64 + kLzReach + 4 && kLzSpan % 256 == 0, "a tile holds a window and its longest chain");
 
 template <int NV>  // match variants staged: 2 (lazy) or 3 (lazy2)
 struct LzLds {
@@ -2489,7 +2499,48 @@ __global__ __launch_bounds__(64) void k_parse_lazy(Config cfg, const uint8_t *__
     const uint64_t lane_below = (1ull << lane) - 1ull;
 
     uint32_t pos = 0, ti = 0, cur_sub = 0;
-    uint32_t t0 = 0xFFFFFFFFu, mis = 0;  // the tile holds positions [t0, t0 + kLzSpan)
+    uint32_t t0 = 0xFFFFFFFFu;  // the tile holds positions [t0, t0 + kLzSpan)
+    const uint32_t mis = (uint32_t)((uintptr_t)in & 3u);  // (tiles start at multiples of four)
+    // Tiles lie on a grid of kLzStep positions (a tile serves the windows that start in its first kLzStep), so the one
+    // behind the current tile is known when the current one is stored to LDS: its loads are issued then, into
+    // registers, and waited for a tile later.  (Round 4: loaded on demand, a tile cost the wave 16 thousand clocks
+    // -- 139 times per BGZF block, a third of the kernel.)
+    uint32_t pf0 = 0xFFFFFFFFu;  // start of the tile in the registers
+    bool here = false;           // the next tile starts at pos, off the grid
+    uint32_t pf_in[kLzInRegs], pf_len[NV][kLzSpan / 256], pf_dist[NV][kLzSpan / 128];
+    auto tile_fetch = [&](uint32_t start) {
+        const uint32_t t_end = start + kLzSpan < n ? start + kLzSpan : n;  // (exclusive)
+        const uint32_t *src = (const uint32_t *)(in + start - mis);
+        const uint32_t ndw = (mis + (t_end - start) + 3u) >> 2;
+        const uint32_t nd4 = (t_end - start + 3u) / 4u, nd2 = (t_end - start + 1u) / 2u;
+#pragma unroll
+        for (uint32_t k = 0; k < kLzInRegs; k++) pf_in[k] = lane + 64u * k < ndw ? src[lane + 64u * k] : 0u;
+#pragma unroll
+        for (int v = 0; v < NV; v++) {
+            const uint32_t *sl = (const uint32_t *)gl[v] + start / 4u;
+            const uint32_t *sd = (const uint32_t *)gd[v] + start / 2u;
+#pragma unroll
+            for (uint32_t k = 0; k < kLzSpan / 256; k++) pf_len[v][k] = lane + 64u * k < nd4 ? sl[lane + 64u * k] : 0u;
+#pragma unroll
+            for (uint32_t k = 0; k < kLzSpan / 128; k++) pf_dist[v][k] = lane + 64u * k < nd2 ? sd[lane + 64u * k] : 0u;
+        }
+        pf0 = start;
+    };
+#ifdef GZPX_EXPERIMENT
+    // measurement builds (tools/exp_parse_lazy.py): the wave's clock per phase, summed over a block's windows: 0 tile
+    // loads, 1 decisions, 2 chase, 3 prefixes + what is due, 4 commit, 5 what was due; 6 windows, 7 tile loads
+    unsigned long long exp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long exp_t = __builtin_readcyclecounter();
+    auto exp_lap = [&](uint32_t slot) {
+        const unsigned long long t = __builtin_readcyclecounter();
+        exp_acc[slot] += t - exp_t;
+        exp_t = t;
+    };
+    auto exp_count = [&](uint32_t slot) { exp_acc[slot] += 1; };
+#else
+    auto exp_lap = [](uint32_t) {};
+    auto exp_count = [](uint32_t) {};
+#endif
     for (;;) {                            // DEFLATE sub-blocks
         const uint32_t sub_start = pos, sub_start_tok = ti;
         const uint32_t max_block_end = hc_sub_limit_of(sub_start, n);
@@ -2503,28 +2554,38 @@ __global__ __launch_bounds__(64) void k_parse_lazy(Config cfg, const uint8_t *__
             L.nw[lane] = 0;
         }
         for (;;) {  // windows of 64 positions from pos
-            if (t0 == 0xFFFFFFFFu || pos - t0 + 64u + kLzReach > kLzSpan) {
-                t0 = pos & ~3u;
-                const uint32_t t_end = t0 + kLzSpan < n ? t0 + kLzSpan : n;  // (exclusive)
-                mis = (uint32_t)((uintptr_t)(in + t0) & 3u);
+            exp_lap(5);
+            if (t0 == 0xFFFFFFFFu || pos - t0 + 64u + kLzNear > kLzSpan) {
+                // the tile of the grid that serves a window at pos -- or, when a chain ran off its tile, the one that starts here
+                const uint32_t start = here ? (pos & ~3u) : pos / kLzStep * kLzStep;
+                here = false;
+                if (pf0 != start) tile_fetch(start);  // (a block's first tile, or one out of turn)
                 __syncthreads();
-                const uint32_t *src = (const uint32_t *)(in + t0 - mis);
-                const uint32_t ndw = (mis + (t_end - t0) + 3u) >> 2;
-                for (uint32_t i = lane; i < kLzSpan / 4 + 2; i += 64) L.in8[i] = i < ndw ? src[i] : 0u;
-                const uint32_t nd4 = (t_end - t0 + 3u) / 4u, nd2 = (t_end - t0 + 1u) / 2u;
+#pragma unroll
+                for (uint32_t k = 0; k < kLzInRegs; k++)
+                    if (lane + 64u * k < kLzSpan / 4 + 2) L.in8[lane + 64u * k] = pf_in[k];
 #pragma unroll
                 for (int v = 0; v < NV; v++) {
-                    const uint32_t *sl = (const uint32_t *)gl[v] + t0 / 4u;
-                    const uint32_t *sd = (const uint32_t *)gd[v] + t0 / 2u;
-                    for (uint32_t i = lane; i < kLzSpan / 4; i += 64) L.len[v][i] = i < nd4 ? sl[i] : 0u;
-                    for (uint32_t i = lane; i < kLzSpan / 2; i += 64) L.dist[v][i] = i < nd2 ? sd[i] : 0u;
+#pragma unroll
+                    for (uint32_t k = 0; k < kLzSpan / 256; k++) L.len[v][lane + 64u * k] = pf_len[v][k];
+#pragma unroll
+                    for (uint32_t k = 0; k < kLzSpan / 128; k++) L.dist[v][lane + 64u * k] = pf_dist[v][k];
                 }
                 __syncthreads();
+                t0 = start;
+                // the next tile of the grid travels in registers while this one is parsed
+                pf0 = (start / kLzStep + 1u) * kLzStep;
+                if (pf0 < n) tile_fetch(pf0);
+                else pf0 = 0xFFFFFFFFu;
+                exp_count(7);
             }
+            exp_lap(0);
+            exp_count(6);
             const uint8_t *t_in = (const uint8_t *)L.in8 + mis;
             // ---- the decision a lane's position would start
             const uint32_t p = pos + lane, r = p - t0;
             uint32_t nlit = 0, mlen = 0, moff = 0, nrel = lane + 1u;
+            bool off_tile = false;  // the chain needs positions behind the tile
             if (p < n) {
                 const uint32_t d = t_d0[r], l = (uint32_t)t_l0[r] + 3u;
                 if (d == 0 || l < min_len || (l == 3u && d > 8192u)) {
@@ -2537,7 +2598,10 @@ __global__ __launch_bounds__(64) void k_parse_lazy(Config cfg, const uint8_t *__
                         const uint32_t nice_len = max_len < nice_level ? max_len : nice_level;
                         if (cl >= nice_len) break;  // take it as it is
                         const uint32_t rr = cp + 1u - t0;
-                        if (rr + 1u >= kLzSpan) break;  // (beyond kLzReach: cannot happen)
+                        if (rr + 1u >= kLzSpan) {
+                            off_tile = true;
+                            break;
+                        }
                         const int bsr_cur = 31 - __clz((int)co);
                         {
                             const uint32_t d1 = t_d1[rr], l1 = (uint32_t)t_l1[rr] + 3u;
@@ -2567,7 +2631,11 @@ __global__ __launch_bounds__(64) void k_parse_lazy(Config cfg, const uint8_t *__
                 }
                 if (mlen == 0) nrel = lane + 1u;
             }
+            exp_lap(1);
             // ---- where decisions really start: chase from the window's first position
+            // (Round 4, tried: every lane learns its second, third and fourth successor with two rounds of ds_bpermute
+            // and the chase takes four decisions a step -- the dependent v_readlane chain shrinks from 17 hops to 5, the
+            // kernel grows from 4.33 to 4.8 ms: what it is short of while all its waves are resident is VALU issue.)
             uint64_t reach = 0;
             uint32_t q = 0;
             while (q < 64u) {
@@ -2575,6 +2643,7 @@ __global__ __launch_bounds__(64) void k_parse_lazy(Config cfg, const uint8_t *__
                 q = (uint32_t)__builtin_amdgcn_readlane((int)nrel, (int)q);
             }
             const uint32_t exit_rel = q;
+            exp_lap(2);
             const bool in_r = (reach >> lane) & 1ull;
             const uint32_t cnt = in_r ? nlit + (mlen ? 1u : 0u) : 0u;
             const uint32_t inc = wave_incl_add(cnt);
@@ -2585,9 +2654,11 @@ __global__ __launch_bounds__(64) void k_parse_lazy(Config cfg, const uint8_t *__
             const bool due = in_r && (p >= max_block_end || nseq + mb >= kHcSeqPerSub ||
                                       (num_new + tb >= 512u && p - sub_start >= kMinBlockLen && n - p >= kMinBlockLen) ||
                                       p >= next_recalc);
-            const uint64_t dm = __ballot(due);
+            const uint64_t dm_real = __ballot(due);
+            const uint64_t dm = dm_real | (__ballot(off_tile) & reach);
             const uint32_t e = dm ? (uint32_t)__ffsll((long long)dm) - 1u : 64u;
             const uint64_t commit = e < 64u ? reach & ((1ull << e) - 1ull) : reach;
+            exp_lap(3);
             if ((commit >> lane) & 1ull) {
                 const uint32_t o = ti + tb;
                 for (uint32_t j = 0; j < nlit; j++) {
@@ -2607,7 +2678,13 @@ __global__ __launch_bounds__(64) void k_parse_lazy(Config cfg, const uint8_t *__
             num_new += done_tok;
             nseq += (uint32_t)__popcll(mm & commit);
             pos += e < 64u ? e : exit_rel;
+            exp_lap(4);
             if (e == 64u) continue;
+            if (!((dm_real >> e) & 1ull)) {  // nothing is due: the decision at pos needs a tile that starts here
+                t0 = 0xFFFFFFFFu;
+                here = true;
+                continue;
+            }
             // ---- what is due at pos, in deflate_compress_lazy_generic's order
             if (pos >= max_block_end || nseq >= kHcSeqPerSub) break;
             if (num_new >= 512u && pos - sub_start >= kMinBlockLen && n - pos >= kMinBlockLen) {  // do_end_block_check
@@ -2662,6 +2739,11 @@ __global__ __launch_bounds__(64) void k_parse_lazy(Config cfg, const uint8_t *__
         meta->ntok = ti;
         meta->nsub = cur_sub;
     }
+#ifdef GZPX_EXPERIMENT
+    exp_lap(5);
+    if (lane == 0)
+        for (uint32_t k = 0; k < 8; k++) atomicAdd(&g_exp_cycles[(b & 1023u) * 8u + k], exp_acc[k]);
+#endif
 }
 
 __global__ void k_hc_init(uint32_t nb, HcState *hc, uint32_t *pending) {
