@@ -1633,6 +1633,8 @@ __device__ uint32_t hc_calc_min_len(const Config &cfg, const uint8_t *in, uint32
     __syncthreads();
     const bool short_scan = cfg.compat == 0 && data_len < 512;  // libdeflate >= 1.1x
     if (data_len > 4096) data_len = 4096;
+    // (Round 4, tried: whole dwords, four loads in flight per thread -- k_parse_lazy calls this with ONE wave, 64 round
+    // trips in a row -- no change at levels 6 / 9, k_parse_hc + 0.1 ms: a sub-block starts too rarely to matter.)
     for (uint32_t i = tid; i < data_len; i += nthreads) {
         const uint32_t v = in[start + i];
         atomicOr(&used[v >> 5], 1u << (v & 31u));
@@ -1823,28 +1825,78 @@ __global__ __launch_bounds__(1024) void k_match_hc(Config cfg, const uint8_t *__
     const uint32_t min_len = 3;
     const uint32_t nice_level = cfg.hc_nice, depth = GZPX_EXP(cfg, 12) ? 1u : cfg.hc_depth;
 
+    // The window slides: from its second tile on a block keeps what the previous tile's window shares with this one
+    // -- up to 32 KiB of bytes and 64 KiB of links, moved down INSIDE the LDS -- and appends the 16 KiB of bytes and
+    // 32 KiB of links that are new, which were loaded into registers (5 + 8 dwords a thread; the kernel has 128 VGPRs
+    // to itself at one workgroup per CU) while the previous tile was searched.  (Round 4: every tile staged its whole
+    // window from HBM, 144 KiB, with the CU's only workgroup waiting for it.)
+    auto fix_links = [](uint32_t v) {  // two links; 0 = none
+        if ((v & 0xFFFFu) == 0) v |= kHcNoLink;
+        if ((v >> 16) == 0) v |= kHcNoLink << 16;
+        return v;
+    };
+    constexpr uint32_t kPfIn = 5, kPfLk = kHcTile / 2 / 1024, kMvIn = (kHcInWords - kHcTile / 4 + 1023) / 1024, kMvLk = 32768 / 2 / 1024;
+    uint32_t pf_in[kPfIn], pf_lk[kPfLk];
+    uint32_t prev_win = 0, prev_ndw = 0, prev_nlw = 0;  // the window in LDS (prev_ndw = 0: none)
     for (uint32_t tile_begin = resume / kHcTile * kHcTile; tile_begin < n; tile_begin += kHcTile) {
         const uint32_t tile_end = tile_begin + kHcTile < n ? tile_begin + kHcTile : n;
         const uint32_t win_begin = tile_begin >= 32768u ? tile_begin - 32768u : 0;
         const uint32_t win_end = tile_end + 264 < n ? tile_end + 264 : n;
-        const uint32_t mis = (uint32_t)((uintptr_t)(in + win_begin) & 3u);
+        const uint32_t mis = (uint32_t)((uintptr_t)(in + win_begin) & 3u);  // (the same for every tile: win_begin is a multiple of four)
+        const uint32_t ndw = (mis + (win_end - win_begin) + 3) >> 2;  // dwords of bytes in the window
+        const uint32_t nlw = (tile_end - win_begin + 1) / 2;           // dwords of links (win_begin is a multiple of 16384: aligned u16 pairs)
         __syncthreads();
-        {
+        if (prev_ndw == 0) {  // a block's first tile: everything from memory
             const uint32_t *src = (const uint32_t *)(in + win_begin - mis);
-            const uint32_t ndw = (mis + (win_end - win_begin) + 3) >> 2;
             for (uint32_t i = tid; i < ndw; i += 1024) in_w[i] = src[i];
-            for (uint32_t i = ndw + tid; i < ndw + 3 && i < kHcInWords; i += 1024) in_w[i] = 0;
-            // win_begin is a multiple of 16384 and the stride of 1024: dword-aligned u16 pairs
             const uint32_t *lsrc = (const uint32_t *)(d4 + win_begin);
-            for (uint32_t i = tid; i < (tile_end - win_begin + 1) / 2; i += 1024) {
-                uint32_t v = lsrc[i];  // two links; 0 = none
-                if ((v & 0xFFFFu) == 0) v |= kHcNoLink;
-                if ((v >> 16) == 0) v |= kHcNoLink << 16;
-                link_w[i] = v;
+            for (uint32_t i = tid; i < nlw; i += 1024) link_w[i] = fix_links(lsrc[i]);
+        } else {
+            const uint32_t sh = win_begin - prev_win;  // 0 while the window still grows, then kHcTile
+            const uint32_t keep_in = prev_ndw - sh / 4, keep_lk = prev_nlw - sh / 2;
+            if (sh) {
+                uint32_t mv_in[kMvIn], mv_lk[kMvLk];
+#pragma unroll
+                for (uint32_t k = 0; k < kMvIn; k++) mv_in[k] = tid + 1024u * k < keep_in ? in_w[tid + 1024u * k + sh / 4] : 0u;
+#pragma unroll
+                for (uint32_t k = 0; k < kMvLk; k++) mv_lk[k] = tid + 1024u * k < keep_lk ? link_w[tid + 1024u * k + sh / 2] : 0u;
+                __syncthreads();
+#pragma unroll
+                for (uint32_t k = 0; k < kMvIn; k++)
+                    if (tid + 1024u * k < keep_in) in_w[tid + 1024u * k] = mv_in[k];
+#pragma unroll
+                for (uint32_t k = 0; k < kMvLk; k++)
+                    if (tid + 1024u * k < keep_lk) link_w[tid + 1024u * k] = mv_lk[k];
             }
-            for (uint32_t i = tid; i < kHcTile / 32; i += 1024) mbits[i] = 0;
+#pragma unroll
+            for (uint32_t k = 0; k < kPfIn; k++)
+                if (keep_in + tid + 1024u * k < ndw) in_w[keep_in + tid + 1024u * k] = pf_in[k];
+#pragma unroll
+            for (uint32_t k = 0; k < kPfLk; k++)
+                if (keep_lk + tid + 1024u * k < nlw) link_w[keep_lk + tid + 1024u * k] = fix_links(pf_lk[k]);
         }
-        // the hash3 distance of a lane's next position travels while it searches the current one
+        for (uint32_t i = ndw + tid; i < ndw + 3 && i < kHcInWords; i += 1024) in_w[i] = 0;
+        for (uint32_t i = tid; i < kHcTile / 32; i += 1024) mbits[i] = 0;
+        prev_win = win_begin;
+        prev_ndw = ndw;
+        prev_nlw = nlw;
+        if (tile_end < n) {  // what the next tile's window adds to this one
+            const uint32_t nt_end = tile_end + kHcTile < n ? tile_end + kHcTile : n;
+            const uint32_t nw_begin = tile_end >= 32768u ? tile_end - 32768u : 0;
+            const uint32_t nw_end = nt_end + 264 < n ? nt_end + 264 : n;
+            const uint32_t nsh = nw_begin - win_begin;
+            const uint32_t n_ndw = (mis + (nw_end - nw_begin) + 3) >> 2, n_nlw = (nt_end - nw_begin + 1) / 2;
+            const uint32_t *src = (const uint32_t *)(in + nw_begin - mis) + (ndw - nsh / 4);
+            const uint32_t *lsrc = (const uint32_t *)(d4 + nw_begin) + (nlw - nsh / 2);
+            const uint32_t more_in = n_ndw - (ndw - nsh / 4), more_lk = n_nlw - (nlw - nsh / 2);
+#pragma unroll
+            for (uint32_t k = 0; k < kPfIn; k++) pf_in[k] = tid + 1024u * k < more_in ? src[tid + 1024u * k] : 0u;
+#pragma unroll
+            for (uint32_t k = 0; k < kPfLk; k++) pf_lk[k] = tid + 1024u * k < more_lk ? lsrc[tid + 1024u * k] : 0u;
+        }
+        // the hash3 distance of a lane's next position travels while it searches the current one.  (Tried: the
+        // sixteen of a tile prefetched with the window, packed in eight registers that the loop shifts through, so
+        // that no load is waited for inside the loop: level 9 110.5 -> 113.5 ms, the others +0.1 ... 0.4.)
         uint32_t d3_next = tile_begin + tid + 5 <= n && tile_begin + tid < tile_end ? d3[tile_begin + tid] : 0u;
         __syncthreads();
         uint8_t *lzl = lz_len_all + (uint64_t)b * 2u * cfg.stride;
