@@ -1698,6 +1698,9 @@ __device__ __forceinline__ uint32_t lds_extend_from(const uint32_t *in_w, uint32
 // A staged d4 link that says "no live predecessor" (k_candidates writes 0): any distance above 32767 ends
 // a walk, so the test for the end of the chain and the test for the window are one comparison.
 constexpr uint32_t kHcNoLink = 0x8000u;
+// bit 15 of a match distance in k_match_hc's arrays: the match is with position 0 and lies behind an empty hash3 bucket
+// (k_hc_orphan writes it) -- libdeflate finds it only with a search that starts from best_len >= 4
+constexpr uint32_t kHcOrphan = 0x8000u;
 
 // hc_matchfinder_longest_match (started from best_len = 2) for the position at LDS byte address a /
 // link index li: ONE loop with one chain node per iteration.  libdeflate's two loops ("first node whose
@@ -1962,6 +1965,96 @@ __global__ __launch_bounds__(1024) void k_match_hc(Config cfg, const uint8_t *__
 }
 
 // ------------------------------------------------------------------------------------------
+// k_hc_orphan: position 0 and the hash3 gate (levels 2-9; one wave per block, behind k_match_hc).
+//   libdeflate files a buffer's first position under bucket 0 of BOTH hc_matchfinder tables (next_hashes starts as
+//   {0, 0}), not under its own hashes.  A search that starts from best_len < 4 gives up at once when its hash3 bucket
+//   is empty; one that starts from best_len >= 4 (min_len >= 5, or a lazy lookahead behind a match of >= 5) never looks
+//   at hash3 and walks the hash4 chain.  k_match_hc searches every position once, from best_len 2, behind the gate --
+//   and for every position but one the two kinds of search agree, because four equal bytes imply an occupied hash3
+//   bucket.  The exception ("orphan") is the first later position with the buffer's first four bytes, when those hash
+//   to hash4 bucket 0: position 0 is in its chain but not in its hash3 bucket.  One buffer in ~ 65 thousand starts that
+//   way; the round-4 soak found one (seed 20260928, 'repeats', level 7: a stream one byte longer than libdeflate's).
+//   Nothing else in that chain can have the position's four bytes, so its ungated search is: follow the chain to
+//   position 0, within the depth budget, and extend.  This kernel does that for the one position per block that can
+//   have it and writes the result over k_match_hc's "no match" with bit 15 of the distance set; the parsers use a
+//   marked match only where libdeflate's search would have started at >= 4 (k_parse_hc: sub-blocks with min_len >= 5,
+//   the position is in HcState.pad; k_parse_lazy: min_len >= 5 for a decision's first search, cur_len >= 5 for a
+//   lookahead).  All but one block in 65 thousand leave after one load.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_hc_orphan(Config cfg, const uint8_t *__restrict__ slab,
+                                                  const BlockMeta *__restrict__ meta_all, HcState *__restrict__ hc_all,
+                                                  const uint16_t *__restrict__ d3_all, const uint16_t *__restrict__ d4_all,
+                                                  uint8_t *__restrict__ len8_all, uint32_t *__restrict__ mbits_all,
+                                                  uint16_t *__restrict__ dist_all, uint8_t *__restrict__ lz_len_all,
+                                                  uint16_t *__restrict__ lz_dist_all) {
+    const uint32_t lane = threadIdx.x, b = blockIdx.x;
+    const uint32_t n = meta_all[b].n;
+    if (n <= cfg.passthrough || n < 9u) return;  // (uniform)
+    const uint8_t *in = slab + (uint64_t)b * cfg.block_size;
+    auto le32 = [&](uint32_t p) {
+        return (uint32_t)in[p] | (uint32_t)in[p + 1] << 8 | (uint32_t)in[p + 2] << 16 | (uint32_t)in[p + 3] << 24;
+    };
+    const uint32_t first4 = le32(0);
+    if (((first4 * 0x1E35A7BDu) >> 16) != 0) return;  // position 0 sits in hash4 bucket 0 and in no other chain
+    const uint16_t *d3 = d3_all + (uint64_t)b * cfg.stride;
+    const uint16_t *d4 = d4_all + (uint64_t)b * cfg.stride;
+    // the orphan: four bytes like the buffer's first, an empty hash3 bucket (at most one position: the next one with
+    // those bytes finds this one in the bucket), position 0 still inside the window, five bytes left to hash
+    const uint32_t last = (n - 5u < 32767u ? n - 5u : 32767u);
+    uint32_t at = 0;
+    for (uint32_t base = 1; base <= last && at == 0; base += 64) {
+        const uint32_t p = base + lane;
+        const bool hit = p <= last && d3[p] == 0 && le32(p) == first4;
+        const unsigned long long m = __ballot(hit);
+        if (m) at = base + (uint32_t)__ffsll((long long)m) - 1u;
+    }
+    if (at == 0) return;
+    // position 0's place in the chain, and the match
+    uint32_t pos = at, nodes = 0;
+    bool found = false;
+    const uint32_t depth = cfg.hc_depth;
+    while (nodes < depth) {
+        const uint32_t d = d4[pos];
+        if (d == 0 || d > pos) break;
+        pos -= d;
+        nodes++;
+        if (pos == 0) {
+            found = true;
+            break;
+        }
+    }
+    if (!found) return;
+    const uint32_t max_len = n - at < 258u ? n - at : 258u;
+    uint32_t len = 4;
+    for (;;) {  // 64 bytes a step
+        const uint32_t i = len + lane;
+        const unsigned long long ne = __ballot(i >= max_len || in[i] != in[at + i]);
+        if (ne) {
+            len += (uint32_t)__ffsll((long long)ne) - 1u;
+            break;
+        }
+        len += 64;
+    }
+    if (lane != 0) return;
+    uint8_t *len8 = len8_all + (uint64_t)b * cfg.stride;
+    uint16_t *dist = dist_all + (uint64_t)b * cfg.stride;
+    if (cfg.lazy) {  // the half / quarter depth searches reach position 0 if it is that near in the chain
+        for (uint32_t v = 0; v <= cfg.lazy; v++) {
+            if (nodes > (depth >> v)) continue;
+            uint8_t *lo = v == 0 ? len8 : lz_len_all + ((uint64_t)b * 2u + (v - 1)) * cfg.stride;
+            uint16_t *dd = v == 0 ? dist : lz_dist_all + ((uint64_t)b * 2u + (v - 1)) * cfg.stride;
+            lo[at] = (uint8_t)(len - 3u);
+            dd[at] = (uint16_t)(at | kHcOrphan);
+        }
+        return;
+    }
+    len8[at] = (uint8_t)(len - 3u);
+    dist[at] = (uint16_t)(at | kHcOrphan);
+    atomicOr(mbits_all + (uint64_t)b * (cfg.stride / 32) + at / 32u, 1u << (at & 31u));
+    hc_all[b].pad = at + 1u;
+}
+
+// ------------------------------------------------------------------------------------------
 // k_parse_hc: the greedy parse, token stream and sub-block boundaries of deflate_compress_greedy,
 // per block in tiles of 32 KiB positions.  Walkers / ranks / token build as in k_parse (a match
 // is flagged by a bit, because length 3 shares len8 == 0 with "literal").  A sub-block ends at
@@ -2056,6 +2149,7 @@ __global__ __launch_bounds__(kMpThreads, GZPX_PHC_WAVES) void k_parse_hc(
     uint32_t entry_carry = ld(&st->resume_pos);
     uint32_t tok_carry = ld(&st->tok_carry), mat_carry = ld(&st->mat_carry);
     uint32_t cur_sub = ld(&st->cur_sub);
+    const uint32_t orphan_at = ld(&st->pad);  // position + 1 of the block's orphan match (k_match_hc), 0 = none
     uint32_t sub_start = entry_carry, sub_start_tok = tok_carry, sub_start_mat = mat_carry;
     uint32_t sub_limit = hc_sub_limit_of(sub_start, n);
     uint32_t min_len = ld(&st->min_len);
@@ -2099,6 +2193,10 @@ __global__ __launch_bounds__(kMpThreads, GZPX_PHC_WAVES) void k_parse_hc(
                 }
                 w = keep;
             }
+            // the orphan match exists only for a search that starts at best_len >= 4 (min_len >= 5): below that
+            // its position is a literal, like a match that is too short (the byte comes from the input, see the token pass)
+            if (min_len <= 4 && orphan_at - 1u - tile_begin - tid * 64u < 64u)
+                w &= ~(1ull << ((orphan_at - 1u - tile_begin) & 63u));
             mb[tid] = w;
             tok_bits[tid] = 0;
         }
@@ -2297,7 +2395,7 @@ __global__ __launch_bounds__(kMpThreads, GZPX_PHC_WAVES) void k_parse_hc(
                     const uint32_t r = g * 64 + lane;
                     const bool in_tile = g < ngroups && r < tile_len;
                     vals[k] = in_tile ? val[tile_begin + r] : 0u;
-                    inb[k] = (min_len > 3 && in_tile) ? (uint32_t)in[tile_begin + r] : 0u;
+                    inb[k] = ((min_len > 3 || orphan_at != 0) && in_tile) ? (uint32_t)in[tile_begin + r] : 0u;
                 }
                 __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): no load is pending behind a later store's data
 #pragma unroll
@@ -2314,7 +2412,7 @@ __global__ __launch_bounds__(kMpThreads, GZPX_PHC_WAVES) void k_parse_hc(
                     uint32_t v = vals[k];
                     // a match too short for this sub-block's min_len is a literal: val holds its distance
                     if (!is_match && ((mraw[g] >> lane) & 1ull)) v = inb[k];
-                    vals[k] = is_match ? (kTokMatch | (v << 9) | len) : v;
+                    vals[k] = is_match ? (kTokMatch | ((v & 0x7FFFu) << 9) | len) : v;  // (without k_match_hc's orphan mark)
                     tis[k] = ti;
                     if (ti < stat_from || ti >= lim_tok || GZPX_EXP(cfg, 14)) continue;
                     const uint32_t cls = is_match ? 8u + (len >= 9u ? 1u : 0u) : (((v >> 5) & 6u) | (v & 1u));
@@ -2639,7 +2737,10 @@ __global__ __launch_bounds__(64) void k_parse_lazy(Config cfg, const uint8_t *__
             uint32_t nlit = 0, mlen = 0, moff = 0, nrel = lane + 1u;
             bool off_tile = false;  // the chain needs positions behind the tile
             if (p < n) {
-                const uint32_t d = t_d0[r], l = (uint32_t)t_l0[r] + 3u;
+                uint32_t d = t_d0[r];
+                const uint32_t l = (uint32_t)t_l0[r] + 3u;
+                // (k_match_hc's orphan mark: a match that only a search started at best_len >= 4 finds)
+                if (d & kHcOrphan) d = min_len >= 5u ? d & 0x7FFFu : 0u;
                 if (d == 0 || l < min_len || (l == 3u && d > 8192u)) {
                     nlit = 1;
                 } else {
@@ -2656,7 +2757,9 @@ __global__ __launch_bounds__(64) void k_parse_lazy(Config cfg, const uint8_t *__
                         }
                         const int bsr_cur = 31 - __clz((int)co);
                         {
-                            const uint32_t d1 = t_d1[rr], l1 = (uint32_t)t_l1[rr] + 3u;
+                            uint32_t d1 = t_d1[rr];
+                            const uint32_t l1 = (uint32_t)t_l1[rr] + 3u;
+                            if (d1 & kHcOrphan) d1 = cl >= 5u ? d1 & 0x7FFFu : 0u;  // (the lookahead starts at cur_len - 1)
                             if (d1 != 0 && l1 >= cl && 4 * (int)(l1 - cl) + (bsr_cur - (31 - __clz((int)d1))) > 2) {
                                 nlit += 1u;
                                 cp += 1u;
@@ -2666,7 +2769,9 @@ __global__ __launch_bounds__(64) void k_parse_lazy(Config cfg, const uint8_t *__
                             }
                         }
                         if (lazy2) {
-                            const uint32_t d2 = t_d2[rr + 1u], l2 = (uint32_t)t_l2[rr + 1u] + 3u;
+                            uint32_t d2 = t_d2[rr + 1u];
+                            const uint32_t l2 = (uint32_t)t_l2[rr + 1u] + 3u;
+                            if (d2 & kHcOrphan) d2 = cl >= 5u ? d2 & 0x7FFFu : 0u;
                             if (d2 != 0 && l2 >= cl && 4 * (int)(l2 - cl) + (bsr_cur - (31 - __clz((int)d2))) > 6) {
                                 nlit += 2u;
                                 cp += 2u;
@@ -5028,6 +5133,9 @@ void launch_hc(const Config &cfg, const uint8_t *slab, uint32_t nb, const Scratc
     hipLaunchKernelGGL(k_match_hc, dim3(nb), dim3(1024), 0, stream, cfg, slab, (const BlockMeta *)s.meta, s.hc,
                        (const uint16_t *)s.cand, (const uint16_t *)s.d4, s.len8, s.which, s.alt,
                        (uint8_t *)nullptr, (uint16_t *)nullptr);
+    hipLaunchKernelGGL(k_hc_orphan, dim3(nb), dim3(64), 0, stream, cfg, slab, (const BlockMeta *)s.meta, s.hc,
+                       (const uint16_t *)s.cand, (const uint16_t *)s.d4, s.len8, s.which, s.alt, (uint8_t *)nullptr,
+                       (uint16_t *)nullptr);
     // two single rounds (the second finds nearly every block done), then the looping form for the rest
     for (int r = 0; r < 2; r++)
         hipLaunchKernelGGL(k_parse_hc<false>, dim3(nb), dim3(kMpThreads), 0, stream, cfg, slab, s.meta, s.sub, s.hc,
@@ -5043,6 +5151,8 @@ void launch_lazy(const Config &cfg, const uint8_t *slab, uint32_t nb, const Scra
     hipLaunchKernelGGL(k_match_hc, dim3(nb), dim3(1024), 0, stream, cfg, slab, (const BlockMeta *)s.meta, s.hc,
                        (const uint16_t *)s.cand, (const uint16_t *)s.d4, s.len8, s.which, s.alt, s.lz_len,
                        s.lz_dist);
+    hipLaunchKernelGGL(k_hc_orphan, dim3(nb), dim3(64), 0, stream, cfg, slab, (const BlockMeta *)s.meta, s.hc,
+                       (const uint16_t *)s.cand, (const uint16_t *)s.d4, s.len8, s.which, s.alt, s.lz_len, s.lz_dist);
     if (cfg.lazy >= 2)
         hipLaunchKernelGGL(k_parse_lazy<3>, dim3(nb), dim3(64), 0, stream, cfg, slab, s.meta, s.sub,
                            (const uint8_t *)s.len8, (const uint16_t *)s.alt, (const uint8_t *)s.lz_len,
