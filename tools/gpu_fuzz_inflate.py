@@ -14,7 +14,8 @@ from gzp_amd import _native, synth
 
 secs = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 99)
-lib = _native.load()
+# (GZPX_LIB=<path>: another build of the library, e.g. tests/emu/libgzpx_emu.so -- the same soak without a GPU)
+lib = _native.GzpxLib(os.environ["GZPX_LIB"]) if os.environ.get("GZPX_LIB") else _native.load()
 classes = sorted(synth.CLASSES)
 strategies = [zlib.Z_DEFAULT_STRATEGY, zlib.Z_FILTERED, zlib.Z_HUFFMAN_ONLY, zlib.Z_RLE, zlib.Z_FIXED]
 

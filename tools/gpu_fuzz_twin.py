@@ -15,7 +15,8 @@ from oracle import oracle
 
 secs = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 7)
-lib = _native.load()
+# (GZPX_LIB=<path>: another build of the library, e.g. tests/emu/libgzpx_emu.so -- the same soak without a GPU)
+lib = _native.GzpxLib(os.environ["GZPX_LIB"]) if os.environ.get("GZPX_LIB") else _native.load()
 classes = sorted(synth.CLASSES)
 t_end = time.time() + secs
 cases = bad = 0

@@ -14,6 +14,7 @@ to build:
     searches -- but at the price of one search per wave STEP, whatever the number of lanes in it.
 
     python tools/sim_hc_wave.py            (levels 3, 6, 9: a few seconds of pure Python)
+    python tools/sim_hc_wave.py --parked   (also the model of parked-and-compacted walks)
 """
 import collections
 import os
@@ -118,5 +119,39 @@ for level, depth0, nice in ((3, 12, 14), (6, 35, 65), (9, 600, 258)):
           "%.0f %% of the positions start a token"
           % (level, depth0, nice, nodes.mean(), hits.mean(), rounds / nw, 100.0 * nodes.sum() / (rounds * 64), hit_rounds / nw,
              ext16 / nw, seq / (3 * 16 * 16), 100.0 * ntok / N), flush=True)
+
+
+def parked(nodes, q0, q, pop_cost=2.0, push_cost=1.0):
+    """Walks parked and compacted (not built): every position gets q0 nodes of its walk, the searches that are not
+    over are parked in a per-wave list and continued q nodes at a time, 64 to a wave; a pop is charged two rounds, a
+    push one.  Returns (rounds of the plain lockstep wave, rounds of this scheme)."""
+    base = new = 0.0
+    for t0 in range(0, N - 16384 + 1, 16384):
+        for w in range(16):
+            lst = []
+            for k in range(16):
+                g = [int(nodes[t0 + 1024 * k + 64 * w + l]) for l in range(64)]
+                base += max(g)
+                new += min(max(g), q0) + push_cost
+                lst += [x - q0 for x in g if x > q0]
+                while len(lst) >= 64:
+                    cur, lst = lst[:64], lst[64:]
+                    new += pop_cost + min(max(cur), q) + push_cost
+                    lst += [x - q for x in cur if x > q]
+            while lst:
+                cur, lst = lst[:64], lst[64:]
+                new += pop_cost + min(max(cur), q) + push_cost
+                lst += [x - q for x in cur if x > q]
+    return base, new
+
+
+if "--parked" in sys.argv:
+    for level, depth0, nice in ((3, 12, 14), (6, 35, 65), (9, 600, 258)):
+        nodes = np.array([len(t) for t in trace(depth0, nice)[0]])
+        for q0, q in ((4, 8), (8, 16), (16, 32)):
+            if q0 < depth0:
+                b, n_ = parked(nodes, q0, q)
+                print("level %d, first stretch %d nodes, then %d at a time: %.2f x the wave-rounds (model; a full round costs about "
+                      "twice a sparse one on the GPU)" % (level, q0, q, n_ / b), flush=True)
 first = collections.Counter(next((i for i, e in enumerate(t) if e[0] == "h"), -1) for t in trace(12, 14)[0])
 print("level 3: the first hit of a walk is at node", sorted(first.items())[:6], "(-1: the walk has none)")
