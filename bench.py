@@ -704,6 +704,8 @@ def run_config(args, env, fmt, level, bs, kind, n, label):
     cap = ctx.slab_bound(n)
     d_out = torch.empty(cap, dtype=torch.uint8, device=env.dev)
     ctx.set_profiling(True)
+    if getattr(args, "debug_flags", 0):  # (experiments: Config.debug, as in the level-1 workload)
+        ctx.debug_set_flags(args.debug_flags)
     acc = {}
     out_len = 0
     for _ in range(args.warmup):
@@ -745,7 +747,8 @@ def run_config(args, env, fmt, level, bs, kind, n, label):
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": label, "slab_bytes": n, "block_size": bs, "level": level,
                        "format": "bgzf" if fmt == _native.FORMAT_BGZF else "mgzip", "ratio": round(out_len / n, 4),
-                       "gpu_inflate_crc_roundtrip_ok": bool(ok), "inflate_of_output": inflate_leg,
+                       "gpu_inflate_crc_roundtrip_ok": bool(ok), "stream_sha256": hashlib.sha256(host).hexdigest(),
+                       "inflate_of_output": inflate_leg,
                        "device": ctx.device_name()},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
