@@ -1,7 +1,7 @@
 """CPU-only randomised parity hunt through the emulated kernels (tests/emu): small buffers whose FIRST bytes are chosen
 to hit the matchfinders' special cases -- libdeflate files position 0 under bucket 0 of every table, so starts whose
 hash4 / hash3 / level-1 hash is 0 are where "position 0" behaves unlike any other -- mixed with ordinary synthetic
-classes, every level 0-9 (10-12 with --near-optimal), both compat rules, raw DEFLATE against the oracle.
+classes and with copies at the distance / length thresholds of the matchfinders and parsers (case_edges), every level 0-9 (10-12 with --near-optimal), both compat rules, raw DEFLATE against the oracle.
 usage: emu_fuzz.py [seconds] [seed] [--near-optimal]      (the round-4 position-0 / hash3-gate bug is the reason it exists)"""
 import itertools
 import os
@@ -63,6 +63,26 @@ def case(rng, h4, h15, h3):
     return np.ascontiguousarray(body)
 
 
+def case_edges(rng):
+    """Copies at distances around the window size and the parsers' distance rules (32,767 +- 3, 4,096 / 4,097, 8,192 / 8,193)
+    and of lengths around every level's nice_match_length (and 258), some of them ending with the buffer."""
+    sym = np.frombuffer(ALPHA if rng.random() < 0.6 else bytes(range(32, 127)), np.uint8)
+    far = rng.random() < 0.4
+    n = int(rng.integers(33000, 100000)) if far else int(rng.integers(300, 30000))
+    a = sym[rng.integers(0, len(sym), n)].copy()
+    lens = [3, 4, 5, 8, 9, 10, 11, 13, 14, 15, 29, 30, 31, 64, 65, 66, 129, 130, 131, 257, 258, 259, 300, 600]
+    for _ in range(int(rng.integers(1, 6)) if far else int(rng.integers(2, 40))):
+        ln = min(int(rng.choice(lens)), n // 3)
+        dist = int(rng.choice([32765, 32766, 32767, 32768, 32769, 32770, 16384, 4096, 4097, 8192, 8193])) if far else \
+            int(rng.integers(1, min(n - ln, 9000)))
+        if n - ln <= dist:
+            continue
+        at = n - ln if rng.random() < 0.1 else int(rng.integers(dist, n - ln + 1))
+        for i in range(ln):  # (byte by byte: a copy may overlap its source)
+            a[at + i] = a[at + i - dist]
+    return np.ascontiguousarray(a)
+
+
 def main():
     args = [a for a in sys.argv[1:] if not a.startswith("--")]
     secs = float(args[0]) if args else 120.0
@@ -73,7 +93,7 @@ def main():
     rng = np.random.default_rng(seed)
     comps, t_end, cases, bad = {}, time.time() + secs, 0, 0
     while time.time() < t_end:
-        a = case(rng, h4, h15, h3)
+        a = case_edges(rng) if rng.random() < 0.25 else case(rng, h4, h15, h3)
         level, compat = int(levels[rng.integers(len(levels))]), int(rng.integers(0, 2))
         if (level, compat) not in comps:
             comps[(level, compat)] = _native.Compressor(level, compat, lib=lib)
