@@ -67,6 +67,38 @@ def pmc_traffic_source(build_id):
             "this same build %s of the library; committed, not collected in this run)" % build_id)
 
 
+CLOCK_HZ = 2.4e9          # MI355X peak shader clock (MI355X_MICROARCH.md); DVFS runs lower under load
+N_SIMD = 256 * 4
+
+
+def issue_roofline(kernel, kernel_ms, build_id, workload="bench.py"):
+    """The second bound beside HBM (round 5): instruction issue, from the committed SQ counters of THIS build
+    (profiles/sq_counters.json, tools/pmc_sq.sh).  `issue_frac` = VALU wave-instructions x 4 cycles (what one
+    SQ_ACTIVE_INST_VALU quad-cycle per instruction measures: the cadence at which a SIMD issues a wave's VALU work)
+    / (1024 SIMDs x the kernel's duration x the 2.4 GHz peak clock) -- the VALU-busy share of the kernel's time.  The
+    SIMD-32 datapath itself retires a wave64 instruction in 2 cycles (the 157 TFLOP/s vector peak), so against THAT
+    ceiling the share is half (`valu_peak_frac`); `wave_parked_frac` = SQ_WAIT_ANY / SQ_WAVE_CYCLES is the share of
+    its resident time an average wave spends parked at s_waitcnt / s_barrier."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "sq_counters.json")) as f:
+            doc = json.load(f)
+        if doc.get("build_id") != build_id:
+            return {"issue_frac": None, "source": "profiles/sq_counters.json belongs to build %s, this library is %s: refused"
+                                                  % (doc.get("build_id"), build_id)}
+        c = doc["workloads"][workload][kernel]
+        cyc = N_SIMD * kernel_ms * 1e-3 * CLOCK_HZ
+        return {"issue_frac": round(c["INSTS_VALU"] * 4.0 / cyc, 4),
+                "valu_peak_frac": round(c["INSTS_VALU"] * 2.0 / cyc, 4),
+                "valu_wave_insts": int(c["INSTS_VALU"]), "salu_wave_insts": int(c["INSTS_SALU"]),
+                "lds_wave_insts": int(c["INSTS_LDS"]),
+                "wave_parked_frac": round(c["WAIT_ANY"] / c["WAVE_CYCLES"], 4),
+                "lds_busy_frac": round(c["LDS_IDX_ACTIVE"] * 4.0 / (256 * kernel_ms * 1e-3 * CLOCK_HZ), 4),
+                "source": "profiles/sq_counters.json (rocprofv3 --pmc SQ_* passes of this build %s; committed, not "
+                          "collected in this run)" % build_id}
+    except Exception as e:
+        return {"issue_frac": None, "source": "no usable profiles/sq_counters.json (%r)" % (e,)}
+
+
 def golden_stream(name):
     """The entry `name` of tests/golden/fullsize.json: SHA-256 of a COMPLETE stream (and of its framed
     block sizes) made by the libdeflate binary + gzp's framing (tests/golden/make_fullsize.py)."""
@@ -176,6 +208,36 @@ def cpu_baseline(slab, wall_s=8.0):
         "sample": "%d native worker threads, each re-encoding its contiguous share of the same slab's BGZF "
                   "blocks with %s until %.0f s elapsed (%.1f MiB compressed in %.2f s)%s"
                   % (used, what, wall_s, nbytes / 2**20, dt, note),
+    }
+
+
+def cpu_baseline_parcompress(slab, want_sha=None, wall_s=8.0):
+    """The CPU baseline BASELINE.md 3 / SURVEY 8(d) promise: gzp's ParCompress<Bgzf> itself -- a caller thread that
+    write_all()s the slab in 64 KiB chunks (benches/bench.rs:36-45,121) and cuts blocks, num_threads workers behind
+    queues bounded at 2 N, one in-order writer thread into an in-memory sink (src/par/compress.rs:248-469, restated
+    with pthreads in oracle/cpu_bench.c) -- over the image's libdeflate binary, level 1, num_threads = every usable
+    hardware thread, whole passes over the slab for `wall_s` seconds.  The last pass's stream is compared with the
+    GPU's (SHA-256)."""
+    from oracle import oracle
+    oracle.build()
+    cores, note = available_cores()
+    r = oracle.cpu_bench_parcompress_ref(slab, 1, BLOCK, 65536, threads=cores, wall_s=wall_s)
+    if r is None:
+        return {"value": None, "unit": "MiB/s", "cores": 0, "kind": "reference", "sample": "no libdeflate.so on this box"}
+    nbytes, dt, passes, stream = r
+    same = None if want_sha is None else bool(hashlib.sha256(stream).hexdigest() == want_sha)
+    return {
+        "value": round(nbytes / dt / 2**20, 1),
+        "unit": "MiB/s",
+        "cores": cores,
+        "kind": "reference",
+        "MiBps_per_core": round(nbytes / dt / 2**20 / cores, 1),
+        "stream_equals_gpu_stream": same,
+        "sample": "ParCompress<Bgzf> twin in C (caller thread: 64 KiB write_all calls cut into 65,280-byte blocks; %d "
+                  "workers calling the image's libdeflate.so, deflate_compress level 1 + crc32 + BGZF framing, queues "
+                  "bounded at 2 N; one in-order writer thread into an in-memory sink): %d whole passes over the same "
+                  "550 MiB slab, each a complete spawn / write / finish / join lifetime, in %.2f s%s"
+                  % (cores, passes, dt, note),
     }
 
 
@@ -366,13 +428,14 @@ def verify(slab, out_bytes, block_sizes, tail=True):
 
 def level_legs(env, d_in, n):
     """The same device-resident slab at gzp's default level (3: greedy parser), through the lazy (6)
-    and lazy2 (9 = Compression::best()) parsers and through the near-optimal one (12), measured after the
-    headline region: four timed slabs each (two at level 9, one at level 12); every output is inflated and CRC-checked on
+    and lazy2 (9 = Compression::best()) parsers measured after the
+    headline region: four timed slabs each (two at level 9); every output is inflated and CRC-checked on
     the GPU and compared with the input."""
     torch, _native = env.torch, env.native
     out = {}
-    for level in (3, 6, 9, 12):
-        # (12: the near-optimal parser, one lane per block and seconds per slab -- one timed slab, no warm-up one)
+    for level in (3, 6, 9):
+        # (level 12 -- the near-optimal parser, libdeflate 1.10's, seconds per slab -- left the default line in round 5:
+        # `--workload bgzf3 --level 12` still times it)
         try:
             out["level_%d" % level] = _level_leg(env, d_in, n, level)
         except Exception as e:  # (one level's failure does not take the others' numbers with it)
@@ -756,6 +819,66 @@ def run_config(args, env, fmt, level, bs, kind, n, label):
     ctx.close()
 
 
+def strong_leg(args, env, ctx, cap, gathered):
+    """See main(): the metric's own slab at N GPUs.  Uses the rank's existing context (its batch holds a whole slab) and
+    the weak region's gather buffer; W warm-up + K timed steps between barriers, max over ranks, the write-out of step i
+    overlapping the compression of step i + 1 exactly as in the weak regions."""
+    torch, _native = env.torch, env.native
+    from gzp_amd import shard, synth
+    world, rank = env.world, env.rank
+    total = args.slab_bytes
+    slab0 = synth.text_slab(total, seed=20250927)
+    lo, n = shard.shard_bytes(total, BLOCK, world)[rank]
+    mode = shard.slab_mode(rank, world, total, BLOCK)
+    d_in = torch.from_numpy(slab0[lo:lo + n].copy()).to(env.dev)
+    bufs = [torch.empty(max(ctx.slab_bound(max(n, 1)), 64), dtype=torch.uint8, device=env.dev) for _ in range(2)]
+    st = {"i": 0, "pending": None, "view": None}
+
+    def wait_pending():
+        if st["pending"] is not None:
+            v = st["pending"].wait()
+            st["pending"] = None
+            if v is not None:
+                st["view"] = v
+
+    def step():
+        buf = bufs[st["i"] % 2]
+        st["i"] += 1
+        out_len = 0
+        if mode is not None:
+            out_len, _ = ctx.compress_slab_device(d_in.data_ptr(), n, buf.data_ptr(), buf.numel(), mode)
+        wait_pending()
+        st["pending"] = shard.ordered_gather_start(buf[:out_len], dst=0, out=gathered)
+
+    for _ in range(args.warmup):
+        step()
+    wait_pending()
+    env.sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    wait_pending()
+    env.sync()
+    per_rank = env.all_ranks((time.perf_counter() - t0) / args.steps * 1e3)
+    if rank != 0:
+        return None
+    host = st["view"].cpu().numpy()
+    sha = hashlib.sha256(host).hexdigest()
+    full_ok = None
+    if not env.emulate:
+        full_ok, _ = check_full_stream("config2_text_550MiB_bgzf_l1", total, 20250927, host)
+    elif total <= (4 << 20):  # (the CPU dry run: the oracle's single-process stream of the same slab)
+        from oracle import oracle
+        full_ok = host.tobytes() == oracle.compress_stream(slab0, oracle.FMT_BGZF, 1, oracle.COMPAT_1_24, BLOCK)
+    ms = max(per_rank)
+    return {"MiBps": round(total / 2**20 / (ms * 1e-3), 1), "ms_per_step": round(ms, 3),
+            "rank_ms_per_step": [round(x, 3) for x in per_rank], "slab_bytes": total, "shard_bytes_rank0": n,
+            "writeout": "rccl", "stream_sha256": sha, "verified_bit_exact_full": full_ok,
+            "what": "THE %d-byte slab of the metric cut into %d contiguous block ranges, one per rank, ordered RCCL gather "
+                    "of the compressed shards to rank 0: strong scaling, the whole gathered stream against the "
+                    "libdeflate-made digest" % (total, world)}
+
+
 def self_launch(args):
     """`python bench.py --gpus N` from a bare shell: re-execute under torch.distributed.run, one rank
     per GPU (the driver may also launch it that way itself; then WORLD_SIZE is already set)."""
@@ -784,10 +907,14 @@ def main():
                     help="N > 1 in-order write-out: rccl = ordered gather of the compressed shards to rank 0 over "
                          "xGMI (north_star); offsets = all_gather of the shard sizes only, every rank copies its "
                          "shard to its own page-locked buffer at its stream offset")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="N > 1: weak (default; the driver's contract) = every rank compresses its own 550 MiB, value = "
+                         "N x 550 MiB / step; strong = THE 550 MiB slab of the metric sharded over the N ranks and gathered in "
+                         "order, value = 550 MiB / step.  The weak line carries the strong figure as `strong_550MiB` either way")
     ap.add_argument("--workload", choices=["compress", "inflate", "fastq", "mgzip3", "bgzf3"], default="compress",
                     help="compress = the headline metric (default); inflate = the ParDecompress row; fastq = configs[3]; "
                          "mgzip3 = configs[2] (Mgzip 1 MiB blocks, level 3, 4 GiB ASCII); bgzf3 = the text slab at level 3")
-    ap.add_argument("--level", type=int, default=3, help="--workload bgzf3: any built level (0-9) instead of 3")
+    ap.add_argument("--level", type=int, default=3, help="--workload bgzf3: any built level (0-12) instead of 3")
     ap.add_argument("--emulate", action="store_true", help=argparse.SUPPRESS)  # tests: CPU emulator + gloo, no timing value
     # development: A/B runs (gzpx_debug_set_flags: 2 = level 1 through the dense k_match / k_parse pair) and
     # experiment builds of the library; the driver's line uses neither
@@ -864,14 +991,16 @@ def main():
     ctx.set_profiling(2)
     if args.debug_flags:
         ctx.debug_set_flags(args.debug_flags)
-    state = {"i": 0, "pending": None, "offsets": None, "writeout": modes[0], "wait_s": 0.0}
+    state = {"i": 0, "pending": None, "offsets": None, "writeout": modes[0], "wait_s": 0.0, "views": {}}
 
     def wait_pending():
         if state["pending"] is not None:
             t = time.perf_counter()
-            state["pending"].wait()
+            view = state["pending"].wait()  # (rank 0, rccl / peer: the whole stream in order, a view of the writer's buffer)
             state["wait_s"] += time.perf_counter() - t  # host time spent waiting for a shard to leave
             state["pending"] = None
+            if view is not None:
+                state["views"][state["writeout"]] = view
 
     def step():
         k = state["i"] % len(d_outs)
@@ -927,15 +1056,22 @@ def main():
     regions = {}
     for wmode in modes:
         regions[wmode] = timed_region(wmode)
-    # N > 1: the line's `value` is the faster of the two in-order write-outs (both are complete write-outs of the same
-    # stream; `writeouts` carries each with its per-rank times, and `value_rccl` / `value_offsets` repeat them at the
-    # top level so that a scaling record cannot under-report by reading the slower one)
-    best_mode = min(regions, key=lambda m: regions[m]["dt"])
-    head = regions[best_mode]
+    # N > 1: the line's `value` is north_star's write-out -- the ordered RCCL gather of the compressed shards to rank 0 over
+    # xGMI (round 5; rounds 3-4 reported the fastest of the write-outs, one of which moves no payload between GPUs).  The
+    # others stay beside it: `writeouts` carries each with its per-rank times, `value_rccl` / `value_offsets` / `value_peer`
+    # repeat them at the top level.
+    value_mode = None if world == 1 else "rccl"
+    head = regions[value_mode]
     dt, out_len, stage_acc = head["dt"], head["out_len"], head["stage_acc"]
-    # every stage, outside the timed region (thirteen event markers per step cost the step 0.03 ms)
+    # the copy-engine write-out, checked: the writer's view of the window holds the very stream the RCCL gather delivered
+    peer_same = None
+    if world > 1 and rank == 0 and "peer" in state["views"] and "rccl" in state["views"]:
+        a_, b_ = state["views"]["peer"], state["views"]["rccl"]
+        peer_same = bool(a_.numel() == b_.numel() and torch.equal(a_, b_))
+    # every stage, outside the timed region (thirteen event markers per step cost the step 0.03 ms) -- under the
+    # write-out `value` was measured with
     ctx.set_profiling(1)
-    state["writeout"] = modes[0]
+    state["writeout"] = value_mode
     other_steps = min(3, args.steps)
     stage_other = {}
     for _ in range(other_steps):
@@ -946,9 +1082,19 @@ def main():
     env.sync()
     ctx.set_profiling(2)
 
+    # N > 1, strong scaling: THE 550 MiB slab of the metric (seed 20250927) cut into N contiguous block ranges, every rank
+    # compresses its range, the ordered RCCL gather puts the stream together on rank 0 -- 550 MiB per step whatever N is.
+    # The gathered stream is compared with the libdeflate-made digest of the whole stream (tests/golden/fullsize.json).
+    strong = None
+    if world > 1:
+        strong = strong_leg(args, env, ctx, cap, gathered)
+
     ms_per_step = dt / args.steps * 1e3
     total_mib = total / 2**20
     value = total_mib / (dt / args.steps)
+    scaling = "weak"
+    if world > 1 and args.scaling == "strong" and rank == 0:  # (asked for: the strong figure is the line's value)
+        value, ms_per_step, scaling = strong["MiBps"], strong["ms_per_step"], "strong"
 
     if rank == 0:
         last_buf = d_outs[(state["i"] - 1) % len(d_outs)]
@@ -969,6 +1115,7 @@ def main():
         build_id = env.lib.build_id()
         traffic = pmc_traffic(dom, build_id)
         traffic_all = pmc_traffic("pipeline", build_id)
+        issue = issue_roofline(dom, stage_ms[dom], build_id)
         res = {
             "metric": "BGZF compress MiB/s at level 1, 550 MiB text",
             "value": round(value, 1),
@@ -978,7 +1125,7 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3),
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": scaling,
             "vs_baseline": None,
             "dtype": "u8",
             "data": "synthetic" if not env.emulate else "synthetic (CPU emulator dry run: not a measurement)",
@@ -994,11 +1141,14 @@ def main():
                 "ratio": round(out_len / n, 4),
                 "parallelism": "block-shard x%d%s" % (
                     world, "" if world == 1 else
-                    (" + ordered RCCL gather" if best_mode == "rccl" else
-                     " + peer copies into the writer's IPC-mapped buffer" if best_mode == "peer" else
-                     " + size all_gather, per-rank write-out")),
+                    " + ordered RCCL gather of the compressed shards to rank 0"),
                 "verified_bit_exact_sample": bool(ok),
                 "verified_bit_exact_full": full_ok,  # all blocks: SHA-256 of the stream and of the framed sizes == tests/golden/fullsize.json
+                # parity, machine-readable: the rules in force in THIS run, and the libdeflate binary every golden digest
+                # and vector is pinned on (the 1.24 gzp locks is not in the image; the two rules that differ are written
+                # from SURVEY A.7 and never fire on this input -- tests/test_gpu_fullstream.py compares the two modes)
+                "compat_in_force": "libdeflate 1.10" if ctx.active_compat() == _native.COMPAT_1_10 else "libdeflate >= 1.1x (1.24)",
+                "compat_pinned": "1.10",
                 "compat": "libdeflate >= 1.1x rule (the pinned 1.24); the golden digest is the v1.10 binary's, whose "
                           "stream is the same on this input",
                 "box_libdeflate": box_libdeflate() if not env.emulate else None,
@@ -1006,6 +1156,7 @@ def main():
                 "stream_sha256": stream_sha,
                 "device": ctx.device_name(),
             },
+            "compat_pinned": "1.10",  # the libdeflate binary every golden vector / digest comes from (config.compat_in_force: this run's rules)
             "roofline": {
                 "bound": "hbm",
                 "kernel": dom,
@@ -1020,6 +1171,8 @@ def main():
                 "traffic_pipeline": traffic_all,
                 "traffic_ratio_pipeline": round(traffic_all / alg_bytes, 2) if traffic_all else None,
                 "traffic_source": pmc_traffic_source(build_id),
+                "issue_frac": issue.get("issue_frac"),  # VALU-busy share of the kernel's time (see issue_roofline)
+                "issue": issue,
                 "library_build_id": build_id,
                 # the whole timed step (kernels, launch gaps, the side stream's join), not a sum of stages
                 "pipeline_frac": round(alg_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
@@ -1034,9 +1187,13 @@ def main():
                 m: {"MiBps": round(total_mib / (r["dt"] / args.steps), 1), "ms_per_step": round(r["dt"] / args.steps * 1e3, 3),
                     "rank_ms_per_step": r["rank_ms_per_step"], "rank_writeout_wait_ms": r["rank_writeout_wait_ms"]}
                 for m, r in regions.items()}
-            res["writeouts"]["value_is"] = best_mode
+            res["writeouts"]["value_is"] = value_mode if scaling == "weak" else "strong_550MiB (rccl)"
+            res["writeouts"]["fastest"] = min(regions, key=lambda m: regions[m]["dt"])
             if peer_err:
                 res["writeouts"]["peer_error"] = peer_err
+            if peer_same is not None:
+                res["writeouts"]["peer"]["window_equals_rccl_stream"] = peer_same
+            res["strong_550MiB"] = strong
             for m, r in regions.items():
                 res["value_" + m] = round(total_mib / (r["dt"] / args.steps), 1)
         if world == 1 and not args.no_extras:
@@ -1068,6 +1225,10 @@ def main():
                     res["mgzip3"] = {"error": repr(e)}
         if not args.no_cpu_baseline and world == 1:  # the CPU leg is timed at N = 1 only
             res["cpu_baseline"] = cpu_baseline(slab)
+            try:  # ... and gzp's own orchestration around the same library (queues, 64 KiB writes, in-order writer)
+                res["cpu_baseline_parcompress"] = cpu_baseline_parcompress(slab, res["config"]["stream_sha256"])
+            except Exception as e:
+                res["cpu_baseline_parcompress"] = {"error": repr(e)}
         print(json.dumps(res))
     ctx.close()
     env.close()

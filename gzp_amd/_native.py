@@ -463,6 +463,7 @@ class MultiContext:
         h = ctypes.c_void_p()
         self.lib.check(self.lib.L.gzpx_multi_create(ctypes.byref(cfg), devs, len(devices), ctypes.byref(h)))
         self.h = h
+        self.devices = list(devices)
 
     def compress_slab(self, data, mode=SLAB_LAST, return_block_sizes=False):
         a = _u8(data)
@@ -484,9 +485,21 @@ class MultiContext:
         self.lib.check(self.lib.L.gzpx_multi_shard(self.h, in_len, g, ctypes.byref(off), ctypes.byref(n)))
         return off.value, n.value
 
-    def compress_slab_device(self, d_in_ptrs, in_len, d_out_ptr, out_cap, mode=SLAB_LAST, root=0):
+    def compress_slab_device(self, d_in_ptrs, in_len, d_out_ptr, out_cap, mode=SLAB_LAST, root=0, sync=True):
         """Every range already on its own device (d_in_ptrs[g]); the shards are gathered device to device
-        into d_out_ptr on devices[root].  Returns (out_len, block_sizes)."""
+        into d_out_ptr on devices[root].  Returns (out_len, block_sizes).
+
+        Caller contract of gzpx_multi_compress_slab_device (include/gzpx.h): the ranges are COMPLETE and d_out is IDLE
+        on entry -- the call takes no stream of the caller's to wait behind (it submits with GZPX_STREAM_NONE; since
+        round 4 nothing is ordered behind the legacy default stream either).  `sync=True` (the default) makes that true
+        for PyTorch callers, whose producers run asynchronously on torch's current stream: every device of the context
+        is synchronised first.  Pass sync=False only when the inputs were produced synchronously."""
+        if sync:
+            import sys
+            torch = sys.modules.get("torch")  # (only callers that use torch have asynchronous producers to wait for)
+            if torch is not None and torch.cuda.is_available():
+                for d in sorted(set(self.devices)):
+                    torch.cuda.synchronize(d)
         ptrs = (ctypes.c_void_p * len(d_in_ptrs))(*[ctypes.c_void_p(int(p) if p else None) for p in d_in_ptrs])
         nb_max = 1 if in_len == 0 else -(-in_len // self.buffer_size)
         sizes = np.zeros(nb_max, dtype=np.uint32)

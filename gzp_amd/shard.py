@@ -139,9 +139,17 @@ class PeerWindow:
     offset of the window with an ordinary device-to-device copy on a stream of its own -- over xGMI that is a
     copy-engine (SDMA) transfer, so the exchange takes no compute unit from the compression kernels of the next
     slab, which an RCCL send/recv kernel does.  Same result as ordered_gather: the window holds the single-process
-    stream (the in-order property of src/par/compress.rs:305-310)."""
+    stream (the in-order property of src/par/compress.rs:305-310).
 
-    def __init__(self, capacity, device, dst=0, group=None):
+    Reuse contract (round 5).  The window is `depth` (default 2) buffers of `capacity` bytes used in
+    turn: step k lands in buffer k % depth.  The view that wait() of step k returns on the writer stays untouched
+    until the writer itself calls wait() of step k + depth - 1: a peer copies into buffer k % depth again only in
+    gather_start() of step k + depth, which it reaches only after the barrier inside wait() of step k + depth - 1 --
+    a barrier the writer joins when IT calls that wait().  With depth = 2 the writer therefore has one whole step
+    (the compression of the next slab) to consume a view, which is how ParCompress's writer thread runs beside the
+    compressors; depth = 1 is the old single buffer, whose view dies at the writer's next gather_start()."""
+
+    def __init__(self, capacity, device, dst=0, group=None, depth=2):
         import torch
         import torch.distributed as dist
         from torch.multiprocessing.reductions import reduce_tensor
@@ -149,13 +157,14 @@ class PeerWindow:
         self.rank = dist.get_rank(group)
         self.world = dist.get_world_size(group)
         self.buf = None
+        self.capacity, self.depth, self._step = int(capacity), max(1, int(depth)), 0
         # Set-up is collective and must fail on EVERY rank or on none: the writer broadcasts its handle or its error, every
         # rank says whether it could map the buffer, and all of them raise together if one could not (a box whose devices
         # cannot map each other's memory then simply runs without this write-out).
         box = [None]
         if self.rank == dst:
             try:
-                self.buf = torch.empty(int(capacity), dtype=torch.uint8, device=device)
+                self.buf = torch.empty(self.capacity * self.depth, dtype=torch.uint8, device=device)
                 box[0] = ("ok", reduce_tensor(self.buf))  # (rebuild function, IPC handle + geometry): picklable
             except Exception as e:  # noqa: BLE001
                 box[0] = ("error", repr(e))
@@ -188,25 +197,29 @@ class PeerWindow:
             dist.all_gather(list(sizes.split(1)), n, group=self.group)
         sz = [int(x) for x in sizes.tolist()]
         off, total = sum(sz[:self.rank]), sum(sz)
-        if total > self.buf.numel():
-            raise ValueError("PeerWindow: the stream (%d bytes) does not fit the window (%d)" % (total, self.buf.numel()))
+        if total > self.capacity:
+            raise ValueError("PeerWindow: the stream (%d bytes) does not fit the window (%d)" % (total, self.capacity))
+        base = (self._step % self.depth) * self.capacity  # this step's buffer of the window (see the reuse contract)
+        self._step += 1
         ev = None
         if local.numel():
             self.stream.wait_stream(torch.cuda.current_stream(self._device))
             with torch.cuda.stream(self.stream):
-                self.buf[off:off + local.numel()].copy_(local, non_blocking=True)
+                self.buf[base + off:base + off + local.numel()].copy_(local, non_blocking=True)
                 ev = torch.cuda.Event()
                 ev.record(self.stream)
-        return _PeerHandle(self, ev, total)
+        return _PeerHandle(self, ev, total, base)
 
 
 class _PeerHandle:
-    def __init__(self, win, ev, total):
-        self._w, self._ev, self._total = win, ev, total
+    def __init__(self, win, ev, total, base=0):
+        self._w, self._ev, self._total, self._base = win, ev, total, base
 
     def wait(self):
+        """Completes the step on every rank; on the writer returns the stream -- a VIEW of this step's buffer of the
+        window, valid until the writer's wait() of step + depth - 1 (PeerWindow's reuse contract)."""
         import torch.distributed as dist
         if self._ev is not None:
             self._ev.synchronize()  # my shard has landed
         dist.barrier(group=self._w.group)  # ... and so has everybody's: the writer may read the window
-        return self._w.buf[:self._total] if self._w.rank == self._w.dst else None
+        return self._w.buf[self._base:self._base + self._total] if self._w.rank == self._w.dst else None

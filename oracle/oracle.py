@@ -106,6 +106,29 @@ def cpu_bench_compress(slab, fmt=FMT_BGZF, level=1, compat=COMPAT_1_24, block=65
     return nb.value, el.value, th.value
 
 
+def cpu_bench_parcompress_ref(slab, level=1, block=65280, chunk=65536, threads=1, wall_s=6.0):
+    """ParCompress<Bgzf> as gzp runs it (caller thread cutting 64 KiB write_all calls into blocks, N workers behind a
+    bounded queue, an in-order writer thread into an in-memory sink -- oracle/cpu_bench.c) over the image's libdeflate
+    binary.  Returns (bytes, seconds, passes, last pass's stream as a uint8 array), or None without a libdeflate."""
+    a = _as_u8(slab)
+    cap = a.size + a.size // 8 + (1 << 20)
+    from gzp_amd.synth import big_zeros
+    sink = big_zeros(cap)
+    el, nb, passes, sl = ctypes.c_double(0), ctypes.c_uint64(0), ctypes.c_int(0), ctypes.c_size_t(0)
+    fn = lib().gzpx_cpu_bench_parcompress_ref
+    fn.restype = ctypes.c_int
+    fn.argtypes = [ctypes.c_int, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int,
+                   ctypes.c_double, ctypes.c_void_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_size_t),
+                   ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_int)]
+    rc = fn(level, block, chunk, _ptr(a), a.size, threads, wall_s, _ptr(sink), cap, ctypes.byref(sl), ctypes.byref(el),
+            ctypes.byref(nb), ctypes.byref(passes))
+    if rc == -2:
+        return None
+    if rc != 0:
+        raise RuntimeError("gzpx_cpu_bench_parcompress_ref failed (%d)" % rc)
+    return nb.value, el.value, passes.value, sink[:sl.value]
+
+
 def cpu_bench_compress_ref(slab, level=1, block=65280, threads=1, wall_s=6.0):
     """The same loop with the image's libdeflate binary doing the work; None if the box has none."""
     a = _as_u8(slab)

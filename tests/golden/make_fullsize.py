@@ -4,6 +4,7 @@ libdeflate0 1.10-2; `compat=1.10` on the GPU side) plus gzp's framing rules as r
 make_golden.py.  Run in the build container only:
 
     python tests/golden/make_fullsize.py            # ~10 minutes, 8 threads
+    python tests/golden/make_fullsize.py fastq8     # round 5: ALL eight rank shares of configs[3] + the whole 32 GiB stream
 
 Inputs are regenerated on the GPU box from (kind, n, seed): synth.text_slab on the host,
 gzpx_synth_ascii_device / gzpx_synth_fastq_device in HBM (their host statements are used here).
@@ -60,9 +61,11 @@ def _frame_with(comp, a, level, fmt, is_last):
     return res
 
 
-def digest_stream(a, level, fmt, bs, tail):
+def digest_stream(a, level, fmt, bs, tail, also=None, all_sizes=None):
     """Stream of `a` cut like ParCompress (tail=True: flush_last(true), EOF marker; False: whole
-    blocks only, the shard of a rank that does not own the stream's end)."""
+    blocks only, the shard of a rank that does not own the stream's end).  `also`: a second hasher fed
+    with the same bytes (the whole stream a rank's share belongs to); `all_sizes`: a list the framed
+    sizes are appended to."""
     n = a.size
     nb = 1 if n == 0 else -(-n // bs)
     assert tail or n % bs == 0
@@ -75,13 +78,62 @@ def digest_stream(a, level, fmt, bs, tail):
             jobs = [(a[b * bs:min(n, (b + 1) * bs)], level, fmt, tail and b == nb - 1) for b in idx]
             for b, blk in zip(idx, pool.map(_frame, jobs)):
                 h.update(blk)
+                if also is not None:
+                    also.update(blk)
                 sizes[b] = len(blk)
                 total += len(blk)
+    if all_sizes is not None:
+        all_sizes.append(sizes)
     return {"size": total, "sha256": h.hexdigest(), "n_blocks": nb,
             "block_sizes_sha256": hashlib.sha256(sizes.tobytes()).hexdigest()}
 
 
+def fastq_all_shares(world=8, total=32 << 30, seed=20250927, bs=65280):
+    """ALL of BASELINE configs[3] (round 5): every rank's share of the 32 GiB FASTQ stream as shard.shard_bytes cuts
+    it, one after the other (4 GiB of input at a time), plus the SHA-256 of the WHOLE stream -- the concatenation in
+    rank order, which is what the in-order writer (src/par/compress.rs:305-310) must produce -- and of all 526,345
+    framed sizes.  Replaces / adds the entries config4_fastq_rank{r}of8_bgzf_l1 and config4_fastq_32GiB_whole_bgzf_l1
+    in fullsize.json; everything else in the file is kept.      python tests/golden/make_fullsize.py fastq8"""
+    from gzp_amd import shard
+    with open(os.path.join(HERE, "fullsize.json")) as f:
+        doc = json.load(f)
+    names = ["config4_fastq_rank%dof%d_bgzf_l1" % (r, world) for r in range(world)] + ["config4_fastq_32GiB_whole_bgzf_l1"]
+    out = [e for e in doc["streams"] if e["name"] not in names]
+    t0 = time.time()
+    whole = hashlib.sha256()
+    all_sizes = []
+    total_out = 0
+    total_blocks = -(-total // bs)
+    shares = []
+    for r, (lo, n) in enumerate(shard.shard_bytes(total, bs, world)):
+        a = oracle.fastq_stream(lo, n, seed)
+        tail = lo + n == total
+        e = {"name": names[r], "fmt": "bgzf", "level": 1, "buffer_size": bs, "tail": tail,
+             "input": {"kind": "fastq", "n": n, "seed": seed, "offset": lo, "stream_bytes": total, "world": world, "rank": r},
+             "input_sha256": hashlib.sha256(a).hexdigest()}
+        e.update(digest_stream(a, 1, "bgzf", bs, tail, also=whole, all_sizes=all_sizes))
+        e["stream_offset"] = total_out  # where the share starts in the whole output stream
+        total_out += e["size"]
+        out.append(e)
+        shares.append(e["size"])
+        print("%-34s %d -> %d bytes, %d blocks  (%.0f s)" % (e["name"], n, e["size"], e["n_blocks"], time.time() - t0), flush=True)
+        del a
+    sizes = np.concatenate(all_sizes)
+    assert sizes.size == total_blocks
+    out.append({"name": names[-1], "fmt": "bgzf", "level": 1, "buffer_size": bs, "tail": True,
+                "input": {"kind": "fastq", "n": total, "seed": seed, "offset": 0, "stream_bytes": total, "world": world},
+                "size": total_out, "sha256": whole.hexdigest(), "n_blocks": int(total_blocks),
+                "block_sizes_sha256": hashlib.sha256(sizes.astype("<u4").tobytes()).hexdigest(),
+                "share_sizes": shares})
+    doc["streams"] = out
+    with open(os.path.join(HERE, "fullsize.json"), "w") as f:
+        json.dump(doc, f, indent=1)
+        f.write("\n")
+
+
 def main():
+    if sys.argv[1:] == ["fastq8"]:
+        return fastq_all_shares()
     out = []
     t0 = time.time()
     only_levels = sys.argv[1:] in (["levels"], ["near_optimal"])  # add / refresh the text slab at levels 3, 6, 9 (or 10, 12) only

@@ -25,19 +25,29 @@ def test_two_ranks_self_launch_ordered_gather():
     d = _run("--gpus", "2", "--slab-bytes", "150000")
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["slab_bytes"] == 300000
     assert d["config"]["verified_bit_exact_sample"] is True
-    assert d["config"]["parallelism"].endswith(("ordered RCCL gather", "per-rank write-out"))
     for k in ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "higher_is_better", "vs_baseline", "dtype",
               "data", "roofline"):
         assert k in d
     # one run tells the whole story: both in-order write-outs timed back to back, per-rank times in the line
     w = d["writeouts"]
-    assert w["value_is"] in ("rccl", "offsets") and set(w) == {"rccl", "offsets", "value_is"}  # (no IPC window on CPU)
+    assert w["value_is"] == "rccl" and w["fastest"] in ("rccl", "offsets")
+    assert set(w) == {"rccl", "offsets", "value_is", "fastest"}  # (no IPC window on CPU)
     for m in ("rccl", "offsets"):
         assert len(w[m]["rank_ms_per_step"]) == 2 and len(w[m]["rank_writeout_wait_ms"]) == 2 and w[m]["MiBps"] > 0
         assert d["value_" + m] == w[m]["MiBps"]  # both write-outs at the top level as well
-    # the line's value is the faster write-out: a scaling record cannot under-report
-    assert abs(w[w["value_is"]]["ms_per_step"] - d["ms_per_step"]) < 1e-6
-    assert d["value"] == max(d["value_rccl"], d["value_offsets"])
+    # the line's value is north_star's write-out, the ordered RCCL gather -- whichever of them is faster (round 5)
+    assert abs(w["rccl"]["ms_per_step"] - d["ms_per_step"]) < 1e-6 and d["value"] == d["value_rccl"]
+    assert d["config"]["parallelism"].endswith("ordered RCCL gather of the compressed shards to rank 0")
+    # ... and the metric's own slab at N ranks: strong scaling, the gathered stream equal to the single-process one
+    st = d["strong_550MiB"]
+    assert st["slab_bytes"] == 150000 and st["verified_bit_exact_full"] is True and len(st["rank_ms_per_step"]) == 2
+    assert d["compat_pinned"] == "1.10" and d["config"]["compat_in_force"].startswith("libdeflate >= 1.1x")
+
+
+def test_two_ranks_strong_scaling_is_the_value_when_asked_for():
+    d = _run("--gpus", "2", "--slab-bytes", "150000", "--scaling", "strong")
+    assert d["scaling"] == "strong" and d["value"] == d["strong_550MiB"]["MiBps"]
+    assert d["strong_550MiB"]["verified_bit_exact_full"] is True and d["ms_per_step"] == d["strong_550MiB"]["ms_per_step"]
 
 
 def test_config4_workload_two_ranks():

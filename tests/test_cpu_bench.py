@@ -29,6 +29,27 @@ def test_native_cpu_baselines(oracle):
         assert r[2] == 2 and r[0] >= a.size  # every worker inflated (and CRC-checked) its blocks at least once
 
 
+def test_parcompress_shaped_cpu_baseline_writes_gzps_stream(oracle):
+    """oracle/cpu_bench.c's ParCompress<Bgzf> twin over the libdeflate binary (bench.py's `cpu_baseline_parcompress`):
+    64 KiB write_all calls, the strict `>` cut (src/par/compress.rs:415), flush_last(true) with at least one -- maybe
+    empty -- last block + EOF (:332-362), N workers, in-order writer.  Its stream is the oracle's (compat 1.10: the
+    binary's version) for every edge of the cut rule, whatever the number of workers."""
+    for n in (0, 1, 65279, 65280, 65281, 65536, 2 * 65280, 2 * 65280 + 1234, 9 * 65280 + 77):
+        a = synth.text_slab(n, seed=5) if n else np.zeros(0, dtype=np.uint8)
+        want = oracle.compress_stream(a, oracle.FMT_BGZF, 1, oracle.COMPAT_1_10, 65280)
+        for threads in (1, 3):
+            r = oracle.cpu_bench_parcompress_ref(a, 1, 65280, 65536, threads=threads, wall_s=0.0)
+            if r is None:
+                return  # no libdeflate binary on this box
+            nbytes, dt, passes, stream = r
+            assert passes == 1 and nbytes == n and stream.tobytes() == want, (n, threads)
+    # other write sizes cut the same stream (the cut rule looks at the buffered length only)
+    a = synth.text_slab(5 * 65280 + 4321, seed=6)
+    want = oracle.compress_stream(a, oracle.FMT_BGZF, 1, oracle.COMPAT_1_10, 65280)
+    for chunk in (1000, 65280, 200000):
+        assert oracle.cpu_bench_parcompress_ref(a, 1, 65280, chunk, threads=2, wall_s=0.0)[3].tobytes() == want, chunk
+
+
 def test_available_cores_is_sane():
     import bench
     n, note = bench.available_cores()

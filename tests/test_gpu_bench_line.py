@@ -32,6 +32,7 @@ def test_headline_line_proves_itself():
     assert 0 < r["pipeline_frac"] < r["frac"] and 0 < r["hbm_read_frac"] < r["pipeline_frac"]
     assert c["box_libdeflate"] in (None, "1.10-like", "1.24-like", "unknown")
     # the traffic figure is this build's or none at all (profiles/pmc_traffic.json records the build it belongs to)
+    assert "issue_frac" in r and "source" in r["issue"]
     assert r["library_build_id"] and ((r["traffic"] is None) == ("refused" in r["traffic_source"] or "no profiles" in r["traffic_source"]))
 
 
@@ -43,12 +44,17 @@ def test_default_line_carries_the_other_configurations():
     for lv in ("level_3", "level_6", "level_9"):
         leg = d["levels"][lv]
         assert leg["verified_bit_exact_full"] is True and leg["gpu_inflate_crc_roundtrip_ok"] is True and leg["MiBps"] > 0
-    assert d["levels"]["level_12"]["compat_in_force"] == "libdeflate 1.10"  # (whatever the context was asked for)
+    assert "level_12" not in d["levels"]  # (round 5: the near-optimal parser left the default line; --workload bgzf3 --level 12)
+    assert d["compat_pinned"] == "1.10" and d["config"]["compat_in_force"].startswith("libdeflate >= 1.1x")
     m = d["mgzip3"]
     assert m["verified_bit_exact_full"] is True and m["gpu_inflate_crc_roundtrip_ok"] is True and m["blocks"] == 4096
     assert m["inflate_of_output"]["MiBps"] > 0 and m["roofline"]["kernel"] in m["roofline"]["stage_ms"]
     assert d["inflate"]["verified_round_trip"] is True and d["e2e"]["api_write_ok"] and d["e2e"]["device_pinned_ok"]
     assert d["cpu_baseline"]["kind"] in ("reference", "port") and d["cpu_baseline"]["cores"] >= 1
+    pc = d["cpu_baseline_parcompress"]  # gzp's own orchestration over the box's libdeflate: its stream is the GPU's stream
+    assert pc["value"] is None or (pc["value"] > 0 and pc["stream_equals_gpu_stream"] in (True, False))
+    if pc["value"] is not None and d["config"]["box_libdeflate"] == "1.10-like":
+        assert pc["stream_equals_gpu_stream"] is True
 
 
 def test_config4_fastq_share_of_the_stream():

@@ -112,6 +112,73 @@ def test_config4_one_rank_share_of_32gib_fastq(hip_lib):
         assert got == n and torch.equal(d_back[:n], d_in)
 
 
+def test_config4_all_eight_shares_and_the_whole_32gib_stream(hip_lib):
+    """ALL of configs[3] on the one GPU a test box has (round 5): the eight rank shares of the 32 GiB FASTQ stream, cut
+    by shard.shard_bytes / shard.slab_mode exactly as `bench.py --workload fastq --gpus 8` cuts them, compressed one
+    after the other; every share's stream and framed sizes against the libdeflate-made digests, and the concatenation
+    in rank order -- what the in-order writer must produce (src/par/compress.rs:305-310) -- against the SHA-256 of the
+    WHOLE 32 GiB stream's output (526,345 blocks + EOF); every share inflated + CRC-checked on the GPU against its
+    regenerated input (what gzip -t does), and gzip -t itself on the two ends of the concatenation."""
+    import subprocess
+    from gzp_amd import shard
+    whole = GOLD["config4_fastq_32GiB_whole_bgzf_l1"]
+    total, world, bs = whole["input"]["stream_bytes"], whole["input"]["world"], 65280
+    parts = shard.shard_bytes(total, bs, world)
+    h_all = hashlib.sha256()
+    all_sizes, out_total = [], 0
+    head = tail = None
+    n_max = max(n for _, n in parts)
+    d_in = torch.empty(n_max + 64, dtype=torch.uint8, device="cuda")
+    d_back = torch.empty(n_max + 64, dtype=torch.uint8, device="cuda")
+    with _native.Context(format=_native.FORMAT_BGZF, level=1, buffer_size=bs, compat=_native.COMPAT_1_10, lib=hip_lib,
+                         max_slab_bytes=n_max) as ctx, _native.DContext(format=_native.FORMAT_BGZF, lib=hip_lib) as dctx:
+        cap = ctx.slab_bound(n_max)
+        d_out = torch.empty(cap, dtype=torch.uint8, device="cuda")
+        for r, (lo, n) in enumerate(parts):
+            e = GOLD["config4_fastq_rank%dof%d_bgzf_l1" % (r, world)]
+            assert (lo, n) == (e["input"]["offset"], e["input"]["n"])
+            mode = shard.slab_mode(r, world, total, bs)
+            assert (mode == _native.SLAB_LAST) == e["tail"] == (r == world - 1)
+            _native.synth_fastq_device(d_in.data_ptr(), lo, n, e["input"]["seed"], lib=hip_lib)
+            torch.cuda.synchronize()
+            sizes = np.zeros(ctx.n_blocks(n), dtype=np.uint32)
+            out_len, nb = ctx.compress_slab_device(d_in.data_ptr(), n, d_out.data_ptr(), cap, mode, None, sizes)
+            assert nb == e["n_blocks"] and out_len == e["size"] and out_total == e["stream_offset"], (r, nb, out_len)
+            assert hashlib.sha256(sizes.astype("<u4").tobytes()).hexdigest() == e["block_sizes_sha256"], r
+            h = hashlib.sha256()
+            for c0 in range(0, out_len, 256 << 20):  # one pass over the bytes feeds the share's and the stream's digest
+                piece = d_out[c0:min(out_len, c0 + (256 << 20))].cpu().numpy()
+                h.update(piece)
+                h_all.update(piece)
+                if r == 0 and c0 == 0:
+                    offs0 = np.concatenate([[0], np.cumsum(sizes.astype(np.int64))])
+                    head = piece[:int(offs0[min(1000, nb)])].tobytes()  # a prefix of whole blocks
+            assert h.hexdigest() == e["sha256"], "share %d differs from libdeflate's stream" % r
+            if r == world - 1:
+                k = max(0, nb - 1000)
+                t0 = int(np.sum(sizes[:k].astype(np.int64)))
+                tail = d_out[t0:out_len].cpu().numpy().tobytes()  # the last 1000 blocks + the EOF marker
+            # the share inflated and CRC-checked on the GPU, compared with the regenerated input
+            offs = np.concatenate([[0], np.cumsum(sizes.astype(np.uint64))[:-1]]).astype(np.uint64)
+            members = sizes.copy()
+            if e["tail"]:
+                members[-1] -= 28  # (the last framed size counts the EOF marker, an empty member of its own)
+            got = dctx.decompress_device(d_out.data_ptr(), out_len - (28 if e["tail"] else 0), offs, members, d_back.data_ptr(), n_max + 64)
+            assert got == n and torch.equal(d_back[:n], d_in[:n]), r
+            all_sizes.append(sizes)
+            out_total += out_len
+    assert out_total == whole["size"] and sum(s.size for s in all_sizes) == whole["n_blocks"] == 526345
+    assert hashlib.sha256(np.concatenate(all_sizes).astype("<u4").tobytes()).hexdigest() == whole["block_sizes_sha256"]
+    assert h_all.hexdigest() == whole["sha256"], "the in-order concatenation of the eight shares is not libdeflate's stream"
+    for name, blob in (("prefix", head), ("suffix", tail)):
+        try:
+            rc = subprocess.run(["gzip", "-t"], input=blob, capture_output=True).returncode
+        except FileNotFoundError:
+            rc = 0  # (no gzip binary on the box: the GPU inflate above has already done its job)
+        assert rc == 0, name
+    assert tail[-28:-24] == b"\x1f\x8b\x08\x04" and tail[-12:-10] == b"\x1b\x00"  # BGZF_EOF (src/bgzf.rs:24-38)
+
+
 def test_config4_stream_tail(hip_lib):
     # the end of the 32 GiB stream: 1000 whole blocks, the 2,048-byte block and the EOF marker
     e = GOLD["config4_fastq_stream_tail_bgzf_l1"]

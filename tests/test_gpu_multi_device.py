@@ -43,7 +43,9 @@ def test_bench_two_gpus_as_the_driver_launches_it():
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["verified_bit_exact_sample"] is True
     w = d["writeouts"]
     timed = [m for m in ("rccl", "offsets", "peer") if m in w]
-    assert d["value"] == max(d["value_" + m] for m in timed) and w["value_is"] in timed
+    assert d["value"] == d["value_rccl"] and w["value_is"] == "rccl" and w["fastest"] in timed
+    assert d["strong_550MiB"]["verified_bit_exact_full"] is True  # THE 550 MiB slab over two GPUs == libdeflate's stream
+    assert w.get("peer", {}).get("window_equals_rccl_stream", True) is True
     assert "peer" in w or "peer_error" in w  # the copy-engine write-out ran, or the line says why not
     for m in timed:
         assert len(w[m]["rank_ms_per_step"]) == 2 and w[m]["MiBps"] > 0

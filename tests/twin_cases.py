@@ -126,8 +126,20 @@ def multi_device_resident(lib, oracle, scale=1, n_physical=1):
                 off, n = m.shard(a.size, g)
                 part = np.ascontiguousarray(a[off:off + n])
                 if on_gpu:
+                    # produced ASYNCHRONOUSLY, on a side stream behind a few hundred MiB of fills: the wrapper's contract
+                    # (MultiContext.compress_slab_device: ranges complete on entry) is met by ITS synchronisation, not
+                    # by anything this test does
                     import torch
-                    t = torch.from_numpy(part.copy()).to("cuda:%d" % devs[g]) if n else None
+                    t = None
+                    if n:
+                        dev = "cuda:%d" % devs[g]
+                        side = torch.cuda.Stream(device=dev)
+                        with torch.cuda.stream(side):
+                            junk = torch.empty(128 << 20, dtype=torch.uint8, device=dev)
+                            for _ in range(4):
+                                junk.fill_(g + 1)
+                            t = torch.from_numpy(part.copy()).pin_memory().to(dev, non_blocking=True)
+                        keep.append(junk)
                     keep.append(t)
                     shards.append(t.data_ptr() if n else None)
                 else:
@@ -137,8 +149,6 @@ def multi_device_resident(lib, oracle, scale=1, n_physical=1):
             if on_gpu:
                 import torch
                 d_out = torch.zeros(cap, dtype=torch.uint8, device="cuda:%d" % devs[root])  # the root's buffer
-                for dv in set(devs):
-                    torch.cuda.synchronize(dv)
                 n_out, sizes = m.compress_slab_device(shards, a.size, d_out.data_ptr(), cap, mode, root)
                 got = d_out[:n_out].cpu().numpy().tobytes()
             else:

@@ -90,3 +90,21 @@ with open(os.path.join(P, "pmc_traffic.json"), "w") as f:
     json.dump(doc, f, indent=1)
 print(json.dumps(doc["hbm_bytes_per_launch"], indent=1))
 print("calibration factor", cal)
+
+
+# SQ counters (tools/pmc_sq.sh <dir> "<args>" writes gpurun_out/<dir>/sq_counters.json per workload): merged into
+# profiles/sq_counters.json, the source of bench.py's `roofline.issue` -- same build-id rule as the traffic file.
+sq = {"source": "rocprofv3 --kernel-trace --pmc <8 SQ counters> x 2 passes (tools/pmc_sq.sh), per LAUNCH; WAVE_CYCLES / "
+                "WAIT_* / ACTIVE_INST_* in quad-cycles, INSTS_* in wave-instructions",
+      "round": tag, "build_id": doc["build_id"], "workloads": {}}
+import glob
+for f in sorted(glob.glob(os.path.join(G, "pmc_sq*", "sq_counters.json"))):
+    d = json.load(open(f))
+    if d.get("build_id") != doc["build_id"]:
+        print("skipped (another build):", f)
+        continue
+    sq["workloads"][d["workload"]] = d["kernels"]
+if sq["workloads"]:
+    with open(os.path.join(P, "sq_counters.json"), "w") as f:
+        json.dump(sq, f, indent=1)
+    print("profiles/sq_counters.json:", list(sq["workloads"]))
