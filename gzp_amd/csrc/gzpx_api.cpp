@@ -7,6 +7,7 @@
 // a HIP device every entry point fails with GZPX_ERR_NO_DEVICE.
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <condition_variable>
 #include <cmath>
 #include <cstdio>
@@ -738,6 +739,12 @@ int ctx_create(const gzpx_config *cfg, bool crc_only, gzpx_ctx **out) {
     // the later parser on): the 1.10 rules go with it WHATEVER the caller asked for, so the stream is exactly the
     // 1.10 binary's and never a hybrid of two versions.  gzpx_ctx_active_compat() tells which rules a context runs.
     ctx->dcfg.compat = (uint32_t)(cfg->level >= 10 ? GZPX_COMPAT_LIBDEFLATE_1_10 : cfg->compat);
+    if (cfg->level >= 10 && cfg->compat != GZPX_COMPAT_LIBDEFLATE_1_10 && getenv("GZPX_TRACE")) {
+        static std::atomic<bool> told{false};  // (once per process; ADVICE round 4: the override used to be silent)
+        if (!told.exchange(true))
+            fprintf(stderr, "gzpx: level %d runs libdeflate 1.10's near-optimal parser; compat %d was asked for, the 1.10 "
+                            "rules are in force (gzpx_ctx_active_compat)\n", cfg->level, cfg->compat);
+    }
     ctx->dcfg.block_size = (uint32_t)cfg->buffer_size;
     ctx->dcfg.xfl = cfg->level >= 9 ? 2u : cfg->level <= 1 ? 4u : 0u;  // src/bgzf.rs:278-284
     ctx->dcfg.debug = 0;

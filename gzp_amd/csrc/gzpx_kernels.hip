@@ -1571,6 +1571,10 @@ __global__ __launch_bounds__(kMpThreads, 4) void k_mparse(
         meta->nsub = cur_sub + 1;
     }
   }  // staged
+    // (a block that was not staged met no barrier in this iteration: without this one, thread 0 could overwrite
+    // s_claimed while a slower wave has not read the previous iteration's value yet -- ADVICE round 4.  Unreachable
+    // today, only a slab's last block can be that short, but the parse must not depend on how batches are cut)
+    if (!staged) __syncthreads();
     if (tid == 0) s_claimed = 2u * gridDim.x + my_ticket;
     if (next_b >= nb) break;  // (tickets only grow: nothing is left for this workgroup either)
     // (a block handed back in its first pass, or one of a single pass: the next block's d0 is not on its way yet)

@@ -25,3 +25,20 @@ def test_bucket0_starts_vs_oracle(emu_lib, oracle):
         assert comps[(level, compat)].deflate_compress(a) == oracle.deflate_compress(a, level, compat), (it, level, compat, a.size)
     for c in comps.values():
         c.close()
+
+
+def test_thresholds_and_full_sub_blocks_vs_oracle(emu_lib, oracle):
+    """The other two committed classes of tests/fuzz_classes.py through the emulated kernels (a short slice: the MI355X
+    runs the long one, tests/test_gpu_fuzz_slice.py)."""
+    import fuzz_classes as fc
+    rng = np.random.default_rng(5)
+    cases = [(fc.thresholds(rng), int(rng.integers(0, 10)), int(rng.integers(0, 2))) for _ in range(40)]
+    cases += [(a, 1, int(rng.integers(0, 2))) for a in fc.full_sub_block_cuts(rng, 1, oracle)]  # the 8,192nd match + k bytes
+    cases += [(a, 3, 1) for a in fc.full_sub_block_cuts(rng, 3, oracle, deltas=(0, 2))]          # the 50,000th at level 3
+    comps = {}
+    for it, (a, level, compat) in enumerate(cases):
+        if (level, compat) not in comps:
+            comps[(level, compat)] = _native.Compressor(level, compat, lib=emu_lib)
+        assert comps[(level, compat)].deflate_compress(a) == oracle.deflate_compress(a, level, compat), (it, level, compat, a.size)
+    for c in comps.values():
+        c.close()
