@@ -70,7 +70,15 @@ struct HcState {
     uint32_t cur_sub;     // index of the sub-block that starts at resume_pos
     uint32_t rounds;      // diagnostics
     uint32_t pad;
+    // what k_match_hc's arrays (len8 / which / alt) hold for this block (round 5, k_match_hc_sparse):
+    //   0 nothing yet, or not usable: the dense k_match_hc must run (from resume_pos)
+    //   1 the full search ONLY for the token starts of the greedy parse from position 0 with HcState.min_len (every other
+    //     position: the search's first chain node) -- all a parse needs as long as min_len does not change
+    //   2 a later sub-block needs another min_len (k_parse_hc found out): as 0
+    //   3 the full search of every position (the dense kernel ran)
+    uint32_t sparse;
 };
+constexpr uint32_t kHcArraysNone = 0, kHcArraysPath = 1, kHcArraysStale = 2, kHcArraysDense = 3;
 
 struct CrcConsts {
     uint32_t pow64[10];  // x^(8*64*2^l) mod P (reflected), l = 0..9

@@ -1167,6 +1167,8 @@ __device__ unsigned long long g_exp_huff[1024 * 8];
 // k_mparse: stage, first walk, later rounds, settle, build, barrier rounds, re-walks (x 1024 rows, a
 // block adds to row blockIdx & 1023: same-address atomics serialise at the L2)
 __device__ unsigned long long g_exp_cycles[1024 * 8];
+// k_match_hc_sparse: window, first nodes, walks, lists, searches (cycles); rounds, listed searches, tiles (counts)
+__device__ unsigned long long g_exp_sparse[1024 * 8];
 #endif
 
 // ht_matchfinder_longest_match at block position p (block byte i sits at LDS byte i + mis; d0_h[i] =
@@ -1732,7 +1734,8 @@ template <int NV>
 __device__ __forceinline__ void hc_search(const uint32_t *in_w, const uint16_t *link, const uint32_t a,
                                           const uint32_t li, const uint32_t d3v, const uint32_t max_len,
                                           const uint32_t nice_len, const uint32_t depth0, uint32_t (&len_out)[NV],
-                                          uint32_t (&dist_out)[NV], const uint32_t dbg = 0) {
+                                          uint32_t (&dist_out)[NV], const uint32_t dbg = 0,
+                                          uint32_t *tot_out = nullptr) {
     const uint32_t seq4 = lds_le32(in_w, a);
     uint32_t best_len = 2, best_dist = 0;
     uint32_t aoff = a;     // a + best_len - 3 once a node of the chain has matched (pre-filter address), a before
@@ -1788,6 +1791,9 @@ __device__ __forceinline__ void hc_search(const uint32_t *in_w, const uint16_t *
         len_out[v] = best_len;
         dist_out[v] = best_dist;
     }
+    // (k_match_hc_sparse) where the walk stands when its budget is used up: > 32767 = it is over -- the chain ended, left
+    // the window or reached nice_len -- so a deeper search of this position would return the same match
+    if (tot_out) *tot_out = tot;
 }
 
 // One workgroup's LDS as ONE array, the window of input bytes first: the byte reads of the walk then
@@ -1816,6 +1822,10 @@ __global__ __launch_bounds__(1024) void k_match_hc(Config cfg, const uint8_t *__
     const uint32_t n = meta_all[b].n;
     HcState *st = hc_all + b;
     if (n <= cfg.passthrough || st->done) return;  // uniform
+    // (round 5) the arrays already hold what the parse needs: k_match_hc_sparse searched the block's token starts, or
+    // this kernel has been over the block before
+    const uint32_t have = st->sparse;
+    if (have == kHcArraysPath || have == kHcArraysDense) return;  // uniform
     const uint8_t *in = slab + (uint64_t)b * cfg.block_size;
     const uint16_t *d3 = d3_all + (uint64_t)b * cfg.stride;
     const uint16_t *d4 = d4_all + (uint64_t)b * cfg.stride;
@@ -1965,6 +1975,342 @@ __global__ __launch_bounds__(1024) void k_match_hc(Config cfg, const uint8_t *__
         __syncthreads();
         for (uint32_t i = tid; i < (tile_end - tile_begin + 31) / 32; i += 1024)
             mbits_out[tile_begin / 32 + i] = mbits[i];
+    }
+    if (tid == 0) st->sparse = kHcArraysDense;  // (read at the top by every thread: behind the loop's barriers)
+}
+
+// ------------------------------------------------------------------------------------------
+// k_match_hc_sparse (round 5; levels 2-4): the COMPACTION form of k_match_hc.
+//   libdeflate searches only where a token of the greedy parse starts -- a quarter of the positions of text -- and the
+//   lockstep wave of the dense kernel pays for the longest chain walk of its 64 lanes at every position (DESIGN 7:
+//   11.9 rounds per wave at level 3, the lanes using 48 % of them).  Here, per tile of a block:
+//     A  every position gets the search's FIRST chain node only (hash3 check, one node, its extension): lockstep work, all
+//        lanes busy, no divergent loop around it.  For a third of the positions of text that IS the whole search (`fin`).
+//     B  the greedy parse over those lengths, as a speculative segment walk (32 positions per thread, one LDS byte per hop),
+//        says where tokens start;
+//     C  the token starts whose search is not over are listed and dealt out ONE PER LANE for the full search -- full waves
+//        of long walks instead of a long walk holding 63 short ones; a lane then follows the corrected path for a few
+//        steps and searches what it lands on (most corrections move the next token start by a byte or two);
+//     D  the segments with a new length walk again, the few new token starts are searched the same way, until the path
+//        holds only finished searches.  By induction from the tile's entry the path is then libdeflate's: every token
+//        start on it has the full search's match, so the next token start is right as well.
+//   Positions OFF the path keep their first-node match in len8 / which / alt; k_parse_hc never uses them unless a later
+//   sub-block of the block needs another min_len (the path was walked with the first sub-block's) -- it then marks the
+//   block kHcArraysStale and the dense kernel goes over it before the next parse round.  Blocks that can hold an orphan
+//   match (k_hc_orphan: the first four bytes hash to hash4 bucket 0, one block in 65 thousand) are left to the dense
+//   kernel altogether.
+//   LDS: the window (bytes + links) of a 13,056-position tile (five per BGZF block), the tile's lengths and four bitmaps.
+// ------------------------------------------------------------------------------------------
+constexpr uint32_t kHsTile = 13056;  // 65280 / 5; a multiple of 256
+constexpr uint32_t kHsInWords = (32768 + kHsTile + 264) / 4 + 8;
+constexpr uint32_t kHsLinkWords = (32768 + kHsTile) / 2;
+constexpr uint32_t kHsSeg = 32;                      // positions per walk segment = one 32-bit mask
+constexpr uint32_t kHsSegs = kHsTile / kHsSeg;       // 408
+constexpr uint32_t kHsList = 1280;                   // list entries (u16) per round; what does not fit waits a round (the LDS is full: 336 bytes to spare, 264 of them __syncthreads_or's)
+constexpr uint32_t kHsChase = 6;                     // searches a lane may add while it follows the corrected path
+constexpr uint32_t kHsLdsWords = kHsInWords + kHsLinkWords + kHsTile / 4 + 4 * kHsSegs + 2 * kHsSegs + kHsList / 2 + 16;
+static_assert(kHsLdsWords * 4 <= 160 * 1024, "k_match_hc_sparse: one workgroup's LDS");
+static_assert(kHsTile % 256 == 0 && kHsSegs <= 1024, "tile geometry");
+
+__global__ __launch_bounds__(1024) void k_match_hc_sparse(Config cfg, const uint8_t *__restrict__ slab,
+                                                          const BlockMeta *__restrict__ meta_all,
+                                                          HcState *__restrict__ hc_all,
+                                                          const uint16_t *__restrict__ d3_all,
+                                                          const uint16_t *__restrict__ d4_all,
+                                                          uint8_t *__restrict__ len8_all,
+                                                          uint32_t *__restrict__ mbits_all,
+                                                          uint16_t *__restrict__ dist_all) {
+    __shared__ uint32_t hs_lds[kHsLdsWords];
+    uint32_t *in_w = hs_lds;                         // window of the block's bytes (LDS address 0: immediate offsets)
+    uint32_t *link_w = in_w + kHsInWords;            // d4 of every position in the window
+    uint32_t *len_w = link_w + kHsLinkWords;         // len - 3 of the tile's positions (u8)
+    uint32_t *mbits = len_w + kHsTile / 4;           // a match was accepted here (min_len 3: what k_parse_hc reads)
+    uint32_t *mbf = mbits + kHsSegs;                 // ... and is long enough for the sub-block's min_len: the walk's mask
+    uint32_t *fin = mbf + kHsSegs;                   // the position's search is over: its match is the full search's
+    uint32_t *marks = fin + kHsSegs;                 // a token starts here (the current walk)
+    uint32_t *seg_exit = marks + kHsSegs;            // [2][kHsSegs] where the walk leaves segment s (tile-relative)
+    uint32_t *list_w = seg_exit + 2 * kHsSegs;       // u16 tile-relative positions to search
+    uint32_t *misc = list_w + kHsList / 2;           // [0..7] hc_calc_min_len's census, [8] list length
+    const uint16_t *link = (const uint16_t *)link_w;
+    uint8_t *len_l = (uint8_t *)len_w;
+    uint16_t *list = (uint16_t *)list_w;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    const uint32_t b = blockIdx.x;
+    const uint32_t n = meta_all[b].n;
+    HcState *st = hc_all + b;
+    if (n <= cfg.passthrough || st->done || cfg.lazy) return;  // uniform
+    const uint8_t *in = slab + (uint64_t)b * cfg.block_size;
+    {   // a block that may hold an orphan match (k_hc_orphan) is the dense kernel's
+        const uint32_t first4 = n >= 9u ? (uint32_t)in[0] | (uint32_t)in[1] << 8 | (uint32_t)in[2] << 16 | (uint32_t)in[3] << 24 : 1u;
+        if (n >= 9u && ((first4 * 0x1E35A7BDu) >> 16) == 0) return;  // uniform (HcState.sparse stays kHcArraysNone)
+    }
+    const uint16_t *d3 = d3_all + (uint64_t)b * cfg.stride;
+    const uint16_t *d4 = d4_all + (uint64_t)b * cfg.stride;
+    uint8_t *len8 = len8_all + (uint64_t)b * cfg.stride;
+    uint32_t *mbits_out = mbits_all + (uint64_t)b * (cfg.stride / 32);
+    uint16_t *dist = dist_all + (uint64_t)b * cfg.stride;
+#ifdef GZPX_EXPERIMENT
+    // measurement builds (tools/exp_hc_sparse2.py): thread 0's clock per phase, summed over the blocks of a launch:
+    // 0 window, 1 first nodes (A), 2 walks (B, D), 3 lists, 4 searches (C), 5 rounds, 6 listed searches, 7 tiles
+    unsigned long long exp_t = __builtin_readcyclecounter();
+    auto exp_lap = [&](uint32_t slot) {
+        const unsigned long long t = __builtin_readcyclecounter();
+        if (tid == 0) atomicAdd(&g_exp_sparse[(b & 1023u) * 8u + slot], t - exp_t);
+        exp_t = t;
+    };
+    auto exp_count = [&](uint32_t slot, uint32_t v) {
+        if (tid == 0) atomicAdd(&g_exp_sparse[(b & 1023u) * 8u + slot], (unsigned long long)v);
+    };
+#else
+    auto exp_lap = [](uint32_t) {};
+    auto exp_count = [](uint32_t, uint32_t) {};
+#endif
+
+    // the first sub-block's min_len (calculate_min_match_len): the path is walked with it, k_parse_hc parses with it
+    const uint32_t min_len = hc_calc_min_len(cfg, in, 0, n, misc, tid, 1024);
+    const uint32_t nice_level = cfg.hc_nice, depth = cfg.hc_depth;
+
+    auto fix_links = [](uint32_t v) {  // two links; 0 = none
+        if ((v & 0xFFFFu) == 0) v |= kHcNoLink;
+        if ((v >> 16) == 0) v |= kHcNoLink << 16;
+        return v;
+    };
+    // the window slides inside the LDS and what is new arrives in registers, as in k_match_hc
+    constexpr uint32_t kPfIn = (kHsTile / 4 + 1023) / 1024, kPfLk = (kHsTile / 2 + 1023) / 1024;
+    constexpr uint32_t kMvIn = (kHsInWords + 1023) / 1024, kMvLk = (32768 / 2 + 1023) / 1024;
+    uint32_t pf_in[kPfIn], pf_lk[kPfLk];
+    uint32_t prev_win = 0, prev_ndw = 0, prev_nlw = 0;
+    uint32_t entry_carry = 0;  // where the parse enters the tile (block position; uniform)
+    for (uint32_t tile_begin = 0; tile_begin < n; tile_begin += kHsTile) {
+        const uint32_t tile_end = tile_begin + kHsTile < n ? tile_begin + kHsTile : n;
+        const uint32_t tile_len = tile_end - tile_begin;
+        const uint32_t n_seg = (tile_len + kHsSeg - 1) / kHsSeg;
+        const uint32_t win_begin = tile_begin >= 32768u ? tile_begin - 32768u : 0;
+        const uint32_t win_end = tile_end + 264 < n ? tile_end + 264 : n;
+        const uint32_t mis = (uint32_t)((uintptr_t)(in + win_begin) & 3u);  // (the same for every tile: win_begin is a multiple of 256)
+        const uint32_t ndw = (mis + (win_end - win_begin) + 3) >> 2;
+        const uint32_t nlw = (tile_end - win_begin + 1) / 2;
+        __syncthreads();
+        if (prev_ndw == 0) {  // a block's first tile: everything from memory
+            const uint32_t *src = (const uint32_t *)(in + win_begin - mis);
+            for (uint32_t i = tid; i < ndw; i += 1024) in_w[i] = src[i];
+            const uint32_t *lsrc = (const uint32_t *)(d4 + win_begin);
+            for (uint32_t i = tid; i < nlw; i += 1024) link_w[i] = fix_links(lsrc[i]);
+        } else {
+            const uint32_t sh = win_begin - prev_win;  // 0 while the window still grows
+            const uint32_t keep_in = prev_ndw - sh / 4, keep_lk = prev_nlw - sh / 2;
+            if (sh) {
+                uint32_t mv_in[kMvIn], mv_lk[kMvLk];
+#pragma unroll
+                for (uint32_t k = 0; k < kMvIn; k++) mv_in[k] = tid + 1024u * k < keep_in ? in_w[tid + 1024u * k + sh / 4] : 0u;
+#pragma unroll
+                for (uint32_t k = 0; k < kMvLk; k++) mv_lk[k] = tid + 1024u * k < keep_lk ? link_w[tid + 1024u * k + sh / 2] : 0u;
+                __syncthreads();
+#pragma unroll
+                for (uint32_t k = 0; k < kMvIn; k++)
+                    if (tid + 1024u * k < keep_in) in_w[tid + 1024u * k] = mv_in[k];
+#pragma unroll
+                for (uint32_t k = 0; k < kMvLk; k++)
+                    if (tid + 1024u * k < keep_lk) link_w[tid + 1024u * k] = mv_lk[k];
+            }
+#pragma unroll
+            for (uint32_t k = 0; k < kPfIn; k++)
+                if (keep_in + tid + 1024u * k < ndw) in_w[keep_in + tid + 1024u * k] = pf_in[k];
+#pragma unroll
+            for (uint32_t k = 0; k < kPfLk; k++)
+                if (keep_lk + tid + 1024u * k < nlw) link_w[keep_lk + tid + 1024u * k] = fix_links(pf_lk[k]);
+        }
+        for (uint32_t i = ndw + tid; i < ndw + 3 && i < kHsInWords; i += 1024) in_w[i] = 0;
+        if (tid == 0) misc[8] = 0;
+        prev_win = win_begin;
+        prev_ndw = ndw;
+        prev_nlw = nlw;
+        if (tile_end < n) {  // what the next tile's window adds to this one
+            const uint32_t nt_end = tile_end + kHsTile < n ? tile_end + kHsTile : n;
+            const uint32_t nw_begin = tile_end >= 32768u ? tile_end - 32768u : 0;
+            const uint32_t nw_end = nt_end + 264 < n ? nt_end + 264 : n;
+            const uint32_t nsh = nw_begin - win_begin;
+            const uint32_t n_ndw = (mis + (nw_end - nw_begin) + 3) >> 2, n_nlw = (nt_end - nw_begin + 1) / 2;
+            const uint32_t *src = (const uint32_t *)(in + nw_begin - mis) + (ndw - nsh / 4);
+            const uint32_t *lsrc = (const uint32_t *)(d4 + nw_begin) + (nlw - nsh / 2);
+            const uint32_t more_in = n_ndw - (ndw - nsh / 4), more_lk = n_nlw - (nlw - nsh / 2);
+#pragma unroll
+            for (uint32_t k = 0; k < kPfIn; k++) pf_in[k] = tid + 1024u * k < more_in ? src[tid + 1024u * k] : 0u;
+#pragma unroll
+            for (uint32_t k = 0; k < kPfLk; k++) pf_lk[k] = tid + 1024u * k < more_lk ? lsrc[tid + 1024u * k] : 0u;
+        }
+        uint32_t d3_next = tile_begin + tid + 5 <= n && tile_begin + tid < tile_end ? d3[tile_begin + tid] : 0u;
+        __syncthreads();
+        exp_lap(0);
+
+        // one position's search with `budget` nodes; the LDS lengths and bitmaps are the caller's to update
+        auto search = [&](uint32_t p, uint32_t d3v, uint32_t budget, uint32_t &len, uint32_t &dst, bool &over) {
+            const uint32_t rem = n - p;
+            const uint32_t max_len = rem < 258u ? rem : 258u;
+            const uint32_t nice_len = max_len < nice_level ? max_len : nice_level;
+            const uint32_t a = p - win_begin + mis, li = p - win_begin;
+            uint32_t ln[1], ds[1], tot;
+            hc_search<1>(in_w, link, a, li, d3v, max_len, nice_len, budget, ln, ds, 0, &tot);
+            len = ln[0];
+            dst = ds[0];
+            over = tot > 32767u;
+        };
+
+        // ---- A: the first chain node of every position
+        for (uint32_t r0 = 0; r0 < tile_len; r0 += 1024) {  // (uniform trip count: the ballots below need whole waves)
+            const uint32_t r = r0 + tid, p = tile_begin + r;
+            const bool have = r < tile_len;
+            const uint32_t d3v = d3_next;
+            const uint32_t pn = p + 1024u;
+            d3_next = pn + 5 <= n && pn < tile_end ? d3[pn] : 0u;
+            uint32_t len = 0, dst = 0;
+            bool over = true;
+            if (have) search(p, d3v, 1u, len, dst, over);
+            if (depth <= 1u) over = true;
+            // deflate_compress_greedy: a length-3 match is only worth it at a short distance
+            const bool take = have && len >= 3u && (len > 3u || dst <= 4096u);
+            const unsigned long long bt = __ballot(take), bf = __ballot(take && len >= min_len), bo = __ballot(over || !have);
+            if (have) {
+                len_l[r] = (uint8_t)(take ? len - 3u : 0u);
+                len8[p] = (uint8_t)(take ? len - 3u : 0u);
+                dist[p] = (uint16_t)(take ? dst : lds_le32(in_w, p - win_begin + mis) & 0xFFu);
+            }
+            if (lane == 0 && r < tile_len + 64u) {  // (a wave covers two words of each bitmap)
+                const uint32_t w = r >> 5;
+                if (w < kHsSegs) {
+                    mbits[w] = (uint32_t)bt;
+                    mbf[w] = (uint32_t)bf;
+                    fin[w] = (uint32_t)bo;
+                }
+                if (w + 1 < kHsSegs) {
+                    mbits[w + 1] = (uint32_t)(bt >> 32);
+                    mbf[w + 1] = (uint32_t)(bf >> 32);
+                    fin[w + 1] = (uint32_t)(bo >> 32);
+                }
+            }
+        }
+        __syncthreads();
+        exp_lap(1);
+
+        // ---- B: the greedy parse over the lengths in LDS; thread s walks segment s from `pos` (tile-relative)
+        auto walk_seg = [&](uint32_t sg, uint32_t pos) -> uint32_t {
+            const uint32_t sb = sg * kHsSeg, se = sb + kHsSeg < tile_len ? sb + kHsSeg : tile_len;
+            const uint32_t mbm = mbf[sg];
+            uint32_t mk = 0;
+            while (pos < se) {
+                const uint32_t rel = pos - sb;
+                const uint32_t rest = mbm >> rel;
+                if (rest == 0) {  // literals to the end of the segment
+                    mk |= ~0u << rel;
+                    pos = se;
+                    break;
+                }
+                const uint32_t k = (uint32_t)__ffs((int)rest) - 1u;  // literals rel .. rel+k-1, a match at rel+k
+                mk |= ((2u << k) - 1u) << rel;
+                pos = sb + rel + k + (uint32_t)len_l[sb + rel + k] + 3u;
+            }
+            if (se - sb < 32u) mk &= (1u << (se - sb)) - 1u;
+            marks[sg] = mk;
+            return pos;
+        };
+        const bool active = tid < n_seg;
+        const uint32_t seg_begin = tid * kHsSeg;
+        uint32_t entry = tid == 0 ? entry_carry - tile_begin : seg_begin;
+        uint32_t my_exit = active ? walk_seg(tid, entry) : 0u;
+        uint32_t cur = 0;
+        if (active) seg_exit[tid] = my_exit;
+        bool dirty = false;  // a search changed a length in my segment
+        for (uint32_t iter = 0;; iter++) {
+            // the entries settle: one barrier per round, two copies of the exits (as in k_mparse)
+            for (;;) {
+                __syncthreads();
+                uint32_t new_entry = entry;
+                if (active && tid > 0) new_entry = seg_exit[cur * kHsSegs + tid - 1];
+                const bool changed = active && (new_entry != entry || dirty);
+                dirty = false;
+                if (changed) {
+                    entry = new_entry;
+                    my_exit = walk_seg(tid, entry);
+                }
+                cur ^= 1u;
+                if (active) seg_exit[cur * kHsSegs + tid] = my_exit;
+                if (!__syncthreads_or(changed)) break;
+            }
+            exp_lap(2);
+            // ---- C: the token starts whose search is not over, one per lane
+            if (active) {
+                uint32_t need = marks[tid] & ~fin[tid];
+                if (iter >= 12u) need = ~fin[tid] & (seg_begin + 32u <= tile_len ? ~0u : (1u << (tile_len - seg_begin)) - 1u);  // give up predicting: every open search of the tile
+                const uint32_t cnt = (uint32_t)__popc(need);
+                if (cnt) {
+                    uint32_t at = atomicAdd(&misc[8], cnt);
+                    while (need && at < kHsList) {
+                        list[at++] = (uint16_t)(seg_begin + (uint32_t)__ffs((int)need) - 1u);
+                        need &= need - 1u;
+                    }
+                }
+            }
+            __syncthreads();
+            const uint32_t listed = misc[8] < kHsList ? misc[8] : kHsList;  // (what did not fit is still open next round)
+            exp_lap(3);
+            if (listed == 0) break;  // uniform: the path holds only finished searches
+            exp_count(5, 1);
+            exp_count(6, listed);
+            for (uint32_t i = tid; i < listed; i += 1024) {
+                uint32_t r = list[i];
+                for (uint32_t hop = 0;; hop++) {
+                    const uint32_t p = tile_begin + r;
+                    uint32_t len, dst;
+                    bool over;
+                    search(p, p + 5 <= n ? (uint32_t)d3[p] : 0u, depth, len, dst, over);
+                    const bool take = len >= 3u && (len > 3u || dst <= 4096u);
+                    const uint32_t old = (mbits[r >> 5] >> (r & 31u)) & 1u ? (uint32_t)len_l[r] + 3u : 0u;
+                    const uint32_t bit = 1u << (r & 31u);
+                    atomicOr(&fin[r >> 5], bit);
+                    uint32_t step = (mbf[r >> 5] & bit) ? old : 1u;  // what the walk took here so far
+                    if (take && len != old) {  // (a deeper search only ever finds longer matches: bits are set, never cleared)
+                        len_l[r] = (uint8_t)(len - 3u);
+                        len8[p] = (uint8_t)(len - 3u);
+                        dist[p] = (uint16_t)dst;
+                        atomicOr(&mbits[r >> 5], bit);
+                        if (len >= min_len) {
+                            atomicOr(&mbf[r >> 5], bit);
+                            step = len;
+                        }
+                        // the segment walks again
+                        seg_exit[(cur ^ 1u) * kHsSegs + (r >> 5)] = 0xFFFFFFFFu;
+                    }
+                    // follow the corrected path while it runs over finished positions; search the first open one
+                    if (hop >= kHsChase) break;
+                    uint32_t q = r + step;
+                    bool found = false;
+                    for (uint32_t g = 0; g < 8u && q < tile_len; g++) {
+                        const uint32_t qb = 1u << (q & 31u);
+                        if (marks[q >> 5] & qb) break;  // the old path: whatever is open on it has been listed
+                        if (!(fin[q >> 5] & qb)) {
+                            found = true;
+                            break;
+                        }
+                        q += (mbf[q >> 5] & qb) ? (uint32_t)len_l[q] + 3u : 1u;
+                    }
+                    if (!found) break;
+                    r = q;
+                }
+            }
+            __syncthreads();
+            if (tid == 0) misc[8] = 0;
+            // ---- D: segments with a new length walk again (their exit in the copy nobody reads was poisoned)
+            if (active) dirty = seg_exit[(cur ^ 1u) * kHsSegs + tid] == 0xFFFFFFFFu;
+            exp_lap(4);
+        }
+        entry_carry = tile_begin + uniform(seg_exit[cur * kHsSegs + n_seg - 1]);
+        // the accepted-match bits of the tile (k_parse_hc reads them); tile_begin is a multiple of 32
+        for (uint32_t i = tid; i < (tile_len + 31) / 32; i += 1024) mbits_out[tile_begin / 32 + i] = mbits[i];
+        exp_count(7, 1);
+    }
+    if (tid == 0) {
+        st->min_len = min_len;
+        st->sparse = kHcArraysPath;
     }
 }
 
@@ -2547,6 +2893,9 @@ __global__ __launch_bounds__(kMpThreads, GZPX_PHC_WAVES) void k_parse_hc(
                 // the "long enough" filter of the matches from bp on was another sub-block's: parse
                 // again from there (k_match_hc's results stand, they do not depend on min_len)
                 if (tid == 0) {
+                    // (round 5) arrays that hold the full search for ONE min_len's token starts only are no use from
+                    // here on: the dense k_match_hc goes over the block from bp before the next round parses it
+                    if (st->sparse == kHcArraysPath) st->sparse = kHcArraysStale;
                     st->min_len = new_min_len;
                     st->resume_pos = bp;
                     st->tok_carry = bti;
@@ -2920,6 +3269,7 @@ __global__ void k_hc_init(uint32_t nb, HcState *hc, uint32_t *pending) {
     s.cur_sub = 0;
     s.rounds = 0;
     s.pad = 0;
+    s.sparse = kHcArraysNone;
     hc[b] = s;
 }
 
@@ -5105,6 +5455,19 @@ extern "C" int gzpx_exp_cycles(unsigned long long out[8], int reset) {
     }
     return 0;
 }
+
+extern "C" int gzpx_exp_sparse(unsigned long long out[8], int reset) {
+    static unsigned long long rows[1024 * 8];
+    if (hipMemcpyFromSymbol(rows, HIP_SYMBOL(g_exp_sparse), sizeof(rows)) != hipSuccess) return -1;
+    for (int k = 0; k < 8; k++) out[k] = 0;
+    for (int r = 0; r < 1024; r++)
+        for (int k = 0; k < 8; k++) out[k] += rows[r * 8 + k];
+    if (reset) {
+        memset(rows, 0, sizeof(rows));
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_exp_sparse), rows, sizeof(rows)) != hipSuccess) return -1;
+    }
+    return 0;
+}
 #endif
 
 void launch_match(const Config &cfg, const uint8_t *slab, uint64_t slab_len, uint32_t nb, const Scratch &s,
@@ -5134,17 +5497,32 @@ void launch_parse(const Config &cfg, const uint8_t *slab, uint64_t, uint32_t nb,
 // greedy parse with its re-parse rounds: nothing comes back to the host
 void launch_hc(const Config &cfg, const uint8_t *slab, uint32_t nb, const Scratch &s, hipStream_t stream) {
     hipLaunchKernelGGL(k_hc_init, dim3((nb + 255) / 256), dim3(256), 0, stream, nb, s.hc, s.pending);
-    hipLaunchKernelGGL(k_match_hc, dim3(nb), dim3(1024), 0, stream, cfg, slab, (const BlockMeta *)s.meta, s.hc,
-                       (const uint16_t *)s.cand, (const uint16_t *)s.d4, s.len8, s.which, s.alt,
-                       (uint8_t *)nullptr, (uint16_t *)nullptr);
-    hipLaunchKernelGGL(k_hc_orphan, dim3(nb), dim3(64), 0, stream, cfg, slab, (const BlockMeta *)s.meta, s.hc,
-                       (const uint16_t *)s.cand, (const uint16_t *)s.d4, s.len8, s.which, s.alt, (uint8_t *)nullptr,
-                       (uint16_t *)nullptr);
-    // two single rounds (the second finds nearly every block done), then the looping form for the rest
-    for (int r = 0; r < 2; r++)
+    auto dense = [&]() {  // (returns at once for the blocks whose arrays already hold what the parse needs)
+        hipLaunchKernelGGL(k_match_hc, dim3(nb), dim3(1024), 0, stream, cfg, slab, (const BlockMeta *)s.meta, s.hc,
+                           (const uint16_t *)s.cand, (const uint16_t *)s.d4, s.len8, s.which, s.alt,
+                           (uint8_t *)nullptr, (uint16_t *)nullptr);
+    };
+    auto parse_round = [&]() {
         hipLaunchKernelGGL(k_parse_hc<false>, dim3(nb), dim3(kMpThreads), 0, stream, cfg, slab, s.meta, s.sub, s.hc,
                            (const uint8_t *)s.len8, (const uint32_t *)s.which, (const uint16_t *)s.alt, s.tok,
                            s.pending);
+    };
+    // Round 5: the full search only where the greedy parse starts a token (k_match_hc_sparse); the dense kernel behind it
+    // takes the blocks that kernel leaves alone (orphan candidates).  Config.debug bit 4: the dense kernel for every
+    // block, as in rounds 2-4 (A/B runs and the tests that compare the two routes).
+    if (!(cfg.debug & 16u))
+        hipLaunchKernelGGL(k_match_hc_sparse, dim3(nb), dim3(1024), 0, stream, cfg, slab, (const BlockMeta *)s.meta, s.hc,
+                           (const uint16_t *)s.cand, (const uint16_t *)s.d4, s.len8, s.which, s.alt);
+    dense();
+    hipLaunchKernelGGL(k_hc_orphan, dim3(nb), dim3(64), 0, stream, cfg, slab, (const BlockMeta *)s.meta, s.hc,
+                       (const uint16_t *)s.cand, (const uint16_t *)s.d4, s.len8, s.which, s.alt, (uint8_t *)nullptr,
+                       (uint16_t *)nullptr);
+    // two single rounds (the second finds nearly every block done), then the looping form for the rest.  A block whose
+    // first round ended at a sub-block with another min_len has arrays that are no use from there on if they came from
+    // the sparse kernel (kHcArraysStale): the dense kernel goes over it before its second round.
+    parse_round();
+    if (!(cfg.debug & 16u)) dense();
+    parse_round();
     hipLaunchKernelGGL(k_parse_hc<true>, dim3(nb), dim3(kMpThreads), 0, stream, cfg, slab, s.meta, s.sub, s.hc,
                        (const uint8_t *)s.len8, (const uint32_t *)s.which, (const uint16_t *)s.alt, s.tok,
                        s.pending);
