@@ -2030,7 +2030,7 @@ __global__ __launch_bounds__(1024) void k_match_hc_sparse(Config cfg, const uint
     uint32_t *marks = fin + kHsSegs;                 // a token starts here (the current walk)
     uint32_t *seg_exit = marks + kHsSegs;            // [2][kHsSegs] where the walk leaves segment s (tile-relative)
     uint32_t *list_w = seg_exit + 2 * kHsSegs;       // u16 tile-relative positions to search
-    uint32_t *misc = list_w + kHsList / 2;           // [0..7] hc_calc_min_len's census, [8] list length
+    uint32_t *misc = list_w + kHsList / 2;           // [0..7] hc_calc_min_len's census, [8] the ring's tail, [9] open searches of the first tile
     const uint16_t *link = (const uint16_t *)link_w;
     uint8_t *len_l = (uint8_t *)len_w;
     uint16_t *list = (uint16_t *)list_w;
@@ -2121,7 +2121,10 @@ __global__ __launch_bounds__(1024) void k_match_hc_sparse(Config cfg, const uint
                 if (keep_lk + tid + 1024u * k < nlw) link_w[keep_lk + tid + 1024u * k] = fix_links(pf_lk[k]);
         }
         for (uint32_t i = ndw + tid; i < ndw + 3 && i < kHsInWords; i += 1024) in_w[i] = 0;
-        if (tid == 0) misc[8] = 0;
+        if (tid == 0) {
+            misc[8] = 0;
+            misc[9] = 0;
+        }
         prev_win = win_begin;
         prev_ndw = ndw;
         prev_nlw = nlw;
@@ -2215,12 +2218,20 @@ __global__ __launch_bounds__(1024) void k_match_hc_sparse(Config cfg, const uint
         };
         const bool active = tid < n_seg;
         const uint32_t seg_begin = tid * kHsSeg;
+        if (tile_begin == 0) {
+            // A block whose searches are nearly all over after their first node (noise: empty hash3 buckets, no chains) has
+            // nothing to compact -- the dense kernel is the cheaper way through it: leave (HcState.sparse stays
+            // kHcArraysNone; what this tile wrote is what the dense kernel writes again).
+            if (active) atomicAdd(&misc[9], (uint32_t)__popc(~fin[tid] & (seg_begin + 32u <= tile_len ? ~0u : (1u << (tile_len - seg_begin)) - 1u)));
+            __syncthreads();
+            if (misc[9] * 8u < tile_len && !(cfg.debug & 32u)) return;  // uniform
+        }
         uint32_t entry = tid == 0 ? entry_carry - tile_begin : seg_begin;
         uint32_t my_exit = active ? walk_seg(tid, entry) : 0u;
         uint32_t cur = 0;
         if (active) seg_exit[tid] = my_exit;
         bool dirty = false;  // a search changed a length in my segment
-        for (uint32_t iter = 0;; iter++) {
+        for (uint32_t pass = 0;; pass++) {
             // the entries settle: one barrier per round, two copies of the exits (as in k_mparse)
             for (;;) {
                 __syncthreads();
@@ -2237,38 +2248,48 @@ __global__ __launch_bounds__(1024) void k_match_hc_sparse(Config cfg, const uint
                 if (!__syncthreads_or(changed)) break;
             }
             exp_lap(2);
-            // ---- C: the token starts whose search is not over, one per lane
+            // ---- C: the token starts whose search is not over go on the list (a ring of kHsList entries)
             if (active) {
                 uint32_t need = marks[tid] & ~fin[tid];
-                if (iter >= 12u) need = ~fin[tid] & (seg_begin + 32u <= tile_len ? ~0u : (1u << (tile_len - seg_begin)) - 1u);  // give up predicting: every open search of the tile
+                if (pass >= 12u) need = ~fin[tid] & (seg_begin + 32u <= tile_len ? ~0u : (1u << (tile_len - seg_begin)) - 1u);  // give up predicting: every open search of the tile
                 const uint32_t cnt = (uint32_t)__popc(need);
                 if (cnt) {
                     uint32_t at = atomicAdd(&misc[8], cnt);
-                    while (need && at < kHsList) {
+                    while (need && at < kHsList) {  // (what does not fit is found again by the next pass)
                         list[at++] = (uint16_t)(seg_begin + (uint32_t)__ffs((int)need) - 1u);
                         need &= need - 1u;
                     }
                 }
             }
             __syncthreads();
-            const uint32_t listed = misc[8] < kHsList ? misc[8] : kHsList;  // (what did not fit is still open next round)
+            uint32_t head = 0, tail = misc[8] < kHsList ? misc[8] : kHsList;
             exp_lap(3);
-            if (listed == 0) break;  // uniform: the path holds only finished searches
-            exp_count(5, 1);
-            exp_count(6, listed);
-            for (uint32_t i = tid; i < listed; i += 1024) {
-                uint32_t r = list[i];
-                for (uint32_t hop = 0;; hop++) {
+            if (tail == 0) break;  // uniform: the path holds only finished searches
+            __syncthreads();       // (everybody has read the count)
+            if (tid == 0) misc[8] = tail;
+            // Rounds without a walk of the whole tile: one listed search per lane; a lane whose search changed a length follows
+            // the corrected path over the lengths in LDS until it meets the old one again, marks what it passes as token
+            // starts and appends the open searches among them to the ring -- the next round's list.  Marks that fall off
+            // the path stay behind and a walk may stop at one too early: the pass that follows (walks from the poisoned
+            // segments on, list from the true marks) finds what that missed; it is empty nearly every time.
+            while (head < tail) {
+                __syncthreads();  // misc[8] == tail is visible; the ring's entries [head, tail) are complete
+                exp_count(5, 1);
+                exp_count(6, tail - head);
+                for (uint32_t i = head + tid; i < tail; i += 1024) {
+                    const uint32_t r = list[i % kHsList];
+                    const uint32_t bit = 1u << (r & 31u);
+                    if (fin[r >> 5] & bit) continue;  // (listed twice)
                     const uint32_t p = tile_begin + r;
                     uint32_t len, dst;
                     bool over;
                     search(p, p + 5 <= n ? (uint32_t)d3[p] : 0u, depth, len, dst, over);
                     const bool take = len >= 3u && (len > 3u || dst <= 4096u);
-                    const uint32_t old = (mbits[r >> 5] >> (r & 31u)) & 1u ? (uint32_t)len_l[r] + 3u : 0u;
-                    const uint32_t bit = 1u << (r & 31u);
+                    const bool had = (mbf[r >> 5] & bit) != 0;
+                    const uint32_t old_step = had ? (uint32_t)len_l[r] + 3u : 1u;  // what the walk took here so far
+                    uint32_t step = old_step;
                     atomicOr(&fin[r >> 5], bit);
-                    uint32_t step = (mbf[r >> 5] & bit) ? old : 1u;  // what the walk took here so far
-                    if (take && len != old) {  // (a deeper search only ever finds longer matches: bits are set, never cleared)
+                    if (take && (!had || len != old_step)) {  // (a deeper search only ever finds longer matches: bits are set, never cleared)
                         len_l[r] = (uint8_t)(len - 3u);
                         len8[p] = (uint8_t)(len - 3u);
                         dist[p] = (uint16_t)dst;
@@ -2277,25 +2298,26 @@ __global__ __launch_bounds__(1024) void k_match_hc_sparse(Config cfg, const uint
                             atomicOr(&mbf[r >> 5], bit);
                             step = len;
                         }
-                        // the segment walks again
-                        seg_exit[(cur ^ 1u) * kHsSegs + (r >> 5)] = 0xFFFFFFFFu;
                     }
-                    // follow the corrected path while it runs over finished positions; search the first open one
-                    if (hop >= kHsChase) break;
+                    if (step == old_step) continue;
+                    seg_exit[(cur ^ 1u) * kHsSegs + (r >> 5)] = 0xFFFFFFFFu;  // the segment walks again in the next pass
                     uint32_t q = r + step;
-                    bool found = false;
-                    for (uint32_t g = 0; g < 8u && q < tile_len; g++) {
+                    for (uint32_t hop = 0; hop < 16u && q < tile_len; hop++) {
                         const uint32_t qb = 1u << (q & 31u);
-                        if (marks[q >> 5] & qb) break;  // the old path: whatever is open on it has been listed
+                        if (atomicOr(&marks[q >> 5], qb) & qb) break;  // the old path (or somebody else's new one)
                         if (!(fin[q >> 5] & qb)) {
-                            found = true;
-                            break;
+                            const uint32_t at = atomicAdd(&misc[8], 1u);
+                            if (at - head < kHsList) list[at % kHsList] = (uint16_t)q;  // (else: the next pass finds it)
                         }
                         q += (mbf[q >> 5] & qb) ? (uint32_t)len_l[q] + 3u : 1u;
                     }
-                    if (!found) break;
-                    r = q;
                 }
+                __syncthreads();
+                const uint32_t ring_end = head + kHsList;  // entries from here on were dropped, not stored
+                head = tail;
+                tail = misc[8] < ring_end ? misc[8] : ring_end;
+                __syncthreads();
+                if (tid == 0) misc[8] = tail;
             }
             __syncthreads();
             if (tid == 0) misc[8] = 0;
@@ -5510,7 +5532,10 @@ void launch_hc(const Config &cfg, const uint8_t *slab, uint32_t nb, const Scratc
     // Round 5: the full search only where the greedy parse starts a token (k_match_hc_sparse); the dense kernel behind it
     // takes the blocks that kernel leaves alone (orphan candidates).  Config.debug bit 4: the dense kernel for every
     // block, as in rounds 2-4 (A/B runs and the tests that compare the two routes).
-    if (!(cfg.debug & 16u))
+    // Level 2 (six chain nodes at most) is the dense kernel's: there is too little behind the first node to compact.
+    // (Config.debug bit 5: the sparse kernel at every greedy level and for every block, noise included -- tests.)
+    const bool sparse = !(cfg.debug & 16u) && (cfg.level >= 3 || (cfg.debug & 32u));
+    if (sparse)
         hipLaunchKernelGGL(k_match_hc_sparse, dim3(nb), dim3(1024), 0, stream, cfg, slab, (const BlockMeta *)s.meta, s.hc,
                            (const uint16_t *)s.cand, (const uint16_t *)s.d4, s.len8, s.which, s.alt);
     dense();
@@ -5521,7 +5546,7 @@ void launch_hc(const Config &cfg, const uint8_t *slab, uint32_t nb, const Scratc
     // first round ended at a sub-block with another min_len has arrays that are no use from there on if they came from
     // the sparse kernel (kHcArraysStale): the dense kernel goes over it before its second round.
     parse_round();
-    if (!(cfg.debug & 16u)) dense();
+    if (sparse) dense();
     parse_round();
     hipLaunchKernelGGL(k_parse_hc<true>, dim3(nb), dim3(kMpThreads), 0, stream, cfg, slab, s.meta, s.sub, s.hc,
                        (const uint8_t *)s.len8, (const uint32_t *)s.which, (const uint16_t *)s.alt, s.tok,

@@ -11,7 +11,8 @@ import numpy as np
 from gzp_amd import _native, synth
 
 
-def fuzz(lib, oracle, seed=12345, secs=None, max_cases=None, max_n=1_500_000, verbose=True, max_level=9, min_level=0):
+def fuzz(lib, oracle, seed=12345, secs=None, max_cases=None, max_n=1_500_000, verbose=True, max_level=9, min_level=0,
+         debug_flags=0):
     """Returns (cases, failures); failures is a list of case tuples."""
     rng = np.random.default_rng(seed)
     classes = sorted(synth.CLASSES)
@@ -44,6 +45,8 @@ def fuzz(lib, oracle, seed=12345, secs=None, max_cases=None, max_n=1_500_000, ve
                 ctxs.clear()
             ctxs[key] = _native.Context(format=fmt, level=level, buffer_size=bs, compat=compat, lib=lib,
                                         max_slab_bytes=2_000_000)
+            if debug_flags:  # (e.g. 32: k_match_hc_sparse at every greedy level and for every block; 16: never)
+                ctxs[key].debug_set_flags(debug_flags)
         try:
             got = ctxs[key].compress_slab(a, True)
         except _native.GzpxError as e:

@@ -1,7 +1,7 @@
 # round 5: k_match_hc_sparse against the dense kernel -- phase clocks (experiment build), A/B of the product build, parity
 cd $GRAFT_REPO_ROOT
 O=gpurun_out/${1:-r5_sparse}; mkdir -p $O
-timeout 600 python tools/exp_hc_sparse2.py 2,3,4 > $O/exp.log 2>&1; tail -12 $O/exp.log
+timeout 600 python tools/exp_hc_sparse2.py ${2:-3,4} > $O/exp.log 2>&1; tail -12 $O/exp.log
 for A in "--workload bgzf3 --level 3 --debug-flags 16" "--workload bgzf3 --level 3" "--workload bgzf3 --level 2 --debug-flags 16" "--workload bgzf3 --level 2" "--workload bgzf3 --level 4 --debug-flags 16" "--workload bgzf3 --level 4" "--workload mgzip3 --debug-flags 16" "--workload mgzip3"; do
   timeout 300 python bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-extras $A > $O/ab.json 2> $O/ab.err
   python - <<PY
