@@ -2007,7 +2007,7 @@ constexpr uint32_t kHsLinkWords = (32768 + kHsTile) / 2;
 constexpr uint32_t kHsSeg = 32;                      // positions per walk segment = one 32-bit mask
 constexpr uint32_t kHsSegs = kHsTile / kHsSeg;       // 408
 constexpr uint32_t kHsList = 1280;                   // list entries (u16) per round; what does not fit waits a round (the LDS is full: 336 bytes to spare, 264 of them __syncthreads_or's)
-constexpr uint32_t kHsChase = 6;                     // searches a lane may add while it follows the corrected path
+constexpr uint32_t kHsSerial = 128;                  // a list this short: its lanes search what they run into themselves
 constexpr uint32_t kHsLdsWords = kHsInWords + kHsLinkWords + kHsTile / 4 + 4 * kHsSegs + 2 * kHsSegs + kHsList / 2 + 16;
 static_assert(kHsLdsWords * 4 <= 160 * 1024, "k_match_hc_sparse: one workgroup's LDS");
 static_assert(kHsTile % 256 == 0 && kHsSegs <= 1024, "tile geometry");
@@ -2030,7 +2030,7 @@ __global__ __launch_bounds__(1024) void k_match_hc_sparse(Config cfg, const uint
     uint32_t *marks = fin + kHsSegs;                 // a token starts here (the current walk)
     uint32_t *seg_exit = marks + kHsSegs;            // [2][kHsSegs] where the walk leaves segment s (tile-relative)
     uint32_t *list_w = seg_exit + 2 * kHsSegs;       // u16 tile-relative positions to search
-    uint32_t *misc = list_w + kHsList / 2;           // [0..7] hc_calc_min_len's census, [8] the ring's tail, [9] open searches of the first tile
+    uint32_t *misc = list_w + kHsList / 2;           // [0..7] hc_calc_min_len's census, [8] the ring's tail, [9] the first tile's occupied hash3 buckets
     const uint16_t *link = (const uint16_t *)link_w;
     uint8_t *len_l = (uint8_t *)len_w;
     uint16_t *list = (uint16_t *)list_w;
@@ -2066,6 +2066,18 @@ __global__ __launch_bounds__(1024) void k_match_hc_sparse(Config cfg, const uint
     auto exp_count = [](uint32_t, uint32_t) {};
 #endif
 
+    {   // A block whose hash3 buckets are nearly all empty (noise) has no chains to walk and nothing to compact: the dense
+        // kernel is the cheaper way through it.  Told from the first tile's hash3 distances before anything is staged.
+        const uint32_t t0 = n < kHsTile ? n : kHsTile;
+        uint32_t have3 = 0;
+        for (uint32_t i = tid; i < t0; i += 1024) have3 += d3[i] != 0 ? 1u : 0u;
+        if (tid == 0) misc[9] = 0;
+        __syncthreads();
+        const uint32_t wave_have3 = wave_reduce_add(have3);
+        if (lane == 0) atomicAdd(&misc[9], wave_have3);
+        __syncthreads();
+        if (misc[9] * 4u < t0 && !(cfg.debug & 32u)) return;  // uniform (HcState.sparse stays kHcArraysNone)
+    }
     // the first sub-block's min_len (calculate_min_match_len): the path is walked with it, k_parse_hc parses with it
     const uint32_t min_len = hc_calc_min_len(cfg, in, 0, n, misc, tid, 1024);
     const uint32_t nice_level = cfg.hc_nice, depth = cfg.hc_depth;
@@ -2121,10 +2133,7 @@ __global__ __launch_bounds__(1024) void k_match_hc_sparse(Config cfg, const uint
                 if (keep_lk + tid + 1024u * k < nlw) link_w[keep_lk + tid + 1024u * k] = fix_links(pf_lk[k]);
         }
         for (uint32_t i = ndw + tid; i < ndw + 3 && i < kHsInWords; i += 1024) in_w[i] = 0;
-        if (tid == 0) {
-            misc[8] = 0;
-            misc[9] = 0;
-        }
+        if (tid == 0) misc[8] = 0;
         prev_win = win_begin;
         prev_ndw = ndw;
         prev_nlw = nlw;
@@ -2218,14 +2227,6 @@ __global__ __launch_bounds__(1024) void k_match_hc_sparse(Config cfg, const uint
         };
         const bool active = tid < n_seg;
         const uint32_t seg_begin = tid * kHsSeg;
-        if (tile_begin == 0) {
-            // A block whose searches are nearly all over after their first node (noise: empty hash3 buckets, no chains) has
-            // nothing to compact -- the dense kernel is the cheaper way through it: leave (HcState.sparse stays
-            // kHcArraysNone; what this tile wrote is what the dense kernel writes again).
-            if (active) atomicAdd(&misc[9], (uint32_t)__popc(~fin[tid] & (seg_begin + 32u <= tile_len ? ~0u : (1u << (tile_len - seg_begin)) - 1u)));
-            __syncthreads();
-            if (misc[9] * 8u < tile_len && !(cfg.debug & 32u)) return;  // uniform
-        }
         uint32_t entry = tid == 0 ? entry_carry - tile_begin : seg_begin;
         uint32_t my_exit = active ? walk_seg(tid, entry) : 0u;
         uint32_t cur = 0;
@@ -2249,16 +2250,17 @@ __global__ __launch_bounds__(1024) void k_match_hc_sparse(Config cfg, const uint
             }
             exp_lap(2);
             // ---- C: the token starts whose search is not over go on the list (a ring of kHsList entries)
-            if (active) {
-                uint32_t need = marks[tid] & ~fin[tid];
-                if (pass >= 12u) need = ~fin[tid] & (seg_begin + 32u <= tile_len ? ~0u : (1u << (tile_len - seg_begin)) - 1u);  // give up predicting: every open search of the tile
+            if (tid < ((n_seg + 63u) & ~63u)) {  // (whole waves: one atomic per wave -- 400 lanes at one LDS word are 400 turns)
+                uint32_t need = active ? marks[tid] & ~fin[tid] : 0u;
+                if (pass >= 12u && active) need = ~fin[tid] & (seg_begin + 32u <= tile_len ? ~0u : (1u << (tile_len - seg_begin)) - 1u);  // give up predicting: every open search of the tile
                 const uint32_t cnt = (uint32_t)__popc(need);
-                if (cnt) {
-                    uint32_t at = atomicAdd(&misc[8], cnt);
-                    while (need && at < kHsList) {  // (what does not fit is found again by the next pass)
-                        list[at++] = (uint16_t)(seg_begin + (uint32_t)__ffs((int)need) - 1u);
-                        need &= need - 1u;
-                    }
+                const uint32_t inc = wave_incl_add(cnt);
+                uint32_t base = 0;
+                if (lane == 63) base = atomicAdd(&misc[8], inc);
+                uint32_t at = rdlane(base, 63) + inc - cnt;
+                while (need && at < kHsList) {  // (what does not fit is found again by the next pass)
+                    list[at++] = (uint16_t)(seg_begin + (uint32_t)__ffs((int)need) - 1u);
+                    need &= need - 1u;
                 }
             }
             __syncthreads();
@@ -2267,19 +2269,25 @@ __global__ __launch_bounds__(1024) void k_match_hc_sparse(Config cfg, const uint
             if (tail == 0) break;  // uniform: the path holds only finished searches
             __syncthreads();       // (everybody has read the count)
             if (tid == 0) misc[8] = tail;
+            __syncthreads();
             // Rounds without a walk of the whole tile: one listed search per lane; a lane whose search changed a length follows
             // the corrected path over the lengths in LDS until it meets the old one again, marks what it passes as token
             // starts and appends the open searches among them to the ring -- the next round's list.  Marks that fall off
             // the path stay behind and a walk may stop at one too early: the pass that follows (walks from the poisoned
             // segments on, list from the true marks) finds what that missed; it is empty nearly every time.
-            while (head < tail) {
-                __syncthreads();  // misc[8] == tail is visible; the ring's entries [head, tail) are complete
+            while (head < tail) {  // (on entry: misc[8] == tail is visible, the ring's entries [head, tail) are complete)
                 exp_count(5, 1);
                 exp_count(6, tail - head);
+                // A short list (the later rounds of a tile) leaves most lanes idle anyway: its lanes then search what their
+                // walk runs into themselves, one position after the other, instead of handing it to another round (a
+                // round is a search's latency plus two barriers for the whole CU, however few lanes work in it)
+                const bool serial = tail - head <= kHsSerial;
                 for (uint32_t i = head + tid; i < tail; i += 1024) {
-                    const uint32_t r = list[i % kHsList];
+                  uint32_t r = list[i % kHsList];
+                  for (uint32_t chain = 0;; chain++) {
+                    uint32_t follow = 0xFFFFFFFFu;
                     const uint32_t bit = 1u << (r & 31u);
-                    if (fin[r >> 5] & bit) continue;  // (listed twice)
+                    if (chain == 0 && (fin[r >> 5] & bit)) break;  // (listed twice)
                     const uint32_t p = tile_begin + r;
                     uint32_t len, dst;
                     bool over;
@@ -2299,25 +2307,36 @@ __global__ __launch_bounds__(1024) void k_match_hc_sparse(Config cfg, const uint
                             step = len;
                         }
                     }
-                    if (step == old_step) continue;
+                    if (step == old_step) break;
                     seg_exit[(cur ^ 1u) * kHsSegs + (r >> 5)] = 0xFFFFFFFFu;  // the segment walks again in the next pass
                     uint32_t q = r + step;
                     for (uint32_t hop = 0; hop < 16u && q < tile_len; hop++) {
                         const uint32_t qb = 1u << (q & 31u);
                         if (atomicOr(&marks[q >> 5], qb) & qb) break;  // the old path (or somebody else's new one)
                         if (!(fin[q >> 5] & qb)) {
+                            if (serial && chain < 8u) {
+                                follow = q;  // (its own search says where the path goes on from there)
+                                break;
+                            }
                             const uint32_t at = atomicAdd(&misc[8], 1u);
                             if (at - head < kHsList) list[at % kHsList] = (uint16_t)q;  // (else: the next pass finds it)
                         }
                         q += (mbf[q >> 5] & qb) ? (uint32_t)len_l[q] + 3u : 1u;
                     }
+                    if (follow == 0xFFFFFFFFu) break;
+                    r = follow;
+                  }
                 }
                 __syncthreads();
                 const uint32_t ring_end = head + kHsList;  // entries from here on were dropped, not stored
+                const uint32_t appended = misc[8];
                 head = tail;
-                tail = misc[8] < ring_end ? misc[8] : ring_end;
-                __syncthreads();
-                if (tid == 0) misc[8] = tail;
+                tail = appended < ring_end ? appended : ring_end;
+                __syncthreads();  // (everybody has read the ring's tail: the next round may append)
+                if (appended > ring_end) {  // uniform, rare: the counter goes back to the last entry that was stored
+                    if (tid == 0) misc[8] = tail;
+                    __syncthreads();
+                }
             }
             __syncthreads();
             if (tid == 0) misc[8] = 0;
