@@ -2007,6 +2007,7 @@ constexpr uint32_t kHsLinkWords = (32768 + kHsTile) / 2;
 constexpr uint32_t kHsSeg = 32;                      // positions per walk segment = one 32-bit mask
 constexpr uint32_t kHsSegs = kHsTile / kHsSeg;       // 408
 constexpr uint32_t kHsList = 1280;                   // list entries (u16) per round; what does not fit waits a round (the LDS is full: 336 bytes to spare, 264 of them __syncthreads_or's)
+constexpr uint32_t kHsFirst = 1024;                  // entries a pass lists at once: one search per thread
 constexpr uint32_t kHsSerial = 128;                  // a list this short: its lanes search what they run into themselves
 constexpr uint32_t kHsLdsWords = kHsInWords + kHsLinkWords + kHsTile / 4 + 4 * kHsSegs + 2 * kHsSegs + kHsList / 2 + 16;
 static_assert(kHsLdsWords * 4 <= 160 * 1024, "k_match_hc_sparse: one workgroup's LDS");
@@ -2030,7 +2031,7 @@ __global__ __launch_bounds__(1024) void k_match_hc_sparse(Config cfg, const uint
     uint32_t *marks = fin + kHsSegs;                 // a token starts here (the current walk)
     uint32_t *seg_exit = marks + kHsSegs;            // [2][kHsSegs] where the walk leaves segment s (tile-relative)
     uint32_t *list_w = seg_exit + 2 * kHsSegs;       // u16 tile-relative positions to search
-    uint32_t *misc = list_w + kHsList / 2;           // [0..7] hc_calc_min_len's census, [8] the ring's tail, [9] the first tile's occupied hash3 buckets
+    uint32_t *misc = list_w + kHsList / 2;           // [0..7] hc_calc_min_len's census, [8] the ring's tail
     const uint16_t *link = (const uint16_t *)link_w;
     uint8_t *len_l = (uint8_t *)len_w;
     uint16_t *list = (uint16_t *)list_w;
@@ -2066,17 +2067,18 @@ __global__ __launch_bounds__(1024) void k_match_hc_sparse(Config cfg, const uint
     auto exp_count = [](uint32_t, uint32_t) {};
 #endif
 
-    {   // A block whose hash3 buckets are nearly all empty (noise) has no chains to walk and nothing to compact: the dense
-        // kernel is the cheaper way through it.  Told from the first tile's hash3 distances before anything is staged.
+    {   // A block without matches (noise) has no chains to walk and nothing to compact: the dense kernel is the cheaper way
+        // through it.  Told from a sample of 1,024 positions of the first tile: how many have a predecessor with the same
+        // three bytes (an occupied hash3 bucket alone says little: random data fills the table by collisions).
         const uint32_t t0 = n < kHsTile ? n : kHsTile;
-        uint32_t have3 = 0;
-        for (uint32_t i = tid; i < t0; i += 1024) have3 += d3[i] != 0 ? 1u : 0u;
-        if (tid == 0) misc[9] = 0;
-        __syncthreads();
-        const uint32_t wave_have3 = wave_reduce_add(have3);
-        if (lane == 0) atomicAdd(&misc[9], wave_have3);
-        __syncthreads();
-        if (misc[9] * 4u < t0 && !(cfg.debug & 32u)) return;  // uniform (HcState.sparse stays kHcArraysNone)
+        const uint32_t p = t0 / 1024u * tid + 64u;  // (t0 >= 1024 or nothing is sampled: small blocks go the sparse way)
+        bool real = false;
+        if (t0 >= 4096u && p + 4u <= t0) {
+            const uint32_t d = d3[p];
+            real = d != 0 && in[p] == in[p - d] && in[p + 1] == in[p - d + 1] && in[p + 2] == in[p - d + 2];
+        }
+        const uint32_t n_real = (uint32_t)__syncthreads_count(real);
+        if (t0 >= 4096u && n_real * 8u < 1024u && !(cfg.debug & 32u)) return;  // uniform (HcState.sparse stays kHcArraysNone)
     }
     // the first sub-block's min_len (calculate_min_match_len): the path is walked with it, k_parse_hc parses with it
     const uint32_t min_len = hc_calc_min_len(cfg, in, 0, n, misc, tid, 1024);
@@ -2232,9 +2234,10 @@ __global__ __launch_bounds__(1024) void k_match_hc_sparse(Config cfg, const uint
         uint32_t cur = 0;
         if (active) seg_exit[tid] = my_exit;
         bool dirty = false;  // a search changed a length in my segment
+        bool relist = false;  // (uniform) the last list did not hold every open token start: list again, without a walk
         for (uint32_t pass = 0;; pass++) {
             // the entries settle: one barrier per round, two copies of the exits (as in k_mparse)
-            for (;;) {
+            while (!relist) {
                 __syncthreads();
                 uint32_t new_entry = entry;
                 if (active && tid > 0) new_entry = seg_exit[cur * kHsSegs + tid - 1];
@@ -2258,15 +2261,20 @@ __global__ __launch_bounds__(1024) void k_match_hc_sparse(Config cfg, const uint
                 uint32_t base = 0;
                 if (lane == 63) base = atomicAdd(&misc[8], inc);
                 uint32_t at = rdlane(base, 63) + inc - cnt;
-                while (need && at < kHsList) {  // (what does not fit is found again by the next pass)
+                while (need && at < kHsFirst) {  // (what does not fit is listed next: 1,024 entries are one search per thread)
                     list[at++] = (uint16_t)(seg_begin + (uint32_t)__ffs((int)need) - 1u);
                     need &= need - 1u;
                 }
             }
             __syncthreads();
-            uint32_t head = 0, tail = misc[8] < kHsList ? misc[8] : kHsList;
+            uint32_t head = 0, tail = misc[8] < kHsFirst ? misc[8] : kHsFirst;
+            const bool was_relist = relist;
+            relist = misc[8] > kHsFirst;
             exp_lap(3);
-            if (tail == 0) break;  // uniform: the path holds only finished searches
+            if (tail == 0) {  // uniform
+                if (!was_relist) break;  // a walk of the whole tile found no open search on the path: done
+                continue;                // (the list built without a walk is empty: let the walk confirm)
+            }
             __syncthreads();       // (everybody has read the count)
             if (tid == 0) misc[8] = tail;
             __syncthreads();
