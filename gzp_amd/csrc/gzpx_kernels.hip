@@ -1802,17 +1802,14 @@ __device__ __forceinline__ void hc_search(const uint32_t *in_w, const uint16_t *
 constexpr uint32_t kHcLinkWords = (32768 + kHcTile) / 2;  // d4 of every position in the window (u16)
 constexpr uint32_t kHcLdsWords = kHcInWords + kHcLinkWords + kHcTile / 32;
 
-__global__ __launch_bounds__(1024) void k_match_hc(Config cfg, const uint8_t *__restrict__ slab,
-                                                   const BlockMeta *__restrict__ meta_all,
-                                                   HcState *__restrict__ hc_all,
-                                                   const uint16_t *__restrict__ d3_all,
-                                                   const uint16_t *__restrict__ d4_all,
-                                                   uint8_t *__restrict__ len8_all,
-                                                   uint32_t *__restrict__ mbits_all,
-                                                   uint16_t *__restrict__ dist_all,
-                                                   uint8_t *__restrict__ lz_len_all,
-                                                   uint16_t *__restrict__ lz_dist_all) {
-    __shared__ uint32_t hc_lds[kHcLdsWords];
+// The dense search of one block by the calling workgroup (1024 threads), out of `hc_lds` (kHcLdsWords words at LDS address 0):
+// k_match_hc's body, and what k_match_hc_sparse does itself with the blocks it does not compact (round 5).
+__device__ __forceinline__ void hc_dense_block(uint32_t *hc_lds, const Config &cfg, const uint8_t *__restrict__ slab,
+                                               const BlockMeta *__restrict__ meta_all, HcState *__restrict__ hc_all,
+                                               const uint16_t *__restrict__ d3_all, const uint16_t *__restrict__ d4_all,
+                                               uint8_t *__restrict__ len8_all, uint32_t *__restrict__ mbits_all,
+                                               uint16_t *__restrict__ dist_all, uint8_t *__restrict__ lz_len_all,
+                                               uint16_t *__restrict__ lz_dist_all) {
     uint32_t *in_w = hc_lds;                     // 48 KiB window of the block's bytes
     uint32_t *link_w = hc_lds + kHcInWords;      // d4 of every position in the window
     uint32_t *mbits = link_w + kHcLinkWords;
@@ -1979,6 +1976,20 @@ __global__ __launch_bounds__(1024) void k_match_hc(Config cfg, const uint8_t *__
     if (tid == 0) st->sparse = kHcArraysDense;  // (read at the top by every thread: behind the loop's barriers)
 }
 
+__global__ __launch_bounds__(1024) void k_match_hc(Config cfg, const uint8_t *__restrict__ slab,
+                                                   const BlockMeta *__restrict__ meta_all,
+                                                   HcState *__restrict__ hc_all,
+                                                   const uint16_t *__restrict__ d3_all,
+                                                   const uint16_t *__restrict__ d4_all,
+                                                   uint8_t *__restrict__ len8_all,
+                                                   uint32_t *__restrict__ mbits_all,
+                                                   uint16_t *__restrict__ dist_all,
+                                                   uint8_t *__restrict__ lz_len_all,
+                                                   uint16_t *__restrict__ lz_dist_all) {
+    __shared__ uint32_t hc_lds[kHcLdsWords];
+    hc_dense_block(hc_lds, cfg, slab, meta_all, hc_all, d3_all, d4_all, len8_all, mbits_all, dist_all, lz_len_all, lz_dist_all);
+}
+
 // ------------------------------------------------------------------------------------------
 // k_match_hc_sparse (round 5; levels 2-4): the COMPACTION form of k_match_hc.
 //   libdeflate searches only where a token of the greedy parse starts -- a quarter of the positions of text -- and the
@@ -2007,7 +2018,6 @@ constexpr uint32_t kHsLinkWords = (32768 + kHsTile) / 2;
 constexpr uint32_t kHsSeg = 32;                      // positions per walk segment = one 32-bit mask
 constexpr uint32_t kHsSegs = kHsTile / kHsSeg;       // 408
 constexpr uint32_t kHsList = 1280;                   // list entries (u16) per round; what does not fit waits a round (the LDS is full: 336 bytes to spare, 264 of them __syncthreads_or's)
-constexpr uint32_t kHsFirst = 1024;                  // entries a pass lists at once: one search per thread
 constexpr uint32_t kHsSerial = 128;                  // a list this short: its lanes search what they run into themselves
 constexpr uint32_t kHsLdsWords = kHsInWords + kHsLinkWords + kHsTile / 4 + 4 * kHsSegs + 2 * kHsSegs + kHsList / 2 + 16;
 static_assert(kHsLdsWords * 4 <= 160 * 1024, "k_match_hc_sparse: one workgroup's LDS");
@@ -2041,9 +2051,17 @@ __global__ __launch_bounds__(1024) void k_match_hc_sparse(Config cfg, const uint
     HcState *st = hc_all + b;
     if (n <= cfg.passthrough || st->done || cfg.lazy) return;  // uniform
     const uint8_t *in = slab + (uint64_t)b * cfg.block_size;
-    {   // a block that may hold an orphan match (k_hc_orphan) is the dense kernel's
+    static_assert(kHcLdsWords <= kHsLdsWords, "the dense search fits this kernel's LDS");
+    auto dense_instead = [&]() {  // (uniform) this block is searched the dense way, by this very workgroup
+        hc_dense_block(hs_lds, cfg, slab, meta_all, hc_all, d3_all, d4_all, len8_all, mbits_all, dist_all,
+                       (uint8_t *)nullptr, (uint16_t *)nullptr);
+    };
+    {   // a block that may hold an orphan match (k_hc_orphan) is not compacted
         const uint32_t first4 = n >= 9u ? (uint32_t)in[0] | (uint32_t)in[1] << 8 | (uint32_t)in[2] << 16 | (uint32_t)in[3] << 24 : 1u;
-        if (n >= 9u && ((first4 * 0x1E35A7BDu) >> 16) == 0) return;  // uniform (HcState.sparse stays kHcArraysNone)
+        if (n >= 9u && ((first4 * 0x1E35A7BDu) >> 16) == 0) {  // uniform
+            dense_instead();
+            return;
+        }
     }
     const uint16_t *d3 = d3_all + (uint64_t)b * cfg.stride;
     const uint16_t *d4 = d4_all + (uint64_t)b * cfg.stride;
@@ -2078,7 +2096,10 @@ __global__ __launch_bounds__(1024) void k_match_hc_sparse(Config cfg, const uint
             real = d != 0 && in[p] == in[p - d] && in[p + 1] == in[p - d + 1] && in[p + 2] == in[p - d + 2];
         }
         const uint32_t n_real = (uint32_t)__syncthreads_count(real);
-        if (t0 >= 4096u && n_real * 8u < 1024u && !(cfg.debug & 32u)) return;  // uniform (HcState.sparse stays kHcArraysNone)
+        if (t0 >= 4096u && n_real * 8u < 1024u && !(cfg.debug & 32u)) {  // uniform
+            dense_instead();
+            return;
+        }
     }
     // the first sub-block's min_len (calculate_min_match_len): the path is walked with it, k_parse_hc parses with it
     const uint32_t min_len = hc_calc_min_len(cfg, in, 0, n, misc, tid, 1024);
@@ -2234,10 +2255,9 @@ __global__ __launch_bounds__(1024) void k_match_hc_sparse(Config cfg, const uint
         uint32_t cur = 0;
         if (active) seg_exit[tid] = my_exit;
         bool dirty = false;  // a search changed a length in my segment
-        bool relist = false;  // (uniform) the last list did not hold every open token start: list again, without a walk
         for (uint32_t pass = 0;; pass++) {
             // the entries settle: one barrier per round, two copies of the exits (as in k_mparse)
-            while (!relist) {
+            for (;;) {
                 __syncthreads();
                 uint32_t new_entry = entry;
                 if (active && tid > 0) new_entry = seg_exit[cur * kHsSegs + tid - 1];
@@ -2261,20 +2281,17 @@ __global__ __launch_bounds__(1024) void k_match_hc_sparse(Config cfg, const uint
                 uint32_t base = 0;
                 if (lane == 63) base = atomicAdd(&misc[8], inc);
                 uint32_t at = rdlane(base, 63) + inc - cnt;
-                while (need && at < kHsFirst) {  // (what does not fit is listed next: 1,024 entries are one search per thread)
+                while (need && at < kHsList) {  // (what does not fit is found again by the next pass.  Measured: lists of
+                    // 1,024 -- one search per thread -- with the rest listed again without a walk: 27.7 rounds per block
+                    // instead of 18.6, level 3 match + parse 13.33 -> 13.75 ms)
                     list[at++] = (uint16_t)(seg_begin + (uint32_t)__ffs((int)need) - 1u);
                     need &= need - 1u;
                 }
             }
             __syncthreads();
-            uint32_t head = 0, tail = misc[8] < kHsFirst ? misc[8] : kHsFirst;
-            const bool was_relist = relist;
-            relist = misc[8] > kHsFirst;
+            uint32_t head = 0, tail = misc[8] < kHsList ? misc[8] : kHsList;
             exp_lap(3);
-            if (tail == 0) {  // uniform
-                if (!was_relist) break;  // a walk of the whole tile found no open search on the path: done
-                continue;                // (the list built without a walk is empty: let the walk confirm)
-            }
+            if (tail == 0) break;  // uniform: the path holds only finished searches
             __syncthreads();       // (everybody has read the count)
             if (tid == 0) misc[8] = tail;
             __syncthreads();
@@ -5556,16 +5573,16 @@ void launch_hc(const Config &cfg, const uint8_t *slab, uint32_t nb, const Scratc
                            (const uint8_t *)s.len8, (const uint32_t *)s.which, (const uint16_t *)s.alt, s.tok,
                            s.pending);
     };
-    // Round 5: the full search only where the greedy parse starts a token (k_match_hc_sparse); the dense kernel behind it
-    // takes the blocks that kernel leaves alone (orphan candidates).  Config.debug bit 4: the dense kernel for every
-    // block, as in rounds 2-4 (A/B runs and the tests that compare the two routes).
+    // Round 5: the full search only where the greedy parse starts a token (k_match_hc_sparse).  Config.debug bit 4: the
+    // dense kernel for every block, as in rounds 2-4 (A/B runs and the tests that compare the two routes).
     // Level 2 (six chain nodes at most) is the dense kernel's: there is too little behind the first node to compact.
     // (Config.debug bit 5: the sparse kernel at every greedy level and for every block, noise included -- tests.)
     const bool sparse = !(cfg.debug & 16u) && (cfg.level >= 3 || (cfg.debug & 32u));
-    if (sparse)
+    if (sparse)  // (searches the blocks it does not compact -- noise, orphan candidates -- the dense way itself)
         hipLaunchKernelGGL(k_match_hc_sparse, dim3(nb), dim3(1024), 0, stream, cfg, slab, (const BlockMeta *)s.meta, s.hc,
                            (const uint16_t *)s.cand, (const uint16_t *)s.d4, s.len8, s.which, s.alt);
-    dense();
+    else
+        dense();
     hipLaunchKernelGGL(k_hc_orphan, dim3(nb), dim3(64), 0, stream, cfg, slab, (const BlockMeta *)s.meta, s.hc,
                        (const uint16_t *)s.cand, (const uint16_t *)s.d4, s.len8, s.which, s.alt, (uint8_t *)nullptr,
                        (uint16_t *)nullptr);

@@ -21,6 +21,42 @@ def hetero(n, seed):
     return np.ascontiguousarray(np.concatenate(parts)[:n])
 
 
+def _three_routes(lib, oracle, cases):
+    """Levels 2-4 by every route to k_match_hc's arrays (round 5): the default (k_match_hc_sparse at levels 3-4, which
+    searches noise and orphan-candidate blocks the dense way itself; the dense kernel at level 2), the dense kernel for
+    every block (Config.debug bit 4: rounds 2-4's path) and the sparse kernel forced on every block at every greedy level,
+    noise included (bit 5) -- one stream, the oracle's."""
+    for name, a, level, fmt, ofmt, bs in cases:
+        want = oracle.compress_stream(a, ofmt, level, oracle.COMPAT_1_24, bs)
+        for flags in (0, 16, 32):
+            with _native.Context(format=fmt, level=level, buffer_size=bs, compat=_native.COMPAT_1_24, lib=lib,
+                                 max_slab_bytes=max(a.size, 1)) as c:
+                c.debug_set_flags(flags)
+                assert c.compress_slab(a, True) == want, (name, level, flags)
+
+
+def _route_cases(scale=1):
+    import numpy as np
+    B, M = (_native.FORMAT_BGZF, 0), (_native.FORMAT_MGZIP, 1)
+    orphan = synth.make("repeats", 163416, 228638812)[:70000 * scale].copy()  # starts " oeh": hash4 bucket 0 (k_hc_orphan)
+    out = [("text", synth.make("text", (2 * 65280 + 777) * scale, 31), 3) + B + (65280,),
+           ("text-l4", synth.make("text", 140000 * scale, 32), 4) + B + (65280,),
+           ("text-l2", synth.make("text", 70000 * scale, 33), 2) + B + (65280,),
+           ("noise", synth.make("ascii", 150000 * scale, 34), 3) + M + (131072,),            # the census sends it the dense way
+           ("hetero", hetero(260000 * scale, 35), 3) + M + (300001,),                         # min_len changes: kHcArraysStale
+           ("hetero-l4", hetero(200000 * scale, 36), 4) + B + (65280,),
+           ("orphan", orphan, 3) + M + (65536,),
+           ("dna", synth.make("dna", 100000 * scale, 37), 4) + B + (65280,),
+           ("short", synth.make("text", 3000, 38), 3) + B + (65280,),
+           ("tile-edge", synth.make("text", 13056 * 2 + 1, 39), 3) + B + (65280,),            # k_match_hc_sparse's tile is 13,056 positions
+           ("zeros", synth.make("zeros", 40000, 40), 3) + B + (65280,)]
+    return out
+
+
+def test_greedy_levels_by_every_route(emu_lib, oracle):
+    _three_routes(emu_lib, oracle, _route_cases())
+
+
 def test_golden_raw_deflate_levels(emu_lib, golden_hc):
     comps = {L: _native.Compressor(L, _native.COMPAT_1_10, lib=emu_lib) for L in (0, 2, 3, 4)}
     for e in golden_hc["raw_deflate"]:

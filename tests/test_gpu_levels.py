@@ -40,6 +40,11 @@ def test_golden_vectors_levels(hip_lib, golden_hc):
         assert list(sizes) == e["block_sizes"]
 
 
+def test_greedy_levels_by_every_route(hip_lib, oracle):
+    from test_emu_levels import _route_cases, _three_routes
+    _three_routes(hip_lib, oracle, _route_cases(scale=4))
+
+
 @pytest.mark.parametrize("level", [2, 3, 4])
 def test_heterogeneous_blocks_vs_oracle(hip_lib, oracle, level):
     for fmt, ofmt, bs, n in [(_native.FORMAT_BGZF, 0, 65280, 40 * 65280 + 99),
