@@ -2017,9 +2017,9 @@ constexpr uint32_t kHsInWords = (32768 + kHsTile + 264) / 4 + 8;
 constexpr uint32_t kHsLinkWords = (32768 + kHsTile) / 2;
 constexpr uint32_t kHsSeg = 32;                      // positions per walk segment = one 32-bit mask
 constexpr uint32_t kHsSegs = kHsTile / kHsSeg;       // 408
-constexpr uint32_t kHsList = 1280;                   // list entries (u16) per round; what does not fit waits a round (the LDS is full: 336 bytes to spare, 264 of them __syncthreads_or's)
+constexpr uint32_t kHsList = 2048;                   // ring entries (u16): a tile of text lists 1,300-2,000 open token starts after its first walk -- with 1,280 entries the rest waited for another walk of the tile, a pass per tile
 constexpr uint32_t kHsSerial = 128;                  // a list this short: its lanes search what they run into themselves
-constexpr uint32_t kHsLdsWords = kHsInWords + kHsLinkWords + kHsTile / 4 + 4 * kHsSegs + 2 * kHsSegs + kHsList / 2 + 16;
+constexpr uint32_t kHsLdsWords = kHsInWords + kHsLinkWords + kHsTile / 4 + 3 * kHsSegs + 2 * kHsSegs + kHsList / 2 + 16;
 static_assert(kHsLdsWords * 4 <= 160 * 1024, "k_match_hc_sparse: one workgroup's LDS");
 static_assert(kHsTile % 256 == 0 && kHsSegs <= 1024, "tile geometry");
 
@@ -2035,8 +2035,9 @@ __global__ __launch_bounds__(1024) void k_match_hc_sparse(Config cfg, const uint
     uint32_t *in_w = hs_lds;                         // window of the block's bytes (LDS address 0: immediate offsets)
     uint32_t *link_w = in_w + kHsInWords;            // d4 of every position in the window
     uint32_t *len_w = link_w + kHsLinkWords;         // len - 3 of the tile's positions (u8)
-    uint32_t *mbits = len_w + kHsTile / 4;           // a match was accepted here (min_len 3: what k_parse_hc reads)
-    uint32_t *mbf = mbits + kHsSegs;                 // ... and is long enough for the sub-block's min_len: the walk's mask
+    // (the bits "a match was accepted here" at min_len 3 -- what k_parse_hc reads -- go straight to memory: whole words in
+    // pass A, an atomic OR where a listed search finds a match its position did not have; their 1.6 KiB of LDS are ring)
+    uint32_t *mbf = len_w + kHsTile / 4;             // a match long enough for the sub-block's min_len: the walk's mask
     uint32_t *fin = mbf + kHsSegs;                   // the position's search is over: its match is the full search's
     uint32_t *marks = fin + kHsSegs;                 // a token starts here (the current walk)
     uint32_t *seg_exit = marks + kHsSegs;            // [2][kHsSegs] where the walk leaves segment s (tile-relative)
@@ -2213,12 +2214,12 @@ __global__ __launch_bounds__(1024) void k_match_hc_sparse(Config cfg, const uint
             if (lane == 0 && r < tile_len + 64u) {  // (a wave covers two words of each bitmap)
                 const uint32_t w = r >> 5;
                 if (w < kHsSegs) {
-                    mbits[w] = (uint32_t)bt;
+                    mbits_out[tile_begin / 32 + w] = (uint32_t)bt;  // (tile_begin is a multiple of 32)
                     mbf[w] = (uint32_t)bf;
                     fin[w] = (uint32_t)bo;
                 }
                 if (w + 1 < kHsSegs) {
-                    mbits[w + 1] = (uint32_t)(bt >> 32);
+                    if (r + 32u < tile_len) mbits_out[tile_begin / 32 + w + 1] = (uint32_t)(bt >> 32);
                     mbf[w + 1] = (uint32_t)(bf >> 32);
                     fin[w + 1] = (uint32_t)(bo >> 32);
                 }
@@ -2326,7 +2327,7 @@ __global__ __launch_bounds__(1024) void k_match_hc_sparse(Config cfg, const uint
                         len_l[r] = (uint8_t)(len - 3u);
                         len8[p] = (uint8_t)(len - 3u);
                         dist[p] = (uint16_t)dst;
-                        atomicOr(&mbits[r >> 5], bit);
+                        if (!had) atomicOr(&mbits_out[p >> 5], 1u << (p & 31u));  // (had: long enough at min_len, so accepted at 3)
                         if (len >= min_len) {
                             atomicOr(&mbf[r >> 5], bit);
                             step = len;
@@ -2370,8 +2371,6 @@ __global__ __launch_bounds__(1024) void k_match_hc_sparse(Config cfg, const uint
             exp_lap(4);
         }
         entry_carry = tile_begin + uniform(seg_exit[cur * kHsSegs + n_seg - 1]);
-        // the accepted-match bits of the tile (k_parse_hc reads them); tile_begin is a multiple of 32
-        for (uint32_t i = tid; i < (tile_len + 31) / 32; i += 1024) mbits_out[tile_begin / 32 + i] = mbits[i];
         exp_count(7, 1);
     }
     if (tid == 0) {
