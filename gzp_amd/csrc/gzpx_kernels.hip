@@ -2017,9 +2017,12 @@ constexpr uint32_t kHsInWords = (32768 + kHsTile + 264) / 4 + 8;
 constexpr uint32_t kHsLinkWords = (32768 + kHsTile) / 2;
 constexpr uint32_t kHsSeg = 32;                      // positions per walk segment = one 32-bit mask
 constexpr uint32_t kHsSegs = kHsTile / kHsSeg;       // 408
-constexpr uint32_t kHsList = 2048;                   // ring entries (u16): a tile of text lists 1,300-2,000 open token starts after its first walk -- with 1,280 entries the rest waited for another walk of the tile, a pass per tile
+constexpr uint32_t kHsList = 1280;                   // ring entries (u16); what does not fit waits for the next pass.  (Measured: 2,048 entries --
+                                                     // the accepted-match bits straight to memory, their LDS given to the ring -- so that a tile's
+                                                     // first list fits: level 3 match + parse 13.20 -> 14.19 ms, pass A's two global stores per
+                                                     // wave and iteration cost more than the pass they save)
 constexpr uint32_t kHsSerial = 128;                  // a list this short: its lanes search what they run into themselves
-constexpr uint32_t kHsLdsWords = kHsInWords + kHsLinkWords + kHsTile / 4 + 3 * kHsSegs + 2 * kHsSegs + kHsList / 2 + 16;
+constexpr uint32_t kHsLdsWords = kHsInWords + kHsLinkWords + kHsTile / 4 + 4 * kHsSegs + 2 * kHsSegs + kHsList / 2 + 16;
 static_assert(kHsLdsWords * 4 <= 160 * 1024, "k_match_hc_sparse: one workgroup's LDS");
 static_assert(kHsTile % 256 == 0 && kHsSegs <= 1024, "tile geometry");
 
@@ -2035,9 +2038,8 @@ __global__ __launch_bounds__(1024) void k_match_hc_sparse(Config cfg, const uint
     uint32_t *in_w = hs_lds;                         // window of the block's bytes (LDS address 0: immediate offsets)
     uint32_t *link_w = in_w + kHsInWords;            // d4 of every position in the window
     uint32_t *len_w = link_w + kHsLinkWords;         // len - 3 of the tile's positions (u8)
-    // (the bits "a match was accepted here" at min_len 3 -- what k_parse_hc reads -- go straight to memory: whole words in
-    // pass A, an atomic OR where a listed search finds a match its position did not have; their 1.6 KiB of LDS are ring)
-    uint32_t *mbf = len_w + kHsTile / 4;             // a match long enough for the sub-block's min_len: the walk's mask
+    uint32_t *mbits = len_w + kHsTile / 4;           // a match was accepted here (min_len 3: what k_parse_hc reads)
+    uint32_t *mbf = mbits + kHsSegs;                 // ... and is long enough for the sub-block's min_len: the walk's mask
     uint32_t *fin = mbf + kHsSegs;                   // the position's search is over: its match is the full search's
     uint32_t *marks = fin + kHsSegs;                 // a token starts here (the current walk)
     uint32_t *seg_exit = marks + kHsSegs;            // [2][kHsSegs] where the walk leaves segment s (tile-relative)
@@ -2214,12 +2216,12 @@ __global__ __launch_bounds__(1024) void k_match_hc_sparse(Config cfg, const uint
             if (lane == 0 && r < tile_len + 64u) {  // (a wave covers two words of each bitmap)
                 const uint32_t w = r >> 5;
                 if (w < kHsSegs) {
-                    mbits_out[tile_begin / 32 + w] = (uint32_t)bt;  // (tile_begin is a multiple of 32)
+                    mbits[w] = (uint32_t)bt;
                     mbf[w] = (uint32_t)bf;
                     fin[w] = (uint32_t)bo;
                 }
                 if (w + 1 < kHsSegs) {
-                    if (r + 32u < tile_len) mbits_out[tile_begin / 32 + w + 1] = (uint32_t)(bt >> 32);
+                    mbits[w + 1] = (uint32_t)(bt >> 32);
                     mbf[w + 1] = (uint32_t)(bf >> 32);
                     fin[w + 1] = (uint32_t)(bo >> 32);
                 }
@@ -2327,7 +2329,7 @@ __global__ __launch_bounds__(1024) void k_match_hc_sparse(Config cfg, const uint
                         len_l[r] = (uint8_t)(len - 3u);
                         len8[p] = (uint8_t)(len - 3u);
                         dist[p] = (uint16_t)dst;
-                        if (!had) atomicOr(&mbits_out[p >> 5], 1u << (p & 31u));  // (had: long enough at min_len, so accepted at 3)
+                        atomicOr(&mbits[r >> 5], bit);
                         if (len >= min_len) {
                             atomicOr(&mbf[r >> 5], bit);
                             step = len;
@@ -2371,6 +2373,8 @@ __global__ __launch_bounds__(1024) void k_match_hc_sparse(Config cfg, const uint
             exp_lap(4);
         }
         entry_carry = tile_begin + uniform(seg_exit[cur * kHsSegs + n_seg - 1]);
+        // the accepted-match bits of the tile (k_parse_hc reads them); tile_begin is a multiple of 32
+        for (uint32_t i = tid; i < (tile_len + 31) / 32; i += 1024) mbits_out[tile_begin / 32 + i] = mbits[i];
         exp_count(7, 1);
     }
     if (tid == 0) {
