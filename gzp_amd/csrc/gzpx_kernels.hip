@@ -1991,7 +1991,7 @@ __global__ __launch_bounds__(1024) void k_match_hc(Config cfg, const uint8_t *__
 }
 
 // ------------------------------------------------------------------------------------------
-// k_match_hc_sparse (round 5; levels 2-4): the COMPACTION form of k_match_hc.
+// k_match_hc_sparse (round 5; levels 3-4): the COMPACTION form of k_match_hc.
 //   libdeflate searches only where a token of the greedy parse starts -- a quarter of the positions of text -- and the
 //   lockstep wave of the dense kernel pays for the longest chain walk of its 64 lanes at every position (DESIGN 7:
 //   11.9 rounds per wave at level 3, the lanes using 48 % of them).  Here, per tile of a block:
@@ -2000,17 +2000,23 @@ __global__ __launch_bounds__(1024) void k_match_hc(Config cfg, const uint8_t *__
 //     B  the greedy parse over those lengths, as a speculative segment walk (32 positions per thread, one LDS byte per hop),
 //        says where tokens start;
 //     C  the token starts whose search is not over are listed and dealt out ONE PER LANE for the full search -- full waves
-//        of long walks instead of a long walk holding 63 short ones; a lane then follows the corrected path for a few
-//        steps and searches what it lands on (most corrections move the next token start by a byte or two);
-//     D  the segments with a new length walk again, the few new token starts are searched the same way, until the path
-//        holds only finished searches.  By induction from the tile's entry the path is then libdeflate's: every token
-//        start on it has the full search's match, so the next token start is right as well.
+//        of long walks instead of a long walk holding 63 short ones.  A lane whose search changed a length follows the
+//        corrected path over the lengths in LDS until it meets the old path, marks what it passes as token starts and
+//        appends the open searches among them to the ring: the next round's list, without a walk of the tile (most
+//        corrections move the next token start by a byte or two).  Short lists are searched serially by their own lanes.
+//     D  when the ring runs dry the segments with a new length walk again and the list is built from the true marks: a
+//        pass that finds nothing open on the path ends the tile.  By induction from the tile's entry the path is then
+//        libdeflate's: every token start on it has the full search's match, so the next token start is right as well.
 //   Positions OFF the path keep their first-node match in len8 / which / alt; k_parse_hc never uses them unless a later
 //   sub-block of the block needs another min_len (the path was walked with the first sub-block's) -- it then marks the
 //   block kHcArraysStale and the dense kernel goes over it before the next parse round.  Blocks that can hold an orphan
-//   match (k_hc_orphan: the first four bytes hash to hash4 bucket 0, one block in 65 thousand) are left to the dense
-//   kernel altogether.
-//   LDS: the window (bytes + links) of a 13,056-position tile (five per BGZF block), the tile's lengths and four bitmaps.
+//   match (k_hc_orphan: the first four bytes hash to hash4 bucket 0, one block in 65 thousand) and blocks without real
+//   hash3 matches (noise) are searched the dense way by this kernel's own workgroup (hc_dense_block).
+//   Measured on the 550 MiB text slab (match + parse): level 3 13.97 -> 13.20 ms, level 4 15.84 -> 14.13; level 2 (six
+//   nodes at most: too little behind the first one) stays with the dense kernel; configs[2]'s noise 37.2 -> 37.0.
+//   What it is bound by: a correction round is a search's latency (a dependent chain of LDS reads, a hit path in nearly
+//   every round of a full wave) with the rest of the CU idle -- half of the kernel's time for a fifth of its instructions.
+//   LDS: the window (bytes + links) of a 13,056-position tile (five per BGZF block), the tile's lengths, four bitmaps, ring.
 // ------------------------------------------------------------------------------------------
 constexpr uint32_t kHsTile = 13056;  // 65280 / 5; a multiple of 256
 constexpr uint32_t kHsInWords = (32768 + kHsTile + 264) / 4 + 8;

@@ -13,7 +13,7 @@ rocprofv3 --kernel-trace --stats -d $O/prof_$tag -o $tag --output-format csv -- 
 rocprofv3 --kernel-trace --stats -d $O/prof_${tag}_inflate -o ${tag}_inflate --output-format csv -- $B --workload inflate > $O/prof_${tag}_inflate.log 2>&1
 rocprofv3 --kernel-trace --stats -d $O/prof_${tag}_bgzf3 -o ${tag}_bgzf3 --output-format csv -- $B --workload bgzf3 > $O/prof_${tag}_bgzf3.log 2>&1
 rocprofv3 --kernel-trace --stats -d $O/prof_${tag}_mgzip3 -o ${tag}_mgzip3 --output-format csv -- $B --workload mgzip3 --steps 2 > $O/prof_${tag}_mgzip3.log 2>&1
-for L in 6 9 12; do
+for L in 6 9 ${PROFILE_L12:+12}; do
   rocprofv3 --kernel-trace --stats -d $O/prof_${tag}_bgzf$L -o ${tag}_bgzf$L --output-format csv -- $B --workload bgzf3 --level $L --steps 2 > $O/prof_${tag}_bgzf$L.log 2>&1
 done
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/pmc_fetch -o f --output-format csv -- $B > $O/pmc_fetch.log 2>&1
