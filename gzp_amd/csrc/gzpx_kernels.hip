@@ -4635,7 +4635,7 @@ __global__ __launch_bounds__(kEmitThreads, 8) void k_emit(Config cfg, const uint
 //              the real ones, a prefix sum places them, and each output pass writes 64 bytes.
 //   k_crc32    (shared with the compressor) CRC-32 of the inflated bytes, checked against the footer
 // ------------------------------------------------------------------------------------------
-template <bool GWIN, int SEG = 0>
+template <bool GWIN>
 struct InfLdsT {
     // GWIN = false: a 32 KiB ring of the most recent output bytes (the DEFLATE window) lives here and
     // is flushed to HBM in dwords.  GWIN = true: no ring -- output bytes go straight to the block's
@@ -4645,11 +4645,8 @@ struct InfLdsT {
     uint32_t win[GWIN ? 1 : 8192];
     uint32_t lfast[1024];   // litlen entries for codes of <= 10 bits, 0 = longer code
     uint32_t ofast[256];    // offset entries for codes of <= 8 bits (and the 7-bit precode table)
-    uint32_t inr[SEG >= 128 ? 512 : 256];  // ring of compressed dwords (absolute dword index & its size - 1)
+    uint32_t inr[256];      // ring of compressed dwords (absolute dword index & 255)
     uint32_t own[64];       // output pass: which symbol starts at each output byte
-    // SEG (round 5): the symbols of a round of 64 x SEG bit positions, in output order: (offset in the round's output |
-    // literal << 24, distance | length << 16) -- 0 in the second word = a literal
-    uint32_t list[SEG ? 2 * (SEG >= 128 ? 1024 : 512) : 2];
     uint16_t lsorted[288];  // symbols in canonical order
     uint16_t osorted[32];
     uint8_t lens[320];      // code lengths: litlen then offset
@@ -4661,7 +4658,6 @@ struct InfLdsT {
 #define GZPX_INF_R 2
 #endif
 constexpr uint32_t kInfR = GZPX_INF_R;  // groups of 64 bit positions decoded per round
-constexpr int kInflateSegDefault = 0;   // launch_inflate: which symbol loop k_inflate runs unless GZPX_INFLATE_SEG says otherwise
 
 enum InflateStatus : uint32_t { kInfOk = 0, kInfBadData = 1, kInfInsufficientSpace = 2, kInfShortOutput = 3 };
 
@@ -4841,21 +4837,12 @@ __global__ __launch_bounds__(256) void k_dscan(uint32_t nb, const DBlock *__rest
 #ifndef GZPX_INF_WAVES
 #define GZPX_INF_WAVES 5  // waves per SIMD the global-window k_inflate is compiled for (VGPR budget 512 / n)
 #endif
-#ifndef GZPX_INF_WAVES_SEG64
-#define GZPX_INF_WAVES_SEG64 3   // (segment decode: the symbol list makes it 11.8 KiB of LDS per wave, 13 waves per CU)
-#endif
-#ifndef GZPX_INF_WAVES_SEG128
-#define GZPX_INF_WAVES_SEG128 2  // (16.8 KiB per wave, 9 waves per CU)
-#endif
-template <bool DBG, bool GWIN, int SEG = 0>
-__global__ __launch_bounds__(64, GWIN ? (SEG >= 128 ? GZPX_INF_WAVES_SEG128 : SEG ? GZPX_INF_WAVES_SEG64 : GZPX_INF_WAVES) : 1) void k_inflate(uint32_t hdr_len, const uint8_t *__restrict__ in_all,
+template <bool DBG, bool GWIN>
+__global__ __launch_bounds__(64, GWIN ? GZPX_INF_WAVES : 1) void k_inflate(uint32_t hdr_len, const uint8_t *__restrict__ in_all,
                                                               DBlock *__restrict__ blk_all,
                                                               const uint64_t *__restrict__ out_off,
                                                               uint8_t *out_all, uint64_t out_cap) {
-    static_assert(SEG == 0 || GWIN, "segment decode: the window is the output in HBM");
-    __shared__ InfLdsT<GWIN, SEG> h;
-    constexpr uint32_t kRingM = (SEG >= 128 ? 511u : 255u);  // the compressed-dword ring's index mask
-    constexpr uint32_t kNP = SEG ? (uint32_t)SEG / 32u : 1u;  // pieces of 64 dwords prefetched in registers
+    __shared__ InfLdsT<GWIN> h;
     const uint32_t lane = threadIdx.x;
     DBlock *blk = blk_all + blockIdx.x;
     const uint32_t isize = blk->isize;
@@ -4890,31 +4877,26 @@ __global__ __launch_bounds__(64, GWIN ? (SEG >= 128 ? GZPX_INF_WAVES_SEG128 : SE
         else if (bit_end - wb < 32u) v &= (1u << (bit_end - wb)) - 1u;
         return v;
     };
-    uint32_t pre[kNP];  // pre[k] holds dwords [hi_w + 64 k, hi_w + 64 k + 64)
-#pragma unroll
-    for (uint32_t t = 0; t < kNP; t++) pre[t] = fetch(64u * t + lane);
+    uint32_t pre = fetch(lane);
     auto ensure = [&](uint32_t bpos) {  // the ring covers dwords (bpos >> 5) .. (bpos >> 5) + 5
         const uint32_t w = bpos >> 5;
-        if (w >= hi_w + 64u * kNP) {  // a jump (after a stored block)
+        if (w >= hi_w + 64) {  // a jump (after a stored block)
             hi_w = w;
-#pragma unroll
-            for (uint32_t t = 0; t < kNP; t++) pre[t] = fetch(hi_w + 64u * t + lane);
+            pre = fetch(hi_w + lane);
         }
         if (w + 6 > hi_w) {
             wave_sync();
             do {
-                h.inr[(hi_w + lane) & kRingM] = pre[0];
-#pragma unroll
-                for (uint32_t t = 0; t + 1 < kNP; t++) pre[t] = pre[t + 1];
+                h.inr[(hi_w + lane) & 255u] = pre;
                 hi_w += 64;
-                pre[kNP - 1] = fetch(hi_w + 64u * (kNP - 1) + lane);
+                pre = fetch(hi_w + lane);
             } while (w + 6 > hi_w);
             wave_sync();
         }
     };
     auto bits_at = [&](uint32_t bpos) -> uint32_t {  // 32 payload bits from bit position bpos
         const uint32_t w = bpos >> 5;
-        const uint32_t lo = h.inr[w & kRingM], hi = h.inr[(w + 1) & kRingM];
+        const uint32_t lo = h.inr[w & 255u], hi = h.inr[(w + 1) & 255u];
         return (uint32_t)(((((uint64_t)hi) << 32) | lo) >> (bpos & 31u));
     };
 
@@ -5143,221 +5125,6 @@ __global__ __launch_bounds__(64, GWIN ? (SEG >= 128 ? GZPX_INF_WAVES_SEG128 : SE
             flushed = uniform(flushed);
             hi_w = uniform(hi_w);
             status = uniform(status);
-            if constexpr (SEG != 0) {
-                // ---- Segment decode (round 5).  A round covers 64 x SEG bit positions: lane i decodes, one after the
-                // other, the symbols that START in its segment [bp + SEG i, bp + SEG (i + 1)) -- from a guessed entry
-                // (the segment's first bit) in the first pass, from the exit of lane i - 1 in the passes that follow,
-                // until every lane's entry is its left neighbour's exit (Huffman streams re-synchronise within a few
-                // symbols, so most lanes leave their segment at the right bit from a wrong entry already).  The round
-                // above decodes ALL 128 bit positions for the ~17 that hold symbols and picks those with a scalar walk
-                // of six instructions per symbol; here a symbol costs one decode per pass and the scalar unit nothing.
-                // Codewords outside the fast tables are decoded in the lane (inflate_slow); what ends a round early is
-                // an end-of-block / invalid symbol or the input's end (the one-symbol path below takes over there), a
-                // lane with kSegK symbols, or a full symbol list.
-                constexpr uint32_t kSegK = (uint32_t)SEG / 4u, kSegCap = SEG >= 128 ? 1024u : 512u;
-                ensure(bp + 64u * (uint32_t)SEG + 64u);
-                const uint32_t seg_lo = bp + (uint32_t)SEG * lane, seg_hi = seg_lo + (uint32_t)SEG;
-                // one symbol at bit q: false for what the lanes do not take (end of block, invalid, undecodable)
-                auto dec = [&](uint32_t q, uint32_t &adv, uint32_t &olen, uint32_t &lit, uint32_t &p2) -> bool {
-                    const uint32_t qw = q >> 5;
-                    const uint32_t d0 = h.inr[qw & kRingM], d1 = h.inr[(qw + 1) & kRingM], d2 = h.inr[(qw + 2) & kRingM];
-                    const uint32_t b_lo = __builtin_amdgcn_alignbit(d1, d0, q & 31u);
-                    const uint32_t b_hi = __builtin_amdgcn_alignbit(d2, d1, q & 31u);
-                    uint32_t e = h.lfast[b_lo & 1023u];
-                    if ((e & 15u) == 0) e = inflate_slow<kInfLitlen>(b_lo, h.lsorted, h.lcount, h.lfirst, h.loffs);
-                    const uint32_t cl = e & 15u, type = (e >> 4) & 3u;
-                    if (cl == 0 || type >= 2u) return false;
-                    if (type == 0) {
-                        adv = cl;
-                        olen = 1;
-                        lit = (e >> 8) & 0xFFu;
-                        p2 = 0;
-                        return true;
-                    }
-                    const uint32_t xb = (e >> 8) & 7u, used1 = cl + xb;  // <= 20
-                    const uint32_t b2 = (uint32_t)(((((uint64_t)b_hi) << 32) | b_lo) >> used1);
-                    uint32_t oe = h.ofast[b2 & 255u];
-                    if ((oe & 15u) == 0) oe = inflate_slow<kInfOffset>(b2, h.osorted, h.ocount, h.ofirst, h.ooffs);
-                    const uint32_t dcl = oe & 15u, dxb = (oe >> 8) & 15u;
-                    if (dcl == 0 || (oe & 16u)) return false;
-                    const uint32_t mlen = (e >> 16) + ((b_lo >> cl) & ((1u << xb) - 1u));
-                    const uint32_t mdist = (oe >> 16) + ((b2 >> dcl) & ((1u << dxb) - 1u));
-                    adv = used1 + dcl + dxb;
-                    olen = mlen;
-                    lit = 0;
-                    p2 = mdist | (mlen << 16);
-                    return true;
-                };
-                uint32_t entry = seg_lo, ex = seg_lo, cnt = 0, outb = 0;
-                bool stopped = false, hard = false, has_match = false, redo = true;
-                uint32_t L = 64;  // the lane the round ends in (64: it runs through all segments)
-                for (;;) {
-                    if (redo) {
-                        uint32_t pos = entry;
-                        cnt = 0;
-                        outb = 0;
-                        stopped = false;
-                        hard = false;
-                        has_match = false;
-                        while (pos < seg_hi) {
-                            if (pos >= bit_lim) {  // a symbol may not start there (the one-symbol path says BadData)
-                                stopped = true;
-                                hard = true;
-                                break;
-                            }
-                            if (cnt == kSegK) {  // a lane's share is full: the round ends here, the next one starts here
-                                stopped = true;
-                                break;
-                            }
-                            uint32_t adv, olen, lit, p2;
-                            if (!dec(pos, adv, olen, lit, p2)) {
-                                stopped = true;
-                                hard = true;
-                                break;
-                            }
-                            has_match = has_match || p2 != 0;
-                            cnt++;
-                            outb += olen;
-                            pos += adv;
-                        }
-                        ex = pos;
-                    }
-                    const uint32_t prev_ex = (uint32_t)__shfl_up((int)ex, 1);
-                    const bool ok = lane == 0 || entry == prev_ex;
-                    const uint64_t bad = __ballot(!ok);
-                    const uint32_t first_bad = bad ? (uint32_t)__ffsll((long long)bad) - 1u : 64u;  // the lanes below are final
-                    const uint64_t below = first_bad >= 64u ? ~0ull : (1ull << first_bad) - 1ull;
-                    const uint64_t stops = __ballot(stopped) & below;
-                    if (stops) {
-                        L = (uint32_t)__ffsll((long long)stops) - 1u;
-                        break;
-                    }
-                    if (first_bad == 64u) break;
-                    redo = lane >= first_bad && entry != prev_ex;
-                    if (redo) entry = prev_ex;
-                    if (DBG) dbg[6]++;
-                }
-                // lanes 0 .. L hold the round's symbols (lane L those in front of its stop)
-                const uint32_t last_lane = L < 64u ? L : 63u;
-                uint32_t n_i = lane <= last_lane ? cnt : 0u, o_i = lane <= last_lane ? outb : 0u;
-                const bool any_m = __ballot(lane <= last_lane && has_match) != 0;
-                uint32_t next_bp = rdlane(ex, last_lane);
-                bool hit_stop_seg = L < 64u && rdlane(hard ? 1u : 0u, last_lane) != 0;
-                uint32_t sym_incl = wave_incl_add(n_i);
-                if (any_m && rdlane(sym_incl, 63) > kSegCap) {  // the list is full: the round ends in front of the lane that overflows it
-                    const uint64_t over = __ballot(sym_incl > kSegCap);
-                    const uint32_t lc = (uint32_t)__ffsll((long long)over) - 1u;  // (>= 1: a lane holds kSegK <= kSegCap symbols)
-                    next_bp = rdlane(entry, lc);
-                    hit_stop_seg = false;
-                    if (lane >= lc) {
-                        n_i = 0;
-                        o_i = 0;
-                    }
-                    sym_incl = wave_incl_add(n_i);
-                }
-                const uint32_t n_sym = rdlane(sym_incl, 63), sym_base = sym_incl - n_i;
-                const uint32_t out_incl = wave_incl_add(o_i);
-                const uint32_t tout = rdlane(out_incl, 63);
-                if (DBG) {
-                    dbg[2] += (uint32_t)(clock64() - t_round);
-                    dbg[4]++;
-                    dbg[5] += n_sym;
-                }
-                const long long t_out = DBG ? clock64() : 0;
-                // the symbols again, now with their places: records into the list (or, in a round without a match, the
-                // bytes straight to the output); the first symbol that does not fit the output or reaches behind the
-                // buffer's start decides the error class (the earlier symbol, as in a sequential decoder)
-                const bool fits = o + tout <= isize;  // (uniform)
-                uint32_t first_ovf = 0xFFFFFFFFu, first_bd = 0xFFFFFFFFu;
-                {
-                    uint32_t pos = entry, opos = out_incl - o_i;
-                    for (uint32_t k = 0; k < n_i; k++) {
-                        uint32_t adv, olen, lit, p2;
-                        (void)dec(pos, adv, olen, lit, p2);
-                        if (o + opos + olen > isize && first_ovf == 0xFFFFFFFFu) first_ovf = sym_base + k;
-                        if (p2 != 0 && (p2 & 0xFFFFu) > o + opos && first_bd == 0xFFFFFFFFu) first_bd = sym_base + k;
-                        if (any_m) {
-                            h.list[2u * (sym_base + k)] = opos | (lit << 24);
-                            h.list[2u * (sym_base + k) + 1u] = p2;
-                        } else if (fits) {
-                            out[o + opos] = (uint8_t)lit;
-                        }
-                        opos += olen;
-                        pos += adv;
-                    }
-                }
-                if (!fits || __ballot(first_bd != 0xFFFFFFFFu) != 0) {
-                    uint32_t mo = first_ovf, mb = first_bd;
-                    for (int m = 32; m >= 1; m >>= 1) {
-                        const uint32_t a = (uint32_t)__shfl_xor((int)mo, m), c = (uint32_t)__shfl_xor((int)mb, m);
-                        mo = a < mo ? a : mo;
-                        mb = c < mb ? c : mb;
-                    }
-                    // (both on one symbol: the distance check wins, as in the rounds above)
-                    status = mb <= mo ? kInfBadData : kInfInsufficientSpace;
-                    break;
-                }
-                if (any_m) {
-                    wave_sync();
-                    uint32_t carry = 0, s_lo = 0;
-                    for (uint32_t pass = 0; pass < tout; pass += 64) {
-                        // owner (list index + 1) of every output byte of this pass: the symbols that start in it are the
-                        // next <= 64 entries of the list
-                        wave_sync();
-                        h.own[lane] = 0;
-                        wave_sync();
-                        const uint32_t idx = s_lo + lane;
-                        const uint32_t op = idx < n_sym ? h.list[2u * idx] & 0xFFFFFFu : 0xFFFFFFFFu;
-                        const bool here = op - pass < 64u;
-                        if (here) h.own[op - pass] = idx + 1u;
-                        s_lo += (uint32_t)__popcll(__ballot(here));
-                        wave_sync();
-                        uint32_t own = h.own[lane];
-                        if (lane == 0 && own < carry) own = carry;
-                        own = wave_incl_max(own);
-                        carry = rdlane(own, 63);
-                        const uint32_t p1 = h.list[2u * (own - 1u)], p2 = h.list[2u * (own - 1u) + 1u];  // (own >= 1: a symbol starts at byte 0 of the round)
-                        const uint32_t prel = pass + lane;
-                        const bool active = prel < tout;
-                        const bool m = p2 != 0;
-                        const uint32_t sdist = p2 & 0xFFFFu, slen = p2 >> 16, spos = p1 & 0xFFFFFFu;
-                        uint32_t r = prel - spos;
-                        if (m && sdist < slen) {  // overlapping copy: the source repeats with period dist
-                            uint32_t rr = r - (uint32_t)((float)r * (1.0f / (float)sdist)) * sdist;
-                            if ((int32_t)rr < 0) rr += sdist;
-                            if (rr >= sdist) rr -= sdist;
-                            r = rr;
-                        }
-                        const uint32_t srcrel = spos - sdist + r;  // relative to o; "negative" = older
-                        uint64_t done = __ballot(!active);
-                        bool pending = active;
-                        const bool in_pass = m && (int32_t)(srcrel - pass) >= 0;
-                        uint32_t myv = p1 >> 24;  // the literal
-                        if (active && m && !in_pass) myv = out[o + srcrel];
-                        const bool have = active && (!m || !in_pass);
-                        if (have) out[o + prel] = (uint8_t)myv;
-                        done |= __ballot(have);
-                        pending = pending && !have;
-                        while (__ballot(pending) != 0) {
-                            const uint32_t sl = (srcrel - pass) & 63u;
-                            const uint32_t got = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(sl << 2), (int)myv);
-                            const bool ready = pending && ((done >> sl) & 1ull) != 0;
-                            if (ready) {
-                                myv = got;
-                                out[o + prel] = (uint8_t)myv;
-                            }
-                            done |= __ballot(ready);
-                            pending = pending && !ready;
-                        }
-                    }
-                }
-                o += tout;
-                flushed = o;
-                if (DBG) dbg[3] += (uint32_t)(clock64() - t_out);
-                bp = next_bp;
-                if (!hit_stop_seg) continue;
-            }
-            if constexpr (SEG == 0) {
             ensure(bp + 64 * kInfR - 64);
             // (1) every lane decodes the symbols that would start at bits bp + 64 * g + lane
             // (g < kInfR), completely: litlen codeword, extra bits, offset codeword, extra bits
@@ -5368,7 +5135,7 @@ __global__ __launch_bounds__(64, GWIN ? (SEG >= 128 ? GZPX_INF_WAVES_SEG128 : SE
 #pragma unroll
             for (uint32_t hf = 0; hf < kInfR; hf++) {
                 const uint32_t q = bp + 64 * hf + lane, qw = q >> 5;
-                const uint32_t d0 = h.inr[qw & kRingM], d1 = h.inr[(qw + 1) & kRingM], d2 = h.inr[(qw + 2) & kRingM];
+                const uint32_t d0 = h.inr[qw & 255u], d1 = h.inr[(qw + 1) & 255u], d2 = h.inr[(qw + 2) & 255u];
                 const uint32_t b_lo = __builtin_amdgcn_alignbit(d1, d0, q & 31u);
                 const uint32_t b_hi = __builtin_amdgcn_alignbit(d2, d1, q & 31u);
                 le[hf] = h.lfast[b_lo & 1023u];
@@ -5577,16 +5344,15 @@ __global__ __launch_bounds__(64, GWIN ? (SEG >= 128 ? GZPX_INF_WAVES_SEG128 : SE
                 bp += pos;
                 continue;
             }
-            bp += last;
-            }  // SEG == 0
             // (4) one symbol the slow way: end of block, long codewords, errors
+            bp += last;
             if (bp >= bit_lim) {
                 status = kInfBadData;
                 break;
             }
             ensure(bp);
             const uint32_t sw = bp >> 5;
-            const uint32_t s0 = h.inr[sw & kRingM], s1 = h.inr[(sw + 1) & kRingM], s2 = h.inr[(sw + 2) & kRingM];
+            const uint32_t s0 = h.inr[sw & 255u], s1 = h.inr[(sw + 1) & 255u], s2 = h.inr[(sw + 2) & 255u];
             const uint32_t sb_lo = uniform(__builtin_amdgcn_alignbit(s1, s0, bp & 31u));
             const uint32_t sb_hi = uniform(__builtin_amdgcn_alignbit(s2, s1, bp & 31u));
             uint32_t e = uniform(h.lfast[sb_lo & 1023u]);
@@ -5892,26 +5658,12 @@ void launch_inflate(uint32_t hdr_len, const uint8_t *d_in, const uint64_t *d_off
     hipLaunchKernelGGL(k_dinit, dim3((nb + 255) / 256), dim3(256), 0, stream, nb, d_in, d_offsets, d_sizes, blk);
     hipLaunchKernelGGL(k_dscan, dim3(1), dim3(256), 0, stream, nb, (const DBlock *)blk, d_out_off);
     if (ev_begin) (void)hipEventRecord(ev_begin, stream);
-    // which symbol loop (development knob; the default is the measured best): GZPX_INFLATE_SEG = 0 (128 bit positions per
-    // round, every position decoded, scalar walk), 64 or 128 (segment decode, round 5)
-    static const int seg = [] {
-        const char *e = getenv("GZPX_INFLATE_SEG");
-        const int v = e ? atoi(e) : kInflateSegDefault;
-        return v == 64 || v == 128 ? v : 0;
-    }();
-#define GZPX_LAUNCH_INFLATE(DBG_, SEG_)                                                                     \
-    hipLaunchKernelGGL((k_inflate<DBG_, true, SEG_>), dim3(nb), dim3(64), 0, stream, hdr_len, d_in, blk, \
-                       (const uint64_t *)d_out_off, d_out, out_cap)
-    if (debug) {
-        if (seg == 64) GZPX_LAUNCH_INFLATE(true, 64);
-        else if (seg == 128) GZPX_LAUNCH_INFLATE(true, 128);
-        else GZPX_LAUNCH_INFLATE(true, 0);
-    } else {
-        if (seg == 64) GZPX_LAUNCH_INFLATE(false, 64);
-        else if (seg == 128) GZPX_LAUNCH_INFLATE(false, 128);
-        else GZPX_LAUNCH_INFLATE(false, 0);
-    }
-#undef GZPX_LAUNCH_INFLATE
+    if (debug)
+        hipLaunchKernelGGL((k_inflate<true, true>), dim3(nb), dim3(64), 0, stream, hdr_len, d_in, blk,
+                           (const uint64_t *)d_out_off, d_out, out_cap);
+    else
+        hipLaunchKernelGGL((k_inflate<false, true>), dim3(nb), dim3(64), 0, stream, hdr_len, d_in, blk,
+                           (const uint64_t *)d_out_off, d_out, out_cap);
     if (ev_end) (void)hipEventRecord(ev_end, stream);
     hipLaunchKernelGGL(k_dcrc32, dim3(nb), dim3(kCrcThreads), 0, stream, (const uint8_t *)d_out,
                        (const uint64_t *)d_out_off, (const DBlock *)blk, d_crc_found, cc);
