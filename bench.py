@@ -73,12 +73,12 @@ N_SIMD = 256 * 4
 
 def issue_roofline(kernel, kernel_ms, build_id, workload="bench.py"):
     """The second bound beside HBM (round 5): instruction issue, from the committed SQ counters of THIS build
-    (profiles/sq_counters.json, tools/pmc_sq.sh).  `issue_frac` = VALU wave-instructions x 4 cycles (what one
-    SQ_ACTIVE_INST_VALU quad-cycle per instruction measures: the cadence at which a SIMD issues a wave's VALU work)
-    / (1024 SIMDs x the kernel's duration x the 2.4 GHz peak clock) -- the VALU-busy share of the kernel's time.  The
-    SIMD-32 datapath itself retires a wave64 instruction in 2 cycles (the 157 TFLOP/s vector peak), so against THAT
-    ceiling the share is half (`valu_peak_frac`); `wave_parked_frac` = SQ_WAIT_ANY / SQ_WAVE_CYCLES is the share of
-    its resident time an average wave spends parked at s_waitcnt / s_barrier."""
+    (profiles/sq_counters.json, tools/pmc_sq.sh).  `issue_frac` = VALU wave-instructions x 4 cycles / (1024 SIMDs x the
+    kernel's duration x the 2.4 GHz peak clock): the share of the kernel's time in which its SIMDs issue VALU work.  Four
+    cycles per wave-instruction and SIMD is what the counters themselves say for this integer code (one quad-cycle of
+    SQ_ACTIVE_INST_VALU per SQ_INSTS_VALU); the 2-cycle rate behind the 157 TFLOP/s vector peak is packed FP32.
+    `wave_parked_frac` = SQ_WAIT_ANY / SQ_WAVE_CYCLES: the share of its resident time an average wave spends parked at
+    s_waitcnt / s_barrier; `lds_busy_frac` = SQ_LDS_IDX_ACTIVE (cycles) / (256 CUs x the kernel's cycles)."""
     try:
         with open(os.path.join(ROOT, "profiles", "sq_counters.json")) as f:
             doc = json.load(f)
@@ -88,11 +88,10 @@ def issue_roofline(kernel, kernel_ms, build_id, workload="bench.py"):
         c = doc["workloads"][workload][kernel]
         cyc = N_SIMD * kernel_ms * 1e-3 * CLOCK_HZ
         return {"issue_frac": round(c["INSTS_VALU"] * 4.0 / cyc, 4),
-                "valu_peak_frac": round(c["INSTS_VALU"] * 2.0 / cyc, 4),
                 "valu_wave_insts": int(c["INSTS_VALU"]), "salu_wave_insts": int(c["INSTS_SALU"]),
                 "lds_wave_insts": int(c["INSTS_LDS"]),
                 "wave_parked_frac": round(c["WAIT_ANY"] / c["WAVE_CYCLES"], 4),
-                "lds_busy_frac": round(c["LDS_IDX_ACTIVE"] * 4.0 / (256 * kernel_ms * 1e-3 * CLOCK_HZ), 4),
+                "lds_busy_frac": round(c["LDS_IDX_ACTIVE"] / (256 * kernel_ms * 1e-3 * CLOCK_HZ), 4),
                 "source": "profiles/sq_counters.json (rocprofv3 --pmc SQ_* passes of this build %s; committed, not "
                           "collected in this run)" % build_id}
     except Exception as e:
@@ -395,6 +394,7 @@ def run_inflate(args, env, emit=True, d_stream=None, comp_host=None, slab=None, 
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 5),
                 "traffic": pmc_traffic("k_inflate", env.lib.build_id()),
+                "issue": issue_roofline("k_inflate", kern_ms, env.lib.build_id(), "bench.py --workload inflate"),
                 "kernel_ms": round(kern_ms, 3),
             },
         }
