@@ -50,6 +50,15 @@ def test_two_ranks_strong_scaling_is_the_value_when_asked_for():
     assert d["strong_550MiB"]["verified_bit_exact_full"] is True and d["ms_per_step"] == d["strong_550MiB"]["ms_per_step"]
 
 
+def test_eight_ranks_three_blocks():
+    """configs[3]'s world size on the CPU: 8 ranks, a slab of three blocks -- five ranks own no block at all and take part
+    in every gather with nothing; the strong-scaling leg's gathered stream is still the single-process stream."""
+    d = _run("--gpus", "8", "--slab-bytes", "150000")
+    assert d["n_gpus"] == 8 and d["value"] == d["value_rccl"] and len(d["writeouts"]["rccl"]["rank_ms_per_step"]) == 8
+    st = d["strong_550MiB"]
+    assert st["verified_bit_exact_full"] is True and st["shard_bytes_rank0"] == 65280 and len(st["rank_ms_per_step"]) == 8
+
+
 def test_config4_workload_two_ranks():
     d = _run("--gpus", "2", "--workload", "fastq", "--stream-bytes", "400000")
     c = d["config"]
