@@ -581,7 +581,12 @@ __global__ __launch_bounds__(64 * kCandWaves) void k_candidates_h4(Config cfg, c
     __shared__ uint32_t turn;               // the iteration of the current 32768-position chunk whose turn it is
     __shared__ uint32_t bad_any;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    constexpr uint32_t kIterPos = 64 * kCandSteps, kChunk = 32768;
+    constexpr uint32_t kIterPos = 64 * kCandSteps, kChunkBig = 32768;
+    // A block of fewer than 65536 positions (every BGZF block) is ONE chunk: entries are p + 1 (0 = empty), nothing ever
+    // aliases, no marker and no sweep -- one table reset and one pair of barriers per block.  Larger blocks (Mgzip) go in
+    // chunks of 32768 positions with entries p mod 65536, the dead marker and a sweep per chunk.
+    const bool small_blocks = cfg.block_size < 65536u;  // (uniform for the launch)
+    const uint32_t kChunk = small_blocks ? 65536u : kChunkBig;
     auto block_len = [&](uint32_t blk) -> uint32_t {
         const uint64_t begin = (uint64_t)blk * cfg.block_size;
         const uint64_t len = slab_len > begin ? slab_len - begin : 0;
@@ -633,8 +638,9 @@ __global__ __launch_bounds__(64 * kCandWaves) void k_candidates_h4(Config cfg, c
         for (uint32_t ch = 0; ch * kChunk < n; ch++) {
             const uint32_t cbase = ch * kChunk;
             __syncthreads();  // every atomic of the chunk before has been applied
-            if (ch == 0) {  // a new block: every bucket dead for positions 0 .. 32767
-                for (uint32_t i = tid; i < kH4Words; i += 64 * kCandWaves) tab[i] = 0x80008000u;
+            if (ch == 0) {  // a new block: every bucket empty (small blocks) / dead for positions 0 .. 32767
+                const uint32_t init = small_blocks ? 0u : 0x80008000u;
+                for (uint32_t i = tid; i < kH4Words; i += 64 * kCandWaves) tab[i] = init;
             } else {  // entries more than 32767 behind cbase -- and the old marker -- become the new marker
                 const uint32_t dead = (cbase + 0x8000u) & 0xFFFFu;
                 for (uint32_t i = tid; i < kH4Words; i += 64 * kCandWaves) {
@@ -659,7 +665,7 @@ __global__ __launch_bounds__(64 * kCandWaves) void k_candidates_h4(Config cfg, c
                     const uint32_t sh = (h16 & 1u) << 4;
                     addr[k] = 4u * (valid ? h16 >> 1 : kH4Words + lane);  // (a lane without a bucket: a spare word of its own, nothing written)
                     msk[k] = valid ? 0xFFFFu << sh : 0u;
-                    val[k] = valid ? (p & 0xFFFFu) << sh : 0u;
+                    val[k] = valid ? ((small_blocks ? p + 1u : p) & 0xFFFFu) << sh : 0u;
                     GZPX_PIN_VGPR(addr[k]);
                     GZPX_PIN_VGPR(msk[k]);
                     GZPX_PIN_VGPR(val[k]);
@@ -690,9 +696,9 @@ __global__ __launch_bounds__(64 * kCandWaves) void k_candidates_h4(Config cfg, c
                     const bool valid = msk[k] != 0;
                     const uint32_t sh = msk[k] >> 16 ? 16u : 0u;
                     const uint32_t prev = (old[k] >> sh) & 0xFFFFu;
-                    uint32_t d = (p - prev) & 0xFFFFu;
+                    uint32_t d = small_blocks ? (prev ? p + 1u - prev : 0u) : (p - prev) & 0xFFFFu;  // (prev > p + 1: see the order check)
                     // the order check: the value of a higher lane of this very instruction (same bucket) came back
-                    const uint32_t ahead = (prev - p) & 0xFFFFu;  // 1 .. 63 - lane if so
+                    const uint32_t ahead = small_blocks ? prev - (p + 1u) : (prev - p) & 0xFFFFu;  // 1 .. 63 - lane if so
                     const bool suspect = valid && ahead >= 1u && ahead <= 63u - lane;
                     const int from = (int)((suspect ? lane + ahead : lane) << 2);  // (every lane takes part: a bpermute reads active lanes only)
                     const uint32_t a_hi = (uint32_t)__builtin_amdgcn_ds_bpermute(from, (int)addr[k]);
