@@ -529,211 +529,6 @@ __global__ __launch_bounds__(64 * kCandWaves) void k_candidates(Config cfg,
 }
 
 // ------------------------------------------------------------------------------------------
-// k_candidates_h4 (round 5): hc_matchfinder's hash4 chain links in ONE pass.
-//   The 2^16-bucket table does not fit LDS with a word per bucket, which is why k_candidates<2> / <3> each own half of
-//   the buckets and the slab is read twice.  With 16 bits per bucket it is 128 KiB -- and ds_mskor_rtn_b32
-//   (MEM = (MEM & ~mask) | data, returns the old dword) writes one half of a dword and hands back what was there:
-//   tools/probes/lds_mskor_order.hip shows that the LDS applies the same-address operations of one wave instruction in
-//   ascending lane order for it too (4000 / 4000 patterns) and leaves the other half alone, so the returned half IS
-//   the bucket's previous entry, as with atomicMax in k_candidates.
-//   16-bit entries hold positions mod 65536, so entries must not grow older than 65535: the table is reset to a
-//   "dead" marker per block, and every 32768 positions a sweep turns entries more than 32767 behind -- and the old
-//   marker -- into the marker of the next 32768 positions (cand_block_safe's scheme, libdeflate's window slide).
-//   One persistent workgroup per CU, sixteen waves taking turns at the table as in k_candidates; barriers only
-//   around the resets / sweeps (two per 32768 positions).  The order assumption is checked exactly: a lane that is
-//   handed the value a HIGHER lane of the same instruction wrote flags the block, which is then redone by the
-//   order-independent cand_block_safe<2> / <3> in the same LDS.
-//   Output as k_candidates<2> + <3>: d4[p] = distance to the previous position with the same 16-bit hash of four
-//   bytes (0: none within 32767, or fewer than five bytes left).
-// ------------------------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t lds_mskor_rtn(uint32_t *word, uint32_t mask, uint32_t data) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    uint32_t old;
-    const uint32_t addr = (uint32_t)(size_t)word;  // LDS byte address
-    asm volatile("ds_mskor_rtn_b32 %0, %1, %2, %3" : "=v"(old) : "v"(addr), "v"(mask), "v"(data) : "memory");
-    return old;
-#else
-    // the CPU emulator (tests/emu): its fibers reach an operation in no particular lane order, so one wave instruction is
-    // restated as what the hardware does -- lane 0 applies the 64 operations in ascending lane order
-    static uint32_t *e_word[16][64];
-    static uint32_t e_mask[16][64], e_data[16][64], e_old[16][64];
-    const uint32_t w = (threadIdx.x >> 6) & 15u, l = threadIdx.x & 63u;
-    e_word[w][l] = word;
-    e_mask[w][l] = mask;
-    e_data[w][l] = data;
-    (void)__ballot(1);
-    if (l == 0)
-        for (uint32_t k = 0; k < 64; k++) {
-            e_old[w][k] = *e_word[w][k];
-            *e_word[w][k] = (e_old[w][k] & ~e_mask[w][k]) | e_data[w][k];
-        }
-    (void)__ballot(1);
-    return e_old[w][l];
-#endif
-}
-
-constexpr uint32_t kH4Words = 32768;  // 2^16 buckets x 16 bits
-
-__global__ __launch_bounds__(64 * kCandWaves) void k_candidates_h4(Config cfg, const uint8_t *__restrict__ slab,
-                                                                    uint16_t *__restrict__ d4_all, uint64_t slab_len,
-                                                                    uint32_t nb) {
-    __shared__ uint32_t tab[kH4Words + 64];  // + one spare word per lane for lanes without a bucket
-    __shared__ uint32_t turn;               // the iteration of the current 32768-position chunk whose turn it is
-    __shared__ uint32_t bad_any;
-    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    constexpr uint32_t kIterPos = 64 * kCandSteps, kChunkBig = 32768;
-    // A block of fewer than 65536 positions (every BGZF block) is ONE chunk: entries are p + 1 (0 = empty), nothing ever
-    // aliases, no marker and no sweep -- one table reset and one pair of barriers per block.  Larger blocks (Mgzip) go in
-    // chunks of 32768 positions with entries p mod 65536, the dead marker and a sweep per chunk.
-    const bool small_blocks = cfg.block_size < 65536u;  // (uniform for the launch)
-    const uint32_t kChunk = small_blocks ? 65536u : kChunkBig;
-    auto block_len = [&](uint32_t blk) -> uint32_t {
-        const uint64_t begin = (uint64_t)blk * cfg.block_size;
-        const uint64_t len = slab_len > begin ? slab_len - begin : 0;
-        return (uint32_t)(len > cfg.block_size ? cfg.block_size : len);
-    };
-    // a wave's next piece of work: iteration `it` (of 1024 positions) of chunk `ch` of block `b`; it is found -- and its
-    // input requested -- while the current one is worked on, across chunk and block boundaries
-    struct Item {
-        uint32_t b, ch, it;
-    };
-    auto advance = [&](Item &x) -> bool {  // the first iteration this wave owns at or behind x
-        for (;;) {
-            if (x.b >= nb) return false;
-            const uint32_t n = block_len(x.b);
-            const uint32_t chunks = n > cfg.passthrough ? (n + kChunk - 1) / kChunk : 0u;
-            if (x.ch < chunks) {
-                const uint32_t left = n - x.ch * kChunk;
-                const uint32_t iters = (left < kChunk ? left + kIterPos - 1 : kChunk) / kIterPos;
-                if (x.it < iters) return true;
-                x.ch++;
-                x.it = wave;
-                continue;
-            }
-            x.b += gridDim.x;
-            x.ch = 0;
-            x.it = wave;
-        }
-    };
-    auto request = [&](const Item &x, uint2 (&ring)[kCandSteps]) {
-        const uint8_t *in = slab + (uint64_t)x.b * cfg.block_size;
-        const uint32_t mis = (uint32_t)((uintptr_t)in & 3u), n = block_len(x.b);
-#pragma unroll
-        for (uint32_t k = 0; k < kCandSteps; k++)
-            ring[k] = cand_fetch((const uint32_t *)(in - mis), mis, x.ch * kChunk + x.it * kIterPos + k * 64 + lane, (mis + n - 1) >> 2);
-    };
-    if (tid == 0) bad_any = 0;
-    const bool force_safe = (cfg.debug & 1u) != 0;
-    Item mine{blockIdx.x, 0, wave};
-    bool have = advance(mine);
-    uint2 ring[kCandSteps];
-    if (have) request(mine, ring);
-    for (uint32_t b = blockIdx.x; b < nb; b += gridDim.x) {  // (uniform: every wave walks every block and chunk)
-        const uint32_t n = block_len(b);
-        if (n <= cfg.passthrough) continue;
-        const uint8_t *in = slab + (uint64_t)b * cfg.block_size;
-        const uint32_t mis = (uint32_t)((uintptr_t)in & 3u);
-        uint16_t *d4 = d4_all + (uint64_t)b * cfg.stride;
-        bool bad = false;
-        for (uint32_t ch = 0; ch * kChunk < n; ch++) {
-            const uint32_t cbase = ch * kChunk;
-            __syncthreads();  // every atomic of the chunk before has been applied
-            if (ch == 0) {  // a new block: every bucket empty (small blocks) / dead for positions 0 .. 32767
-                const uint32_t init = small_blocks ? 0u : 0x80008000u;
-                for (uint32_t i = tid; i < kH4Words; i += 64 * kCandWaves) tab[i] = init;
-            } else {  // entries more than 32767 behind cbase -- and the old marker -- become the new marker
-                const uint32_t dead = (cbase + 0x8000u) & 0xFFFFu;
-                for (uint32_t i = tid; i < kH4Words; i += 64 * kCandWaves) {
-                    const uint32_t e = tab[i];
-                    const uint32_t a0 = (cbase - e) & 0xFFFFu, a1 = (cbase - (e >> 16)) & 0xFFFFu;
-                    const uint32_t lo = (a0 == 0 || a0 > 32767u) ? dead : (e & 0xFFFFu);
-                    const uint32_t hi = (a1 == 0 || a1 > 32767u) ? dead : (e >> 16);
-                    tab[i] = lo | (hi << 16);
-                }
-            }
-            if (tid == 0) turn = 0;
-            __syncthreads();
-            while (have && mine.b == b && mine.ch == ch && !force_safe) {  // (wave-uniform) this wave's iterations of the chunk
-                const uint32_t base0 = cbase + mine.it * kIterPos, my_turn = mine.it;
-                uint32_t addr[kCandSteps], msk[kCandSteps], val[kCandSteps], old[kCandSteps];
-#pragma unroll
-                for (uint32_t k = 0; k < kCandSteps; k++) {
-                    const uint32_t p = base0 + k * 64 + lane;
-                    const uint32_t v = __builtin_amdgcn_alignbyte(ring[k].y, ring[k].x, (p + mis) & 3u);
-                    const uint32_t h16 = p != 0 ? (v * 0x1E35A7BDu) >> 16 : 0u;  // (position 0 is filed under bucket 0)
-                    const bool valid = p + 5 <= n;  // positions the matchfinder hashes (REQUIRED_NBYTES = 5)
-                    const uint32_t sh = (h16 & 1u) << 4;
-                    addr[k] = 4u * (valid ? h16 >> 1 : kH4Words + lane);  // (a lane without a bucket: a spare word of its own, nothing written)
-                    msk[k] = valid ? 0xFFFFu << sh : 0u;
-                    val[k] = valid ? ((small_blocks ? p + 1u : p) & 0xFFFFu) << sh : 0u;
-                    GZPX_PIN_VGPR(addr[k]);
-                    GZPX_PIN_VGPR(msk[k]);
-                    GZPX_PIN_VGPR(val[k]);
-                }
-                Item nxt = mine;
-                nxt.it += kCandWaves;
-                const bool more = advance(nxt);
-                if (more) request(nxt, ring);
-                wave_sync();
-                while (__hip_atomic_load(&turn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != my_turn)
-                    __builtin_amdgcn_s_sleep(1);
-#pragma unroll
-                for (uint32_t k = 0; k < kCandSteps; k++) {
-                    old[k] = lds_mskor_rtn((uint32_t *)((uint8_t *)tab + addr[k]), msk[k], val[k]);
-                }
-#if defined(__HIP_DEVICE_COMPILE__)
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#endif
-                uint32_t seen = 0;
-#pragma unroll
-                for (uint32_t k = 0; k < kCandSteps; k++) seen |= old[k];
-                GZPX_PIN_VGPR(seen);  // (the returned values are in registers: every operation of this turn has been applied)
-                wave_sync();
-                if (lane == 0) __hip_atomic_store(&turn, my_turn + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-#pragma unroll
-                for (uint32_t k = 0; k < kCandSteps; k++) {
-                    const uint32_t p = base0 + k * 64 + lane;
-                    const bool valid = msk[k] != 0;
-                    const uint32_t sh = msk[k] >> 16 ? 16u : 0u;
-                    const uint32_t prev = (old[k] >> sh) & 0xFFFFu;
-                    uint32_t d = small_blocks ? (prev ? p + 1u - prev : 0u) : (p - prev) & 0xFFFFu;  // (prev > p + 1: see the order check)
-                    // the order check: the value of a higher lane of this very instruction (same bucket) came back
-                    const uint32_t ahead = small_blocks ? prev - (p + 1u) : (prev - p) & 0xFFFFu;  // 1 .. 63 - lane if so
-                    const bool suspect = valid && ahead >= 1u && ahead <= 63u - lane;
-                    const int from = (int)((suspect ? lane + ahead : lane) << 2);  // (every lane takes part: a bpermute reads active lanes only)
-                    const uint32_t a_hi = (uint32_t)__builtin_amdgcn_ds_bpermute(from, (int)addr[k]);
-                    const uint32_t m_hi = (uint32_t)__builtin_amdgcn_ds_bpermute(from, (int)msk[k]);
-                    bad |= suspect && a_hi == addr[k] && m_hi == msk[k];
-                    if (d > 32767u) d = 0;  // farther than the window (or a dead marker): no live predecessor
-                    if (p < cfg.stride) d4[p] = (uint16_t)(valid ? d : 0u);  // (positions that are never hashed: 0)
-                }
-                mine = nxt;
-                have = more;
-            }
-        }
-        // (expected: never) the order check failed: this block again, order-independently, half of the buckets at a time
-        if (__ballot(bad) && lane == 0) atomicOr(&bad_any, 1u);
-        __syncthreads();
-        if (bad_any || force_safe) {
-            if (wave == 0) {
-                cand_block_safe<2>(tab, (const uint32_t *)(in - mis), mis, (mis + n - 1) >> 2, n, lane, d4);
-                wave_sync();
-                cand_block_safe<3>(tab, (const uint32_t *)(in - mis), mis, (mis + n - 1) >> 2, n, lane, d4);
-            }
-            __syncthreads();
-            if (tid == 0) bad_any = 0;
-            if (force_safe) {  // (diagnostics: this wave's iterations of the block are skipped, their input requested anew)
-                while (have && mine.b == b) {
-                    mine.it += kCandWaves;
-                    have = advance(mine);
-                }
-                if (have) request(mine, ring);
-            }
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------
 // k_match: ht_matchfinder_longest_match for EVERY position of a block in parallel.
 //   1024 threads per block, ~74 KiB of LDS (a window of the block's bytes + one bit per
 //   position), so two workgroups = 32 waves share a CU and hide each other's LDS / L2 latency.
@@ -5699,14 +5494,8 @@ void launch_candidates(const Config &cfg, const uint8_t *slab, uint64_t slab_len
         launch_candidates_mode<0>(cfg, slab, slab_len, nb, is_last, s, s.cand, stream);
     } else {  // hc_matchfinder: hash3 predecessor in cand, hash4 chain links in d4
         launch_candidates_mode<1>(cfg, slab, slab_len, nb, is_last, s, s.cand, stream);
-        if (cfg.debug & 64u) {  // (Config.debug bit 6: the hash4 links in two passes over half of the buckets each, as in rounds 2-4)
-            launch_candidates_mode<2>(cfg, slab, slab_len, nb, is_last, s, s.d4, stream);
-            launch_candidates_mode<3>(cfg, slab, slab_len, nb, is_last, s, s.d4, stream);
-        } else {
-            const uint32_t wgs = cfg.n_cu ? cfg.n_cu : 256u;
-            hipLaunchKernelGGL(k_candidates_h4, dim3(nb < wgs ? nb : wgs), dim3(64 * kCandWaves), 0, stream, cfg, slab, s.d4,
-                               slab_len, nb);
-        }
+        launch_candidates_mode<2>(cfg, slab, slab_len, nb, is_last, s, s.d4, stream);
+        launch_candidates_mode<3>(cfg, slab, slab_len, nb, is_last, s, s.d4, stream);
     }
 }
 
