@@ -1809,7 +1809,10 @@ __device__ __forceinline__ void hc_dense_block(uint32_t *hc_lds, const Config &c
                                                const uint16_t *__restrict__ d3_all, const uint16_t *__restrict__ d4_all,
                                                uint8_t *__restrict__ len8_all, uint32_t *__restrict__ mbits_all,
                                                uint16_t *__restrict__ dist_all, uint8_t *__restrict__ lz_len_all,
-                                               uint16_t *__restrict__ lz_dist_all) {
+                                               uint16_t *__restrict__ lz_dist_all, const uint32_t from_pos = 0xFFFFFFFFu,
+                                               const bool mark_dense = true) {
+    // (from_pos / mark_dense: k_match_hc_sparse handing the REST of a block over -- from the tile that holds from_pos on,
+    // the arrays in front of it keep what that kernel wrote, and the block's state stays that kernel's to set)
     uint32_t *in_w = hc_lds;                     // 48 KiB window of the block's bytes
     uint32_t *link_w = hc_lds + kHcInWords;      // d4 of every position in the window
     uint32_t *mbits = link_w + kHcLinkWords;
@@ -1835,7 +1838,7 @@ __device__ __forceinline__ void hc_dense_block(uint32_t *hc_lds, const Config &c
     // best_len -- it only raises the bar a node must clear -- so the search that libdeflate starts at
     // min_len - 1 returns this very match whenever it is long enough and nothing otherwise.  k_parse_hc
     // applies `len >= min_len`; a sub-block with another min_len re-parses, it does not re-match.
-    const uint32_t resume = st->resume_pos;
+    const uint32_t resume = from_pos != 0xFFFFFFFFu ? from_pos : st->resume_pos;
     const uint32_t min_len = 3;
     const uint32_t nice_level = cfg.hc_nice, depth = GZPX_EXP(cfg, 12) ? 1u : cfg.hc_depth;
 
@@ -1973,7 +1976,7 @@ __device__ __forceinline__ void hc_dense_block(uint32_t *hc_lds, const Config &c
         for (uint32_t i = tid; i < (tile_end - tile_begin + 31) / 32; i += 1024)
             mbits_out[tile_begin / 32 + i] = mbits[i];
     }
-    if (tid == 0) st->sparse = kHcArraysDense;  // (read at the top by every thread: behind the loop's barriers)
+    if (tid == 0 && mark_dense) st->sparse = kHcArraysDense;  // (read at the top by every thread: behind the loop's barriers)
 }
 
 __global__ __launch_bounds__(1024) void k_match_hc(Config cfg, const uint8_t *__restrict__ slab,
@@ -2263,8 +2266,18 @@ __global__ __launch_bounds__(1024) void k_match_hc_sparse(Config cfg, const uint
         uint32_t my_exit = active ? walk_seg(tid, entry) : 0u;
         uint32_t cur = 0;
         if (active) seg_exit[tid] = my_exit;
+        // Two kinds of input do not compact, and the first walk of a tile tells (measured, 256 MiB per class, level 3 against
+        // the dense kernel: DNA + 103 %, FASTQ + 94 %, low-entropy binary + 93 %, period-2 + 158 %, byte runs + 13 % before
+        // this test; text - 4 %, repeated phrases - 11 %):
+        //  * long matches -- segments left by a match that overshoots them by two segments or more: entries then settle one
+        //    segment per round (what k_mparse hands its blocks back for);
+        //  * small alphabets with long chains -- nearly every token start still has its search open after the first node
+        //    (DNA: 96 % of them, FASTQ 74 %; text 18 %), so there is nothing to save and the corrections cascade.
+        // The rest of the block then goes the dense way, by this workgroup, from this tile on.
+        const uint32_t n_over = (uint32_t)__syncthreads_count(active && my_exit >= seg_begin + kHsSeg + 2u * kHsSeg);
+        bool dense_rest = n_over * 8u > n_seg && !(cfg.debug & 32u);
         bool dirty = false;  // a search changed a length in my segment
-        for (uint32_t pass = 0;; pass++) {
+        for (uint32_t pass = 0; !dense_rest; pass++) {
             // the entries settle: one barrier per round, two copies of the exits (as in k_mparse)
             for (;;) {
                 __syncthreads();
@@ -2300,6 +2313,8 @@ __global__ __launch_bounds__(1024) void k_match_hc_sparse(Config cfg, const uint
             __syncthreads();
             uint32_t head = 0, tail = misc[8] < kHsList ? misc[8] : kHsList;
             exp_lap(3);
+            if (pass == 0 && misc[8] * 6u > tile_len && !(cfg.debug & 32u)) dense_rest = true;  // (uniform; misc[8] counts what did not fit too)
+            if (dense_rest) break;
             if (tail == 0) break;  // uniform: the path holds only finished searches
             __syncthreads();       // (everybody has read the count)
             if (tid == 0) misc[8] = tail;
@@ -2377,6 +2392,12 @@ __global__ __launch_bounds__(1024) void k_match_hc_sparse(Config cfg, const uint
             // ---- D: segments with a new length walk again (their exit in the copy nobody reads was poisoned)
             if (active) dirty = seg_exit[(cur ^ 1u) * kHsSegs + tid] == 0xFFFFFFFFu;
             exp_lap(4);
+        }
+        if (dense_rest) {  // uniform
+            __syncthreads();
+            hc_dense_block(hs_lds, cfg, slab, meta_all, hc_all, d3_all, d4_all, len8_all, mbits_all, dist_all, (uint8_t *)nullptr,
+                           (uint16_t *)nullptr, tile_begin, false);
+            break;
         }
         entry_carry = tile_begin + uniform(seg_exit[cur * kHsSegs + n_seg - 1]);
         // the accepted-match bits of the tile (k_parse_hc reads them); tile_begin is a multiple of 32
