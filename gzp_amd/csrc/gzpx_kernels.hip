@@ -2203,6 +2203,24 @@ __global__ __launch_bounds__(1024) void k_match_hc_sparse(Config cfg, const uint
             over = tot > 32767u;
         };
 
+        if (tile_begin == 0 && tile_len >= 4096u && !(cfg.debug & 32u)) {
+            // Does this block compact at all?  Asked of 1,024 positions at the end of the first tile (their chains have
+            // 12 KiB of history) before anything else is spent on it: the first chain node of each -- if more than four in
+            // five searches are still open behind it (small alphabets, long chains: DNA 99 %, FASTQ and low-entropy
+            // binary 92 %; text 62 %), or one match in eight is long enough to fly over two walk segments (runs), the
+            // dense search is the cheaper way through the block, and this workgroup does it.
+            const uint32_t p = tile_len - 1024u + tid;
+            uint32_t len, dst;
+            bool over;
+            search(p, p + 5 <= n ? (uint32_t)d3[p] : 0u, 1u, len, dst, over);
+            const uint32_t n_open = (uint32_t)__syncthreads_count(!over && depth > 1u);
+            const uint32_t n_long = (uint32_t)__syncthreads_count(len >= 3u * kHsSeg);
+            if (n_open * 5u > 1024u * 4u || n_long * 8u > 1024u) {  // uniform
+                hc_dense_block(hs_lds, cfg, slab, meta_all, hc_all, d3_all, d4_all, len8_all, mbits_all, dist_all,
+                               (uint8_t *)nullptr, (uint16_t *)nullptr);
+                return;
+            }
+        }
         // ---- A: the first chain node of every position
         for (uint32_t r0 = 0; r0 < tile_len; r0 += 1024) {  // (uniform trip count: the ballots below need whole waves)
             const uint32_t r = r0 + tid, p = tile_begin + r;
@@ -2313,7 +2331,7 @@ __global__ __launch_bounds__(1024) void k_match_hc_sparse(Config cfg, const uint
             __syncthreads();
             uint32_t head = 0, tail = misc[8] < kHsList ? misc[8] : kHsList;
             exp_lap(3);
-            if (pass == 0 && misc[8] * 6u > tile_len && !(cfg.debug & 32u)) dense_rest = true;  // (uniform; misc[8] counts what did not fit too)
+            if (pass == 0 && misc[8] * 4u > tile_len && !(cfg.debug & 32u)) dense_rest = true;  // (uniform; misc[8] counts what did not fit too)
             if (dense_rest) break;
             if (tail == 0) break;  // uniform: the path holds only finished searches
             __syncthreads();       // (everybody has read the count)
