@@ -2064,16 +2064,13 @@ __global__ __launch_bounds__(1024) void k_match_hc_sparse(Config cfg, const uint
     if (n <= cfg.passthrough || st->done || cfg.lazy) return;  // uniform
     const uint8_t *in = slab + (uint64_t)b * cfg.block_size;
     static_assert(kHcLdsWords <= kHsLdsWords, "the dense search fits this kernel's LDS");
-    auto dense_instead = [&]() {  // (uniform) this block is searched the dense way, by this very workgroup
-        hc_dense_block(hs_lds, cfg, slab, meta_all, hc_all, d3_all, d4_all, len8_all, mbits_all, dist_all,
-                       (uint8_t *)nullptr, (uint16_t *)nullptr);
-    };
+    // (uniform) the block, or what is left of it, is searched the dense way by this very workgroup -- ONE call site at the
+    // end of the kernel: four inlined copies of hc_dense_block cost this kernel 52 spilled VGPRs and level 3 on text 10 %
+    bool go_dense = false, dense_whole = false;
+    uint32_t dense_from = 0;
     {   // a block that may hold an orphan match (k_hc_orphan) is not compacted
         const uint32_t first4 = n >= 9u ? (uint32_t)in[0] | (uint32_t)in[1] << 8 | (uint32_t)in[2] << 16 | (uint32_t)in[3] << 24 : 1u;
-        if (n >= 9u && ((first4 * 0x1E35A7BDu) >> 16) == 0) {  // uniform
-            dense_instead();
-            return;
-        }
+        if (n >= 9u && ((first4 * 0x1E35A7BDu) >> 16) == 0) go_dense = dense_whole = true;  // uniform
     }
     const uint16_t *d3 = d3_all + (uint64_t)b * cfg.stride;
     const uint16_t *d4 = d4_all + (uint64_t)b * cfg.stride;
@@ -2108,10 +2105,7 @@ __global__ __launch_bounds__(1024) void k_match_hc_sparse(Config cfg, const uint
             real = d != 0 && in[p] == in[p - d] && in[p + 1] == in[p - d + 1] && in[p + 2] == in[p - d + 2];
         }
         const uint32_t n_real = (uint32_t)__syncthreads_count(real);
-        if (t0 >= 4096u && n_real * 8u < 1024u && !(cfg.debug & 32u)) {  // uniform
-            dense_instead();
-            return;
-        }
+        if (t0 >= 4096u && n_real * 8u < 1024u && !(cfg.debug & 32u)) go_dense = dense_whole = true;  // uniform
     }
     // the first sub-block's min_len (calculate_min_match_len): the path is walked with it, k_parse_hc parses with it
     const uint32_t min_len = hc_calc_min_len(cfg, in, 0, n, misc, tid, 1024);
@@ -2128,7 +2122,7 @@ __global__ __launch_bounds__(1024) void k_match_hc_sparse(Config cfg, const uint
     uint32_t pf_in[kPfIn], pf_lk[kPfLk];
     uint32_t prev_win = 0, prev_ndw = 0, prev_nlw = 0;
     uint32_t entry_carry = 0;  // where the parse enters the tile (block position; uniform)
-    for (uint32_t tile_begin = 0; tile_begin < n; tile_begin += kHsTile) {
+    for (uint32_t tile_begin = 0; tile_begin < n && !go_dense; tile_begin += kHsTile) {
         const uint32_t tile_end = tile_begin + kHsTile < n ? tile_begin + kHsTile : n;
         const uint32_t tile_len = tile_end - tile_begin;
         const uint32_t n_seg = (tile_len + kHsSeg - 1) / kHsSeg;
@@ -2216,9 +2210,8 @@ __global__ __launch_bounds__(1024) void k_match_hc_sparse(Config cfg, const uint
             const uint32_t n_open = (uint32_t)__syncthreads_count(!over && depth > 1u);
             const uint32_t n_long = (uint32_t)__syncthreads_count(len >= 3u * kHsSeg);
             if (n_open * 5u > 1024u * 4u || n_long * 8u > 1024u) {  // uniform
-                hc_dense_block(hs_lds, cfg, slab, meta_all, hc_all, d3_all, d4_all, len8_all, mbits_all, dist_all,
-                               (uint8_t *)nullptr, (uint16_t *)nullptr);
-                return;
+                go_dense = dense_whole = true;
+                break;
             }
         }
         // ---- A: the first chain node of every position
@@ -2412,15 +2405,20 @@ __global__ __launch_bounds__(1024) void k_match_hc_sparse(Config cfg, const uint
             exp_lap(4);
         }
         if (dense_rest) {  // uniform
-            __syncthreads();
-            hc_dense_block(hs_lds, cfg, slab, meta_all, hc_all, d3_all, d4_all, len8_all, mbits_all, dist_all, (uint8_t *)nullptr,
-                           (uint16_t *)nullptr, tile_begin, false);
+            go_dense = true;
+            dense_from = tile_begin;
             break;
         }
         entry_carry = tile_begin + uniform(seg_exit[cur * kHsSegs + n_seg - 1]);
         // the accepted-match bits of the tile (k_parse_hc reads them); tile_begin is a multiple of 32
         for (uint32_t i = tid; i < (tile_len + 31) / 32; i += 1024) mbits_out[tile_begin / 32 + i] = mbits[i];
         exp_count(7, 1);
+    }
+    if (go_dense) {  // uniform
+        __syncthreads();
+        hc_dense_block(hs_lds, cfg, slab, meta_all, hc_all, d3_all, d4_all, len8_all, mbits_all, dist_all, (uint8_t *)nullptr,
+                       (uint16_t *)nullptr, dense_from, dense_whole);
+        if (dense_whole) return;  // (the block's state is kHcArraysDense)
     }
     if (tid == 0) {
         st->min_len = min_len;
