@@ -2068,6 +2068,7 @@ __global__ __launch_bounds__(1024) void k_match_hc_sparse(Config cfg, const uint
     // end of the kernel: four inlined copies of hc_dense_block cost this kernel 52 spilled VGPRs and level 3 on text 10 %
     bool go_dense = false, dense_whole = false;
     uint32_t dense_from = 0;
+    const bool depth_is_deep = cfg.hc_depth > 1u;
     {   // a block that may hold an orphan match (k_hc_orphan) is not compacted
         const uint32_t first4 = n >= 9u ? (uint32_t)in[0] | (uint32_t)in[1] << 8 | (uint32_t)in[2] << 16 | (uint32_t)in[3] << 24 : 1u;
         if (n >= 9u && ((first4 * 0x1E35A7BDu) >> 16) == 0) go_dense = dense_whole = true;  // uniform
@@ -2094,18 +2095,29 @@ __global__ __launch_bounds__(1024) void k_match_hc_sparse(Config cfg, const uint
     auto exp_count = [](uint32_t, uint32_t) {};
 #endif
 
-    {   // A block without matches (noise) has no chains to walk and nothing to compact: the dense kernel is the cheaper way
-        // through it.  Told from a sample of 1,024 positions of the first tile: how many have a predecessor with the same
-        // three bytes (an occupied hash3 bucket alone says little: random data fills the table by collisions).
+    {   // Does this block compact at all?  Asked of 1,024 positions of the first tile's upper half (their chains have some
+        // history), straight from memory, before anything is staged:
+        //  * noise has no chains to walk: how many samples have a predecessor with the same three bytes (an occupied hash3
+        //    bucket alone says little: random data fills the table by collisions) -- under one in eight: dense;
+        //  * small alphabets have long chains everywhere: how many samples' searches are still OPEN behind their first chain
+        //    node (a second live node follows it) -- DNA 99 %, FASTQ and low-entropy binary 92 %, text 62 %: over four in
+        //    five, nearly every token start would need the deep search and the corrections would cascade (measured before
+        //    this test: DNA + 103 %, FASTQ + 94 % against the dense kernel): dense.
+        // The dense search is then done by this very workgroup (hc_dense_block at the end of the kernel).
         const uint32_t t0 = n < kHsTile ? n : kHsTile;
-        const uint32_t p = t0 / 1024u * tid + 64u;  // (t0 >= 1024 or nothing is sampled: small blocks go the sparse way)
-        bool real = false;
-        if (t0 >= 4096u && p + 4u <= t0) {
-            const uint32_t d = d3[p];
+        const uint32_t p = t0 / 2u + t0 / 2048u * tid;  // (t0 >= 4096 or nothing is sampled: small blocks go the sparse way)
+        bool real = false, open = false;
+        if (t0 >= 4096u && p + 5u <= t0) {
+            const uint32_t d = d3[p], l1 = d4[p];
             real = d != 0 && in[p] == in[p - d] && in[p + 1] == in[p - d + 1] && in[p + 2] == in[p - d + 2];
+            if (d != 0 && l1 != 0) {
+                const uint32_t l2 = d4[p - l1];
+                open = l2 != 0 && l1 + l2 <= 32767u;
+            }
         }
-        const uint32_t n_real = (uint32_t)__syncthreads_count(real);
-        if (t0 >= 4096u && n_real * 8u < 1024u && !(cfg.debug & 32u)) go_dense = dense_whole = true;  // uniform
+        const uint32_t n_real = (uint32_t)__syncthreads_count(real), n_open = (uint32_t)__syncthreads_count(open);
+        if (t0 >= 4096u && (n_real * 8u < 1024u || (n_open * 5u > 1024u * 4u && depth_is_deep)) && !(cfg.debug & 32u))
+            go_dense = dense_whole = true;  // uniform
     }
     // the first sub-block's min_len (calculate_min_match_len): the path is walked with it, k_parse_hc parses with it
     const uint32_t min_len = hc_calc_min_len(cfg, in, 0, n, misc, tid, 1024);
@@ -2197,23 +2209,6 @@ __global__ __launch_bounds__(1024) void k_match_hc_sparse(Config cfg, const uint
             over = tot > 32767u;
         };
 
-        if (tile_begin == 0 && tile_len >= 4096u && !(cfg.debug & 32u)) {
-            // Does this block compact at all?  Asked of 1,024 positions at the end of the first tile (their chains have
-            // 12 KiB of history) before anything else is spent on it: the first chain node of each -- if more than four in
-            // five searches are still open behind it (small alphabets, long chains: DNA 99 %, FASTQ and low-entropy
-            // binary 92 %; text 62 %), or one match in eight is long enough to fly over two walk segments (runs), the
-            // dense search is the cheaper way through the block, and this workgroup does it.
-            const uint32_t p = tile_len - 1024u + tid;
-            uint32_t len, dst;
-            bool over;
-            search(p, p + 5 <= n ? (uint32_t)d3[p] : 0u, 1u, len, dst, over);
-            const uint32_t n_open = (uint32_t)__syncthreads_count(!over && depth > 1u);
-            const uint32_t n_long = (uint32_t)__syncthreads_count(len >= 3u * kHsSeg);
-            if (n_open * 5u > 1024u * 4u || n_long * 8u > 1024u) {  // uniform
-                go_dense = dense_whole = true;
-                break;
-            }
-        }
         // ---- A: the first chain node of every position
         for (uint32_t r0 = 0; r0 < tile_len; r0 += 1024) {  // (uniform trip count: the ballots below need whole waves)
             const uint32_t r = r0 + tid, p = tile_begin + r;
