@@ -2012,11 +2012,17 @@ __global__ __launch_bounds__(1024) void k_match_hc(Config cfg, const uint8_t *__
 //        libdeflate's: every token start on it has the full search's match, so the next token start is right as well.
 //   Positions OFF the path keep their first-node match in len8 / which / alt; k_parse_hc never uses them unless a later
 //   sub-block of the block needs another min_len (the path was walked with the first sub-block's) -- it then marks the
-//   block kHcArraysStale and the dense kernel goes over it before the next parse round.  Blocks that can hold an orphan
-//   match (k_hc_orphan: the first four bytes hash to hash4 bucket 0, one block in 65 thousand) and blocks without real
-//   hash3 matches (noise) are searched the dense way by this kernel's own workgroup (hc_dense_block).
-//   Measured on the 550 MiB text slab (match + parse): level 3 13.97 -> 13.20 ms, level 4 15.84 -> 14.13; level 2 (six
-//   nodes at most: too little behind the first one) stays with the dense kernel; configs[2]'s noise 37.2 -> 37.0.
+//   block kHcArraysStale and the dense kernel goes over it before the next parse round.
+//   What does not compact is searched the dense way by this kernel's own workgroup (hc_dense_block, one call site at the
+//   end): blocks that can hold an orphan match (k_hc_orphan: one in 65 thousand); blocks whose sample says "noise" (no
+//   real hash3 matches) or "open chains everywhere" (small alphabets: DNA, FASTQ, low-entropy binary -- nearly every
+//   token start would need the deep search and the corrections cascade); and, from the tile that shows it on, blocks
+//   with long matches (entries settle a segment per round) or with most token starts open after the first node.
+//   Measured (match + parse, 550 MiB text): level 3 13.97 -> 12.9-13.3 ms, level 4 15.84 -> 14.0-14.3; 256 MiB per
+//   class, whole step, against the dense kernel for every block: text - 3 ... - 9 %, repeated phrases - 10 ... - 20 %,
+//   DNA / FASTQ / low-entropy / runs / noise + 1 ... + 3 % (the sample and the way round), mixed + 5 %; before the
+//   sample and the per-tile tests existed DNA was + 103 %, FASTQ + 94 %, period-2 + 158 %.  Level 2 (six nodes at most:
+//   too little behind the first one) stays with the dense kernel.
 //   What it is bound by: a correction round is a search's latency (a dependent chain of LDS reads, a hit path in nearly
 //   every round of a full wave) with the rest of the CU idle -- half of the kernel's time for a fifth of its instructions.
 //   LDS: the window (bytes + links) of a 13,056-position tile (five per BGZF block), the tile's lengths, four bitmaps, ring.
@@ -2120,7 +2126,7 @@ __global__ __launch_bounds__(1024) void k_match_hc_sparse(Config cfg, const uint
             go_dense = dense_whole = true;  // uniform
     }
     // the first sub-block's min_len (calculate_min_match_len): the path is walked with it, k_parse_hc parses with it
-    const uint32_t min_len = hc_calc_min_len(cfg, in, 0, n, misc, tid, 1024);
+    const uint32_t min_len = go_dense ? 0u : hc_calc_min_len(cfg, in, 0, n, misc, tid, 1024);  // (uniform)
     const uint32_t nice_level = cfg.hc_nice, depth = cfg.hc_depth;
 
     auto fix_links = [](uint32_t v) {  // two links; 0 = none

@@ -46,7 +46,13 @@ def _route_cases(scale=1):
            ("hetero", hetero(260000 * scale, 35), 3) + M + (300001,),                         # min_len changes: kHcArraysStale
            ("hetero-l4", hetero(200000 * scale, 36), 4) + B + (65280,),
            ("orphan", orphan, 3) + M + (65536,),
-           ("dna", synth.make("dna", 100000 * scale, 37), 4) + B + (65280,),
+           ("dna", synth.make("dna", 100000 * scale, 37), 4) + B + (65280,),                  # open chains everywhere: the sample sends it the dense way
+           ("fastq", synth.make("fastq", 90000 * scale, 41), 3) + B + (65280,),
+           ("lowent", synth.make("lowent", 70000 * scale, 42), 3) + M + (65536,),
+           ("runs", synth.make("runs", 80000 * scale, 43), 4) + B + (65280,),                  # long matches: segments overshot, dense from that tile on
+           ("period2", synth.make("period2", 70000, 44), 3) + B + (65280,),
+           ("text-then-runs", np.concatenate([synth.make("text", 30000, 45), synth.make("runs", 40000, 46)]), 3) + B + (65280,),
+           ("text-then-dna", np.concatenate([synth.make("text", 28000, 47), synth.make("dna", 60000, 48)]), 3) + M + (131072,),
            ("short", synth.make("text", 3000, 38), 3) + B + (65280,),
            ("tile-edge", synth.make("text", 13056 * 2 + 1, 39), 3) + B + (65280,),            # k_match_hc_sparse's tile is 13,056 positions
            ("zeros", synth.make("zeros", 40000, 40), 3) + B + (65280,)]
