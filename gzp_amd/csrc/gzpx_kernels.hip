@@ -1810,15 +1810,16 @@ __device__ __forceinline__ void hc_dense_block(uint32_t *hc_lds, const Config &c
                                                uint8_t *__restrict__ len8_all, uint32_t *__restrict__ mbits_all,
                                                uint16_t *__restrict__ dist_all, uint8_t *__restrict__ lz_len_all,
                                                uint16_t *__restrict__ lz_dist_all, const uint32_t from_pos = 0xFFFFFFFFu,
-                                               const bool mark_dense = true) {
+                                               const bool mark_dense = true, const uint32_t block = 0xFFFFFFFFu) {
     // (from_pos / mark_dense: k_match_hc_sparse handing the REST of a block over -- from the tile that holds from_pos on,
-    // the arrays in front of it keep what that kernel wrote, and the block's state stays that kernel's to set)
+    // the arrays in front of it keep what that kernel wrote, and the block's state stays that kernel's to set;
+    // block: k_match_hc_stale walking the blocks of a batch with a few workgroups)
     uint32_t *in_w = hc_lds;                     // 48 KiB window of the block's bytes
     uint32_t *link_w = hc_lds + kHcInWords;      // d4 of every position in the window
     uint32_t *mbits = link_w + kHcLinkWords;
     const uint16_t *link = (const uint16_t *)link_w;
     const uint32_t tid = threadIdx.x;
-    const uint32_t b = blockIdx.x;
+    const uint32_t b = block != 0xFFFFFFFFu ? block : blockIdx.x;
     const uint32_t n = meta_all[b].n;
     HcState *st = hc_all + b;
     if (n <= cfg.passthrough || st->done) return;  // uniform
@@ -1991,6 +1992,24 @@ __global__ __launch_bounds__(1024) void k_match_hc(Config cfg, const uint8_t *__
                                                    uint16_t *__restrict__ lz_dist_all) {
     __shared__ uint32_t hc_lds[kHcLdsWords];
     hc_dense_block(hc_lds, cfg, slab, meta_all, hc_all, d3_all, d4_all, len8_all, mbits_all, dist_all, lz_len_all, lz_dist_all);
+}
+
+// The dense search for the blocks k_parse_hc marked kHcArraysStale (round 5: behind k_match_hc_sparse, between the first
+// and the second parse round) -- one in thousands, if any: a workgroup per CU walks the batch and looks at a word per
+// block, instead of a workgroup per block that leaves at once (8,835 of those with 146 KiB of LDS each took 0.28 ms of
+// level 3's 15.8 on the bench slab).
+__global__ __launch_bounds__(1024) void k_match_hc_stale(Config cfg, const uint8_t *__restrict__ slab,
+                                                         const BlockMeta *__restrict__ meta_all, HcState *__restrict__ hc_all,
+                                                         const uint16_t *__restrict__ d3_all, const uint16_t *__restrict__ d4_all,
+                                                         uint8_t *__restrict__ len8_all, uint32_t *__restrict__ mbits_all,
+                                                         uint16_t *__restrict__ dist_all, uint32_t nb) {
+    __shared__ uint32_t hc_lds[kHcLdsWords];
+    for (uint32_t b = blockIdx.x; b < nb; b += gridDim.x) {
+        if (hc_all[b].sparse != kHcArraysStale || hc_all[b].done) continue;  // uniform
+        __syncthreads();  // (the block before is done with the LDS)
+        hc_dense_block(hc_lds, cfg, slab, meta_all, hc_all, d3_all, d4_all, len8_all, mbits_all, dist_all, (uint8_t *)nullptr,
+                       (uint16_t *)nullptr, 0xFFFFFFFFu, true, b);
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -5637,7 +5656,11 @@ void launch_hc(const Config &cfg, const uint8_t *slab, uint32_t nb, const Scratc
     // first round ended at a sub-block with another min_len has arrays that are no use from there on if they came from
     // the sparse kernel (kHcArraysStale): the dense kernel goes over it before its second round.
     parse_round();
-    if (sparse) dense();
+    if (sparse) {
+        const uint32_t wgs = cfg.n_cu ? cfg.n_cu : 256u;
+        hipLaunchKernelGGL(k_match_hc_stale, dim3(nb < wgs ? nb : wgs), dim3(1024), 0, stream, cfg, slab, (const BlockMeta *)s.meta,
+                           s.hc, (const uint16_t *)s.cand, (const uint16_t *)s.d4, s.len8, s.which, s.alt, nb);
+    }
     parse_round();
     hipLaunchKernelGGL(k_parse_hc<true>, dim3(nb), dim3(kMpThreads), 0, stream, cfg, slab, s.meta, s.sub, s.hc,
                        (const uint8_t *)s.len8, (const uint32_t *)s.which, (const uint16_t *)s.alt, s.tok,
