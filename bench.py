@@ -25,6 +25,7 @@ import os
 import socket
 import subprocess
 import sys
+import threading
 import time
 
 import numpy as np
@@ -534,11 +535,15 @@ def _level_leg(env, d_in, n, level):
     ctx.close()
     dom = max(stage_acc, key=stage_acc.get)
     achieved = (n + out_len) / (max(stage_acc[dom], 1e-9) * 1e-3) / 1e9
+    # the library's stage label covers a launch GROUP; at levels 3-4 the matcher inside it is the compaction kernel
+    launches = {"k_match_hc+k_parse_hc": ("k_hc_init, k_match_hc_sparse, k_hc_orphan, k_parse_hc, k_match_hc_stale, k_parse_hc x2"
+                                          if level in (3, 4) else "k_hc_init, k_match_hc, k_hc_orphan, k_parse_hc x3")}
     res = {"MiBps": round(n / 2**20 / dt, 1), "ms_per_step": round(dt * 1e3, 3), "steps": steps,
                                "compat_in_force": compat_name,  # (levels 10-12: the 1.10 rules whatever was asked for)
                                "ratio": round(out_len / n, 4), "gpu_inflate_crc_roundtrip_ok": bool(ok),
                                "stream_sha256": sha, "verified_bit_exact_full": full_ok,
-                               "roofline": {"bound": "hbm", "kernel": dom, "kernel_ms": round(stage_acc[dom], 3),
+                               "roofline": {"bound": "hbm", "kernel": dom, "launches": launches.get(dom, dom),
+                                            "kernel_ms": round(stage_acc[dom], 3),
                                             "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                             "frac": round(achieved / HBM_PEAK_GBS, 5),
                                             "pipeline_frac": round((n + out_len) / dt / 1e9 / HBM_PEAK_GBS, 5)}}
@@ -819,6 +824,41 @@ def run_config(args, env, fmt, level, bs, kind, n, label):
     ctx.close()
 
 
+class PeerWatchdog:
+    """Bounds the peer-window leg of an N > 1 run (main()): after `seconds` rank 0 prints the line it already has, with
+    `writeouts.peer_error`, and every rank ends with exit code 0 -- a write-out that hangs on some box must not take the
+    measured RCCL figures with it."""
+
+    def __init__(self, seconds, rank, res):
+        self.seconds, self.rank, self.res = seconds, rank, res
+        self.lock, self.done = threading.Lock(), False
+        self.timer = threading.Timer(seconds, self._fire)
+        self.timer.daemon = True
+        self.timer.start()
+
+    def _fire(self):
+        with self.lock:
+            if self.done:
+                return
+            self.done = True
+        if self.res is not None:
+            self.res.setdefault("writeouts", {})["peer_error"] = (
+                "the peer-window write-out did not finish within %.0f s (watchdog; GZPX_BENCH_PEER_TIMEOUT): the line "
+                "carries the other write-outs only" % self.seconds)
+            print(json.dumps(self.res), flush=True)
+        else:
+            time.sleep(2.0)  # (rank 0 writes first)
+        os._exit(0)
+
+    def stop(self):
+        """True when the leg ended before the watchdog fired."""
+        with self.lock:
+            mine = not self.done
+            self.done = True
+        self.timer.cancel()
+        return mine
+
+
 def strong_leg(args, env, ctx, cap, gathered):
     """See main(): the metric's own slab at N GPUs.  Uses the rank's existing context (its batch holds a whole slab) and
     the weak region's gather buffer; W warm-up + K timed steps between barriers, max over ranks, the write-out of step i
@@ -971,15 +1011,9 @@ def main():
     # names (default rccl: north_star's ordered gather), then the other; the line's `value` is the faster one.
     modes = [None] if world == 1 else [args.writeout] + [m for m in ("rccl", "offsets") if m != args.writeout]
     gathered = torch.empty(cap * world, dtype=torch.uint8, device=env.dev) if (world > 1 and rank == 0) else None
-    # ... and a third one where the devices can map each other's memory: the writer's buffer IPC-mapped into every rank,
-    # every rank copies its shard to its stream offset itself (copy engines over xGMI: no RCCL kernel on any CU)
-    peer_win, peer_err = None, None
-    if world > 1 and not env.emulate:
-        try:
-            peer_win = shard.PeerWindow(cap * world, env.dev, dst=0)
-            modes.append("peer")
-        except Exception as e:  # (all ranks fail or succeed together: the handle broadcast is collective)
-            peer_err = repr(e)
+    # (a third one -- the writer's buffer IPC-mapped into every rank -- is timed LAST, behind everything else the line
+    # carries and under a watchdog: see peer_leg below)
+    peer_box = {"win": None}
     host_out = None
     if world > 1 and not env.emulate:
         host_out = [torch.empty(cap, dtype=torch.uint8).pin_memory() for _ in range(2)]
@@ -1011,7 +1045,7 @@ def main():
         if world > 1:
             wait_pending()  # the previous shard has left (it travelled while this step compressed)
             if state["writeout"] == "peer":
-                state["pending"] = peer_win.gather_start(buf[:out_len])
+                state["pending"] = peer_box["win"].gather_start(buf[:out_len])
             elif state["writeout"] == "rccl":
                 # in-order write-out: ordered variable-size gather of the shards to rank 0 (RCCL),
                 # started now and completed while the next step compresses
@@ -1063,11 +1097,6 @@ def main():
     value_mode = None if world == 1 else "rccl"
     head = regions[value_mode]
     dt, out_len, stage_acc = head["dt"], head["out_len"], head["stage_acc"]
-    # the copy-engine write-out, checked: the writer's view of the window holds the very stream the RCCL gather delivered
-    peer_same = None
-    if world > 1 and rank == 0 and "peer" in state["views"] and "rccl" in state["views"]:
-        a_, b_ = state["views"]["peer"], state["views"]["rccl"]
-        peer_same = bool(a_.numel() == b_.numel() and torch.equal(a_, b_))
     # every stage, outside the timed region (thirteen event markers per step cost the step 0.03 ms) -- under the
     # write-out `value` was measured with
     ctx.set_profiling(1)
@@ -1086,7 +1115,10 @@ def main():
     # compresses its range, the ordered RCCL gather puts the stream together on rank 0 -- 550 MiB per step whatever N is.
     # The gathered stream is compared with the libdeflate-made digest of the whole stream (tests/golden/fullsize.json).
     strong = None
+    rccl_stream = None
     if world > 1:
+        if rank == 0 and "rccl" in state["views"]:  # (the strong leg gathers into the same buffer: keep this stream for the
+            rccl_stream = state["views"]["rccl"].clone()  # comparison with the peer window's)
         strong = strong_leg(args, env, ctx, cap, gathered)
 
     ms_per_step = dt / args.steps * 1e3
@@ -1189,10 +1221,6 @@ def main():
                 for m, r in regions.items()}
             res["writeouts"]["value_is"] = value_mode if scaling == "weak" else "strong_550MiB (rccl)"
             res["writeouts"]["fastest"] = min(regions, key=lambda m: regions[m]["dt"])
-            if peer_err:
-                res["writeouts"]["peer_error"] = peer_err
-            if peer_same is not None:
-                res["writeouts"]["peer"]["window_equals_rccl_stream"] = peer_same
             res["strong_550MiB"] = strong
             for m, r in regions.items():
                 res["value_" + m] = round(total_mib / (r["dt"] / args.steps), 1)
@@ -1229,6 +1257,44 @@ def main():
                 res["cpu_baseline_parcompress"] = cpu_baseline_parcompress(slab, res["config"]["stream_sha256"])
             except Exception as e:
                 res["cpu_baseline_parcompress"] = {"error": repr(e)}
+    # N > 1, the third in-order write-out, where the devices can map each other's memory: the writer's buffer IPC-mapped
+    # into every rank, every rank copies its shard to its stream offset itself (copy engines over xGMI: no RCCL kernel on
+    # any CU).  It runs LAST and under a watchdog: the line above is complete without it, and this is the one leg that no
+    # box with a single GPU can rehearse -- if it does not finish, rank 0 prints the line it has (with `peer_error`) and
+    # every rank leaves.
+    hang_test = bool(os.environ.get("GZPX_BENCH_TEST_PEER_HANG")) and env.emulate  # (tests/test_bench_dryrun.py)
+    if world > 1 and (not env.emulate or hang_test):
+        dist.barrier()  # (rank 0 has just spent seconds checking its stream: every rank's clock starts here)
+        dog = PeerWatchdog(float(os.environ.get("GZPX_BENCH_PEER_TIMEOUT", "90")), rank, res if rank == 0 else None)
+        peer_err = None
+        try:
+            if hang_test:
+                time.sleep(3600)
+            peer_box["win"] = shard.PeerWindow(cap * world, env.dev, dst=0)
+            ctx.set_profiling(2)
+            r = timed_region("peer")
+            if rank == 0:
+                mib = round(total_mib / (r["dt"] / args.steps), 1)
+                regions["peer"] = r
+                res["writeouts"]["peer"] = {"MiBps": mib, "ms_per_step": round(r["dt"] / args.steps * 1e3, 3),
+                                            "rank_ms_per_step": r["rank_ms_per_step"],
+                                            "rank_writeout_wait_ms": r["rank_writeout_wait_ms"]}
+                res["value_peer"] = mib
+                res["writeouts"]["fastest"] = min(regions, key=lambda m: regions[m]["dt"])
+                if rccl_stream is not None and "peer" in state["views"]:  # the window holds the stream RCCL delivered
+                    a_ = state["views"]["peer"]
+                    res["writeouts"]["peer"]["window_equals_rccl_stream"] = bool(a_.numel() == rccl_stream.numel() and
+                                                                                 torch.equal(a_, rccl_stream))
+        except Exception as e:  # (PeerWindow's set-up fails on every rank or on none)
+            peer_err = repr(e)
+        if not dog.stop():  # the watchdog has fired and is writing the line: it ends the process
+            time.sleep(30)
+        if peer_err is not None:
+            if rank == 0:
+                res["writeouts"]["peer_error"] = peer_err
+                print(json.dumps(res), flush=True)
+            os._exit(0)  # (a rank that failed alone leaves the others inside a collective: nobody waits for a clean close)
+    if rank == 0:
         print(json.dumps(res))
     ctx.close()
     env.close()

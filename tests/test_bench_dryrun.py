@@ -10,8 +10,9 @@ import sys
 ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
 
 
-def _run(*extra):
+def _run(*extra, **more_env):
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(more_env)
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--emulate", "--steps", "1", "--warmup", "1",
                         "--no-cpu-baseline", "--no-extras"] + list(extra), capture_output=True, text=True, timeout=900,
                        env=env, cwd="/tmp")
@@ -48,6 +49,16 @@ def test_two_ranks_strong_scaling_is_the_value_when_asked_for():
     d = _run("--gpus", "2", "--slab-bytes", "150000", "--scaling", "strong")
     assert d["scaling"] == "strong" and d["value"] == d["strong_550MiB"]["MiBps"]
     assert d["strong_550MiB"]["verified_bit_exact_full"] is True and d["ms_per_step"] == d["strong_550MiB"]["ms_per_step"]
+
+
+def test_a_hanging_peer_window_leg_does_not_take_the_line_with_it():
+    """The IPC-window write-out is the one leg no single-GPU box can rehearse: it runs last and under a watchdog.  Here
+    the leg is made to hang on every rank: rank 0 still prints the complete line (RCCL value, strong leg) with
+    `peer_error`, every rank ends with exit code 0."""
+    d = _run("--gpus", "2", "--slab-bytes", "150000", GZPX_BENCH_TEST_PEER_HANG="1", GZPX_BENCH_PEER_TIMEOUT="3")
+    assert "did not finish within 3 s" in d["writeouts"]["peer_error"]
+    assert d["value"] == d["value_rccl"] and d["strong_550MiB"]["verified_bit_exact_full"] is True
+    assert "peer" not in d["writeouts"] and "value_peer" not in d
 
 
 def test_eight_ranks_three_blocks():
