@@ -74,7 +74,8 @@ struct HcState {
     //   0 nothing yet, or not usable: the dense k_match_hc must run (from resume_pos)
     //   1 the full search ONLY for the token starts of the greedy parse from position 0 with HcState.min_len (every other
     //     position: the search's first chain node) -- all a parse needs as long as min_len does not change
-    //   2 a later sub-block needs another min_len (k_parse_hc found out): as 0
+    //   2 a later sub-block needs another min_len (k_parse_hc found out, and listed the block for k_match_hc_stale): as 0
+    //     until that kernel has been over the block, as 3 from resume_pos on behind it (the value stays 2)
     //   3 the full search of every position (the dense kernel ran)
     uint32_t sparse;
 };

@@ -1800,6 +1800,8 @@ __device__ __forceinline__ void hc_search(const uint32_t *in_w, const uint16_t *
 // address LDS from 0 (an immediate offset, no addition per read) and the links sit within the 16-bit
 // offset field of ds_read_u16.
 constexpr uint32_t kHcLinkWords = (32768 + kHcTile) / 2;  // d4 of every position in the window (u16)
+constexpr uint32_t kHcStaleChunk = 4096;  // k_match_hc_stale's unit of work: positions of one block, within one tile
+static_assert(kHcTile % kHcStaleChunk == 0 && kHcStaleChunk % 1024 == 0, "a chunk lies in one tile and is whole strides of the workgroup");
 constexpr uint32_t kHcLdsWords = kHcInWords + kHcLinkWords + kHcTile / 32;
 
 // The dense search of one block by the calling workgroup (1024 threads), out of `hc_lds` (kHcLdsWords words at LDS address 0):
@@ -1810,10 +1812,12 @@ __device__ __forceinline__ void hc_dense_block(uint32_t *hc_lds, const Config &c
                                                uint8_t *__restrict__ len8_all, uint32_t *__restrict__ mbits_all,
                                                uint16_t *__restrict__ dist_all, uint8_t *__restrict__ lz_len_all,
                                                uint16_t *__restrict__ lz_dist_all, const uint32_t from_pos = 0xFFFFFFFFu,
-                                               const bool mark_dense = true, const uint32_t block = 0xFFFFFFFFu) {
+                                               const bool mark_dense = true, const uint32_t block = 0xFFFFFFFFu,
+                                               const uint32_t chunk_lo = 0xFFFFFFFFu) {
     // (from_pos / mark_dense: k_match_hc_sparse handing the REST of a block over -- from the tile that holds from_pos on,
     // the arrays in front of it keep what that kernel wrote, and the block's state stays that kernel's to set;
-    // block: k_match_hc_stale walking the blocks of a batch with a few workgroups)
+    // block / chunk_lo: k_match_hc_stale dealing the kHcStaleChunk-position pieces of a few blocks out to its workgroups --
+    // only the positions [chunk_lo, chunk_lo + kHcStaleChunk) of the one tile that holds them, its window from memory)
     uint32_t *in_w = hc_lds;                     // 48 KiB window of the block's bytes
     uint32_t *link_w = hc_lds + kHcInWords;      // d4 of every position in the window
     uint32_t *mbits = link_w + kHcLinkWords;
@@ -1856,8 +1860,15 @@ __device__ __forceinline__ void hc_dense_block(uint32_t *hc_lds, const Config &c
     constexpr uint32_t kPfIn = 5, kPfLk = kHcTile / 2 / 1024, kMvIn = (kHcInWords - kHcTile / 4 + 1023) / 1024, kMvLk = 32768 / 2 / 1024;
     uint32_t pf_in[kPfIn], pf_lk[kPfLk];
     uint32_t prev_win = 0, prev_ndw = 0, prev_nlw = 0;  // the window in LDS (prev_ndw = 0: none)
-    for (uint32_t tile_begin = resume / kHcTile * kHcTile; tile_begin < n; tile_begin += kHcTile) {
+    const bool chunked = chunk_lo != 0xFFFFFFFFu;
+    if (chunked && (chunk_lo >= n || chunk_lo + kHcStaleChunk <= resume)) return;  // uniform: nothing of it is parsed again
+    const uint32_t tile_first = chunked ? chunk_lo / kHcTile * kHcTile : resume / kHcTile * kHcTile;
+    const uint32_t tile_stop = chunked ? (tile_first + kHcTile < n ? tile_first + kHcTile : n) : n;  // (chunked: that one tile)
+    for (uint32_t tile_begin = tile_first; tile_begin < tile_stop; tile_begin += kHcTile) {
         const uint32_t tile_end = tile_begin + kHcTile < n ? tile_begin + kHcTile : n;
+        // the positions searched: the tile, or the chunk of it that was asked for
+        const uint32_t lo = chunked ? chunk_lo : tile_begin;
+        const uint32_t hi = chunked && chunk_lo + kHcStaleChunk < tile_end ? chunk_lo + kHcStaleChunk : tile_end;
         const uint32_t win_begin = tile_begin >= 32768u ? tile_begin - 32768u : 0;
         const uint32_t win_end = tile_end + 264 < n ? tile_end + 264 : n;
         const uint32_t mis = (uint32_t)((uintptr_t)(in + win_begin) & 3u);  // (the same for every tile: win_begin is a multiple of four)
@@ -1898,7 +1909,7 @@ __device__ __forceinline__ void hc_dense_block(uint32_t *hc_lds, const Config &c
         prev_win = win_begin;
         prev_ndw = ndw;
         prev_nlw = nlw;
-        if (tile_end < n) {  // what the next tile's window adds to this one
+        if (tile_end < tile_stop) {  // what the next tile's window adds to this one
             const uint32_t nt_end = tile_end + kHcTile < n ? tile_end + kHcTile : n;
             const uint32_t nw_begin = tile_end >= 32768u ? tile_end - 32768u : 0;
             const uint32_t nw_end = nt_end + 264 < n ? nt_end + 264 : n;
@@ -1915,15 +1926,15 @@ __device__ __forceinline__ void hc_dense_block(uint32_t *hc_lds, const Config &c
         // the hash3 distance of a lane's next position travels while it searches the current one.  (Tried: the
         // sixteen of a tile prefetched with the window, packed in eight registers that the loop shifts through, so
         // that no load is waited for inside the loop: level 9 110.5 -> 113.5 ms, the others +0.1 ... 0.4.)
-        uint32_t d3_next = tile_begin + tid + 5 <= n && tile_begin + tid < tile_end ? d3[tile_begin + tid] : 0u;
+        uint32_t d3_next = lo + tid + 5 <= n && lo + tid < hi ? d3[lo + tid] : 0u;
         __syncthreads();
         uint8_t *lzl = lz_len_all + (uint64_t)b * 2u * cfg.stride;
         uint16_t *lzd = lz_dist_all + (uint64_t)b * 2u * cfg.stride;
-        for (uint32_t p = tile_begin + tid; p < tile_end; p += 1024) {
+        for (uint32_t p = lo + tid; p < hi; p += 1024) {
             // with fewer than 5 bytes left hc_matchfinder_longest_match bails out: d3v = 0 idles the search
             const uint32_t d3v = d3_next;
             const uint32_t pn = p + 1024u;
-            d3_next = pn + 5 <= n && pn < tile_end ? d3[pn] : 0u;
+            d3_next = pn + 5 <= n && pn < hi ? d3[pn] : 0u;
             const uint32_t rem = n - p;
             const uint32_t max_len = rem < 258u ? rem : 258u;
             const uint32_t nice_len = max_len < nice_level ? max_len : nice_level;
@@ -1974,7 +1985,7 @@ __device__ __forceinline__ void hc_dense_block(uint32_t *hc_lds, const Config &c
         }
         if (cfg.lazy) continue;  // (uniform; the next tile's loads start behind a barrier)
         __syncthreads();
-        for (uint32_t i = tid; i < (tile_end - tile_begin + 31) / 32; i += 1024)
+        for (uint32_t i = (lo - tile_begin) / 32 + tid; i < (hi - tile_begin + 31) / 32; i += 1024)  // (lo: a multiple of 32)
             mbits_out[tile_begin / 32 + i] = mbits[i];
     }
     if (tid == 0 && mark_dense) st->sparse = kHcArraysDense;  // (read at the top by every thread: behind the loop's barriers)
@@ -1995,20 +2006,24 @@ __global__ __launch_bounds__(1024) void k_match_hc(Config cfg, const uint8_t *__
 }
 
 // The dense search for the blocks k_parse_hc marked kHcArraysStale (round 5: behind k_match_hc_sparse, between the first
-// and the second parse round) -- one in thousands, if any: a workgroup per CU walks the batch and looks at a word per
-// block, instead of a workgroup per block that leaves at once (8,835 of those with 146 KiB of LDS each took 0.28 ms of
-// level 3's 15.8 on the bench slab).
+// and the second parse round) -- one in thousands, if any.  k_parse_hc lists them (`stale`: count, then block indices);
+// a workgroup per CU deals the list out in pieces of kHcStaleChunk positions, so that ONE stale block is sixteen
+// workgroups' work of a few searches per thread and not one workgroup's whole block with 255 CUs idle behind it (a
+// slab of text with two stale blocks paid 0.22 ms of its 3.7 for that).  The blocks stay kHcArraysStale: a workgroup
+// that set another state here would race the ones still reading it, and no kernel behind this one asks again.
 __global__ __launch_bounds__(1024) void k_match_hc_stale(Config cfg, const uint8_t *__restrict__ slab,
                                                          const BlockMeta *__restrict__ meta_all, HcState *__restrict__ hc_all,
                                                          const uint16_t *__restrict__ d3_all, const uint16_t *__restrict__ d4_all,
                                                          uint8_t *__restrict__ len8_all, uint32_t *__restrict__ mbits_all,
-                                                         uint16_t *__restrict__ dist_all, uint32_t nb) {
+                                                         uint16_t *__restrict__ dist_all, const uint32_t *__restrict__ stale) {
     __shared__ uint32_t hc_lds[kHcLdsWords];
-    for (uint32_t b = blockIdx.x; b < nb; b += gridDim.x) {
-        if (hc_all[b].sparse != kHcArraysStale || hc_all[b].done) continue;  // uniform
-        __syncthreads();  // (the block before is done with the LDS)
+    const uint32_t per_block = (cfg.block_size + kHcStaleChunk - 1) / kHcStaleChunk;
+    const uint32_t items = stale[0] * per_block;
+    for (uint32_t item = blockIdx.x; item < items; item += gridDim.x) {
+        const uint32_t b = stale[1 + item / per_block];
+        __syncthreads();  // (the piece before is done with the LDS)
         hc_dense_block(hc_lds, cfg, slab, meta_all, hc_all, d3_all, d4_all, len8_all, mbits_all, dist_all, (uint8_t *)nullptr,
-                       (uint16_t *)nullptr, 0xFFFFFFFFu, true, b);
+                       (uint16_t *)nullptr, 0xFFFFFFFFu, false, b, (item % per_block) * kHcStaleChunk);
     }
 }
 
@@ -2051,14 +2066,24 @@ constexpr uint32_t kHsInWords = (32768 + kHsTile + 264) / 4 + 8;
 constexpr uint32_t kHsLinkWords = (32768 + kHsTile) / 2;
 constexpr uint32_t kHsSeg = 32;                      // positions per walk segment = one 32-bit mask
 constexpr uint32_t kHsSegs = kHsTile / kHsSeg;       // 408
-constexpr uint32_t kHsList = 1280;                   // ring entries (u16); what does not fit waits for the next pass.  (Measured: 2,048 entries --
-                                                     // the accepted-match bits straight to memory, their LDS given to the ring -- so that a tile's
-                                                     // first list fits: level 3 match + parse 13.20 -> 14.19 ms, pass A's two global stores per
-                                                     // wave and iteration cost more than the pass they save)
+// Ring entries (u16).  A tile's first list is 1,400-1,750 entries on text (tools/sim_hc_compact.py); what does not fit waits
+// for the next pass -- and that is not only a loss: the searches of a round are SPECULATION on the path behind the ones
+// before them, and an entry listed late is often off the path by the time its turn comes.  Measured (match + parse, ms;
+// tools/gpu_r5_ring.sh, level 3 / level 4; english_like seeds 5-9 against the dense kernel, then the bench slab):
+//   1,280:  -4.2 +6.9 -1.2 -2.7 +5.7 %   13.27 / 14.18      (the kernel's first size: two texts in five LOSE)
+//   1,536:  -4.4 -1.1 -3.8 -4.2 -0.6 %   13.19 / 14.08      <- every text gains, at level 4 by 8-12 %
+//   1,792:  -3.6 -1.6 -2.7 -2.8 -0.5 %   13.37 / 14.36
+//   2,096:  -0.6 +3.3 -0.3 +0.4 +3.0 %   13.83 / 14.88      (the whole first list in one round: a third of it wasted)
+// (Before the exits were u16, at 1,280: 2,048 entries with the accepted-match bits straight to memory and their LDS given
+// to the ring -- 13.20 -> 14.19 ms, put down to pass A's global stores then; the table says the ring's size did its share.)
+#ifndef GZPX_HS_LIST
+#define GZPX_HS_LIST 1536  // (A/B builds: tools/gpu_r5_ring.sh)
+#endif
+constexpr uint32_t kHsList = GZPX_HS_LIST;
 constexpr uint32_t kHsSerial = 128;                  // a list this short: its lanes search what they run into themselves
-constexpr uint32_t kHsLdsWords = kHsInWords + kHsLinkWords + kHsTile / 4 + 4 * kHsSegs + 2 * kHsSegs + kHsList / 2 + 16;
+constexpr uint32_t kHsLdsWords = kHsInWords + kHsLinkWords + kHsTile / 4 + 4 * kHsSegs + kHsSegs + kHsList / 2 + 16;
 static_assert(kHsLdsWords * 4 <= 160 * 1024, "k_match_hc_sparse: one workgroup's LDS");
-static_assert(kHsTile % 256 == 0 && kHsSegs <= 1024, "tile geometry");
+static_assert(kHsTile % 256 == 0 && kHsSegs <= 1024 && kHsTile + 600 < 0xFFFF, "tile geometry (exits are u16; 0xFFFF is the poison)");
 
 __global__ __launch_bounds__(1024) void k_match_hc_sparse(Config cfg, const uint8_t *__restrict__ slab,
                                                           const BlockMeta *__restrict__ meta_all,
@@ -2076,8 +2101,8 @@ __global__ __launch_bounds__(1024) void k_match_hc_sparse(Config cfg, const uint
     uint32_t *mbf = mbits + kHsSegs;                 // ... and is long enough for the sub-block's min_len: the walk's mask
     uint32_t *fin = mbf + kHsSegs;                   // the position's search is over: its match is the full search's
     uint32_t *marks = fin + kHsSegs;                 // a token starts here (the current walk)
-    uint32_t *seg_exit = marks + kHsSegs;            // [2][kHsSegs] where the walk leaves segment s (tile-relative)
-    uint32_t *list_w = seg_exit + 2 * kHsSegs;       // u16 tile-relative positions to search
+    uint16_t *seg_exit = (uint16_t *)(marks + kHsSegs);  // [2][kHsSegs] where the walk leaves segment s (tile-relative, u16; 0xFFFF: walk again)
+    uint32_t *list_w = marks + 2 * kHsSegs;          // u16 tile-relative positions to search
     uint32_t *misc = list_w + kHsList / 2;           // [0..7] hc_calc_min_len's census, [8] the ring's tail
     const uint16_t *link = (const uint16_t *)link_w;
     uint8_t *len_l = (uint8_t *)len_w;
@@ -2296,7 +2321,7 @@ __global__ __launch_bounds__(1024) void k_match_hc_sparse(Config cfg, const uint
         uint32_t entry = tid == 0 ? entry_carry - tile_begin : seg_begin;
         uint32_t my_exit = active ? walk_seg(tid, entry) : 0u;
         uint32_t cur = 0;
-        if (active) seg_exit[tid] = my_exit;
+        if (active) seg_exit[tid] = (uint16_t)my_exit;
         // Two kinds of input do not compact, and the first walk of a tile tells (measured, 256 MiB per class, level 3 against
         // the dense kernel: DNA + 103 %, FASTQ + 94 %, low-entropy binary + 93 %, period-2 + 158 %, byte runs + 13 % before
         // this test; text - 4 %, repeated phrases - 11 %):
@@ -2321,7 +2346,7 @@ __global__ __launch_bounds__(1024) void k_match_hc_sparse(Config cfg, const uint
                     my_exit = walk_seg(tid, entry);
                 }
                 cur ^= 1u;
-                if (active) seg_exit[cur * kHsSegs + tid] = my_exit;
+                if (active) seg_exit[cur * kHsSegs + tid] = (uint16_t)my_exit;
                 if (!__syncthreads_or(changed)) break;
             }
             exp_lap(2);
@@ -2388,7 +2413,7 @@ __global__ __launch_bounds__(1024) void k_match_hc_sparse(Config cfg, const uint
                         }
                     }
                     if (step == old_step) break;
-                    seg_exit[(cur ^ 1u) * kHsSegs + (r >> 5)] = 0xFFFFFFFFu;  // the segment walks again in the next pass
+                    seg_exit[(cur ^ 1u) * kHsSegs + (r >> 5)] = 0xFFFFu;  // the segment walks again in the next pass
                     uint32_t q = r + step;
                     for (uint32_t hop = 0; hop < 16u && q < tile_len; hop++) {
                         const uint32_t qb = 1u << (q & 31u);
@@ -2421,7 +2446,7 @@ __global__ __launch_bounds__(1024) void k_match_hc_sparse(Config cfg, const uint
             __syncthreads();
             if (tid == 0) misc[8] = 0;
             // ---- D: segments with a new length walk again (their exit in the copy nobody reads was poisoned)
-            if (active) dirty = seg_exit[(cur ^ 1u) * kHsSegs + tid] == 0xFFFFFFFFu;
+            if (active) dirty = seg_exit[(cur ^ 1u) * kHsSegs + tid] == 0xFFFFu;
             exp_lap(4);
         }
         if (dense_rest) {  // uniform
@@ -2572,7 +2597,7 @@ __global__ __launch_bounds__(kMpThreads, GZPX_PHC_WAVES) void k_parse_hc(
     Config cfg, const uint8_t *__restrict__ slab, BlockMeta *__restrict__ meta_all,
     SubMeta *__restrict__ sub_all, HcState *__restrict__ hc_all, const uint8_t *__restrict__ len8_all,
     const uint32_t *__restrict__ mbits_all, const uint16_t *__restrict__ val_all,
-    uint32_t *__restrict__ tok_all, uint32_t *__restrict__ pending) {
+    uint32_t *__restrict__ tok_all, uint32_t *__restrict__ pending, uint32_t *__restrict__ stale) {
     __shared__ uint32_t len8_w[kHpTile / 4];
     __shared__ unsigned long long tok_bits[kHpGroups];  // 1 = a token starts here (tile-relative)
     __shared__ unsigned long long mb[kHpGroups];        // 1 = k_match_hc's match here is long enough for min_len
@@ -3027,7 +3052,11 @@ __global__ __launch_bounds__(kMpThreads, GZPX_PHC_WAVES) void k_parse_hc(
                 if (tid == 0) {
                     // (round 5) arrays that hold the full search for ONE min_len's token starts only are no use from
                     // here on: the dense k_match_hc goes over the block from bp before the next round parses it
-                    if (st->sparse == kHcArraysPath) st->sparse = kHcArraysStale;
+                    // (`stale`: their list for k_match_hc_stale -- count, then block indices; Scratch.redo, idle at these levels)
+                    if (st->sparse == kHcArraysPath) {
+                        st->sparse = kHcArraysStale;
+                        stale[1u + atomicAdd(&stale[0], 1u)] = b;
+                    }
                     st->min_len = new_min_len;
                     st->resume_pos = bp;
                     st->tok_carry = bti;
@@ -5637,7 +5666,7 @@ void launch_hc(const Config &cfg, const uint8_t *slab, uint32_t nb, const Scratc
     auto parse_round = [&]() {
         hipLaunchKernelGGL(k_parse_hc<false>, dim3(nb), dim3(kMpThreads), 0, stream, cfg, slab, s.meta, s.sub, s.hc,
                            (const uint8_t *)s.len8, (const uint32_t *)s.which, (const uint16_t *)s.alt, s.tok,
-                           s.pending);
+                           s.pending, s.redo);
     };
     // Round 5: the full search only where the greedy parse starts a token (k_match_hc_sparse).  Config.debug bit 4: the
     // dense kernel for every block, as in rounds 2-4 (A/B runs and the tests that compare the two routes).
@@ -5656,15 +5685,16 @@ void launch_hc(const Config &cfg, const uint8_t *slab, uint32_t nb, const Scratc
     // first round ended at a sub-block with another min_len has arrays that are no use from there on if they came from
     // the sparse kernel (kHcArraysStale): the dense kernel goes over it before its second round.
     parse_round();
-    if (sparse) {
+    if (sparse) {  // (the list of stale blocks is Scratch.redo: zeroed by the batch's first k_candidates launch, filled by the round above)
         const uint32_t wgs = cfg.n_cu ? cfg.n_cu : 256u;
-        hipLaunchKernelGGL(k_match_hc_stale, dim3(nb < wgs ? nb : wgs), dim3(1024), 0, stream, cfg, slab, (const BlockMeta *)s.meta,
-                           s.hc, (const uint16_t *)s.cand, (const uint16_t *)s.d4, s.len8, s.which, s.alt, nb);
+        hipLaunchKernelGGL(k_match_hc_stale, dim3(wgs), dim3(1024), 0, stream, cfg, slab, (const BlockMeta *)s.meta,
+                           s.hc, (const uint16_t *)s.cand, (const uint16_t *)s.d4, s.len8, s.which, s.alt,
+                           (const uint32_t *)s.redo);
     }
     parse_round();
     hipLaunchKernelGGL(k_parse_hc<true>, dim3(nb), dim3(kMpThreads), 0, stream, cfg, slab, s.meta, s.sub, s.hc,
                        (const uint8_t *)s.len8, (const uint32_t *)s.which, (const uint16_t *)s.alt, s.tok,
-                       s.pending);
+                       s.pending, s.redo);
 }
 
 void launch_lazy(const Config &cfg, const uint8_t *slab, uint32_t nb, const Scratch &s, hipStream_t stream) {

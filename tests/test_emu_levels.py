@@ -26,6 +26,7 @@ def _three_routes(lib, oracle, cases):
     searches noise and orphan-candidate blocks the dense way itself; the dense kernel at level 2), the dense kernel for
     every block (Config.debug bit 4: rounds 2-4's path) and the sparse kernel forced on every block at every greedy level,
     noise included (bit 5) -- one stream, the oracle's."""
+    stale = {}  # blocks k_parse_hc listed for k_match_hc_stale (Scratch.redo's count at these levels), per case and route
     for name, a, level, fmt, ofmt, bs in cases:
         want = oracle.compress_stream(a, ofmt, level, oracle.COMPAT_1_24, bs)
         for flags in (0, 16, 32):
@@ -33,6 +34,8 @@ def _three_routes(lib, oracle, cases):
                                  max_slab_bytes=max(a.size, 1)) as c:
                 c.debug_set_flags(flags)
                 assert c.compress_slab(a, True) == want, (name, level, flags)
+                stale[(name, flags)] = c.debug_redo_count()
+    return stale
 
 
 def _route_cases(scale=1):
@@ -60,7 +63,10 @@ def _route_cases(scale=1):
 
 
 def test_greedy_levels_by_every_route(emu_lib, oracle):
-    _three_routes(emu_lib, oracle, _route_cases())
+    stale = _three_routes(emu_lib, oracle, _route_cases())
+    # the path through k_match_hc_stale (a sub-block with another min_len behind a compacted start) is really taken ...
+    assert stale[("hetero", 0)] + stale[("hetero", 32)] + stale[("hetero-l4", 0)] + stale[("hetero-l4", 32)] >= 3, stale
+    assert not any(v for (_, flags), v in stale.items() if flags == 16), stale  # ... and never behind the dense kernel
 
 
 def test_golden_raw_deflate_levels(emu_lib, golden_hc):

@@ -14,6 +14,7 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import sim_hc_wave as W  # noqa: E402  (its tables and trace(); prints its own summary on import)
 
 N, data, d3, d4 = W.N, W.data, W.d3, W.d4
+TILE = int(os.environ.get("SIM_HC_TILE", "13056"))  # k_match_hc_sparse's tile
 
 
 def first_node(depth0, nice):
@@ -41,8 +42,8 @@ def main():
           % (level, 100.0 * (l1 == lf).mean(), 100.0 * (~unfinished).mean()))
     entry, tot_rounds, tot_search, tot_wrounds, tot_tok = 0, 0, 0, 0, 0
     dense_wrounds = sum(max(len(t) for t in traces[w:w + 64]) for w in range(0, N, 64))
-    for t0 in range(0, N, 16384):
-        t1 = min(N, t0 + 16384)
+    for t0 in range(0, N, TILE):
+        t1 = min(N, t0 + TILE)
         L = l1.copy()
         done = ~unfinished
         rounds = 0
@@ -64,7 +65,7 @@ def main():
         entry = exit_pos
     print("level %d: %d tiles, %d rounds in all, %d compacted searches for %d tokens (%.1f %% of the positions); "
           "wave-rounds of the compacted walks %d vs %d dense (beyond the first node: %d)"
-          % (level, (N + 16383) // 16384, tot_rounds, tot_search, tot_tok, 100.0 * tot_search / N, tot_wrounds, dense_wrounds,
+          % (level, (N + TILE - 1) // TILE, tot_rounds, tot_search, tot_tok, 100.0 * tot_search / N, tot_wrounds, dense_wrounds,
              dense_wrounds - (N + 63) // 64))
 
 

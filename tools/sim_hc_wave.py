@@ -27,6 +27,9 @@ from gzp_amd import synth
 
 N = 65280
 data = bytes(synth.text_slab(N * 3, seed=20250927)[N:2 * N])
+if os.environ.get("SIM_HC_DATA"):  # another input for the model: "<class>:<seed>" of gzp_amd.synth, e.g. text:6
+    _cls, _seed = os.environ["SIM_HC_DATA"].split(":")
+    data = bytes(synth.make(_cls, N * 3, int(_seed))[N:2 * N])
 
 
 def le32(i):
