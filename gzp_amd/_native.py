@@ -397,7 +397,9 @@ class Context:
         self.lib.check(self.lib.L.gzpx_debug_set_flags(self.h, flags))
 
     def debug_redo_count(self):
-        """Level 1: blocks of the last batch that k_mparse handed back to the dense kernels."""
+        """Level 1: blocks of the last batch that k_mparse handed back to the dense kernels.  Levels 2-4 (round 5: the same
+        scratch list serves them): blocks that k_parse_hc listed for k_match_hc_stale -- a sub-block with another min_len
+        behind a start that k_match_hc_sparse compacted."""
         c = ctypes.c_uint32(0)
         self.lib.check(self.lib.L.gzpx_debug_redo_count(self.h, ctypes.byref(c)))
         return c.value
