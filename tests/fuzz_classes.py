@@ -13,6 +13,10 @@ CPU) and tests/test_gpu_fuzz_slice.py (the MI355X):
                           the 8,192nd match of level 1 (deflate_compress_fastest's sequence store), the 50,000th of
                           levels 2-9 (SEQ_STORE_LENGTH) -- so that the token behind the last match, the trailing
                           literals and the end of the buffer meet in every order
+  unlike_segments(rng, n) / stale_path_slice(lib, oracle, rng, cases)
+                          (round 5) blocks of unlike segments back to back -- text, DNA, noise, runs ... 300 bytes to 70 KB
+                          each: should_end_block splits them and the split-off sub-block needs another min_len, which
+                          behind a start that k_match_hc_sparse compacted sends the block through k_match_hc_stale
 """
 import os
 import sys
@@ -97,3 +101,41 @@ def full_sub_block_cuts(rng, level, oracle, deltas=(-3, -1, 0, 1, 2, 3, 4, 5, 9,
         if p is not None:
             return [np.ascontiguousarray(a[:p + d]) for d in deltas if 0 < p + d <= a.size]
     raise AssertionError("no buffer filled a sub-block at level %d" % level)
+
+
+_SEGMENT_CLASSES = ["dna", "random", "text", "zeros", "lowent", "fastq", "ascii", "runs", "repeats", "period2"]
+
+
+def unlike_segments(rng, n):
+    from gzp_amd import synth
+    parts, size = [], 0
+    short = rng.random() < 0.4
+    while size < n:
+        ln = int(rng.integers(300, 9000)) if short else int(rng.integers(3000, 70000))
+        parts.append(synth.make(_SEGMENT_CLASSES[rng.integers(len(_SEGMENT_CLASSES))], ln, int(rng.integers(1 << 30))))
+        size += ln
+    return np.ascontiguousarray(np.concatenate(parts)[:n])
+
+
+def stale_path_slice(lib, oracle, rng, cases, block_sizes=(65536, 131072, 300001, 1 << 20), max_n=1_300_000):
+    """`cases` random streams of unlike segments through `lib` (the emulated or the real library) at levels 2-4 -- the
+    default route, and k_match_hc_sparse forced on every block (Config.debug bit 5; always at level 2) -- BGZF and Mgzip,
+    both compat rules, the whole stream against the oracle.  Returns (blocks, blocks that went through k_match_hc_stale)."""
+    from gzp_amd import _native
+    blocks = stale = 0
+    for it in range(cases):
+        bgzf = rng.random() < 0.5
+        bs = 65280 if bgzf else int(rng.choice(list(block_sizes)))
+        n = int(rng.integers(bs // 2, min(3 * bs, max_n)))
+        a = unlike_segments(rng, n)
+        level = int(rng.choice([3, 3, 4, 2]))
+        flags = 32 if level == 2 or rng.random() < 0.4 else 0
+        compat = _native.COMPAT_1_24 if rng.random() < 0.7 else _native.COMPAT_1_10
+        fmt, ofmt = (_native.FORMAT_BGZF, oracle.FMT_BGZF) if bgzf else (_native.FORMAT_MGZIP, oracle.FMT_MGZIP)
+        with _native.Context(format=fmt, level=level, buffer_size=bs, compat=compat, lib=lib, max_slab_bytes=n) as c:
+            c.debug_set_flags(flags)
+            got = c.compress_slab(a, True)
+            stale += c.debug_redo_count()
+        assert got == oracle.compress_stream(a, ofmt, level, compat, bs), (it, level, flags, bs, n, compat)
+        blocks += (n + bs - 1) // bs
+    return blocks, stale

@@ -69,6 +69,15 @@ def test_greedy_levels_by_every_route(emu_lib, oracle):
     assert not any(v for (_, flags), v in stale.items() if flags == 16), stale  # ... and never behind the dense kernel
 
 
+def test_blocks_of_unlike_segments_take_the_stale_path(emu_lib, oracle):
+    """A short slice of tests/fuzz_classes.stale_path_slice through the emulated kernels (the MI355X runs the long one,
+    tests/test_gpu_fuzz_slice.py; tools/emu_fuzz_stale.py is the open-ended hunt)."""
+    import fuzz_classes as fc
+    blocks, stale = fc.stale_path_slice(emu_lib, oracle, np.random.default_rng(20260928), 10, block_sizes=(65536, 131072),
+                                        max_n=200_000)
+    assert blocks >= 10 and stale >= 3, (blocks, stale)
+
+
 def test_golden_raw_deflate_levels(emu_lib, golden_hc):
     comps = {L: _native.Compressor(L, _native.COMPAT_1_10, lib=emu_lib) for L in (0, 2, 3, 4)}
     for e in golden_hc["raw_deflate"]:

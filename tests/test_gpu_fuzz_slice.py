@@ -71,6 +71,16 @@ def test_sub_blocks_that_fill_up_exactly(hip_lib, oracle):
     _raw_vs_oracle(hip_lib, oracle, cases)
 
 
+def test_blocks_of_unlike_segments_take_the_stale_path(hip_lib, oracle):
+    """Round 5: streams of unlike segments back to back (text, DNA, noise, runs ...), levels 2-4 by the default and the
+    forced-sparse route, blocks of 64 KiB ... 1 MiB: a split-off sub-block with another min_len behind a compacted start
+    sends the block through k_match_hc_stale (its pieces dealt out to every CU) -- the whole stream against the oracle."""
+    import numpy as np
+    import fuzz_classes as fc
+    blocks, stale = fc.stale_path_slice(hip_lib, oracle, np.random.default_rng(20260929), 250)
+    assert blocks >= 250 and stale >= 60, (blocks, stale)
+
+
 def test_regression_soft_limit_boundary_on_a_tile_edge(hip_lib, oracle):
     # found by the soak in round 1: a sub-block that starts on the first position of a 64 KiB parse
     # tile ends (65535-byte soft limit) on the tile's last position

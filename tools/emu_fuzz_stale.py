@@ -17,17 +17,9 @@ import build_emu
 from gzp_amd import _native, synth
 from oracle import oracle
 
-NAMES = ["dna", "random", "text", "zeros", "lowent", "fastq", "ascii", "runs", "repeats", "period2"]
+import fuzz_classes  # noqa: E402  (tests/: the committed generator)
 
-
-def segments(rng, n):
-    parts, size = [], 0
-    short = rng.random() < 0.4
-    while size < n:
-        ln = int(rng.integers(300, 9000)) if short else int(rng.integers(3000, 70000))
-        parts.append(synth.make(NAMES[rng.integers(len(NAMES))], ln, int(rng.integers(1 << 30))))
-        size += ln
-    return np.ascontiguousarray(np.concatenate(parts)[:n])
+segments = fuzz_classes.unlike_segments
 
 
 def main():
