@@ -55,6 +55,19 @@ def pmc_traffic(kernel, build_id=None):
         return None
 
 
+def pmc_traffic_bounds(kernel, build_id=None):
+    """(low, high, why) where the FETCH_SIZE correction is not calibrated for the kernel's access pattern (k_inflate's
+    gathers: tools/summarize_profiles.py), else None -- same build rule as pmc_traffic."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+            doc = json.load(f)
+        if build_id is not None and doc.get("build_id") != build_id:
+            return None
+        return doc.get("hbm_bytes_per_launch_bounds", {}).get(kernel)
+    except Exception:
+        return None
+
+
 def pmc_traffic_source(build_id):
     try:
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
@@ -394,7 +407,8 @@ def run_inflate(args, env, emit=True, d_stream=None, comp_host=None, slab=None, 
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 5),
-                "traffic": pmc_traffic("k_inflate", env.lib.build_id()),
+                "traffic": pmc_traffic("k_inflate", env.lib.build_id()),  # (the x2-corrected FETCH_SIZE: an upper bound here)
+                "traffic_bounds": pmc_traffic_bounds("k_inflate", env.lib.build_id()),
                 "issue": issue_roofline("k_inflate", kern_ms, env.lib.build_id(), "bench.py --workload inflate"),
                 "kernel_ms": round(kern_ms, 3),
             },
