@@ -38,6 +38,7 @@ COMPAT_1_24 = 0
 COMPAT_1_10 = 1
 STREAM_NONE = ctypes.c_void_p(-1).value  # GZPX_STREAM_NONE: the caller has synchronized, no stream dependency
 N_STAGES = 9
+INFLATE_SEG, INFLATE_WAVE = 0, 1
 
 EXPORTS = [
     "gzpx_config_default", "gzpx_ctx_create", "gzpx_ctx_destroy", "gzpx_slab_bound",
@@ -55,7 +56,7 @@ EXPORTS = [
     "gzpx_decompress_blocks_wait", "gzpx_alloc_decompressor", "gzpx_deflate_decompress",
     "gzpx_free_decompressor", "gzpx_pard_create", "gzpx_pard_read", "gzpx_pard_destroy",
     "gzpx_pard_last_error", "gzpx_host_alloc", "gzpx_host_free", "gzpx_dctx_last_inflate_ms",
-    "gzpx_debug_inflate", "gzpx_synth_fastq_device", "gzpx_synth_ascii_device",
+    "gzpx_debug_inflate", "gzpx_dctx_set_route", "gzpx_dctx_last_redo_count", "gzpx_synth_fastq_device", "gzpx_synth_ascii_device",
     "gzpx_ctx_active_compat", "gzpx_build_id", "gzpx_multi_create", "gzpx_multi_destroy", "gzpx_multi_devices", "gzpx_multi_compress_slab",
     "gzpx_multi_shard", "gzpx_multi_compress_slab_device",
 ]
@@ -225,6 +226,10 @@ class GzpxLib:
         L.gzpx_dctx_last_inflate_ms.argtypes = [vp, ctypes.POINTER(ctypes.c_float)]
         L.gzpx_debug_inflate.restype = i32
         L.gzpx_debug_inflate.argtypes = [vp, i32, ctypes.POINTER(ctypes.c_uint64)]
+        L.gzpx_dctx_set_route.restype = i32
+        L.gzpx_dctx_set_route.argtypes = [vp, i32]
+        L.gzpx_dctx_last_redo_count.restype = i32
+        L.gzpx_dctx_last_redo_count.argtypes = [vp, ctypes.POINTER(ctypes.c_uint32)]
         L.gzpx_synth_fastq_device.restype = i32
         L.gzpx_synth_fastq_device.argtypes = [vp, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint64, vp]
         L.gzpx_multi_create.restype = i32
@@ -661,8 +666,18 @@ class DContext:
         self.lib.check(self.lib.L.gzpx_dctx_last_inflate_ms(self.h, ctypes.byref(ms)))
         return ms.value
 
+    def set_route(self, route):
+        """INFLATE_SEG (default): k_inflate_seg + k_lzcopy, hand-backs to k_inflate; INFLATE_WAVE: k_inflate for every member."""
+        self.lib.check(self.lib.L.gzpx_dctx_set_route(self.h, int(route)))
+
+    def last_redo_count(self):
+        """Members of the last launch that the decode / copy pair handed to k_inflate."""
+        n = ctypes.c_uint32(0)
+        self.lib.check(self.lib.L.gzpx_dctx_last_redo_count(self.h, ctypes.byref(n)))
+        return n.value
+
     def debug_inflate(self, enable):
-        """Switch the instrumented k_inflate on/off; returns the counters of the last launch."""
+        """Switch the instrumented inflate kernels on/off; returns the counters of the last launch."""
         c = (ctypes.c_uint64 * 8)()
         self.lib.check(self.lib.L.gzpx_debug_inflate(self.h, int(enable), c))
         return list(c)

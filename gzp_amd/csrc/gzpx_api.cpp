@@ -1351,8 +1351,10 @@ struct DSlot {
     uint64_t *h_total = nullptr;  // pinned
     uint8_t *d_in = nullptr, *d_out = nullptr;
     size_t d_in_cap = 0, d_out_cap = 0;
+    InflateScratch sc;  // match records / tile table of k_inflate_seg + k_lzcopy; sc.redo lives with the block tables
+    size_t mlist_cap = 0, tfirst_cap = 0;
     hipEvent_t ev_h2d = nullptr, ev_kernels = nullptr, ev_done = nullptr;
-    hipEvent_t ev_t0 = nullptr, ev_t1 = nullptr;  // around k_inflate (timing enabled)
+    hipEvent_t ev_t0 = nullptr, ev_t1 = nullptr;  // around the inflate kernels (timing enabled)
     size_t nb = 0;
 };
 
@@ -1366,6 +1368,8 @@ void dslot_free_tables(DSlot &c) {
     if (c.h_crc) (void)hipHostFree(c.h_crc);
     if (c.h_offsets) (void)hipHostFree(c.h_offsets);
     if (c.h_sizes) (void)hipHostFree(c.h_sizes);
+    if (c.sc.redo) (void)hipFree(c.sc.redo);
+    c.sc.redo = nullptr;
     c.d_offsets = c.d_out_off = nullptr;
     c.d_sizes = c.d_crc = nullptr;
     c.d_blk = c.h_blk = nullptr;
@@ -1391,6 +1395,7 @@ int dslot_reserve(DSlot &c, size_t nb) {
     HIP_TRY(hipMalloc((void **)&c.d_sizes, cap * 4));
     HIP_TRY(hipMalloc((void **)&c.d_crc, cap * 4));
     HIP_TRY(hipMalloc((void **)&c.d_blk, cap * sizeof(DBlockHost)));
+    HIP_TRY(hipMalloc((void **)&c.sc.redo, (cap + 1) * 4));
     HIP_TRY(hipHostMalloc((void **)&c.h_blk, cap * sizeof(DBlockHost), hipHostMallocDefault));
     HIP_TRY(hipHostMalloc((void **)&c.h_crc, cap * 4, hipHostMallocDefault));
     HIP_TRY(hipHostMalloc((void **)&c.h_offsets, cap * 8, hipHostMallocDefault));
@@ -1410,6 +1415,7 @@ struct gzpx_dctx {
     DSlot slots[kSlots];
     uint64_t next_gen = 1;
     bool debug = false;
+    int route = kInflateRouteSeg;  // GZPX_INFLATE_ROUTE=wave / gzpx_dctx_set_route: k_inflate for every member
     int last_slot = -1;  // the slot of the last completed launch (timing / debug counters)
     size_t last_nb = 0;
     std::mutex mu;
@@ -1494,8 +1500,25 @@ int dsubmit_enqueue(gzpx_dctx *c, const uint8_t *host_in, const uint8_t *d_in, s
         HIP_TRY(hipMemcpyAsync(sl.d_sizes, sl.h_sizes, nb * 4, hipMemcpyHostToDevice, c->s_h2d));
         HIP_TRY(hipEventRecord(sl.ev_h2d, c->s_h2d));
         HIP_TRY(hipStreamWaitEvent(stream, sl.ev_h2d, 0));
+        if (c->route == kInflateRouteSeg) {  // scratch of the decode / copy pair, sized by what the caller can take
+            const size_t need_m = inflate_mlist_bytes(out_cap, nb), need_t = inflate_tfirst_bytes(out_cap, nb);
+            if (need_m > sl.mlist_cap) {
+                if (sl.sc.mlist) (void)hipFree(sl.sc.mlist);
+                sl.sc.mlist = nullptr;
+                sl.mlist_cap = 0;
+                HIP_TRY(hipMalloc(&sl.sc.mlist, need_m + need_m / 8));
+                sl.mlist_cap = need_m + need_m / 8;
+            }
+            if (need_t > sl.tfirst_cap) {
+                if (sl.sc.tfirst) (void)hipFree(sl.sc.tfirst);
+                sl.sc.tfirst = nullptr;
+                sl.tfirst_cap = 0;
+                HIP_TRY(hipMalloc((void **)&sl.sc.tfirst, need_t + need_t / 8));
+                sl.tfirst_cap = need_t + need_t / 8;
+            }
+        }
         launch_inflate(hdr_len, d_in, sl.d_offsets, sl.d_sizes, (uint32_t)nb, sl.d_blk, sl.d_out_off, d_out, out_cap,
-                       sl.d_crc, c->cc, c->debug, sl.ev_t0, sl.ev_t1, stream);
+                       sl.d_crc, c->cc, c->debug, sl.ev_t0, sl.ev_t1, stream, sl.sc, c->route);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipMemcpyAsync(sl.h_blk, sl.d_blk, nb * sizeof(DBlockHost), hipMemcpyDeviceToHost, stream));
         HIP_TRY(hipMemcpyAsync(sl.h_crc, sl.d_crc, nb * 4, hipMemcpyDeviceToHost, stream));
@@ -1588,6 +1611,8 @@ int gzpx_dctx_create(int device, int format, gzpx_dctx **out) {
     if (!c) return GZPX_ERR_DEVICE;
     c->device = device;
     c->format = format;
+    if (const char *e = getenv("GZPX_INFLATE_ROUTE"))
+        if (!strcmp(e, "wave")) c->route = kInflateRouteWave;
     for (unsigned l = 0; l < 10; l++) c->cc.pow64[l] = x2k(9 + l);
     c->cc.pow_tile = x2k(19);
     c->cc.pow_small = x2k(17);
@@ -1613,6 +1638,8 @@ void gzpx_dctx_destroy(gzpx_dctx *c) {
         if (sl.h_total) (void)hipHostFree(sl.h_total);
         if (sl.d_in) (void)hipFree(sl.d_in);
         if (sl.d_out) (void)hipFree(sl.d_out);
+        if (sl.sc.mlist) (void)hipFree(sl.sc.mlist);
+        if (sl.sc.tfirst) (void)hipFree(sl.sc.tfirst);
         for (hipEvent_t e : {sl.ev_h2d, sl.ev_kernels, sl.ev_done, sl.ev_t0, sl.ev_t1})
             if (e) (void)hipEventDestroy(e);
     }
@@ -1859,6 +1886,23 @@ int gzpx_dctx_last_inflate_ms(gzpx_dctx *ctx, float *ms) {
     if (!ctx->last_nb || ctx->last_slot < 0) return GZPX_OK;
     const DSlot &sl = ctx->slots[ctx->last_slot];
     return hipEventElapsedTime(ms, sl.ev_t0, sl.ev_t1) == hipSuccess ? GZPX_OK : GZPX_ERR_DEVICE;
+}
+
+int gzpx_dctx_set_route(gzpx_dctx *ctx, int route) {
+    if (!ctx || (route != GZPX_INFLATE_SEG && route != GZPX_INFLATE_WAVE)) return GZPX_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> g(ctx->mu);
+    ctx->route = route == GZPX_INFLATE_WAVE ? kInflateRouteWave : kInflateRouteSeg;
+    return GZPX_OK;
+}
+
+int gzpx_dctx_last_redo_count(gzpx_dctx *ctx, uint32_t *count) {
+    if (!ctx || !count) return GZPX_ERR_INVALID_ARG;
+    *count = 0;
+    std::lock_guard<std::mutex> g(ctx->mu);
+    if (ctx->last_slot < 0 || !ctx->slots[ctx->last_slot].sc.redo || ctx->route != kInflateRouteSeg) return GZPX_OK;
+    if (hipSetDevice(ctx->device) != hipSuccess) return GZPX_ERR_DEVICE;
+    if (hipMemcpy(count, ctx->slots[ctx->last_slot].sc.redo, 4, hipMemcpyDeviceToHost) != hipSuccess) return GZPX_ERR_DEVICE;
+    return GZPX_OK;
 }
 
 int gzpx_debug_inflate(gzpx_dctx *ctx, int enable, uint64_t sums[8]) {

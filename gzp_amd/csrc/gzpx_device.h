@@ -163,12 +163,22 @@ void launch_emit(const Config &cfg, const uint8_t *slab, uint64_t slab_len, uint
 // ParDecompress side: one record per block (filled by k_dinit / k_inflate)
 struct DBlockHost {
     uint64_t in_off;
-    uint32_t size, isize, crc, status, produced, pad;
+    uint32_t size, isize, crc, status, produced, nmatch;
     uint32_t cyc[8];  // debug launches: see DBlock in gzpx_kernels.hip
 };
+// Scratch of the two-kernel inflate (gzpx_inflate_seg.h): the members' match records, the first record of every
+// 32 KiB output tile, and the list of members handed back to k_inflate ([0] = how many).
+struct InflateScratch {
+    void *mlist = nullptr;       // inflate_mlist_bytes(out_cap, nb)
+    uint32_t *tfirst = nullptr;  // inflate_tfirst_bytes(out_cap, nb)
+    uint32_t *redo = nullptr;    // [1 + nb]
+};
+enum { kInflateRouteSeg = 0, kInflateRouteWave = 1 };  // k_inflate_seg + k_lzcopy (default) | k_inflate for every member
+size_t inflate_mlist_bytes(uint64_t out_cap, uint64_t nb);
+size_t inflate_tfirst_bytes(uint64_t out_cap, uint64_t nb);
 void launch_inflate(uint32_t hdr_len, const uint8_t *d_in, const uint64_t *d_offsets, const uint32_t *d_sizes,
                     uint32_t nb, void *d_blk, uint64_t *d_out_off, uint8_t *d_out, uint64_t out_cap,
                     uint32_t *d_crc_found, const CrcConsts &cc, bool debug, hipEvent_t ev_begin,
-                    hipEvent_t ev_end, hipStream_t stream);
+                    hipEvent_t ev_end, hipStream_t stream, const InflateScratch &sc, int route);
 
 }  // namespace gzpx

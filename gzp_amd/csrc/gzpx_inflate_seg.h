@@ -1,0 +1,946 @@
+// gzpx_inflate_seg.h -- the two-kernel form of ParDecompress's decode_block (src/par/decompress.rs:162-186,
+// src/bgzf.rs:151-170: libdeflate_deflate_decompress of one member).  Included by gzpx_kernels.hip inside
+// namespace gzpx, behind k_inflate (whose DBlock and status codes it shares).
+//
+//   k_inflate_seg  Huffman decode only: bitstream -> literal bytes in place + a list of (position, length,
+//                  distance) records; it never reads the window.  One wave per member.  The bits of a DEFLATE
+//                  block are cut into 64 segments, one per lane; every lane decodes ITS segment serially from
+//                  a speculative start (pass 1), lane i then replays from lane i-1's exit beside its own
+//                  speculative path until the two meet (pass 2: a DEFLATE stream re-synchronises after ~100
+//                  bits, so this is short), a prefix sum of the byte / match counts gives every lane its
+//                  output offsets, and the lanes decode their segment once more from the true entry (pass 3),
+//                  storing literals at their final place and matches in the member's record list.
+//                  The symbol step is straight-line code: two-level tables (no slow path), positional reads of
+//                  the lane's own compressed dwords from a lane-private LDS ring that is refilled for all
+//                  lanes at once, 256 bits at a time (no per-lane memory instruction inside the loop).
+//   k_lzcopy       one workgroup per member: the member's output (literals in place, holes where matches go)
+//                  is staged through a 64 KiB LDS ring, 32 KiB tiles behind a 32 KiB window; matches are
+//                  resolved one per lane, 256 at a time in list order, in rounds against a "byte is final"
+//                  bitmap; finished tiles go back to HBM in 16-byte stores.
+//
+// Anything out of the ordinary on the true path (invalid codes, a distance before the start, output that does
+// not fit, a stream that ends early, lanes that do not re-synchronise) is NOT judged here: the member is put
+// on the redo list and k_inflate, which holds libdeflate's exact error classes, decodes it again.
+
+constexpr uint32_t kInfRedo = 0x80u;     // DBlock.status while a member waits for k_inflate
+constexpr uint32_t kSegMinBits = 512u;   // segment length per lane: remaining bits / 64, within these bounds
+constexpr uint32_t kSegMaxBits = 8192u;
+constexpr uint32_t kSegMaxFix = 6u;      // pass-2 iterations before the member is handed to k_inflate
+constexpr uint32_t kSegWinDw = 8u;       // dwords per refill window (256 bits of every lane's stream)
+constexpr uint32_t kSegRingStride = 17u; // dwords per lane in the ring: 16 + a copy of slot 0 behind slot 15 (odd: no bank conflicts)
+constexpr uint32_t kSegLRoot = 10u, kSegORoot = 8u, kSegPRoot = 7u;  // root bits of the litlen / offset / precode tables
+constexpr uint32_t kSegLSub = 320u, kSegOSub = 160u;  // second-level entries (ENOUGH(288,10,15) - 1024 = 310, (32,8,15): 146)
+constexpr uint32_t kLzTile = 32768u;     // k_lzcopy: tile = window = 32 KiB (members <= 64 KiB: one tile, no window)
+
+struct __attribute__((aligned(8))) LzMatch {
+    uint32_t pos;       // first output byte, relative to the member's output
+    uint32_t len_dist;  // length << 16 | distance (1..32768)
+};
+
+// Table entries (32 bit).  bits 0-3: codeword length; 0 = a pointer (bits 12-15: index bits of the second level,
+// bits 16-31: its first entry) or, all zero, an unused codeword.
+//   litlen:  bits 4-5 type (0 literal, 1 length, 2 end of block, 3 invalid symbol), bits 8-10 extra bits (0 unless a
+//            length), bits 16-24 the literal byte or the base length;
+//   offset:  bit 4 invalid symbol, bits 8-11 extra bits, bits 16-31 base distance;
+//   precode: bits 16-20 the symbol.
+enum SegKind { kSegLitlen = 0, kSegOffset = 1, kSegPrecode = 2 };
+template <int KIND>
+__device__ __forceinline__ uint32_t seg_entry(uint32_t sym, uint32_t cl) {
+    if (KIND == kSegPrecode) return cl | (sym << 16);
+    if (KIND == kSegLitlen) {
+        if (sym < 256) return cl | (sym << 16);
+        if (sym == 256) return cl | (2u << 4);
+        if (sym > 285) return cl | (3u << 4);
+        const uint32_t slot = sym - 257;
+        uint32_t base, xb = 0;
+        if (slot < 8) {
+            base = 3 + slot;
+        } else if (slot == 28) {
+            base = 258;
+        } else {
+            xb = (slot - 4) >> 2;
+            base = 3 + ((4 + (slot & 3)) << xb);
+        }
+        return cl | (1u << 4) | (xb << 8) | (base << 16);
+    }
+    if (sym > 29) return cl | (1u << 4);
+    uint32_t base, xb = 0;
+    if (sym < 4) {
+        base = 1 + sym;
+    } else {
+        xb = (sym - 2) >> 1;
+        base = 1 + ((2 + (sym & 1)) << xb);
+    }
+    return cl | (xb << 8) | (base << 16);
+}
+
+struct InfSegLds {
+    uint32_t lfast[1u << kSegLRoot];  // (its first 416 bytes double as code-length scratch + staged header while a header is parsed)
+    uint32_t lsub[kSegLSub];
+    uint32_t ofast[1u << kSegORoot];  // (and the 7-bit precode table)
+    uint32_t osub[kSegOSub];
+    uint32_t ring[64 * kSegRingStride];  // every lane's own compressed dwords: lane i at [i * 17 + ((dword - first dword) & 15)]
+    uint16_t cw[320];                 // builder scratch: the symbols' codewords (LSB first)
+    uint8_t lens[320];                // code lengths: litlen then offset
+    uint32_t first[16];               // builder scratch: first canonical code of every length
+    uint32_t alloc;                   // builder scratch: next free second-level entry
+};
+
+// Build the two-level decode table of one code from lens[0 .. nsyms) (nsyms <= 320): `root` index bits in
+// main[], longer codewords behind pointer entries in sub[] (sub[0] stays 0: where unused codewords land).  All 64
+// lanes call it.  Returns false for an over-subscribed code or a second level that does not fit.
+template <int KIND>
+__device__ __attribute__((noinline)) bool seg_build(InfSegLds &h, const uint8_t *lens, uint32_t nsyms, uint32_t root, uint32_t *main,
+                                       uint32_t *sub, uint32_t sub_cap, uint32_t lane) {
+    const uint64_t lane_below = (1ull << lane) - 1ull;
+    const uint32_t rounds = (nsyms + 63) >> 6;
+    uint32_t cnt[16];
+#pragma unroll
+    for (uint32_t l = 0; l < 16; l++) cnt[l] = 0;
+    for (uint32_t r = 0; r < rounds; r++) {
+        const uint32_t s = 64 * r + lane;
+        const uint32_t myl = s < nsyms ? lens[s] : 0;
+#pragma unroll
+        for (uint32_t l = 1; l <= 15; l++) cnt[l] += (uint32_t)__popcll(__ballot(myl == l));
+    }
+    uint32_t code = 0, kraft = 0;
+    wave_sync();
+#pragma unroll
+    for (uint32_t l = 1; l <= 15; l++) {
+        code <<= 1;
+        if (lane == 0) h.first[l] = code;
+        code += cnt[l];
+        kraft += cnt[l] << (15 - l);
+    }
+    if (kraft > (1u << 15)) return false;
+    for (uint32_t i = lane; i < (1u << root); i += 64) main[i] = 0;
+    if (sub)
+        for (uint32_t i = lane; i < sub_cap; i += 64) sub[i] = 0;
+    if (lane == 0) h.alloc = 1;
+    wave_sync();
+    // codewords by rank among the symbols of the same length; short ones fill main[], long ones leave their
+    // length at main[first `root` bits] (the longest of the group stays: the size of its second level)
+    uint32_t run[16];
+#pragma unroll
+    for (uint32_t l = 0; l < 16; l++) run[l] = 0;
+    for (uint32_t r = 0; r < rounds; r++) {
+        const uint32_t s = 64 * r + lane;
+        const uint32_t myl = s < nsyms ? lens[s] : 0;
+        uint32_t rank = 0;
+#pragma unroll
+        for (uint32_t l = 1; l <= 15; l++) {
+            const uint64_t m = __ballot(myl == l);
+            if (myl == l) rank = run[l] + (uint32_t)__popcll(m & lane_below);
+            run[l] += (uint32_t)__popcll(m);
+        }
+        if (myl) {
+            const uint32_t cw = __brev(h.first[myl] + rank) >> (32 - myl);
+            h.cw[s] = (uint16_t)cw;
+            if (myl <= root) {
+                const uint32_t e = seg_entry<KIND>(s, myl);
+                for (uint32_t k = cw; k < (1u << root); k += 1u << myl) main[k] = e;
+            } else {
+                atomicMax(&main[cw & ((1u << root) - 1u)], myl);
+            }
+        }
+    }
+    wave_sync();
+    if (cnt[11] + cnt[12] + cnt[13] + cnt[14] + cnt[15] + (root < 10 ? cnt[9] + cnt[10] : 0u) + (root < 8 ? cnt[8] : 0u) == 0)
+        return true;  // (nothing beyond the root: the usual precode / offset code)
+    if (!sub) return false;
+    bool fits = true;
+    for (uint32_t i = lane; i < (1u << root); i += 64) {
+        const uint32_t v = main[i];
+        if (v > root && v <= 15u) {  // (an entry of a short codeword has a length <= root in these bits, or more bits set)
+            const uint32_t sb = v - root;
+            const uint32_t base = atomicAdd(&h.alloc, 1u << sb);
+            if (base + (1u << sb) > sub_cap) fits = false;
+            main[i] = (base << 16) | (sb << 12);
+        }
+    }
+    if (__ballot(!fits)) return false;
+    wave_sync();
+    for (uint32_t r = 0; r < rounds; r++) {
+        const uint32_t s = 64 * r + lane;
+        const uint32_t myl = s < nsyms ? lens[s] : 0;
+        if (myl > root) {
+            const uint32_t cw = h.cw[s];
+            const uint32_t p = main[cw & ((1u << root) - 1u)];
+            const uint32_t base = p >> 16, sb = (p >> 12) & 15u;
+            const uint32_t e = seg_entry<KIND>(s, myl);
+            for (uint32_t k = cw >> root; k < (1u << sb); k += 1u << (myl - root)) sub[base + k] = e;
+        }
+    }
+    wave_sync();
+    return true;
+}
+
+// ---- the lane's compressed bits: relative positions (bit 0 = bit 0 of the lane's first dword `w0`), 32 bits at a time
+struct SegWin {
+    const uint32_t *pay32;
+    uint32_t last_w;  // last readable dword of the member
+    uint32_t *rl;     // the lane's 17 ring dwords
+    uint32_t w0;      // payload dword at relative bit 0
+};
+__device__ __forceinline__ dword4 seg_load16(const SegWin &s, uint32_t w) {
+    dword4 v;
+    if (w + 3 <= s.last_w) {
+        v = *(const dword4 *)(s.pay32 + w);
+    } else {  // (the last dwords of a member: clamped, bits past the payload never count)
+        v.x = s.pay32[w < s.last_w ? w : s.last_w];
+        v.y = s.pay32[w + 1 < s.last_w ? w + 1 : s.last_w];
+        v.z = s.pay32[w + 2 < s.last_w ? w + 2 : s.last_w];
+        v.w = s.pay32[w + 3 < s.last_w ? w + 3 : s.last_w];
+    }
+    return v;
+}
+// window k (relative dwords 8k .. 8k+7) into its half of the ring
+__device__ __forceinline__ void seg_win_put(const SegWin &s, uint32_t k, const dword4 &a, const dword4 &b) {
+    uint32_t *d = s.rl + 8u * (k & 1u);
+    d[0] = a.x;
+    d[1] = a.y;
+    d[2] = a.z;
+    d[3] = a.w;
+    d[4] = b.x;
+    d[5] = b.y;
+    d[6] = b.z;
+    d[7] = b.w;
+    if ((k & 1u) == 0) s.rl[16] = a.x;
+}
+__device__ __forceinline__ void seg_win_load(const SegWin &s, uint32_t k, dword4 &a, dword4 &b) {
+    a = seg_load16(s, s.w0 + 8u * k);
+    b = seg_load16(s, s.w0 + 8u * k + 4u);
+}
+// 32 bits from relative bit position rp (inside the two resident windows)
+__device__ __forceinline__ uint32_t seg_bits(const SegWin &s, uint32_t rp) {
+    const uint32_t *d = s.rl + ((rp >> 5) & 15u);
+    return __builtin_amdgcn_alignbit(d[1], d[0], rp & 31u);
+}
+
+// One symbol at relative position rp, straight-line.  kind: 0 literal (val = the byte), 1 match (val = length << 16 |
+// distance), 2 end of block, 3 invalid; `used` = its bits (0 for an invalid one), `outlen` = bytes it produces.
+__device__ __forceinline__ void seg_sym(const InfSegLds &h, const SegWin &s, uint32_t rp, uint32_t &kind, uint32_t &val,
+                                        uint32_t &used, uint32_t &outlen) {
+    const uint32_t b = seg_bits(s, rp);
+    uint32_t e = h.lfast[b & ((1u << kSegLRoot) - 1u)];
+    {
+        const uint32_t sb = (e >> 12) & 15u;
+        const uint32_t e2 = h.lsub[(e >> 16) + ((b >> kSegLRoot) & ((1u << sb) - 1u))];  // (a plain entry: sb = 0, index <= 258)
+        e = (e & 15u) ? e : e2;
+    }
+    const uint32_t cl = e & 15u, type = (e >> 4) & 3u, xb = (e >> 8) & 7u;
+    const uint32_t lv = (e >> 16) + ((b >> cl) & ((1u << xb) - 1u));  // the byte, or the length
+    const uint32_t u1 = cl + xb;  // <= 20
+    const uint32_t b2 = seg_bits(s, rp + u1);
+    uint32_t oe = h.ofast[b2 & ((1u << kSegORoot) - 1u)];
+    {
+        const uint32_t sb = (oe >> 12) & 15u;
+        const uint32_t idx = ((oe & 15u) ? 0u : (oe >> 16)) + ((b2 >> kSegORoot) & ((1u << sb) - 1u));
+        const uint32_t oe2 = h.osub[idx];
+        oe = (oe & 15u) ? oe : oe2;
+    }
+    const uint32_t dcl = oe & 15u, dxb = (oe >> 8) & 15u;
+    const uint32_t dist = (oe >> 16) + ((b2 >> dcl) & ((1u << dxb) - 1u));
+    const bool is_len = type == 1u;
+    const bool bad = cl == 0 || type == 3u || (is_len && (dcl == 0 || (oe & 16u)));
+    kind = bad ? 3u : type;
+    used = bad ? 0u : is_len ? u1 + dcl + dxb : cl;
+    val = is_len ? (lv << 16) | dist : lv;
+    outlen = bad || type == 2u ? 0u : is_len ? lv : 1u;
+}
+
+__device__ __forceinline__ void seg_redo(DBlock *blk, uint32_t *redo, uint32_t b, uint32_t lane) {
+    if (lane == 0) {
+        blk->status = kInfRedo;
+        const uint32_t slot = atomicAdd(&redo[0], 1u);
+        redo[1 + slot] = b;
+    }
+}
+
+#ifndef GZPX_SEG_WAVES
+#define GZPX_SEG_WAVES 3
+#endif
+
+// DBlock.cyc of a debug launch: [0] whole member, [1] headers + tables, [2] pass 1, [3] pass 2, [4] pass 3,
+// counts [5] spans, [6] pass-2 iterations, [7] symbol steps of passes 1 and 3 (wave iterations)
+template <bool DBG>
+__global__ __launch_bounds__(64, GZPX_SEG_WAVES) void k_inflate_seg(uint32_t hdr_len, const uint8_t *__restrict__ in_all,
+                                                                   DBlock *__restrict__ blk_all,
+                                                                   const uint64_t *__restrict__ out_off, uint8_t *out_all,
+                                                                   uint64_t out_cap, LzMatch *__restrict__ mlist_all,
+                                                                   uint32_t *__restrict__ tfirst_all,
+                                                                   uint32_t *__restrict__ redo) {
+    __shared__ InfSegLds h;
+    const uint32_t lane = threadIdx.x;
+    const uint32_t b = blockIdx.x;
+    DBlock *blk = blk_all + b;
+    const uint32_t isize = blk->isize;
+    if (lane == 0) blk->nmatch = 0;
+    if (isize == 0) return;  // src/par/decompress.rs:163-171: nothing to decode
+    const uint64_t ooff = out_off[b];
+    if (ooff + isize > out_cap) {
+        if (lane == 0) blk->status = kInfInsufficientSpace;
+        return;
+    }
+    uint8_t *out = out_all + ooff;
+    const uint8_t *pay = in_all + blk->in_off + hdr_len;
+    const uint32_t pay_len = blk->size - hdr_len - 8;
+    LzMatch *ml = mlist_all + (ooff / 3u + b);
+    uint32_t *tf = tfirst_all + ((ooff >> 15) + 2ull * b);
+    const bool multi = isize > 65536u;
+    if (multi && lane == 0) tf[0] = 0;
+    const long long t_begin = DBG ? clock64() : 0;
+    uint32_t dbg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+
+    const uint32_t pmis = (uint32_t)((uintptr_t)pay & 3u);
+    const uint32_t *pay32 = (const uint32_t *)(pay - pmis);
+    const uint32_t pay_words = (pmis + pay_len + 8 + 3) >> 2;  // the 8 footer bytes are readable too
+    const uint32_t last_w = pay_words - 1;
+    const uint32_t bit0 = 8u * pmis, bit_end = bit0 + 8u * pay_len;
+    const uint64_t lane_below = (1ull << lane) - 1ull;
+    SegWin win;
+    win.pay32 = pay32;
+    win.last_w = last_w;
+    win.rl = h.ring + lane * kSegRingStride;
+    win.w0 = 0;
+
+    uint32_t *hdr_w = h.lfast + 128;  // 96 staged dwords of a block header (lfast[0..80) is the code-length scratch)
+    uint32_t hbase = 0;
+    auto hbits = [&](uint32_t p) -> uint32_t {
+        const uint32_t w = (p >> 5) - hbase;
+        return __builtin_amdgcn_alignbit(hdr_w[w + 1], hdr_w[w], p & 31u);
+    };
+
+    uint32_t bp = bit0, o = 0, mtot = 0;
+    bool final_block = false, bad = false;
+    while (!final_block && !bad) {
+        bp = uniform(bp);
+        o = uniform(o);
+        mtot = uniform(mtot);
+        if (bp + 3 > bit_end) {
+            bad = true;
+            break;
+        }
+        const long long t_hdr = DBG ? clock64() : 0;
+        wave_sync();
+        hbase = bp >> 5;
+        {
+            const uint32_t w0 = hbase + lane, w1 = hbase + 64 + lane;
+            hdr_w[lane] = pay32[w0 < last_w ? w0 : last_w];
+            if (lane < 32) hdr_w[64 + lane] = pay32[w1 < last_w ? w1 : last_w];
+        }
+        wave_sync();
+        const uint32_t hb = uniform(hbits(bp));
+        final_block = (hb & 1u) != 0;
+        const uint32_t btype = (hb >> 1) & 3u;
+        bp += 3;
+        if (btype == 0) {
+            // stored: LEN, NLEN, raw bytes straight from the payload to their place (final bytes, like literals)
+            bp = (bp + 7u) & ~7u;
+            if (bp + 32 > bit_end) {
+                bad = true;
+                break;
+            }
+            const uint32_t x = uniform(hbits(bp));
+            const uint32_t len = x & 0xFFFFu, nlen = x >> 16;
+            bp += 32;
+            const uint32_t src = (bp - bit0) >> 3;
+            if ((len ^ 0xFFFFu) != nlen || src + len > pay_len || o + len > isize) {
+                bad = true;
+                break;
+            }
+            const uint8_t *sp = pay + src;
+            uint8_t *dp = out + o;
+            uint32_t head = (uint32_t)((4u - ((uintptr_t)dp & 3u)) & 3u);
+            if (head > len) head = len;
+            if (lane < head) dp[lane] = sp[lane];
+            const uint32_t nw = (len - head) >> 2;
+            const uint32_t smis = (uint32_t)((uintptr_t)(sp + head) & 3u);
+            const uint32_t *s32 = (const uint32_t *)(sp + head - smis);
+            for (uint32_t k = lane; k < nw; k += 64) {
+                const uint32_t lo = s32[k], hi = smis ? s32[k + 1] : 0u;  // (hi: inside the member, the footer follows)
+                *(uint32_t *)(dp + head + 4 * k) = __builtin_amdgcn_alignbyte(hi, lo, smis);
+            }
+            const uint32_t donew = head + 4 * nw;
+            if (donew + lane < len) dp[donew + lane] = sp[donew + lane];
+            if (multi && lane == 0)
+                for (uint32_t k = (o >> 15) + 1; k <= ((o + len) >> 15); k++) tf[k] = mtot;
+            o += len;
+            bp += 8u * len;
+            continue;
+        }
+        if (btype == 3) {
+            bad = true;
+            break;
+        }
+        // ---- code lengths
+        if (btype == 1) {
+            for (uint32_t i = lane; i < 320; i += 64)
+                h.lens[i] = (uint8_t)(i < 144 ? 8 : i < 256 ? 9 : i < 280 ? 7 : i < 288 ? 8 : 5);
+            wave_sync();
+        } else {
+            const uint32_t nlit = ((hb >> 3) & 31u) + 257, ndist = ((hb >> 8) & 31u) + 1;
+            const uint32_t nclen = ((hb >> 13) & 15u) + 4;
+            bp += 14;
+            if (nlit > 286 + 2 || ndist > 32) {
+                bad = true;
+                break;
+            }
+            {
+                const uint8_t order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+                const uint32_t v = hbits(bp + 3u * (lane < 19 ? lane : 0)) & 7u;
+                if (lane < 19) h.lens[order[lane]] = (uint8_t)(lane < nclen ? v : 0u);
+            }
+            bp += 3u * nclen;
+            wave_sync();
+            if (!seg_build<kSegPrecode>(h, h.lens, 19, kSegPRoot, h.ofast, nullptr, 0, lane)) {
+                bad = true;
+                break;
+            }
+            uint32_t i = 0;
+            const uint32_t total = nlit + ndist;
+            uint32_t prev = 0;
+            uint8_t *tmp = (uint8_t *)h.lfast;  // 320 bytes of scratch in front of the staged header
+            while (i < total) {
+                if (bp - 32u * hbase > 96u * 32u - 64u) {  // (a header never needs this much: garbage)
+                    bad = true;
+                    break;
+                }
+                const uint32_t bb = uniform(hbits(bp));
+                const uint32_t e = uniform(h.ofast[bb & 127u]);
+                const uint32_t cl = e & 15u, sym = e >> 16;
+                if (cl == 0) {
+                    bad = true;
+                    break;
+                }
+                uint32_t rep = 1, val = sym, used = cl;
+                if (sym == 16) {
+                    if (i == 0) {
+                        bad = true;
+                        break;
+                    }
+                    rep = 3 + ((bb >> cl) & 3u);
+                    used += 2;
+                    val = prev;
+                } else if (sym == 17) {
+                    rep = 3 + ((bb >> cl) & 7u);
+                    used += 3;
+                    val = 0;
+                } else if (sym == 18) {
+                    rep = 11 + ((bb >> cl) & 127u);
+                    used += 7;
+                    val = 0;
+                }
+                bp += used;
+                if (i + rep > total) {
+                    bad = true;
+                    break;
+                }
+                if (lane < rep) tmp[i + lane] = (uint8_t)val;
+                if (lane + 64 < rep) tmp[i + lane + 64] = (uint8_t)val;
+                if (lane + 128 < rep) tmp[i + lane + 128] = (uint8_t)val;
+                prev = val;
+                i += rep;
+            }
+            if (bad) break;
+            wave_sync();
+            uint8_t mine[5];
+            for (uint32_t k = 0; k < 5; k++) {
+                const uint32_t s = lane + 64 * k;
+                uint32_t v = 0;
+                if (s < 288) v = s < nlit ? tmp[s] : 0;
+                else if (s < 320) v = (s - 288) < ndist ? tmp[nlit + (s - 288)] : 0;
+                mine[k] = (uint8_t)v;
+            }
+            wave_sync();
+            for (uint32_t k = 0; k < 5; k++) h.lens[lane + 64 * k] = mine[k];
+            wave_sync();
+            if (h.lens[256] == 0) {
+                bad = true;
+                break;
+            }
+        }
+        if (!seg_build<kSegLitlen>(h, h.lens, 288, kSegLRoot, h.lfast, h.lsub, kSegLSub, lane) ||
+            !seg_build<kSegOffset>(h, h.lens + 288, 32, kSegORoot, h.ofast, h.osub, kSegOSub, lane)) {
+            bad = true;
+            break;
+        }
+        if (DBG) dbg[1] += (uint32_t)(clock64() - t_hdr);
+
+        // ---- the block's symbols, one span of 64 segments after the other until its end-of-block code
+        bool eob = false;
+        while (!eob && !bad) {
+            bp = uniform(bp);
+            o = uniform(o);
+            mtot = uniform(mtot);
+            if (bp >= bit_end) {  // no end-of-block code before the payload's end
+                bad = true;
+                break;
+            }
+            if (DBG) dbg[5]++;
+            const uint32_t rem = bit_end - bp;
+            uint32_t S = (((rem + 63u) >> 6) + 31u) & ~31u;
+            S = S < kSegMinBits ? kSegMinBits : S > kSegMaxBits ? kSegMaxBits : S;
+            const uint32_t my_start = bp + lane * S;
+            win.w0 = my_start >> 5;
+            const uint32_t rel0 = 32u * win.w0;           // absolute position of relative bit 0
+            const uint32_t r_start = my_start - rel0;      // 0..31
+            const uint32_t r_end = r_start + S;            // the segment's end, relative
+            const uint32_t nwin = (S + 31u + 32u * kSegWinDw - 1u) / (32u * kSegWinDw);  // windows that cover any lane's segment
+            const bool has_data = my_start < bit_end;
+            // ---- pass 1: from the speculative start (lane 0: the true one) to the segment's end
+            const long long t_p1 = DBG ? clock64() : 0;
+            uint32_t rp = r_start, n1 = 0, m1 = 0, fl1 = has_data ? 0u : 2u;  // fl: 0 runs / ran through, 1 end of block, 2 invalid / no data
+            {
+                dword4 a0, b0, a1, b1;
+                seg_win_load(win, 0, a0, b0);
+                seg_win_load(win, 1, a1, b1);
+                wave_sync();
+                seg_win_put(win, 0, a0, b0);
+                seg_win_put(win, 1, a1, b1);
+                wave_sync();
+                for (uint32_t k = 0; k < nwin; k++) {
+                    dword4 na, nb;
+                    if (k + 2 < nwin + 1) seg_win_load(win, k + 2, na, nb);
+                    const uint32_t wend = 32u * kSegWinDw * (k + 1);
+                    const uint32_t lim = r_end < wend ? r_end : wend;
+                    while (__ballot(fl1 == 0 && rp < lim)) {
+                        uint32_t kind, val, used, outlen;
+                        seg_sym(h, win, rp, kind, val, used, outlen);
+                        const bool go = fl1 == 0 && rp < lim;
+                        rp += go ? used : 0u;
+                        n1 += go ? outlen : 0u;
+                        m1 += (go && kind == 1u) ? 1u : 0u;
+                        fl1 = (go && kind >= 2u) ? kind - 1u : fl1;
+                        if (DBG) dbg[7]++;
+                    }
+                    if (k + 2 < nwin + 1) {
+                        wave_sync();
+                        seg_win_put(win, k + 2, na, nb);
+                        wave_sync();
+                    }
+                }
+            }
+            const uint32_t exit1 = rel0 + rp;
+            if (DBG) dbg[2] += (uint32_t)(clock64() - t_p1);
+            // ---- pass 2: the true entries.  Lane i enters where lane i - 1 leaves; it replays from there beside
+            // its speculative path until the two meet (then the rest of pass 1 holds) or its segment ends.
+            const long long t_p2 = DBG ? clock64() : 0;
+            uint32_t entry = my_start, ex = exit1, nn = n1, mm = m1, fl = fl1;
+            uint32_t iters = 0;
+            for (;;) {
+                uint32_t new_entry = (uint32_t)__shfl_up((int)ex, 1);
+                if (lane == 0) new_entry = bp;
+                const uint64_t stopped = __ballot(fl != 0);
+                const bool dead = (stopped & lane_below) != 0;
+                const bool need = !dead && new_entry != entry;
+                if (__ballot(need) == 0) break;
+                if (++iters > kSegMaxFix) {
+                    bad = true;
+                    break;
+                }
+                // both replays run in the lane's relative coordinates, window by window like pass 1
+                uint32_t a = new_entry - rel0, bq = r_start, na = 0, ma = 0, nb2 = 0, mb = 0, fa = 0, fb = has_data ? 0u : 2u;
+                bool synced = false, done = !need;
+                dword4 a0, b0, a1, b1;
+                seg_win_load(win, 0, a0, b0);
+                seg_win_load(win, 1, a1, b1);
+                wave_sync();
+                seg_win_put(win, 0, a0, b0);
+                seg_win_put(win, 1, a1, b1);
+                wave_sync();
+                for (uint32_t k = 0; k < nwin; k++) {
+                    dword4 wa, wb;
+                    if (k + 2 < nwin + 1) seg_win_load(win, k + 2, wa, wb);
+                    const uint32_t wend = 32u * kSegWinDw * (k + 1);
+                    for (;;) {
+                        // whose turn: the replay from the true entry (a) unless the speculative one (b) is behind it
+                        const bool a_fin = fa != 0 || a >= r_end;
+                        const bool b_fin = fb != 0 || bq >= r_end;
+                        if (!done && a_fin) done = true;
+                        if (!done && !b_fin && a == bq) {
+                            synced = true;
+                            done = true;
+                        }
+                        const bool step_a = b_fin || a < bq;
+                        const uint32_t p = step_a ? a : bq;
+                        const bool go = !done && p < wend;
+                        if (__ballot(go) == 0) break;
+                        uint32_t kind, val, used, outlen;
+                        seg_sym(h, win, go ? p : r_start, kind, val, used, outlen);
+                        const uint32_t f = kind >= 2u ? kind - 1u : 0u;
+                        if (go && step_a) {
+                            a += used;
+                            na += outlen;
+                            ma += kind == 1u ? 1u : 0u;
+                            fa = f;
+                        }
+                        if (go && !step_a) {
+                            bq += used;
+                            nb2 += outlen;
+                            mb += kind == 1u ? 1u : 0u;
+                            fb = f;
+                        }
+                    }
+                    if (__ballot(!done) == 0) break;
+                    if (k + 2 < nwin + 1) {
+                        wave_sync();
+                        seg_win_put(win, k + 2, wa, wb);
+                        wave_sync();
+                    }
+                }
+                if (need) {
+                    if (synced) {
+                        ex = exit1;
+                        nn = n1 - nb2 + na;
+                        mm = m1 - mb + ma;
+                        fl = fl1;
+                    } else {
+                        ex = rel0 + a;
+                        nn = na;
+                        mm = ma;
+                        fl = fa;
+                    }
+                    entry = new_entry;
+                }
+            }
+            if (DBG) {
+                dbg[3] += (uint32_t)(clock64() - t_p2);
+                dbg[6] += iters;
+            }
+            if (bad) break;
+            // ---- what the span holds: live lanes up to the first one that stopped
+            const uint64_t stopped = __ballot(fl != 0);
+            const uint32_t first_stop = stopped ? (uint32_t)__ffsll((long long)stopped) - 1u : 64u;
+            const bool live = lane <= first_stop;
+            if (first_stop < 64u) {
+                if (rdlane(fl, first_stop) != 1u) {  // an invalid symbol on the true path
+                    bad = true;
+                    break;
+                }
+                eob = true;
+            }
+            const uint32_t my_n = live ? nn : 0u, my_m = live ? mm : 0u;
+            const uint32_t in_n = wave_incl_add(my_n), in_m = wave_incl_add(my_m);
+            const uint32_t tot_n = rdlane(in_n, 63), tot_m = rdlane(in_m, 63);
+            const uint32_t new_bp = rdlane(ex, first_stop < 64u ? first_stop : 63u);
+            if (o + tot_n > isize || new_bp > bit_end + (eob ? 0u : 64u)) {
+                bad = true;
+                break;
+            }
+            // ---- pass 3: the segment again from its true entry, now writing
+            const long long t_p3 = DBG ? clock64() : 0;
+            bool bad_dist = false;
+            {
+                uint32_t pos = o + in_n - my_n, mi = mtot + in_m - my_m;
+                uint32_t f3 = live ? 0u : 2u;
+                rp = entry - rel0;
+                dword4 a0, b0, a1, b1;
+                seg_win_load(win, 0, a0, b0);
+                seg_win_load(win, 1, a1, b1);
+                wave_sync();
+                seg_win_put(win, 0, a0, b0);
+                seg_win_put(win, 1, a1, b1);
+                wave_sync();
+                for (uint32_t k = 0; k < nwin; k++) {
+                    dword4 na, nb;
+                    if (k + 2 < nwin + 1) seg_win_load(win, k + 2, na, nb);
+                    const uint32_t wend = 32u * kSegWinDw * (k + 1);
+                    const uint32_t lim = r_end < wend ? r_end : wend;
+                    while (__ballot(f3 == 0 && rp < lim)) {
+                        uint32_t kind, val, used, outlen;
+                        seg_sym(h, win, rp, kind, val, used, outlen);
+                        const bool go = f3 == 0 && rp < lim;
+                        if (go && kind == 0u) out[pos] = (uint8_t)val;
+                        if (go && kind == 1u) {
+                            if ((val & 0xFFFFu) > pos) bad_dist = true;
+                            LzMatch rec;
+                            rec.pos = pos;
+                            rec.len_dist = val;
+                            ml[mi] = rec;
+                            mi++;
+                        }
+                        if (go) {
+                            const uint32_t np = pos + outlen;
+                            if (multi && ((pos ^ np) >> 15)) tf[np >> 15] = mi;  // the next record is the tile's first
+                            pos = np;
+                            rp += used;
+                            f3 = kind >= 2u ? kind - 1u : 0u;
+                        }
+                        if (DBG) dbg[7]++;
+                    }
+                    if (k + 2 < nwin + 1) {
+                        wave_sync();
+                        seg_win_put(win, k + 2, na, nb);
+                        wave_sync();
+                    }
+                }
+            }
+            if (DBG) dbg[4] += (uint32_t)(clock64() - t_p3);
+            if (__ballot(bad_dist)) {
+                bad = true;
+                break;
+            }
+            o += tot_n;
+            mtot += tot_m;
+            bp = new_bp;
+        }
+    }
+    if (!bad && (o != isize || bp > bit_end)) bad = true;
+    if (bad) {
+        seg_redo(blk, redo, b, lane);
+    } else if (lane == 0) {
+        blk->status = kInfOk;
+        blk->produced = o;
+        blk->nmatch = mtot;
+        if (multi) tf[(isize >> 15) + 1] = mtot;
+    }
+    if (DBG && lane == 0) {
+        dbg[0] = (uint32_t)(clock64() - t_begin);
+        for (uint32_t k = 0; k < 8; k++) blk->cyc[k] = dbg[k];
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// k_lzcopy
+// ------------------------------------------------------------------------------------------
+constexpr uint32_t kLcThreads = 256;
+constexpr uint32_t kLcRing = 65536u;       // bytes
+constexpr uint32_t kLcK = 4u;              // records per lane and chunk: a chunk is 1,024 consecutive matches
+constexpr uint32_t kLcChunk = kLcThreads * kLcK;
+constexpr uint32_t kLcShort = 24u;         // bytes a lane copies itself (two passes of 12); longer or self-overlapping: the wave
+constexpr uint32_t kLcMaxSpins = 1u << 22;
+
+struct LcLds {
+    uint32_t ring[kLcRing / 4];  // output bytes, ring index = (position + phase) & 65535
+    uint32_t bm[kLcRing / 32];   // one bit per ring byte: 1 = final
+    uint32_t chunk_lo;
+    uint32_t gave_up;
+};
+
+// MEM = (MEM & ~mask) | data on an LDS dword, atomically: lanes that write different bytes of one dword in the same
+// instruction (neighbouring matches) do not lose each other's bytes
+__device__ __forceinline__ void lds_mskor(uint32_t *p, uint32_t mask, uint32_t data) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const uint32_t addr = (uint32_t)(size_t)p;
+    asm volatile("ds_mskor_b32 %0, %1, %2" : : "v"(addr), "v"(mask), "v"(data) : "memory");
+#else
+    *p = (*p & ~mask) | data;
+#endif
+}
+
+// bits [a, e) of the bitmap (ring-phase coordinates, e - a <= 258, may wrap): all ones?
+__device__ __forceinline__ bool lc_all_set(const uint32_t *bm, uint32_t a, uint32_t e) {
+    bool ok = true;
+    while (a < e) {
+        const uint32_t w = (a & (kLcRing - 1)) >> 5, lo = a & 31u;
+        const uint32_t n = (e - a) < (32u - lo) ? (e - a) : (32u - lo);
+        const uint32_t mask = (n == 32u ? 0xFFFFFFFFu : ((1u << n) - 1u)) << lo;
+        if ((bm[w] & mask) != mask) ok = false;
+        a += n;
+    }
+    return ok;
+}
+template <bool SET>
+__device__ __forceinline__ void lc_mark(uint32_t *bm, uint32_t a, uint32_t e) {
+    while (a < e) {
+        const uint32_t w = (a & (kLcRing - 1)) >> 5, lo = a & 31u;
+        const uint32_t n = (e - a) < (32u - lo) ? (e - a) : (32u - lo);
+        const uint32_t mask = (n == 32u ? 0xFFFFFFFFu : ((1u << n) - 1u)) << lo;
+        if (SET) atomicOr(&bm[w], mask);
+        else atomicAnd(&bm[w], ~mask);
+        a += n;
+    }
+}
+
+// n <= 12 bytes ring[S ..) -> ring[D ..), the two ranges disjoint: five aligned dword reads, the bytes moved to the
+// destination's alignment, up to four masked dword writes
+__device__ __forceinline__ void lc_copy12(uint32_t *ring, uint32_t S, uint32_t D, uint32_t n) {
+    const uint32_t dofs = D & 3u;
+    const uint32_t sb = S - dofs;  // the source byte that lands on the destination's aligned dword
+    const uint32_t u = sb >> 2, r = sb & 3u;
+    const uint32_t w0 = ring[(u + 0) & (kLcRing / 4 - 1)], w1 = ring[(u + 1) & (kLcRing / 4 - 1)],
+                   w2 = ring[(u + 2) & (kLcRing / 4 - 1)], w3 = ring[(u + 3) & (kLcRing / 4 - 1)],
+                   w4 = ring[(u + 4) & (kLcRing / 4 - 1)];
+    const uint32_t v0 = __builtin_amdgcn_alignbyte(w1, w0, r), v1 = __builtin_amdgcn_alignbyte(w2, w1, r),
+                   v2 = __builtin_amdgcn_alignbyte(w3, w2, r), v3 = __builtin_amdgcn_alignbyte(w4, w3, r);
+    const uint32_t m16 = ((1u << n) - 1u) << dofs;  // one bit per byte of the four destination dwords
+    const uint32_t d = D >> 2;
+    auto bytes = [](uint32_t nib) -> uint32_t { return (((nib & 15u) * 0x00204081u) & 0x01010101u) * 0xFFu; };
+    const uint32_t m0 = bytes(m16), m1 = bytes(m16 >> 4), m2 = bytes(m16 >> 8), m3 = bytes(m16 >> 12);
+    lds_mskor(&ring[(d + 0) & (kLcRing / 4 - 1)], m0, v0 & m0);
+    lds_mskor(&ring[(d + 1) & (kLcRing / 4 - 1)], m1, v1 & m1);
+    if (m2) lds_mskor(&ring[(d + 2) & (kLcRing / 4 - 1)], m2, v2 & m2);
+    if (m3) lds_mskor(&ring[(d + 3) & (kLcRing / 4 - 1)], m3, v3 & m3);
+}
+
+// One match as a lane works on it, in ring-phase coordinates (position + phase; the ring index is the low 16 bits)
+struct LcWork {
+    uint32_t dst, src;        // first byte of the match, of its source
+    uint32_t k0, k1;          // the part [k0, k1) of the match that lies in this tile
+    uint32_t need_a, need_e;  // bytes it reads that it does not write itself: must be final first
+};
+__device__ __forceinline__ bool lc_prepare(LcWork &w, const LzMatch &m, bool valid, uint32_t ts, uint32_t te, uint32_t phase) {
+    const uint32_t pos = m.pos, len = m.len_dist >> 16, dist = m.len_dist & 0xFFFFu;
+    w.k0 = pos < ts ? ts - pos : 0u;
+    w.k1 = pos + len > te ? te - pos : len;
+    w.dst = pos + phase;
+    w.src = pos + phase - dist;
+    w.need_a = w.src + w.k0;
+    w.need_e = w.src + w.k1 < w.dst + w.k0 ? w.src + w.k1 : w.dst + w.k0;
+    return valid && w.k0 < w.k1;
+}
+
+// DBlock.cyc of a debug launch: k_lzcopy adds its polling iterations (all waves) to cyc[5]
+template <bool DBG>
+__global__ __launch_bounds__(kLcThreads, 2) void k_lzcopy(DBlock *__restrict__ blk_all, const uint64_t *__restrict__ out_off,
+                                                         uint8_t *out_all, const LzMatch *__restrict__ mlist_all,
+                                                         const uint32_t *__restrict__ tfirst_all, uint32_t *__restrict__ redo) {
+    __shared__ LcLds l;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    const uint32_t b = blockIdx.x;
+    DBlock *blk = blk_all + b;
+    if (blk->status != kInfOk) return;
+    const uint32_t isize = blk->isize, nmatch = blk->nmatch;
+    if (isize == 0 || nmatch == 0) return;  // literals and stored bytes are in place already
+    const uint64_t ooff = out_off[b];
+    uint8_t *out = out_all + ooff;
+    const LzMatch *ml = mlist_all + (ooff / 3u + b);
+    const uint32_t *tf = tfirst_all + ((ooff >> 15) + 2ull * b);
+    const bool multi = isize > 65536u;
+    const uint32_t phase = (uint32_t)((uintptr_t)out & 15u);  // ring index and address agree modulo 16
+    uint8_t *ring8 = (uint8_t *)l.ring;
+    for (uint32_t i = tid; i < kLcRing / 32; i += kLcThreads) l.bm[i] = 0xFFFFFFFFu;
+    if (tid == 0) l.gave_up = 0;
+    uint32_t spins = 0;
+    bool give_up = false;
+
+    const uint32_t ntiles = multi ? (isize + kLzTile - 1) / kLzTile : 1u;
+    for (uint32_t t = 0; t < ntiles && !give_up; t++) {
+        const uint32_t ts = multi ? t * kLzTile : 0u;
+        const uint32_t te = multi ? (ts + kLzTile < isize ? ts + kLzTile : isize) : isize;
+        // ---- the tile's matches: list entries [m0, m1), and the one before if it reaches into the tile
+        uint32_t m0 = multi ? tf[t] : 0u;
+        const uint32_t m1 = (multi && t + 1 < ntiles) ? tf[t + 1] : nmatch;
+        if (t > 0 && m0 > 0) {
+            const LzMatch pm = ml[m0 - 1];
+            if (pm.pos + (pm.len_dist >> 16) > ts) m0--;
+        }
+        LzMatch nx[kLcK];  // the next chunk's records, on their way while this one is worked on
+#pragma unroll
+        for (uint32_t j = 0; j < kLcK; j++) {
+            const uint32_t mi = m0 + j * kLcThreads + tid;
+            nx[j] = ml[mi < m1 ? mi : m1 - 1 + (m1 == 0)];
+        }
+        __syncthreads();  // (the previous tile's stores have read the ring)
+        // ---- stage the tile: [ts, te) -> ring, 16 bytes per lane where the address allows
+        {
+            const uint32_t a0 = ts + phase, a1 = te + phase;           // ring-phase coordinates (address = out - phase + a)
+            const uint32_t v0 = (a0 + 15u) & ~15u, v1 = a1 & ~15u;     // the 16-byte-aligned middle
+            const uint8_t *src = out - phase;
+            if (v0 < v1) {
+                for (uint32_t a = v0 + 16u * tid; a < v1; a += 16u * kLcThreads) {
+                    const uint4 v = *(const uint4 *)(src + a);
+                    *(uint4 *)(ring8 + (a & (kLcRing - 1))) = v;
+                }
+                for (uint32_t a = a0 + tid; a < v0; a += kLcThreads) ring8[a & (kLcRing - 1)] = src[a];
+                for (uint32_t a = v1 + tid; a < a1; a += kLcThreads) ring8[a & (kLcRing - 1)] = src[a];
+            } else {
+                for (uint32_t a = a0 + tid; a < a1; a += kLcThreads) ring8[a & (kLcRing - 1)] = src[a];
+            }
+        }
+        for (uint32_t c0 = m0; c0 < m1 && !give_up; c0 += kLcChunk) {
+            // this chunk's records: lane `tid` works on c0 + tid, c0 + 256 + tid, ... one after the other
+            LcWork q[kLcK];
+            bool qv[kLcK];
+#pragma unroll
+            for (uint32_t j = 0; j < kLcK; j++) qv[j] = lc_prepare(q[j], nx[j], c0 + j * kLcThreads + tid < m1, ts, te, phase);
+#pragma unroll
+            for (uint32_t j = 0; j < kLcK; j++) {
+                const uint32_t mi = c0 + kLcChunk + j * kLcThreads + tid;
+                nx[j] = ml[mi < m1 ? mi : m1 - 1];
+            }
+            if (tid == 0) l.chunk_lo = q[0].dst + q[0].k0;  // (the chunk's first record exists and lies in the tile)
+#pragma unroll
+            for (uint32_t j = 0; j < kLcK; j++)
+                if (qv[j]) lc_mark<false>(l.bm, q[j].dst + q[j].k0, q[j].dst + q[j].k1);
+            __syncthreads();
+            const uint32_t chunk_lo = l.chunk_lo;
+#pragma unroll
+            for (uint32_t j = 0; j < kLcK; j++)
+                if (q[j].need_a < chunk_lo) q[j].need_a = chunk_lo;  // everything in front of the chunk is final
+            // ---- the wave polls: no barrier between dependency levels, a lane moves on as soon as its match is done
+            LcWork cur = q[0];
+            bool have = qv[0];
+            uint32_t left = kLcK - 1;  // records behind `cur` in the lane's queue (q[1..])
+            for (;;) {
+                // (skip the slots that hold nothing)
+                while (__ballot(!have && left) != 0) {
+                    if (!have && left) {
+                        cur = q[1];
+                        have = qv[1];
+#pragma unroll
+                        for (uint32_t j = 1; j + 1 < kLcK; j++) {
+                            q[j] = q[j + 1];
+                            qv[j] = qv[j + 1];
+                        }
+                        left--;
+                    }
+                }
+                if (__ballot(have) == 0) break;
+                const bool ready = have && (cur.need_a >= cur.need_e || lc_all_set(l.bm, cur.need_a, cur.need_e));
+                const uint32_t n = cur.k1 - cur.k0;
+                const bool coop = ready && (n > kLcShort || cur.dst - cur.src < n);  // long, or its source overlaps it
+                if (ready && !coop) {
+                    const uint32_t n1 = n < 12u ? n : 12u;
+                    lc_copy12(l.ring, cur.src + cur.k0, cur.dst + cur.k0, n1);
+                    if (n > 12u) lc_copy12(l.ring, cur.src + cur.k0 + 12u, cur.dst + cur.k0 + 12u, n - 12u);
+                }
+                // the wave together, 64 bytes per step; a source that overlaps its destination repeats with period
+                // `dist`, and [src, dst) is final
+                uint64_t longs = __ballot(coop);
+                while (longs) {
+                    const uint32_t jl = (uint32_t)__ffsll((long long)longs) - 1u;
+                    longs &= longs - 1ull;
+                    const uint32_t jd = rdlane(cur.dst, jl), js = rdlane(cur.src, jl), jk = rdlane(cur.k0, jl), jk1 = rdlane(cur.k1, jl);
+                    const uint32_t jdist = jd - js;
+                    for (uint32_t i = jk + lane; i < jk1; i += 64) {
+                        const uint32_t r = i < jdist ? i : i % jdist;
+                        ring8[(jd + i) & (kLcRing - 1)] = ring8[(js + r) & (kLcRing - 1)];
+                    }
+                }
+                wave_sync();  // (the wave's byte stores above are other lanes' stores for the owning lane)
+                if (ready) {
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                    lc_mark<true>(l.bm, cur.dst + cur.k0, cur.dst + cur.k1);
+                    have = false;
+                }
+                if (__ballot(ready) == 0) {
+                    __builtin_amdgcn_s_sleep(1);
+                    if (++spins > kLcMaxSpins) l.gave_up = 1;  // (cannot happen: the lowest pending match is always ready)
+                    if (l.gave_up) break;
+                }
+                if (DBG) spins++;
+            }
+            __syncthreads();
+            give_up = l.gave_up != 0;
+        }
+        __syncthreads();
+        // ---- the finished tile back to HBM
+        if (!give_up) {
+            const uint32_t a0 = ts + phase, a1 = te + phase;
+            const uint32_t v0 = (a0 + 15u) & ~15u, v1 = a1 & ~15u;
+            uint8_t *dstp = out - phase;
+            if (v0 < v1) {
+                for (uint32_t a = v0 + 16u * tid; a < v1; a += 16u * kLcThreads)
+                    *(uint4 *)(dstp + a) = *(const uint4 *)(ring8 + (a & (kLcRing - 1)));
+                for (uint32_t a = a0 + tid; a < v0; a += kLcThreads) dstp[a] = ring8[a & (kLcRing - 1)];
+                for (uint32_t a = v1 + tid; a < a1; a += kLcThreads) dstp[a] = ring8[a & (kLcRing - 1)];
+            } else {
+                for (uint32_t a = a0 + tid; a < a1; a += kLcThreads) dstp[a] = ring8[a & (kLcRing - 1)];
+            }
+        }
+    }
+    if (give_up) seg_redo(blk, redo, b, tid);
+    if (DBG && lane == 0) atomicAdd(&blk->cyc[5], spins);
+}

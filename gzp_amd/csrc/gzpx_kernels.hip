@@ -4868,15 +4868,16 @@ struct DBlock {
     uint32_t crc;       // CRC32 from the footer
     uint32_t status;    // InflateStatus
     uint32_t produced;  // bytes actually inflated
-    uint32_t pad;
+    uint32_t nmatch;    // k_inflate_seg: records in the member's match list (0 after k_inflate)
     uint32_t cyc[8];    // debug launches only: shader-clock cycles [0] whole block, [1] headers + table
                         // builds, [2] round set-up (input bits + table gathers), [3] literal stores +
                         // match copies; counts [4] rounds, [5] literals, [6] matches, [7] window flushes
 };
 
 __global__ void k_dinit(uint32_t nb, const uint8_t *__restrict__ in, const uint64_t *__restrict__ offsets,
-                        const uint32_t *__restrict__ sizes, DBlock *__restrict__ blk) {
+                        const uint32_t *__restrict__ sizes, DBlock *__restrict__ blk, uint32_t *__restrict__ redo) {
     const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b == 0 && redo) redo[0] = 0;
     if (b >= nb) return;
     const uint8_t *f = in + offsets[b] + sizes[b] - 8;  // get_footer_values, src/lib.rs:440-447
     DBlock d;
@@ -4886,7 +4887,7 @@ __global__ void k_dinit(uint32_t nb, const uint8_t *__restrict__ in, const uint6
     d.isize = (uint32_t)f[4] | ((uint32_t)f[5] << 8) | ((uint32_t)f[6] << 16) | ((uint32_t)f[7] << 24);
     d.status = kInfOk;
     d.produced = 0;
-    d.pad = 0;
+    d.nmatch = 0;
     for (uint32_t k = 0; k < 8; k++) d.cyc[k] = 0;
     blk[b] = d;
 }
@@ -4927,13 +4928,20 @@ template <bool DBG, bool GWIN>
 __global__ __launch_bounds__(64, GWIN ? GZPX_INF_WAVES : 1) void k_inflate(uint32_t hdr_len, const uint8_t *__restrict__ in_all,
                                                               DBlock *__restrict__ blk_all,
                                                               const uint64_t *__restrict__ out_off,
-                                                              uint8_t *out_all, uint64_t out_cap) {
+                                                              uint8_t *out_all, uint64_t out_cap,
+                                                              const uint32_t *__restrict__ redo) {
     __shared__ InfLdsT<GWIN> h;
     const uint32_t lane = threadIdx.x;
-    DBlock *blk = blk_all + blockIdx.x;
+    // with a redo list (k_inflate_seg / k_lzcopy): the members on it, which those kernels left for this one
+    uint32_t bidx = blockIdx.x;
+    if (redo) {
+        if (bidx >= redo[0]) return;
+        bidx = redo[1 + bidx];
+    }
+    DBlock *blk = blk_all + bidx;
     const uint32_t isize = blk->isize;
     if (isize == 0) return;  // src/par/decompress.rs:163-171: nothing to decode
-    const uint64_t ooff = out_off[blockIdx.x];
+    const uint64_t ooff = out_off[bidx];
     if (ooff + isize > out_cap) {
         if (lane == 0) blk->status = kInfInsufficientSpace;
         return;
@@ -5529,12 +5537,15 @@ __global__ __launch_bounds__(64, GWIN ? GZPX_INF_WAVES : 1) void k_inflate(uint3
     if (lane == 0) {
         blk->status = status;
         blk->produced = o;
+        blk->nmatch = 0;
         if (DBG) {
             dbg[0] = (uint32_t)(clock64() - t_begin);
             for (uint32_t k = 0; k < 8; k++) blk->cyc[k] = dbg[k];
         }
     }
 }
+
+#include "gzpx_inflate_seg.h"
 
 // CRC-32 of the inflated blocks (LibDeflateCrc over the whole orig_size buffer, src/check.rs:45-71):
 // the workgroup routine of k_crc32, blocks addressed through their output offsets.
@@ -5744,20 +5755,44 @@ void launch_emit(const Config &cfg, const uint8_t *slab, uint64_t, uint32_t nb, 
 void launch_inflate(uint32_t hdr_len, const uint8_t *d_in, const uint64_t *d_offsets, const uint32_t *d_sizes,
                     uint32_t nb, void *d_blk, uint64_t *d_out_off, uint8_t *d_out, uint64_t out_cap,
                     uint32_t *d_crc_found, const CrcConsts &cc, bool debug, hipEvent_t ev_begin,
-                    hipEvent_t ev_end, hipStream_t stream) {
+                    hipEvent_t ev_end, hipStream_t stream, const InflateScratch &sc, int route) {
     DBlock *blk = (DBlock *)d_blk;
-    hipLaunchKernelGGL(k_dinit, dim3((nb + 255) / 256), dim3(256), 0, stream, nb, d_in, d_offsets, d_sizes, blk);
+    const bool seg = route != kInflateRouteWave && sc.mlist && sc.tfirst && sc.redo;
+    hipLaunchKernelGGL(k_dinit, dim3((nb + 255) / 256), dim3(256), 0, stream, nb, d_in, d_offsets, d_sizes, blk,
+                       seg ? sc.redo : (uint32_t *)nullptr);
     hipLaunchKernelGGL(k_dscan, dim3(1), dim3(256), 0, stream, nb, (const DBlock *)blk, d_out_off);
     if (ev_begin) (void)hipEventRecord(ev_begin, stream);
-    if (debug)
+    if (seg) {
+        // decode (literals + match records), LZ copy, then k_inflate over whatever the two left on the redo list
+        LzMatch *ml = (LzMatch *)sc.mlist;
+        if (debug) {
+            hipLaunchKernelGGL((k_inflate_seg<true>), dim3(nb), dim3(64), 0, stream, hdr_len, d_in, blk,
+                               (const uint64_t *)d_out_off, d_out, out_cap, ml, sc.tfirst, sc.redo);
+            hipLaunchKernelGGL((k_lzcopy<true>), dim3(nb), dim3(kLcThreads), 0, stream, blk, (const uint64_t *)d_out_off,
+                               d_out, (const LzMatch *)ml, (const uint32_t *)sc.tfirst, sc.redo);
+            hipLaunchKernelGGL((k_inflate<true, true>), dim3(nb), dim3(64), 0, stream, hdr_len, d_in, blk,
+                               (const uint64_t *)d_out_off, d_out, out_cap, (const uint32_t *)sc.redo);
+        } else {
+            hipLaunchKernelGGL((k_inflate_seg<false>), dim3(nb), dim3(64), 0, stream, hdr_len, d_in, blk,
+                               (const uint64_t *)d_out_off, d_out, out_cap, ml, sc.tfirst, sc.redo);
+            hipLaunchKernelGGL((k_lzcopy<false>), dim3(nb), dim3(kLcThreads), 0, stream, blk, (const uint64_t *)d_out_off,
+                               d_out, (const LzMatch *)ml, (const uint32_t *)sc.tfirst, sc.redo);
+            hipLaunchKernelGGL((k_inflate<false, true>), dim3(nb), dim3(64), 0, stream, hdr_len, d_in, blk,
+                               (const uint64_t *)d_out_off, d_out, out_cap, (const uint32_t *)sc.redo);
+        }
+    } else if (debug) {
         hipLaunchKernelGGL((k_inflate<true, true>), dim3(nb), dim3(64), 0, stream, hdr_len, d_in, blk,
-                           (const uint64_t *)d_out_off, d_out, out_cap);
-    else
+                           (const uint64_t *)d_out_off, d_out, out_cap, (const uint32_t *)nullptr);
+    } else {
         hipLaunchKernelGGL((k_inflate<false, true>), dim3(nb), dim3(64), 0, stream, hdr_len, d_in, blk,
-                           (const uint64_t *)d_out_off, d_out, out_cap);
+                           (const uint64_t *)d_out_off, d_out, out_cap, (const uint32_t *)nullptr);
+    }
     if (ev_end) (void)hipEventRecord(ev_end, stream);
     hipLaunchKernelGGL(k_dcrc32, dim3(nb), dim3(kCrcThreads), 0, stream, (const uint8_t *)d_out,
                        (const uint64_t *)d_out_off, (const DBlock *)blk, d_crc_found, cc);
 }
+
+size_t inflate_mlist_bytes(uint64_t out_cap, uint64_t nb) { return (size_t)((out_cap / 3u + nb + 2u) * sizeof(LzMatch)); }
+size_t inflate_tfirst_bytes(uint64_t out_cap, uint64_t nb) { return (size_t)(((out_cap >> 15) + 2u * nb + 4u) * 4u); }
 
 }  // namespace gzpx

@@ -340,11 +340,21 @@ int gzpx_debug_set_flags(gzpx_ctx *ctx, uint32_t flags);
 /* Level 1: how many blocks of the last batch k_mparse handed back to the dense kernels. */
 int gzpx_debug_redo_count(gzpx_ctx *ctx, uint32_t *count);
 
-/* HIP-event duration of k_inflate in the last decompress launch of this context */
+/* HIP-event duration of the inflate kernels (k_inflate_seg + k_lzcopy + k_inflate over the redo list, or
+ * k_inflate alone) in the last decompress launch of this context */
 int gzpx_dctx_last_inflate_ms(gzpx_dctx *ctx, float *ms);
-/* inflate: switch the instrumented k_inflate on/off; sums[] = per-block counters of the last launch
- * summed over its blocks ([0] cycles, [1] headers+tables, [2] round set-up, [3] stores+copies,
- * [4] rounds, [5] literals, [6] matches, [7] window flushes) */
+/* Which kernels inflate (decode_block, src/par/decompress.rs:162-186): GZPX_INFLATE_SEG (default) = the decode /
+ * LZ-copy pair, members they cannot take handed to k_inflate; GZPX_INFLATE_WAVE = k_inflate (one wave per member,
+ * window in HBM) for every member.  Same bytes, same error classes either way. */
+#define GZPX_INFLATE_SEG 0
+#define GZPX_INFLATE_WAVE 1
+int gzpx_dctx_set_route(gzpx_dctx *ctx, int route);
+/* How many members of the last launch the decode / copy pair handed to k_inflate (diagnostics). */
+int gzpx_dctx_last_redo_count(gzpx_dctx *ctx, uint32_t *count);
+/* inflate: switch the instrumented kernels on/off; sums[] = per-member counters of the last launch summed over
+ * its members.  GZPX_INFLATE_SEG: [0] cycles of k_inflate_seg, [1] headers + tables, [2] pass 1, [3] pass 2,
+ * [4] pass 3, [5] spans + k_lzcopy rounds, [6] pass-2 iterations, [7] bytes.  GZPX_INFLATE_WAVE: [0] cycles,
+ * [1] headers + tables, [2] round set-up, [3] stores + copies, [4] rounds, [5] literals, [6] matches, [7] flushes */
 int gzpx_debug_inflate(gzpx_dctx *ctx, int enable, uint64_t sums[8]);
 
 const char *gzpx_strerror(int code);
