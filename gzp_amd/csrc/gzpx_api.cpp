@@ -1414,7 +1414,7 @@ struct gzpx_dctx {
     hipEvent_t ev_dep = nullptr;
     DSlot slots[kSlots];
     uint64_t next_gen = 1;
-    bool debug = false;
+    int debug = 0;  // 1: instrumented k_inflate_seg / k_inflate, 2: instrumented k_lzcopy
     int route = kInflateRouteSeg;  // GZPX_INFLATE_ROUTE=wave / gzpx_dctx_set_route: k_inflate for every member
     int last_slot = -1;  // the slot of the last completed launch (timing / debug counters)
     size_t last_nb = 0;
@@ -1908,7 +1908,7 @@ int gzpx_dctx_last_redo_count(gzpx_dctx *ctx, uint32_t *count) {
 int gzpx_debug_inflate(gzpx_dctx *ctx, int enable, uint64_t sums[8]) {
     if (!ctx) return GZPX_ERR_INVALID_ARG;
     std::lock_guard<std::mutex> g(ctx->mu);
-    ctx->debug = enable != 0;
+    ctx->debug = enable < 0 ? 0 : enable > 2 ? 1 : enable;
     if (sums) {
         for (int k = 0; k < 8; k++) sums[k] = 0;
         if (ctx->last_slot >= 0)

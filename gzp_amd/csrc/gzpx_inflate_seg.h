@@ -708,7 +708,7 @@ constexpr uint32_t kLcThreads = 256;
 constexpr uint32_t kLcRing = 65536u;       // bytes
 constexpr uint32_t kLcK = 4u;              // records per lane and chunk: a chunk is 1,024 consecutive matches
 constexpr uint32_t kLcChunk = kLcThreads * kLcK;
-constexpr uint32_t kLcShort = 24u;         // bytes a lane copies itself (two passes of 12); longer or self-overlapping: the wave
+constexpr uint32_t kLcShort = 16u;         // bytes a lane copies itself; longer or self-overlapping matches: the wave together
 constexpr uint32_t kLcMaxSpins = 1u << 22;
 
 struct LcLds {
@@ -753,25 +753,50 @@ __device__ __forceinline__ void lc_mark(uint32_t *bm, uint32_t a, uint32_t e) {
     }
 }
 
-// n <= 12 bytes ring[S ..) -> ring[D ..), the two ranges disjoint: five aligned dword reads, the bytes moved to the
-// destination's alignment, up to four masked dword writes
-__device__ __forceinline__ void lc_copy12(uint32_t *ring, uint32_t S, uint32_t D, uint32_t n) {
+// n <= 16 bytes ring[S ..) -> ring[D ..), the two ranges disjoint.  The six aligned source dwords are read by
+// lc_src6 (speculatively, beside the bitmap check); lc_put16 moves the bytes to the destination's alignment and
+// writes up to five masked dwords.
+struct LcSrc6 {
+    uint32_t w0, w1, w2, w3, w4, w5;
+};
+__device__ __forceinline__ LcSrc6 lc_src6(const uint32_t *ring, uint32_t S, uint32_t D) {
+    const uint32_t u = (S - (D & 3u)) >> 2;  // the source dword whose bytes land on the destination's first aligned dword
+    LcSrc6 v;
+    v.w0 = ring[(u + 0) & (kLcRing / 4 - 1)];
+    v.w1 = ring[(u + 1) & (kLcRing / 4 - 1)];
+    v.w2 = ring[(u + 2) & (kLcRing / 4 - 1)];
+    v.w3 = ring[(u + 3) & (kLcRing / 4 - 1)];
+    v.w4 = ring[(u + 4) & (kLcRing / 4 - 1)];
+    v.w5 = ring[(u + 5) & (kLcRing / 4 - 1)];
+    return v;
+}
+__device__ __forceinline__ void lc_put16(uint32_t *ring, const LcSrc6 &w, uint32_t S, uint32_t D, uint32_t n) {
     const uint32_t dofs = D & 3u;
-    const uint32_t sb = S - dofs;  // the source byte that lands on the destination's aligned dword
-    const uint32_t u = sb >> 2, r = sb & 3u;
-    const uint32_t w0 = ring[(u + 0) & (kLcRing / 4 - 1)], w1 = ring[(u + 1) & (kLcRing / 4 - 1)],
-                   w2 = ring[(u + 2) & (kLcRing / 4 - 1)], w3 = ring[(u + 3) & (kLcRing / 4 - 1)],
-                   w4 = ring[(u + 4) & (kLcRing / 4 - 1)];
-    const uint32_t v0 = __builtin_amdgcn_alignbyte(w1, w0, r), v1 = __builtin_amdgcn_alignbyte(w2, w1, r),
-                   v2 = __builtin_amdgcn_alignbyte(w3, w2, r), v3 = __builtin_amdgcn_alignbyte(w4, w3, r);
-    const uint32_t m16 = ((1u << n) - 1u) << dofs;  // one bit per byte of the four destination dwords
+    const uint32_t r = (S - dofs) & 3u;
+    const uint32_t v0 = __builtin_amdgcn_alignbyte(w.w1, w.w0, r), v1 = __builtin_amdgcn_alignbyte(w.w2, w.w1, r),
+                   v2 = __builtin_amdgcn_alignbyte(w.w3, w.w2, r), v3 = __builtin_amdgcn_alignbyte(w.w4, w.w3, r),
+                   v4 = __builtin_amdgcn_alignbyte(w.w5, w.w4, r);
+    const uint32_t m20 = ((1u << n) - 1u) << dofs;  // one bit per byte of the five destination dwords
     const uint32_t d = D >> 2;
     auto bytes = [](uint32_t nib) -> uint32_t { return (((nib & 15u) * 0x00204081u) & 0x01010101u) * 0xFFu; };
-    const uint32_t m0 = bytes(m16), m1 = bytes(m16 >> 4), m2 = bytes(m16 >> 8), m3 = bytes(m16 >> 12);
+    const uint32_t m0 = bytes(m20), m1 = bytes(m20 >> 4), m2 = bytes(m20 >> 8), m3 = bytes(m20 >> 12), m4 = bytes(m20 >> 16);
     lds_mskor(&ring[(d + 0) & (kLcRing / 4 - 1)], m0, v0 & m0);
     lds_mskor(&ring[(d + 1) & (kLcRing / 4 - 1)], m1, v1 & m1);
     if (m2) lds_mskor(&ring[(d + 2) & (kLcRing / 4 - 1)], m2, v2 & m2);
     if (m3) lds_mskor(&ring[(d + 3) & (kLcRing / 4 - 1)], m3, v3 & m3);
+    if (m4) lds_mskor(&ring[(d + 4) & (kLcRing / 4 - 1)], m4, v4 & m4);
+}
+// the 64 bitmap bits from the dword that holds bit a (ring-phase coordinate)
+__device__ __forceinline__ uint64_t lc_bm64(const uint32_t *bm, uint32_t a) {
+    const uint32_t w = (a & (kLcRing - 1)) >> 5;
+    return (((uint64_t)bm[(w + 1) & (kLcRing / 32 - 1)]) << 32) | bm[w];
+}
+// bits [a, a + n) := 1, n <= 32: two atomics (the second may have nothing to do)
+__device__ __forceinline__ void lc_set32(uint32_t *bm, uint32_t a, uint32_t n) {
+    const uint32_t w = (a & (kLcRing - 1)) >> 5;
+    const uint64_t m = ((n >= 32u ? 0xFFFFFFFFull : ((1ull << n) - 1ull))) << (a & 31u);
+    atomicOr(&bm[w], (uint32_t)m);
+    if ((uint32_t)(m >> 32)) atomicOr(&bm[(w + 1) & (kLcRing / 32 - 1)], (uint32_t)(m >> 32));
 }
 
 // One match as a lane works on it, in ring-phase coordinates (position + phase; the ring index is the low 16 bits)
@@ -791,7 +816,9 @@ __device__ __forceinline__ bool lc_prepare(LcWork &w, const LzMatch &m, bool val
     return valid && w.k0 < w.k1;
 }
 
-// DBlock.cyc of a debug launch: k_lzcopy adds its polling iterations (all waves) to cyc[5]
+// DBlock.cyc of a debug launch of k_lzcopy (wave 0's clocks): [0] whole member, [1] tile staged in, [2] chunk set-up
+// (records, bitmap cleared, barrier), [3] polling loop, [4] tile written out, counts [5] polling iterations of all
+// waves, [6] of them without a ready lane, [7] matches
 template <bool DBG>
 __global__ __launch_bounds__(kLcThreads, 2) void k_lzcopy(DBlock *__restrict__ blk_all, const uint64_t *__restrict__ out_off,
                                                          uint8_t *out_all, const LzMatch *__restrict__ mlist_all,
@@ -814,6 +841,8 @@ __global__ __launch_bounds__(kLcThreads, 2) void k_lzcopy(DBlock *__restrict__ b
     if (tid == 0) l.gave_up = 0;
     uint32_t spins = 0;
     bool give_up = false;
+    const long long t_begin = DBG ? clock64() : 0;
+    uint32_t dbg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 
     const uint32_t ntiles = multi ? (isize + kLzTile - 1) / kLzTile : 1u;
     for (uint32_t t = 0; t < ntiles && !give_up; t++) {
@@ -833,6 +862,7 @@ __global__ __launch_bounds__(kLcThreads, 2) void k_lzcopy(DBlock *__restrict__ b
             nx[j] = ml[mi < m1 ? mi : m1 - 1 + (m1 == 0)];
         }
         __syncthreads();  // (the previous tile's stores have read the ring)
+        const long long t_in = DBG ? clock64() : 0;
         // ---- stage the tile: [ts, te) -> ring, 16 bytes per lane where the address allows
         {
             const uint32_t a0 = ts + phase, a1 = te + phase;           // ring-phase coordinates (address = out - phase + a)
@@ -849,83 +879,159 @@ __global__ __launch_bounds__(kLcThreads, 2) void k_lzcopy(DBlock *__restrict__ b
                 for (uint32_t a = a0 + tid; a < a1; a += kLcThreads) ring8[a & (kLcRing - 1)] = src[a];
             }
         }
+        if (DBG) {
+            __syncthreads();
+            dbg[1] += (uint32_t)(clock64() - t_in);
+        }
         for (uint32_t c0 = m0; c0 < m1 && !give_up; c0 += kLcChunk) {
-            // this chunk's records: lane `tid` works on c0 + tid, c0 + 256 + tid, ... one after the other
-            LcWork q[kLcK];
-            bool qv[kLcK];
+            const long long t_c = DBG ? clock64() : 0;
+            // this chunk's records: lane `tid` works on c0 + tid, c0 + 256 + tid, ... one after the other.  They stay
+            // where they are (loop-invariant registers); `jn` counts the ones the lane has taken up.
+            LzMatch rc[kLcK];
 #pragma unroll
-            for (uint32_t j = 0; j < kLcK; j++) qv[j] = lc_prepare(q[j], nx[j], c0 + j * kLcThreads + tid < m1, ts, te, phase);
+            for (uint32_t j = 0; j < kLcK; j++) rc[j] = nx[j];
+            const uint32_t navail = c0 + tid >= m1 ? 0u : (m1 - c0 - tid + kLcThreads - 1) / kLcThreads;  // records of this lane in the chunk
+            const uint32_t nmine = navail < kLcK ? navail : kLcK;
 #pragma unroll
             for (uint32_t j = 0; j < kLcK; j++) {
                 const uint32_t mi = c0 + kLcChunk + j * kLcThreads + tid;
                 nx[j] = ml[mi < m1 ? mi : m1 - 1];
             }
-            if (tid == 0) l.chunk_lo = q[0].dst + q[0].k0;  // (the chunk's first record exists and lies in the tile)
+            {
+                LcWork w;
+                const bool v0 = lc_prepare(w, rc[0], nmine > 0, ts, te, phase);
+                if (tid == 0) l.chunk_lo = w.dst + w.k0;  // (the chunk's first record exists and lies in the tile)
+                if (v0) lc_mark<false>(l.bm, w.dst + w.k0, w.dst + w.k1);
 #pragma unroll
-            for (uint32_t j = 0; j < kLcK; j++)
-                if (qv[j]) lc_mark<false>(l.bm, q[j].dst + q[j].k0, q[j].dst + q[j].k1);
+                for (uint32_t j = 1; j < kLcK; j++)
+                    if (lc_prepare(w, rc[j], j < nmine, ts, te, phase)) lc_mark<false>(l.bm, w.dst + w.k0, w.dst + w.k1);
+            }
             __syncthreads();
             const uint32_t chunk_lo = l.chunk_lo;
-#pragma unroll
-            for (uint32_t j = 0; j < kLcK; j++)
-                if (q[j].need_a < chunk_lo) q[j].need_a = chunk_lo;  // everything in front of the chunk is final
-            // ---- the wave polls: no barrier between dependency levels, a lane moves on as soon as its match is done
-            LcWork cur = q[0];
-            bool have = qv[0];
-            uint32_t left = kLcK - 1;  // records behind `cur` in the lane's queue (q[1..])
+            const long long t_p = DBG ? clock64() : 0;
+            if (DBG) dbg[2] += (uint32_t)(t_p - t_c);
+            // ---- the wave polls: no barrier between dependency levels, a lane moves on as soon as its match is done.
+            // Short matches (<= 16 bytes, source and destination disjoint: nearly all of them) take the straight-line
+            // path with everything that does not change between polls worked out when the match is taken up.
+            LzMatch cm = rc[0];        // the lane's current match
+            bool have = false, is_short = false;
+            uint32_t jn = 0;
+            uint32_t f_bw = 0, f_want_lo = 0, f_want_hi = 0;  // bitmap dword of the first byte it needs, the bits it needs there
+            uint32_t f_u = 0, f_r = 0, f_d = 0, f_m20 = 0;    // source dword, byte shift, destination dword, destination byte bits
+            uint32_t f_sw = 0, f_set_lo = 0, f_set_hi = 0;    // bitmap dword of its first own byte, its own bits
             for (;;) {
-                // (skip the slots that hold nothing)
-                while (__ballot(!have && left) != 0) {
-                    if (!have && left) {
-                        cur = q[1];
-                        have = qv[1];
+                // a lane without a match takes up its next record (one that lies outside the tile is dropped at once)
+                if (__ballot(!have && jn < nmine) != 0) {
+                    if (!have && jn < nmine) {
+                        cm = rc[0];
 #pragma unroll
-                        for (uint32_t j = 1; j + 1 < kLcK; j++) {
-                            q[j] = q[j + 1];
-                            qv[j] = qv[j + 1];
+                        for (uint32_t j = 1; j < kLcK; j++)
+                            if (jn == j) cm = rc[j];
+                        jn++;
+                        LcWork w;
+                        have = lc_prepare(w, cm, true, ts, te, phase);
+                        if (w.need_a < chunk_lo) w.need_a = chunk_lo;  // everything in front of the chunk is final
+                        const uint32_t n = w.k1 - w.k0;
+                        is_short = n <= kLcShort && w.dst - w.src >= n;
+                        const uint32_t cnt = w.need_e > w.need_a ? w.need_e - w.need_a : 0u;  // <= 16 when short
+                        const uint64_t want = ((1ull << (cnt & 31u)) - 1ull) << (w.need_a & 31u);
+                        f_bw = (w.need_a & (kLcRing - 1)) >> 5;
+                        f_want_lo = (uint32_t)want;
+                        f_want_hi = (uint32_t)(want >> 32);
+                        const uint32_t S = w.src + w.k0, D = w.dst + w.k0;
+                        f_u = (S - (D & 3u)) >> 2;
+                        f_r = (S - (D & 3u)) & 3u;
+                        f_d = D >> 2;
+                        f_m20 = ((1u << (n & 31u)) - 1u) << (D & 3u);
+                        const uint64_t own = ((1ull << (n & 31u)) - 1ull) << (D & 31u);
+                        f_sw = (D & (kLcRing - 1)) >> 5;
+                        f_set_lo = (uint32_t)own;
+                        f_set_hi = (uint32_t)(own >> 32);
+                    }
+                }
+                if (__ballot(have) == 0) {
+                    if (__ballot(jn < nmine) == 0) break;
+                    continue;
+                }
+                bool progress = false;
+                // ---- short matches: the bitmap words of the bytes it needs and -- not knowing yet whether they are final
+                // -- the bytes themselves, one LDS round trip for both
+                {
+                    const uint32_t b_lo = l.bm[f_bw], b_hi = l.bm[(f_bw + 1) & (kLcRing / 32 - 1)];
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");  // (the bits are read BEFORE the bytes: the compiler must keep the order)
+                    LcSrc6 sw;
+                    sw.w0 = l.ring[(f_u + 0) & (kLcRing / 4 - 1)];
+                    sw.w1 = l.ring[(f_u + 1) & (kLcRing / 4 - 1)];
+                    sw.w2 = l.ring[(f_u + 2) & (kLcRing / 4 - 1)];
+                    sw.w3 = l.ring[(f_u + 3) & (kLcRing / 4 - 1)];
+                    sw.w4 = l.ring[(f_u + 4) & (kLcRing / 4 - 1)];
+                    sw.w5 = l.ring[(f_u + 5) & (kLcRing / 4 - 1)];
+                    const bool go = have && is_short && (b_lo & f_want_lo) == f_want_lo && (b_hi & f_want_hi) == f_want_hi;
+                    if (go) {
+                        const uint32_t v0 = __builtin_amdgcn_alignbyte(sw.w1, sw.w0, f_r), v1 = __builtin_amdgcn_alignbyte(sw.w2, sw.w1, f_r),
+                                       v2 = __builtin_amdgcn_alignbyte(sw.w3, sw.w2, f_r), v3 = __builtin_amdgcn_alignbyte(sw.w4, sw.w3, f_r),
+                                       v4 = __builtin_amdgcn_alignbyte(sw.w5, sw.w4, f_r);
+                        auto bytes = [](uint32_t nib) -> uint32_t { return (((nib & 15u) * 0x00204081u) & 0x01010101u) * 0xFFu; };
+                        const uint32_t m0 = bytes(f_m20), m1 = bytes(f_m20 >> 4), m2 = bytes(f_m20 >> 8), m3 = bytes(f_m20 >> 12),
+                                       m4 = bytes(f_m20 >> 16);
+                        lds_mskor(&l.ring[(f_d + 0) & (kLcRing / 4 - 1)], m0, v0 & m0);
+                        lds_mskor(&l.ring[(f_d + 1) & (kLcRing / 4 - 1)], m1, v1 & m1);
+                        lds_mskor(&l.ring[(f_d + 2) & (kLcRing / 4 - 1)], m2, v2 & m2);
+                        if (f_m20 >> 12) {
+                            lds_mskor(&l.ring[(f_d + 3) & (kLcRing / 4 - 1)], m3, v3 & m3);
+                            lds_mskor(&l.ring[(f_d + 4) & (kLcRing / 4 - 1)], m4, v4 & m4);
                         }
-                        left--;
+                        // (no wait between the bytes and their "final" bits: a wave's LDS operations are carried out in the
+                        // order it issues them, so whoever sees the bits sees the bytes)
+                        atomicOr(&l.bm[f_sw], f_set_lo);
+                        if (f_set_hi) atomicOr(&l.bm[(f_sw + 1) & (kLcRing / 32 - 1)], f_set_hi);
+                        have = false;
+                    }
+                    progress = __ballot(go) != 0;
+                }
+                // ---- long matches and matches whose source overlaps them: checked the long way, copied by the wave
+                // together, 64 bytes per step; an overlapping source repeats with period `dist`, and [src, dst) is final
+                if (__ballot(have && !is_short) != 0) {
+                    LcWork w;
+                    w.dst = w.src = w.k0 = w.k1 = w.need_a = w.need_e = 0;
+                    bool ready = false;
+                    if (have && !is_short) {
+                        lc_prepare(w, cm, true, ts, te, phase);
+                        if (w.need_a < chunk_lo) w.need_a = chunk_lo;
+                        ready = w.need_a >= w.need_e || lc_all_set(l.bm, w.need_a, w.need_e);
+                    }
+                    uint64_t longs = __ballot(ready);
+                    progress = progress || longs != 0;
+                    while (longs) {
+                        const uint32_t jl = (uint32_t)__ffsll((long long)longs) - 1u;
+                        longs &= longs - 1ull;
+                        const uint32_t jd = rdlane(w.dst, jl), js = rdlane(w.src, jl), jk = rdlane(w.k0, jl), jk1 = rdlane(w.k1, jl);
+                        const uint32_t jdist = jd - js;
+                        for (uint32_t i = jk + lane; i < jk1; i += 64) {
+                            const uint32_t r = i < jdist ? i : i % jdist;
+                            ring8[(jd + i) & (kLcRing - 1)] = ring8[(js + r) & (kLcRing - 1)];
+                        }
+                    }
+                    wave_sync();  // (the wave's byte stores above are other lanes' stores for the owning lane)
+                    if (ready) {
+                        lc_mark<true>(l.bm, w.dst + w.k0, w.dst + w.k1);
+                        have = false;
                     }
                 }
-                if (__ballot(have) == 0) break;
-                const bool ready = have && (cur.need_a >= cur.need_e || lc_all_set(l.bm, cur.need_a, cur.need_e));
-                const uint32_t n = cur.k1 - cur.k0;
-                const bool coop = ready && (n > kLcShort || cur.dst - cur.src < n);  // long, or its source overlaps it
-                if (ready && !coop) {
-                    const uint32_t n1 = n < 12u ? n : 12u;
-                    lc_copy12(l.ring, cur.src + cur.k0, cur.dst + cur.k0, n1);
-                    if (n > 12u) lc_copy12(l.ring, cur.src + cur.k0 + 12u, cur.dst + cur.k0 + 12u, n - 12u);
-                }
-                // the wave together, 64 bytes per step; a source that overlaps its destination repeats with period
-                // `dist`, and [src, dst) is final
-                uint64_t longs = __ballot(coop);
-                while (longs) {
-                    const uint32_t jl = (uint32_t)__ffsll((long long)longs) - 1u;
-                    longs &= longs - 1ull;
-                    const uint32_t jd = rdlane(cur.dst, jl), js = rdlane(cur.src, jl), jk = rdlane(cur.k0, jl), jk1 = rdlane(cur.k1, jl);
-                    const uint32_t jdist = jd - js;
-                    for (uint32_t i = jk + lane; i < jk1; i += 64) {
-                        const uint32_t r = i < jdist ? i : i % jdist;
-                        ring8[(jd + i) & (kLcRing - 1)] = ring8[(js + r) & (kLcRing - 1)];
-                    }
-                }
-                wave_sync();  // (the wave's byte stores above are other lanes' stores for the owning lane)
-                if (ready) {
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                    lc_mark<true>(l.bm, cur.dst + cur.k0, cur.dst + cur.k1);
-                    have = false;
-                }
-                if (__ballot(ready) == 0) {
+                if (DBG) dbg[5]++;
+                if (!progress) {
                     __builtin_amdgcn_s_sleep(1);
                     if (++spins > kLcMaxSpins) l.gave_up = 1;  // (cannot happen: the lowest pending match is always ready)
                     if (l.gave_up) break;
+                    if (DBG) dbg[6]++;
                 }
-                if (DBG) spins++;
             }
             __syncthreads();
+            if (DBG) dbg[3] += (uint32_t)(clock64() - t_p);
             give_up = l.gave_up != 0;
         }
         __syncthreads();
+        const long long t_out = DBG ? clock64() : 0;
         // ---- the finished tile back to HBM
         if (!give_up) {
             const uint32_t a0 = ts + phase, a1 = te + phase;
@@ -940,7 +1046,23 @@ __global__ __launch_bounds__(kLcThreads, 2) void k_lzcopy(DBlock *__restrict__ b
                 for (uint32_t a = a0 + tid; a < a1; a += kLcThreads) dstp[a] = ring8[a & (kLcRing - 1)];
             }
         }
+        if (DBG) {
+            __syncthreads();
+            dbg[4] += (uint32_t)(clock64() - t_out);
+        }
     }
     if (give_up) seg_redo(blk, redo, b, tid);
-    if (DBG && lane == 0) atomicAdd(&blk->cyc[5], spins);
+    if (DBG) {
+        if (tid == 0) {
+            blk->cyc[0] = (uint32_t)(clock64() - t_begin);
+            for (uint32_t k = 1; k < 5; k++) blk->cyc[k] = dbg[k];
+            blk->cyc[5] = blk->cyc[6] = 0;
+            blk->cyc[7] = nmatch;
+        }
+        __syncthreads();
+        if (lane == 0) {
+            atomicAdd(&blk->cyc[5], dbg[5]);
+            atomicAdd(&blk->cyc[6], dbg[6]);
+        }
+    }
 }

@@ -5754,7 +5754,7 @@ void launch_emit(const Config &cfg, const uint8_t *slab, uint64_t, uint32_t nb, 
 
 void launch_inflate(uint32_t hdr_len, const uint8_t *d_in, const uint64_t *d_offsets, const uint32_t *d_sizes,
                     uint32_t nb, void *d_blk, uint64_t *d_out_off, uint8_t *d_out, uint64_t out_cap,
-                    uint32_t *d_crc_found, const CrcConsts &cc, bool debug, hipEvent_t ev_begin,
+                    uint32_t *d_crc_found, const CrcConsts &cc, int debug, hipEvent_t ev_begin,
                     hipEvent_t ev_end, hipStream_t stream, const InflateScratch &sc, int route) {
     DBlock *blk = (DBlock *)d_blk;
     const bool seg = route != kInflateRouteWave && sc.mlist && sc.tfirst && sc.redo;
@@ -5765,12 +5765,19 @@ void launch_inflate(uint32_t hdr_len, const uint8_t *d_in, const uint64_t *d_off
     if (seg) {
         // decode (literals + match records), LZ copy, then k_inflate over whatever the two left on the redo list
         LzMatch *ml = (LzMatch *)sc.mlist;
-        if (debug) {
+        if (debug == 1) {
             hipLaunchKernelGGL((k_inflate_seg<true>), dim3(nb), dim3(64), 0, stream, hdr_len, d_in, blk,
+                               (const uint64_t *)d_out_off, d_out, out_cap, ml, sc.tfirst, sc.redo);
+            hipLaunchKernelGGL((k_lzcopy<false>), dim3(nb), dim3(kLcThreads), 0, stream, blk, (const uint64_t *)d_out_off,
+                               d_out, (const LzMatch *)ml, (const uint32_t *)sc.tfirst, sc.redo);
+            hipLaunchKernelGGL((k_inflate<true, true>), dim3(nb), dim3(64), 0, stream, hdr_len, d_in, blk,
+                               (const uint64_t *)d_out_off, d_out, out_cap, (const uint32_t *)sc.redo);
+        } else if (debug == 2) {  // k_lzcopy's clocks instead of k_inflate_seg's
+            hipLaunchKernelGGL((k_inflate_seg<false>), dim3(nb), dim3(64), 0, stream, hdr_len, d_in, blk,
                                (const uint64_t *)d_out_off, d_out, out_cap, ml, sc.tfirst, sc.redo);
             hipLaunchKernelGGL((k_lzcopy<true>), dim3(nb), dim3(kLcThreads), 0, stream, blk, (const uint64_t *)d_out_off,
                                d_out, (const LzMatch *)ml, (const uint32_t *)sc.tfirst, sc.redo);
-            hipLaunchKernelGGL((k_inflate<true, true>), dim3(nb), dim3(64), 0, stream, hdr_len, d_in, blk,
+            hipLaunchKernelGGL((k_inflate<false, true>), dim3(nb), dim3(64), 0, stream, hdr_len, d_in, blk,
                                (const uint64_t *)d_out_off, d_out, out_cap, (const uint32_t *)sc.redo);
         } else {
             hipLaunchKernelGGL((k_inflate_seg<false>), dim3(nb), dim3(64), 0, stream, hdr_len, d_in, blk,

@@ -34,5 +34,10 @@ for cls, n, level in [("text", 64 << 20, 1), ("text", 64 << 20, 3), ("dna", 64 <
     nb = len(offs)
     print("%-8s l%d  %d blocks ratio %.3f | seg %.3f ms (%.1f GiB/s, ok=%s, redo %d) wave %.3f ms (%.1f GiB/s, ok=%s)" % (
         cls, level, nb, comp.size / n, row[0][0], n / 2**30 / (row[0][0] * 1e-3), row[0][1], row[0][2], row[1][0], n / 2**30 / (row[1][0] * 1e-3), row[1][1]))
-    print("         per block: " + ", ".join("%s %.0f" % (k, v / nb) for k, v in zip(names, sums)))
+    print("         k_inflate_seg per block: " + ", ".join("%s %.0f" % (k, v / nb) for k, v in zip(names, sums)))
+    d.debug_inflate(2)
+    d.decompress_device(d_in.data_ptr(), comp.size, offs, sizes, d_out.data_ptr(), n + 64)
+    sums = d.debug_inflate(False)
+    names2 = ["cycles", "stage in", "chunk set-up", "polling", "write out", "poll iters", "idle iters", "matches"]
+    print("         k_lzcopy      per block: " + ", ".join("%s %.0f" % (k, v / nb) for k, v in zip(names2, sums)))
     d.close()
