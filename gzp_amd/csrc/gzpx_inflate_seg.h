@@ -27,8 +27,9 @@ constexpr uint32_t kInfRedo = 0x80u;     // DBlock.status while a member waits f
 constexpr uint32_t kSegMinBits = 512u;   // segment length per lane: remaining bits / 64, within these bounds
 constexpr uint32_t kSegMaxBits = 8192u;
 constexpr uint32_t kSegMaxFix = 6u;      // pass-2 iterations before the member is handed to k_inflate
-constexpr uint32_t kSegWinDw = 8u;       // dwords per refill window (256 bits of every lane's stream)
-constexpr uint32_t kSegRingStride = 17u; // dwords per lane in the ring: 16 + a copy of slot 0 behind slot 15 (odd: no bank conflicts)
+constexpr uint32_t kSegWinDw = 4u;       // dwords per refill window (128 bits of every lane's stream)
+constexpr uint32_t kSegRingDw = 2u * kSegWinDw;  // the ring: two windows
+constexpr uint32_t kSegRingStride = kSegRingDw + 1u;  // dwords per lane: + a copy of slot 0 behind the last slot (odd: no bank conflicts)
 constexpr uint32_t kSegLRoot = 10u, kSegORoot = 8u, kSegPRoot = 7u;  // root bits of the litlen / offset / precode tables
 constexpr uint32_t kSegLSub = 320u, kSegOSub = 160u;  // second-level entries (ENOUGH(288,10,15) - 1024 = 310, (32,8,15): 146)
 constexpr uint32_t kLzTile = 32768u;     // k_lzcopy works on 32 KiB of output at a time
@@ -80,8 +81,8 @@ struct InfSegLds {
     uint32_t lsub[kSegLSub];
     uint32_t ofast[1u << kSegORoot];  // (and the 7-bit precode table)
     uint32_t osub[kSegOSub];
-    uint32_t ring[64 * kSegRingStride];  // every lane's own compressed dwords: lane i at [i * 17 + ((dword - first dword) & 15)]
-    uint16_t cw[320];                 // builder scratch: the symbols' codewords (LSB first)
+    uint32_t ring[64 * kSegRingStride];  // every lane's own compressed dwords: lane i at [i * stride + ((dword - first dword) & (ring - 1))];
+                                      // while a table is built: the symbols' codewords (LSB first, 16 bits each)
     uint8_t lens[320];                // code lengths: litlen then offset
     uint32_t first[16];               // builder scratch: first canonical code of every length
     uint32_t alloc;                   // builder scratch: next free second-level entry
@@ -121,6 +122,7 @@ __device__ __attribute__((noinline)) bool seg_build(InfSegLds &h, const uint8_t 
     wave_sync();
     // codewords by rank among the symbols of the same length; short ones fill main[], long ones leave their
     // length at main[first `root` bits] (the longest of the group stays: the size of its second level)
+    uint16_t *cwtab = (uint16_t *)h.ring;
     uint32_t run[16];
 #pragma unroll
     for (uint32_t l = 0; l < 16; l++) run[l] = 0;
@@ -136,7 +138,7 @@ __device__ __attribute__((noinline)) bool seg_build(InfSegLds &h, const uint8_t 
         }
         if (myl) {
             const uint32_t cw = __brev(h.first[myl] + rank) >> (32 - myl);
-            h.cw[s] = (uint16_t)cw;
+            cwtab[s] = (uint16_t)cw;
             if (myl <= root) {
                 const uint32_t e = seg_entry<KIND>(s, myl);
                 for (uint32_t k = cw; k < (1u << root); k += 1u << myl) main[k] = e;
@@ -165,7 +167,7 @@ __device__ __attribute__((noinline)) bool seg_build(InfSegLds &h, const uint8_t 
         const uint32_t s = 64 * r + lane;
         const uint32_t myl = s < nsyms ? lens[s] : 0;
         if (myl > root) {
-            const uint32_t cw = h.cw[s];
+            const uint32_t cw = cwtab[s];
             const uint32_t p = main[cw & ((1u << root) - 1u)];
             const uint32_t base = p >> 16, sb = (p >> 12) & 15u;
             const uint32_t e = seg_entry<KIND>(s, myl);
@@ -195,26 +197,19 @@ __device__ __forceinline__ dword4 seg_load16(const SegWin &s, uint32_t w) {
     }
     return v;
 }
-// window k (relative dwords 8k .. 8k+7) into its half of the ring
-__device__ __forceinline__ void seg_win_put(const SegWin &s, uint32_t k, const dword4 &a, const dword4 &b) {
-    uint32_t *d = s.rl + 8u * (k & 1u);
+// window k (relative dwords 4k .. 4k+3) into its half of the ring
+__device__ __forceinline__ void seg_win_put(const SegWin &s, uint32_t k, const dword4 &a) {
+    uint32_t *d = s.rl + kSegWinDw * (k & 1u);
     d[0] = a.x;
     d[1] = a.y;
     d[2] = a.z;
     d[3] = a.w;
-    d[4] = b.x;
-    d[5] = b.y;
-    d[6] = b.z;
-    d[7] = b.w;
-    if ((k & 1u) == 0) s.rl[16] = a.x;
+    if ((k & 1u) == 0) s.rl[kSegRingDw] = a.x;
 }
-__device__ __forceinline__ void seg_win_load(const SegWin &s, uint32_t k, dword4 &a, dword4 &b) {
-    a = seg_load16(s, s.w0 + 8u * k);
-    b = seg_load16(s, s.w0 + 8u * k + 4u);
-}
+__device__ __forceinline__ void seg_win_load(const SegWin &s, uint32_t k, dword4 &a) { a = seg_load16(s, s.w0 + kSegWinDw * k); }
 // 32 bits from relative bit position rp (inside the two resident windows)
 __device__ __forceinline__ uint32_t seg_bits(const SegWin &s, uint32_t rp) {
-    const uint32_t *d = s.rl + ((rp >> 5) & 15u);
+    const uint32_t *d = s.rl + ((rp >> 5) & (kSegRingDw - 1u));
     return __builtin_amdgcn_alignbit(d[1], d[0], rp & 31u);
 }
 
@@ -259,7 +254,7 @@ __device__ __forceinline__ void seg_redo(DBlock *blk, uint32_t *redo, uint32_t b
 }
 
 #ifndef GZPX_SEG_WAVES
-#define GZPX_SEG_WAVES 3
+#define GZPX_SEG_WAVES 4
 #endif
 
 // DBlock.cyc of a debug launch: [0] whole member, [1] headers + tables, [2] pass 1, [3] pass 2, [4] pass 3,
@@ -493,16 +488,16 @@ __global__ __launch_bounds__(64, GZPX_SEG_WAVES) void k_inflate_seg(uint32_t hdr
             const long long t_p1 = DBG ? clock64() : 0;
             uint32_t rp = r_start, n1 = 0, m1 = 0, fl1 = has_data ? 0u : 2u;  // fl: 0 runs / ran through, 1 end of block, 2 invalid / no data
             {
-                dword4 a0, b0, a1, b1;
-                seg_win_load(win, 0, a0, b0);
-                seg_win_load(win, 1, a1, b1);
+                dword4 a0, a1;
+                seg_win_load(win, 0, a0);
+                seg_win_load(win, 1, a1);
                 wave_sync();
-                seg_win_put(win, 0, a0, b0);
-                seg_win_put(win, 1, a1, b1);
+                seg_win_put(win, 0, a0);
+                seg_win_put(win, 1, a1);
                 wave_sync();
                 for (uint32_t k = 0; k < nwin; k++) {
-                    dword4 na, nb;
-                    if (k + 2 < nwin + 1) seg_win_load(win, k + 2, na, nb);
+                    dword4 na;
+                    if (k + 2 < nwin + 1) seg_win_load(win, k + 2, na);
                     const uint32_t wend = 32u * kSegWinDw * (k + 1);
                     const uint32_t lim = r_end < wend ? r_end : wend;
                     while (__ballot(fl1 == 0 && rp < lim)) {
@@ -517,7 +512,7 @@ __global__ __launch_bounds__(64, GZPX_SEG_WAVES) void k_inflate_seg(uint32_t hdr
                     }
                     if (k + 2 < nwin + 1) {
                         wave_sync();
-                        seg_win_put(win, k + 2, na, nb);
+                        seg_win_put(win, k + 2, na);
                         wave_sync();
                     }
                 }
@@ -543,16 +538,16 @@ __global__ __launch_bounds__(64, GZPX_SEG_WAVES) void k_inflate_seg(uint32_t hdr
                 // both replays run in the lane's relative coordinates, window by window like pass 1
                 uint32_t a = new_entry - rel0, bq = r_start, na = 0, ma = 0, nb2 = 0, mb = 0, fa = 0, fb = has_data ? 0u : 2u;
                 bool synced = false, done = !need;
-                dword4 a0, b0, a1, b1;
-                seg_win_load(win, 0, a0, b0);
-                seg_win_load(win, 1, a1, b1);
+                dword4 a0, a1;
+                seg_win_load(win, 0, a0);
+                seg_win_load(win, 1, a1);
                 wave_sync();
-                seg_win_put(win, 0, a0, b0);
-                seg_win_put(win, 1, a1, b1);
+                seg_win_put(win, 0, a0);
+                seg_win_put(win, 1, a1);
                 wave_sync();
                 for (uint32_t k = 0; k < nwin; k++) {
-                    dword4 wa, wb;
-                    if (k + 2 < nwin + 1) seg_win_load(win, k + 2, wa, wb);
+                    dword4 wa;
+                    if (k + 2 < nwin + 1) seg_win_load(win, k + 2, wa);
                     const uint32_t wend = 32u * kSegWinDw * (k + 1);
                     for (;;) {
                         // whose turn: the replay from the true entry (a) unless the speculative one (b) is behind it
@@ -586,7 +581,7 @@ __global__ __launch_bounds__(64, GZPX_SEG_WAVES) void k_inflate_seg(uint32_t hdr
                     if (__ballot(!done) == 0) break;
                     if (k + 2 < nwin + 1) {
                         wave_sync();
-                        seg_win_put(win, k + 2, wa, wb);
+                        seg_win_put(win, k + 2, wa);
                         wave_sync();
                     }
                 }
@@ -636,16 +631,16 @@ __global__ __launch_bounds__(64, GZPX_SEG_WAVES) void k_inflate_seg(uint32_t hdr
                 uint32_t pos = o + in_n - my_n, mi = mtot + in_m - my_m;
                 uint32_t f3 = live ? 0u : 2u;
                 rp = entry - rel0;
-                dword4 a0, b0, a1, b1;
-                seg_win_load(win, 0, a0, b0);
-                seg_win_load(win, 1, a1, b1);
+                dword4 a0, a1;
+                seg_win_load(win, 0, a0);
+                seg_win_load(win, 1, a1);
                 wave_sync();
-                seg_win_put(win, 0, a0, b0);
-                seg_win_put(win, 1, a1, b1);
+                seg_win_put(win, 0, a0);
+                seg_win_put(win, 1, a1);
                 wave_sync();
                 for (uint32_t k = 0; k < nwin; k++) {
-                    dword4 na, nb;
-                    if (k + 2 < nwin + 1) seg_win_load(win, k + 2, na, nb);
+                    dword4 na;
+                    if (k + 2 < nwin + 1) seg_win_load(win, k + 2, na);
                     const uint32_t wend = 32u * kSegWinDw * (k + 1);
                     const uint32_t lim = r_end < wend ? r_end : wend;
                     while (__ballot(f3 == 0 && rp < lim)) {
@@ -672,7 +667,7 @@ __global__ __launch_bounds__(64, GZPX_SEG_WAVES) void k_inflate_seg(uint32_t hdr
                     }
                     if (k + 2 < nwin + 1) {
                         wave_sync();
-                        seg_win_put(win, k + 2, na, nb);
+                        seg_win_put(win, k + 2, na);
                         wave_sync();
                     }
                 }
