@@ -1395,7 +1395,7 @@ int dslot_reserve(DSlot &c, size_t nb) {
     HIP_TRY(hipMalloc((void **)&c.d_sizes, cap * 4));
     HIP_TRY(hipMalloc((void **)&c.d_crc, cap * 4));
     HIP_TRY(hipMalloc((void **)&c.d_blk, cap * sizeof(DBlockHost)));
-    HIP_TRY(hipMalloc((void **)&c.sc.redo, (cap + 1) * 4));
+    HIP_TRY(hipMalloc((void **)&c.sc.redo, (cap + 2) * 4));
     HIP_TRY(hipHostMalloc((void **)&c.h_blk, cap * sizeof(DBlockHost), hipHostMallocDefault));
     HIP_TRY(hipHostMalloc((void **)&c.h_crc, cap * 4, hipHostMallocDefault));
     HIP_TRY(hipHostMalloc((void **)&c.h_offsets, cap * 8, hipHostMallocDefault));
@@ -1414,6 +1414,7 @@ struct gzpx_dctx {
     hipEvent_t ev_dep = nullptr;
     DSlot slots[kSlots];
     uint64_t next_gen = 1;
+    int n_cu = 0;
     int debug = 0;  // 1: instrumented k_inflate_seg / k_inflate, 2: instrumented k_lzcopy
     int route = kInflateRouteSeg;  // GZPX_INFLATE_ROUTE=wave / gzpx_dctx_set_route: k_inflate for every member
     int last_slot = -1;  // the slot of the last completed launch (timing / debug counters)
@@ -1500,6 +1501,7 @@ int dsubmit_enqueue(gzpx_dctx *c, const uint8_t *host_in, const uint8_t *d_in, s
         HIP_TRY(hipMemcpyAsync(sl.d_sizes, sl.h_sizes, nb * 4, hipMemcpyHostToDevice, c->s_h2d));
         HIP_TRY(hipEventRecord(sl.ev_h2d, c->s_h2d));
         HIP_TRY(hipStreamWaitEvent(stream, sl.ev_h2d, 0));
+        sl.sc.n_cu = c->n_cu;
         if (c->route == kInflateRouteSeg) {  // scratch of the decode / copy pair, sized by what the caller can take
             const size_t need_m = inflate_mlist_bytes(out_cap, nb), need_t = inflate_tfirst_bytes(out_cap, nb);
             if (need_m > sl.mlist_cap) {
@@ -1611,6 +1613,10 @@ int gzpx_dctx_create(int device, int format, gzpx_dctx **out) {
     if (!c) return GZPX_ERR_DEVICE;
     c->device = device;
     c->format = format;
+    {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) c->n_cu = prop.multiProcessorCount;
+    }
     if (const char *e = getenv("GZPX_INFLATE_ROUTE"))
         if (!strcmp(e, "wave")) c->route = kInflateRouteWave;
     for (unsigned l = 0; l < 10; l++) c->cc.pow64[l] = x2k(9 + l);

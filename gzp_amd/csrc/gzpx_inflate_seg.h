@@ -260,15 +260,11 @@ __device__ __forceinline__ void seg_redo(DBlock *blk, uint32_t *redo, uint32_t b
 // DBlock.cyc of a debug launch: [0] whole member, [1] headers + tables, [2] pass 1, [3] pass 2, [4] pass 3,
 // counts [5] spans, [6] pass-2 iterations, [7] symbol steps of passes 1 and 3 (wave iterations)
 template <bool DBG>
-__global__ __launch_bounds__(64, GZPX_SEG_WAVES) void k_inflate_seg(uint32_t hdr_len, const uint8_t *__restrict__ in_all,
-                                                                   DBlock *__restrict__ blk_all,
-                                                                   const uint64_t *__restrict__ out_off, uint8_t *out_all,
-                                                                   uint64_t out_cap, LzMatch *__restrict__ mlist_all,
-                                                                   uint32_t *__restrict__ tfirst_all,
-                                                                   uint32_t *__restrict__ redo) {
-    __shared__ InfSegLds h;
-    const uint32_t lane = threadIdx.x;
-    const uint32_t b = blockIdx.x;
+__device__ __attribute__((noinline)) void seg_member(const uint32_t b, const uint32_t lane, uint32_t hdr_len, const uint8_t *__restrict__ in_all,
+                                                     DBlock *__restrict__ blk_all, const uint64_t *__restrict__ out_off, uint8_t *out_all,
+                                                     uint64_t out_cap, LzMatch *__restrict__ mlist_all, uint32_t *__restrict__ tfirst_all,
+                                                     uint32_t *__restrict__ redo) {
+    __shared__ InfSegLds h;  // (the wave's tables and ring: its own LDS object, so that every access stays an LDS instruction)
     DBlock *blk = blk_all + b;
     const uint32_t isize = blk->isize;
     if (lane == 0) blk->nmatch = 0;
@@ -694,6 +690,27 @@ __global__ __launch_bounds__(64, GZPX_SEG_WAVES) void k_inflate_seg(uint32_t hdr
     if (DBG && lane == 0) {
         dbg[0] = (uint32_t)(clock64() - t_begin);
         for (uint32_t k = 0; k < 8; k++) blk->cyc[k] = dbg[k];
+    }
+}
+
+// One wave per member, the members claimed from a ticket counter (redo[1 + nb]): the launch holds as many waves as the
+// chip keeps resident, and a wave that finishes a member takes the next one -- 8,835 members on 4,096 wave slots are
+// 2.16 member times, not three.
+template <bool DBG>
+__global__ __launch_bounds__(64, GZPX_SEG_WAVES) void k_inflate_seg(uint32_t hdr_len, const uint8_t *__restrict__ in_all,
+                                                                   DBlock *__restrict__ blk_all,
+                                                                   const uint64_t *__restrict__ out_off, uint8_t *out_all,
+                                                                   uint64_t out_cap, LzMatch *__restrict__ mlist_all,
+                                                                   uint32_t *__restrict__ tfirst_all,
+                                                                   uint32_t *__restrict__ redo, uint32_t nb) {
+    const uint32_t lane = threadIdx.x;
+    for (;;) {
+        uint32_t b = 0;
+        if (lane == 0) b = atomicAdd(&redo[1 + nb], 1u);
+        b = uniform(b);
+        if (b >= nb) break;
+        wave_sync();
+        seg_member<DBG>(b, lane, hdr_len, in_all, blk_all, out_off, out_all, out_cap, mlist_all, tfirst_all, redo);
     }
 }
 

@@ -244,7 +244,10 @@ __device__ __forceinline__ BlockMeta block_meta_of(const Config &cfg, uint64_t s
 __global__ void k_init_meta(Config cfg, uint64_t slab_len, uint32_t nb, uint32_t is_last,
                             BlockMeta *meta, uint32_t *redo) {
     const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b == 0 && redo) redo[0] = 0;        // level 1: nothing handed back to the dense kernels yet
+    if (b == 0 && redo) {
+        redo[0] = 0;       // members handed back to k_inflate
+        redo[1 + nb] = 0;  // k_inflate_seg's ticket counter
+    }        // level 1: nothing handed back to the dense kernels yet
     if (b >= nb) return;
     meta[b] = block_meta_of(cfg, slab_len, nb, is_last, b);
 }
@@ -4877,7 +4880,10 @@ struct DBlock {
 __global__ void k_dinit(uint32_t nb, const uint8_t *__restrict__ in, const uint64_t *__restrict__ offsets,
                         const uint32_t *__restrict__ sizes, DBlock *__restrict__ blk, uint32_t *__restrict__ redo) {
     const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b == 0 && redo) redo[0] = 0;
+    if (b == 0 && redo) {
+        redo[0] = 0;       // members handed back to k_inflate
+        redo[1 + nb] = 0;  // k_inflate_seg's ticket counter
+    }
     if (b >= nb) return;
     const uint8_t *f = in + offsets[b] + sizes[b] - 8;  // get_footer_values, src/lib.rs:440-447
     DBlock d;
@@ -5765,25 +5771,29 @@ void launch_inflate(uint32_t hdr_len, const uint8_t *d_in, const uint64_t *d_off
     if (seg) {
         // decode (literals + match records), LZ copy, then k_inflate over whatever the two left on the redo list
         LzMatch *ml = (LzMatch *)sc.mlist;
+        const uint32_t seg_slots = (uint32_t)(sc.n_cu > 0 ? sc.n_cu : 256) * 4u * GZPX_SEG_WAVES;  // resident waves of k_inflate_seg
+        const uint32_t seg_grid = nb < seg_slots ? nb : seg_slots;
         if (debug == 1) {
-            hipLaunchKernelGGL((k_inflate_seg<true>), dim3(nb), dim3(64), 0, stream, hdr_len, d_in, blk,
-                               (const uint64_t *)d_out_off, d_out, out_cap, ml, sc.tfirst, sc.redo);
+            hipLaunchKernelGGL((k_inflate_seg<true>), dim3(seg_grid), dim3(64), 0, stream, hdr_len, d_in, blk,
+                               (const uint64_t *)d_out_off, d_out, out_cap, ml, sc.tfirst, sc.redo, nb);
             hipLaunchKernelGGL((k_lzcopy<false>), dim3(nb), dim3(kLcThreads), 0, stream, blk, (const uint64_t *)d_out_off,
                                d_out, (const LzMatch *)ml, (const uint32_t *)sc.tfirst, sc.redo);
             hipLaunchKernelGGL((k_inflate<true, true>), dim3(nb), dim3(64), 0, stream, hdr_len, d_in, blk,
                                (const uint64_t *)d_out_off, d_out, out_cap, (const uint32_t *)sc.redo);
         } else if (debug == 2) {  // k_lzcopy's clocks instead of k_inflate_seg's
-            hipLaunchKernelGGL((k_inflate_seg<false>), dim3(nb), dim3(64), 0, stream, hdr_len, d_in, blk,
-                               (const uint64_t *)d_out_off, d_out, out_cap, ml, sc.tfirst, sc.redo);
+            hipLaunchKernelGGL((k_inflate_seg<false>), dim3(seg_grid), dim3(64), 0, stream, hdr_len, d_in, blk,
+                               (const uint64_t *)d_out_off, d_out, out_cap, ml, sc.tfirst, sc.redo, nb);
             hipLaunchKernelGGL((k_lzcopy<true>), dim3(nb), dim3(kLcThreads), 0, stream, blk, (const uint64_t *)d_out_off,
                                d_out, (const LzMatch *)ml, (const uint32_t *)sc.tfirst, sc.redo);
             hipLaunchKernelGGL((k_inflate<false, true>), dim3(nb), dim3(64), 0, stream, hdr_len, d_in, blk,
                                (const uint64_t *)d_out_off, d_out, out_cap, (const uint32_t *)sc.redo);
         } else {
-            hipLaunchKernelGGL((k_inflate_seg<false>), dim3(nb), dim3(64), 0, stream, hdr_len, d_in, blk,
-                               (const uint64_t *)d_out_off, d_out, out_cap, ml, sc.tfirst, sc.redo);
+            hipLaunchKernelGGL((k_inflate_seg<false>), dim3(seg_grid), dim3(64), 0, stream, hdr_len, d_in, blk,
+                               (const uint64_t *)d_out_off, d_out, out_cap, ml, sc.tfirst, sc.redo, nb);
+            if (getenv("GZPX_DBG_SYNC")) { fprintf(stderr, "seg launched grid %u\n", seg_grid); (void)hipStreamSynchronize(stream); fprintf(stderr, "seg done\n"); }
             hipLaunchKernelGGL((k_lzcopy<false>), dim3(nb), dim3(kLcThreads), 0, stream, blk, (const uint64_t *)d_out_off,
                                d_out, (const LzMatch *)ml, (const uint32_t *)sc.tfirst, sc.redo);
+            if (getenv("GZPX_DBG_SYNC")) { (void)hipStreamSynchronize(stream); fprintf(stderr, "lz done\n"); }
             hipLaunchKernelGGL((k_inflate<false, true>), dim3(nb), dim3(64), 0, stream, hdr_len, d_in, blk,
                                (const uint64_t *)d_out_off, d_out, out_cap, (const uint32_t *)sc.redo);
         }
