@@ -56,7 +56,7 @@ EXPORTS = [
     "gzpx_decompress_blocks_wait", "gzpx_alloc_decompressor", "gzpx_deflate_decompress",
     "gzpx_free_decompressor", "gzpx_pard_create", "gzpx_pard_read", "gzpx_pard_destroy",
     "gzpx_pard_last_error", "gzpx_host_alloc", "gzpx_host_free", "gzpx_dctx_last_inflate_ms",
-    "gzpx_debug_inflate", "gzpx_dctx_set_route", "gzpx_dctx_last_redo_count", "gzpx_synth_fastq_device", "gzpx_synth_ascii_device",
+    "gzpx_debug_inflate", "gzpx_dctx_last_inflate_stage_ms", "gzpx_dctx_set_route", "gzpx_dctx_last_redo_count", "gzpx_synth_fastq_device", "gzpx_synth_ascii_device",
     "gzpx_ctx_active_compat", "gzpx_build_id", "gzpx_multi_create", "gzpx_multi_destroy", "gzpx_multi_devices", "gzpx_multi_compress_slab",
     "gzpx_multi_shard", "gzpx_multi_compress_slab_device",
 ]
@@ -226,6 +226,8 @@ class GzpxLib:
         L.gzpx_dctx_last_inflate_ms.argtypes = [vp, ctypes.POINTER(ctypes.c_float)]
         L.gzpx_debug_inflate.restype = i32
         L.gzpx_debug_inflate.argtypes = [vp, i32, ctypes.POINTER(ctypes.c_uint64)]
+        L.gzpx_dctx_last_inflate_stage_ms.restype = i32
+        L.gzpx_dctx_last_inflate_stage_ms.argtypes = [vp, ctypes.POINTER(ctypes.c_float)]
         L.gzpx_dctx_set_route.restype = i32
         L.gzpx_dctx_set_route.argtypes = [vp, i32]
         L.gzpx_dctx_last_redo_count.restype = i32
@@ -665,6 +667,12 @@ class DContext:
         ms = ctypes.c_float(0)
         self.lib.check(self.lib.L.gzpx_dctx_last_inflate_ms(self.h, ctypes.byref(ms)))
         return ms.value
+
+    def last_inflate_stage_ms(self):
+        """(k_inflate_seg ms, k_lzcopy + hand-backs ms) of the last launch on the decode / copy route."""
+        ms = (ctypes.c_float * 2)()
+        self.lib.check(self.lib.L.gzpx_dctx_last_inflate_stage_ms(self.h, ms))
+        return ms[0], ms[1]
 
     def set_route(self, route):
         """INFLATE_SEG (default): k_inflate_seg + k_lzcopy, hand-backs to k_inflate; INFLATE_WAVE: k_inflate for every member."""

@@ -1355,6 +1355,7 @@ struct DSlot {
     size_t mlist_cap = 0, tfirst_cap = 0;
     hipEvent_t ev_h2d = nullptr, ev_kernels = nullptr, ev_done = nullptr;
     hipEvent_t ev_t0 = nullptr, ev_t1 = nullptr;  // around the inflate kernels (timing enabled)
+    hipEvent_t ev_tm = nullptr;                   // behind k_inflate_seg (the decode / copy route)
     size_t nb = 0;
 };
 
@@ -1385,6 +1386,7 @@ int dslot_reserve(DSlot &c, size_t nb) {
         HIP_TRY(hipEventCreateWithFlags(&c.ev_done, hipEventDisableTiming));
         HIP_TRY(hipEventCreate(&c.ev_t0));
         HIP_TRY(hipEventCreate(&c.ev_t1));
+        HIP_TRY(hipEventCreate(&c.ev_tm));
         HIP_TRY(hipHostMalloc((void **)&c.h_total, 64, hipHostMallocDefault));
     }
     if (nb <= c.cap_blocks) return GZPX_OK;
@@ -1520,7 +1522,7 @@ int dsubmit_enqueue(gzpx_dctx *c, const uint8_t *host_in, const uint8_t *d_in, s
             }
         }
         launch_inflate(hdr_len, d_in, sl.d_offsets, sl.d_sizes, (uint32_t)nb, sl.d_blk, sl.d_out_off, d_out, out_cap,
-                       sl.d_crc, c->cc, c->debug, sl.ev_t0, sl.ev_t1, stream, sl.sc, c->route);
+                       sl.d_crc, c->cc, c->debug, sl.ev_t0, sl.ev_t1, stream, sl.sc, c->route, sl.ev_tm);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipMemcpyAsync(sl.h_blk, sl.d_blk, nb * sizeof(DBlockHost), hipMemcpyDeviceToHost, stream));
         HIP_TRY(hipMemcpyAsync(sl.h_crc, sl.d_crc, nb * 4, hipMemcpyDeviceToHost, stream));
@@ -1646,7 +1648,7 @@ void gzpx_dctx_destroy(gzpx_dctx *c) {
         if (sl.d_out) (void)hipFree(sl.d_out);
         if (sl.sc.mlist) (void)hipFree(sl.sc.mlist);
         if (sl.sc.tfirst) (void)hipFree(sl.sc.tfirst);
-        for (hipEvent_t e : {sl.ev_h2d, sl.ev_kernels, sl.ev_done, sl.ev_t0, sl.ev_t1})
+        for (hipEvent_t e : {sl.ev_h2d, sl.ev_kernels, sl.ev_done, sl.ev_t0, sl.ev_t1, sl.ev_tm})
             if (e) (void)hipEventDestroy(e);
     }
     if (c->ev_dep) (void)hipEventDestroy(c->ev_dep);
@@ -1892,6 +1894,17 @@ int gzpx_dctx_last_inflate_ms(gzpx_dctx *ctx, float *ms) {
     if (!ctx->last_nb || ctx->last_slot < 0) return GZPX_OK;
     const DSlot &sl = ctx->slots[ctx->last_slot];
     return hipEventElapsedTime(ms, sl.ev_t0, sl.ev_t1) == hipSuccess ? GZPX_OK : GZPX_ERR_DEVICE;
+}
+
+int gzpx_dctx_last_inflate_stage_ms(gzpx_dctx *ctx, float ms[2]) {
+    if (!ctx || !ms) return GZPX_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> g(ctx->mu);
+    ms[0] = ms[1] = 0.0f;
+    if (!ctx->last_nb || ctx->last_slot < 0 || ctx->route != kInflateRouteSeg) return GZPX_OK;
+    const DSlot &sl = ctx->slots[ctx->last_slot];
+    if (hipEventElapsedTime(&ms[0], sl.ev_t0, sl.ev_tm) != hipSuccess || hipEventElapsedTime(&ms[1], sl.ev_tm, sl.ev_t1) != hipSuccess)
+        return GZPX_ERR_DEVICE;
+    return GZPX_OK;
 }
 
 int gzpx_dctx_set_route(gzpx_dctx *ctx, int route) {

@@ -180,6 +180,6 @@ size_t inflate_tfirst_bytes(uint64_t out_cap, uint64_t nb);
 void launch_inflate(uint32_t hdr_len, const uint8_t *d_in, const uint64_t *d_offsets, const uint32_t *d_sizes,
                     uint32_t nb, void *d_blk, uint64_t *d_out_off, uint8_t *d_out, uint64_t out_cap,
                     uint32_t *d_crc_found, const CrcConsts &cc, int debug, hipEvent_t ev_begin,
-                    hipEvent_t ev_end, hipStream_t stream, const InflateScratch &sc, int route);
+                    hipEvent_t ev_end, hipStream_t stream, const InflateScratch &sc, int route, hipEvent_t ev_mid = nullptr);
 
 }  // namespace gzpx

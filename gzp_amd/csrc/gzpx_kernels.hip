@@ -5761,7 +5761,7 @@ void launch_emit(const Config &cfg, const uint8_t *slab, uint64_t, uint32_t nb, 
 void launch_inflate(uint32_t hdr_len, const uint8_t *d_in, const uint64_t *d_offsets, const uint32_t *d_sizes,
                     uint32_t nb, void *d_blk, uint64_t *d_out_off, uint8_t *d_out, uint64_t out_cap,
                     uint32_t *d_crc_found, const CrcConsts &cc, int debug, hipEvent_t ev_begin,
-                    hipEvent_t ev_end, hipStream_t stream, const InflateScratch &sc, int route) {
+                    hipEvent_t ev_end, hipStream_t stream, const InflateScratch &sc, int route, hipEvent_t ev_mid) {
     DBlock *blk = (DBlock *)d_blk;
     const bool seg = route != kInflateRouteWave && sc.mlist && sc.tfirst && sc.redo;
     hipLaunchKernelGGL(k_dinit, dim3((nb + 255) / 256), dim3(256), 0, stream, nb, d_in, d_offsets, d_sizes, blk,
@@ -5776,6 +5776,7 @@ void launch_inflate(uint32_t hdr_len, const uint8_t *d_in, const uint64_t *d_off
         if (debug == 1) {
             hipLaunchKernelGGL((k_inflate_seg<true>), dim3(seg_grid), dim3(64), 0, stream, hdr_len, d_in, blk,
                                (const uint64_t *)d_out_off, d_out, out_cap, ml, sc.tfirst, sc.redo, nb);
+            if (ev_mid) (void)hipEventRecord(ev_mid, stream);
             hipLaunchKernelGGL((k_lzcopy<false>), dim3(nb), dim3(kLcThreads), 0, stream, blk, (const uint64_t *)d_out_off,
                                d_out, (const LzMatch *)ml, (const uint32_t *)sc.tfirst, sc.redo);
             hipLaunchKernelGGL((k_inflate<true, true>), dim3(nb), dim3(64), 0, stream, hdr_len, d_in, blk,
@@ -5790,10 +5791,10 @@ void launch_inflate(uint32_t hdr_len, const uint8_t *d_in, const uint64_t *d_off
         } else {
             hipLaunchKernelGGL((k_inflate_seg<false>), dim3(seg_grid), dim3(64), 0, stream, hdr_len, d_in, blk,
                                (const uint64_t *)d_out_off, d_out, out_cap, ml, sc.tfirst, sc.redo, nb);
-            if (getenv("GZPX_DBG_SYNC")) { fprintf(stderr, "seg launched grid %u\n", seg_grid); (void)hipStreamSynchronize(stream); fprintf(stderr, "seg done\n"); }
+            if (ev_mid) (void)hipEventRecord(ev_mid, stream);
             hipLaunchKernelGGL((k_lzcopy<false>), dim3(nb), dim3(kLcThreads), 0, stream, blk, (const uint64_t *)d_out_off,
                                d_out, (const LzMatch *)ml, (const uint32_t *)sc.tfirst, sc.redo);
-            if (getenv("GZPX_DBG_SYNC")) { (void)hipStreamSynchronize(stream); fprintf(stderr, "lz done\n"); }
+
             hipLaunchKernelGGL((k_inflate<false, true>), dim3(nb), dim3(64), 0, stream, hdr_len, d_in, blk,
                                (const uint64_t *)d_out_off, d_out, out_cap, (const uint32_t *)sc.redo);
         }

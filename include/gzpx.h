@@ -343,6 +343,9 @@ int gzpx_debug_redo_count(gzpx_ctx *ctx, uint32_t *count);
 /* HIP-event duration of the inflate kernels (k_inflate_seg + k_lzcopy + k_inflate over the redo list, or
  * k_inflate alone) in the last decompress launch of this context */
 int gzpx_dctx_last_inflate_ms(gzpx_dctx *ctx, float *ms);
+/* GZPX_INFLATE_SEG: the same split in two, ms[0] = k_inflate_seg (Huffman decode), ms[1] = k_lzcopy + k_inflate over the
+ * hand-backs (zeros on the other route) */
+int gzpx_dctx_last_inflate_stage_ms(gzpx_dctx *ctx, float ms[2]);
 /* Which kernels inflate (decode_block, src/par/decompress.rs:162-186): GZPX_INFLATE_SEG (default) = the decode /
  * LZ-copy pair, members they cannot take handed to k_inflate; GZPX_INFLATE_WAVE = k_inflate (one wave per member,
  * window in HBM) for every member.  Same bytes, same error classes either way. */

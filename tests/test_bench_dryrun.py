@@ -88,4 +88,4 @@ def test_single_rank_line_has_e2e_and_inflate_legs(capsys, monkeypatch):
     bench.main()
     d = json.loads([l for l in capsys.readouterr().out.splitlines() if l.startswith("{")][0])
     assert d["e2e"]["device_pinned_ok"] and d["e2e"]["api_write_ok"] and d["e2e"]["api_write_64k_ok"]
-    assert d["inflate"]["verified_round_trip"] is True and d["inflate"]["roofline"]["kernel"] == "k_inflate"
+    assert d["inflate"]["verified_round_trip"] is True and d["inflate"]["roofline"]["kernel"] == "k_inflate_seg"

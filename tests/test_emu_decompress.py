@@ -17,9 +17,13 @@ def bgzf_member(chunk, level=6, strategy=zlib.Z_DEFAULT_STRATEGY):
     return hdr + payload + struct.pack("<II", zlib.crc32(chunk), len(chunk))
 
 
-@pytest.fixture(scope="module")
-def dctx(emu_lib):
+@pytest.fixture(scope="module", params=["seg", "wave"])
+def dctx(request, emu_lib):
+    """Both inflate routes: the decode / LZ-copy pair (k_inflate_seg + k_lzcopy, the default; k_inflate takes what they
+    hand back) and k_inflate for every member."""
     c = _native.DContext(lib=emu_lib)
+    c.set_route(_native.INFLATE_SEG if request.param == "seg" else _native.INFLATE_WAVE)
+    c.route_name = request.param
     yield c
     c.close()
 

@@ -19,9 +19,13 @@ def bgzf_member(chunk, level=6, strategy=zlib.Z_DEFAULT_STRATEGY):
     return hdr + payload + struct.pack("<II", zlib.crc32(chunk), len(chunk))
 
 
-@pytest.fixture(scope="module")
-def dctx(hip_lib):
+@pytest.fixture(scope="module", params=["seg", "wave"])
+def dctx(request, hip_lib):
+    """Both inflate routes: the decode / LZ-copy pair (k_inflate_seg + k_lzcopy, the default; k_inflate takes what they
+    hand back) and k_inflate for every member."""
     c = _native.DContext(lib=hip_lib)
+    c.set_route(_native.INFLATE_SEG if request.param == "seg" else _native.INFLATE_WAVE)
+    c.route_name = request.param
     yield c
     c.close()
 
@@ -33,6 +37,29 @@ def test_roundtrip_all_classes(dctx, hip_lib, level):
             a = synth.make(cls, 40 * 65280 + 4321, 17)
             comp = c.compress_slab(a, True)
             assert dctx.decompress(comp) == a.tobytes(), cls
+
+
+def test_decode_copy_pair_takes_ordinary_members_itself(hip_lib):
+    """The default route must not pass by way of k_inflate: nothing of an ordinary stream is handed back; a member
+    that does not decode (a byte of its payload flipped) is, and comes out with the error class k_inflate gives it."""
+    a = synth.text_slab(200 * 65280, seed=11)
+    with _native.Context(level=1, lib=hip_lib) as c:
+        comp = c.compress_slab(a, True)
+    with _native.DContext(lib=hip_lib) as d:
+        assert d.decompress(comp) == a.tobytes() and d.last_redo_count() == 0
+        st = d.last_inflate_stage_ms()
+        assert st[0] > 0 and st[1] > 0
+        bad = bytearray(comp)
+        offs, sizes, _ = d.scan_blocks(bytes(comp))
+        bad[int(offs[3]) + 18 + 40] ^= 0x55
+        with pytest.raises(_native.GzpxError) as e:
+            d.decompress(bytes(bad))
+        assert e.value.code in (_native.ERR_BAD_DATA, _native.ERR_INVALID_CHECK, _native.ERR_INSUFFICIENT_SPACE) and e.value.block == 3
+        with _native.DContext(lib=hip_lib) as w:
+            w.set_route(_native.INFLATE_WAVE)
+            with pytest.raises(_native.GzpxError) as e2:
+                w.decompress(bytes(bad))
+        assert (e2.value.code, e2.value.block) == (e.value.code, e.value.block)
 
 
 def test_config5_shape_256mib(dctx, hip_lib):
