@@ -1504,6 +1504,11 @@ int dsubmit_enqueue(gzpx_dctx *c, const uint8_t *host_in, const uint8_t *d_in, s
         HIP_TRY(hipEventRecord(sl.ev_h2d, c->s_h2d));
         HIP_TRY(hipStreamWaitEvent(stream, sl.ev_h2d, 0));
         sl.sc.n_cu = c->n_cu;
+        {
+            uint64_t csum = 0;
+            for (size_t b = 0; b < nb; b++) csum += sizes[b];
+            sl.sc.big_members = nb && csum / nb >= 131072u ? 1 : 0;
+        }
         if (c->route == kInflateRouteSeg) {  // scratch of the decode / copy pair, sized by what the caller can take
             const size_t need_m = inflate_mlist_bytes(out_cap, nb), need_t = inflate_tfirst_bytes(out_cap, nb);
             if (need_m > sl.mlist_cap) {

@@ -173,6 +173,7 @@ struct InflateScratch {
     uint32_t *tfirst = nullptr;  // inflate_tfirst_bytes(out_cap, nb)
     uint32_t *redo = nullptr;    // [1 + nb] the list, [1 + nb] behind it k_inflate_seg's ticket counter
     int n_cu = 0;                // compute units of the device (the size of the persistent launch)
+    int big_members = 0;         // the slab's members average >= 128 KiB compressed: several waves work on each
 };
 enum { kInflateRouteSeg = 0, kInflateRouteWave = 1 };  // k_inflate_seg + k_lzcopy (default) | k_inflate for every member
 size_t inflate_mlist_bytes(uint64_t out_cap, uint64_t nb);

@@ -26,7 +26,7 @@
 constexpr uint32_t kInfRedo = 0x80u;     // DBlock.status while a member waits for k_inflate
 constexpr uint32_t kSegMinBits = 512u;   // segment length per lane: remaining bits / 64, within these bounds
 constexpr uint32_t kSegMaxBits = 8192u;
-constexpr uint32_t kSegMaxFix = 6u;      // pass-2 iterations before the member is handed to k_inflate
+constexpr uint32_t kSegMaxFix = 8u;      // pass-2 iterations before the member is handed to k_inflate
 constexpr uint32_t kSegWinDw = 4u;       // dwords per refill window (128 bits of every lane's stream)
 constexpr uint32_t kSegRingDw = 2u * kSegWinDw;  // the ring: two windows
 constexpr uint32_t kSegRingStride = kSegRingDw + 1u;  // dwords per lane: + a copy of slot 0 behind the last slot (odd: no bank conflicts)
@@ -81,19 +81,27 @@ struct InfSegLds {
     uint32_t lsub[kSegLSub];
     uint32_t ofast[1u << kSegORoot];  // (and the 7-bit precode table)
     uint32_t osub[kSegOSub];
-    uint32_t ring[64 * kSegRingStride];  // every lane's own compressed dwords: lane i at [i * stride + ((dword - first dword) & (ring - 1))];
-                                      // while a table is built: the symbols' codewords (LSB first, 16 bits each)
     uint8_t lens[320];                // code lengths: litlen then offset
     uint32_t first[16];               // builder scratch: first canonical code of every length
     uint32_t alloc;                   // builder scratch: next free second-level entry
+};
+// A member's LDS: the tables (one copy for the W waves that work on it), every lane's ring of its own compressed dwords
+// (lane i of wave w at [(64 w + i) * stride + ((dword - first dword) & (ring - 1))]; while a table is built, wave 0's
+// part holds the symbols' codewords), what wave 0 found in a block header, and what the waves tell each other.
+template <int W>
+struct InfSegLdsW {
+    InfSegLds t;
+    uint32_t ring[W * 64 * kSegRingStride];
+    uint32_t hres[8];
+    uint32_t x_ex[W], x_first[W], x_fl[W], x_n[W], x_m[W];
 };
 
 // Build the two-level decode table of one code from lens[0 .. nsyms) (nsyms <= 320): `root` index bits in
 // main[], longer codewords behind pointer entries in sub[] (sub[0] stays 0: where unused codewords land).  All 64
 // lanes call it.  Returns false for an over-subscribed code or a second level that does not fit.
 template <int KIND>
-__device__ __attribute__((noinline)) bool seg_build(InfSegLds &h, const uint8_t *lens, uint32_t nsyms, uint32_t root, uint32_t *main,
-                                       uint32_t *sub, uint32_t sub_cap, uint32_t lane) {
+__device__ __attribute__((noinline)) bool seg_build(InfSegLds &h, uint16_t *cwtab, const uint8_t *lens, uint32_t nsyms, uint32_t root,
+                                       uint32_t *main, uint32_t *sub, uint32_t sub_cap, uint32_t lane) {
     const uint64_t lane_below = (1ull << lane) - 1ull;
     const uint32_t rounds = (nsyms + 63) >> 6;
     uint32_t cnt[16];
@@ -122,7 +130,6 @@ __device__ __attribute__((noinline)) bool seg_build(InfSegLds &h, const uint8_t 
     wave_sync();
     // codewords by rank among the symbols of the same length; short ones fill main[], long ones leave their
     // length at main[first `root` bits] (the longest of the group stays: the size of its second level)
-    uint16_t *cwtab = (uint16_t *)h.ring;
     uint32_t run[16];
 #pragma unroll
     for (uint32_t l = 0; l < 16; l++) run[l] = 0;
@@ -256,64 +263,26 @@ __device__ __forceinline__ void seg_redo(DBlock *blk, uint32_t *redo, uint32_t b
 #ifndef GZPX_SEG_WAVES
 #define GZPX_SEG_WAVES 4
 #endif
+constexpr int kSegBigW = 8;                    // waves per member in the launch form for large members (Mgzip)
+constexpr uint32_t kSegBigBytes = 131072u;     // compressed bytes per member (average of the slab) from which it is used
 
-// DBlock.cyc of a debug launch: [0] whole member, [1] headers + tables, [2] pass 1, [3] pass 2, [4] pass 3,
-// counts [5] spans, [6] pass-2 iterations, [7] symbol steps of passes 1 and 3 (wave iterations)
-template <bool DBG>
-__device__ __attribute__((noinline)) void seg_member(const uint32_t b, const uint32_t lane, uint32_t hdr_len, const uint8_t *__restrict__ in_all,
-                                                     DBlock *__restrict__ blk_all, const uint64_t *__restrict__ out_off, uint8_t *out_all,
-                                                     uint64_t out_cap, LzMatch *__restrict__ mlist_all, uint32_t *__restrict__ tfirst_all,
-                                                     uint32_t *__restrict__ redo) {
-    __shared__ InfSegLds h;  // (the wave's tables and ring: its own LDS object, so that every access stays an LDS instruction)
-    DBlock *blk = blk_all + b;
-    const uint32_t isize = blk->isize;
-    if (lane == 0) blk->nmatch = 0;
-    if (isize == 0) return;  // src/par/decompress.rs:163-171: nothing to decode
-    const uint64_t ooff = out_off[b];
-    if (ooff + isize > out_cap) {
-        if (lane == 0) blk->status = kInfInsufficientSpace;
-        return;
-    }
-    uint8_t *out = out_all + ooff;
-    const uint8_t *pay = in_all + blk->in_off + hdr_len;
-    const uint32_t pay_len = blk->size - hdr_len - 8;
-    LzMatch *ml = mlist_all + (ooff / 3u + b);
-    uint32_t *tf = tfirst_all + ((ooff >> 15) + 2ull * b);
-    const bool multi = isize > kLzTile;  // more than one k_lzcopy tile: the first record of every tile is noted
-    if (multi && lane == 0) tf[0] = 0;
-    const long long t_begin = DBG ? clock64() : 0;
-    uint32_t dbg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-
-    const uint32_t pmis = (uint32_t)((uintptr_t)pay & 3u);
-    const uint32_t *pay32 = (const uint32_t *)(pay - pmis);
-    const uint32_t pay_words = (pmis + pay_len + 8 + 3) >> 2;  // the 8 footer bytes are readable too
-    const uint32_t last_w = pay_words - 1;
-    const uint32_t bit0 = 8u * pmis, bit_end = bit0 + 8u * pay_len;
-    const uint64_t lane_below = (1ull << lane) - 1ull;
-    SegWin win;
-    win.pay32 = pay32;
-    win.last_w = last_w;
-    win.rl = h.ring + lane * kSegRingStride;
-    win.w0 = 0;
-
+// A DEFLATE block header, by one wave: block type, code lengths, the three tables.  What it found goes to res[]:
+// [0] bad, [1] final block, [2] type, [3] the bit behind the header (stored: behind LEN / NLEN), [4] stored length.
+__device__ __attribute__((noinline)) void seg_header(InfSegLds &h, uint16_t *cwtab, uint32_t *res, const uint32_t *__restrict__ pay32,
+                                                     uint32_t last_w, uint32_t bit_end, uint32_t bp, uint32_t lane) {
     uint32_t *hdr_w = h.lfast + 128;  // 96 staged dwords of a block header (lfast[0..80) is the code-length scratch)
     uint32_t hbase = 0;
     auto hbits = [&](uint32_t p) -> uint32_t {
         const uint32_t w = (p >> 5) - hbase;
         return __builtin_amdgcn_alignbit(hdr_w[w + 1], hdr_w[w], p & 31u);
     };
-
-    uint32_t bp = bit0, o = 0, mtot = 0;
-    bool final_block = false, bad = false;
-    while (!final_block && !bad) {
-        bp = uniform(bp);
-        o = uniform(o);
-        mtot = uniform(mtot);
+    bool bad = false, final_block = false;
+    uint32_t btype = 3, slen = 0;
+    do {
         if (bp + 3 > bit_end) {
             bad = true;
             break;
         }
-        const long long t_hdr = DBG ? clock64() : 0;
         wave_sync();
         hbase = bp >> 5;
         {
@@ -324,10 +293,9 @@ __device__ __attribute__((noinline)) void seg_member(const uint32_t b, const uin
         wave_sync();
         const uint32_t hb = uniform(hbits(bp));
         final_block = (hb & 1u) != 0;
-        const uint32_t btype = (hb >> 1) & 3u;
+        btype = (hb >> 1) & 3u;
         bp += 3;
-        if (btype == 0) {
-            // stored: LEN, NLEN, raw bytes straight from the payload to their place (final bytes, like literals)
+        if (btype == 0) {  // stored: LEN, NLEN
             bp = (bp + 7u) & ~7u;
             if (bp + 32 > bit_end) {
                 bad = true;
@@ -336,30 +304,9 @@ __device__ __attribute__((noinline)) void seg_member(const uint32_t b, const uin
             const uint32_t x = uniform(hbits(bp));
             const uint32_t len = x & 0xFFFFu, nlen = x >> 16;
             bp += 32;
-            const uint32_t src = (bp - bit0) >> 3;
-            if ((len ^ 0xFFFFu) != nlen || src + len > pay_len || o + len > isize) {
-                bad = true;
-                break;
-            }
-            const uint8_t *sp = pay + src;
-            uint8_t *dp = out + o;
-            uint32_t head = (uint32_t)((4u - ((uintptr_t)dp & 3u)) & 3u);
-            if (head > len) head = len;
-            if (lane < head) dp[lane] = sp[lane];
-            const uint32_t nw = (len - head) >> 2;
-            const uint32_t smis = (uint32_t)((uintptr_t)(sp + head) & 3u);
-            const uint32_t *s32 = (const uint32_t *)(sp + head - smis);
-            for (uint32_t k = lane; k < nw; k += 64) {
-                const uint32_t lo = s32[k], hi = smis ? s32[k + 1] : 0u;  // (hi: inside the member, the footer follows)
-                *(uint32_t *)(dp + head + 4 * k) = __builtin_amdgcn_alignbyte(hi, lo, smis);
-            }
-            const uint32_t donew = head + 4 * nw;
-            if (donew + lane < len) dp[donew + lane] = sp[donew + lane];
-            if (multi && lane == 0)
-                for (uint32_t k = (o >> 15) + 1; k <= ((o + len) >> 15); k++) tf[k] = mtot;
-            o += len;
-            bp += 8u * len;
-            continue;
+            if ((len ^ 0xFFFFu) != nlen) bad = true;
+            slen = len;
+            break;
         }
         if (btype == 3) {
             bad = true;
@@ -385,7 +332,7 @@ __device__ __attribute__((noinline)) void seg_member(const uint32_t b, const uin
             }
             bp += 3u * nclen;
             wave_sync();
-            if (!seg_build<kSegPrecode>(h, h.lens, 19, kSegPRoot, h.ofast, nullptr, 0, lane)) {
+            if (!seg_build<kSegPrecode>(h, cwtab, h.lens, 19, kSegPRoot, h.ofast, nullptr, 0, lane)) {
                 bad = true;
                 break;
             }
@@ -452,28 +399,130 @@ __device__ __attribute__((noinline)) void seg_member(const uint32_t b, const uin
                 break;
             }
         }
-        if (!seg_build<kSegLitlen>(h, h.lens, 288, kSegLRoot, h.lfast, h.lsub, kSegLSub, lane) ||
-            !seg_build<kSegOffset>(h, h.lens + 288, 32, kSegORoot, h.ofast, h.osub, kSegOSub, lane)) {
+        if (!seg_build<kSegLitlen>(h, cwtab, h.lens, 288, kSegLRoot, h.lfast, h.lsub, kSegLSub, lane) ||
+            !seg_build<kSegOffset>(h, cwtab, h.lens + 288, 32, kSegORoot, h.ofast, h.osub, kSegOSub, lane))
             bad = true;
-            break;
+    } while (false);
+    wave_sync();
+    if (lane == 0) {
+        res[0] = bad ? 1u : 0u;
+        res[1] = final_block ? 1u : 0u;
+        res[2] = btype;
+        res[3] = bp;
+        res[4] = slen;
+    }
+    wave_sync();
+}
+
+// DBlock.cyc of a debug launch (wave 0's clocks): [0] whole member, [1] headers + tables, [2] pass 1, [3] pass 2,
+// [4] pass 3, counts [5] spans, [6] pass-2 iterations, [7] symbol steps of passes 1 and 3 (wave iterations)
+//
+// W waves work on one member: wave 0 reads the block headers and builds the tables, a span is 64 W segments, the
+// entries chain from lane to lane and from wave to wave.  W = 1 for BGZF-sized members (one wave each: thousands of
+// members fill the chip), kSegBigW for Mgzip members (a 1 MiB member is a million symbols: one wave would take its
+// lanes through 16 thousand steps each, and a slab holds too few members for the chip).
+template <bool DBG, int W>
+__device__ __attribute__((noinline)) void seg_member(const uint32_t b, const uint32_t tid, uint32_t hdr_len, const uint8_t *__restrict__ in_all,
+                                                     DBlock *__restrict__ blk_all, const uint64_t *__restrict__ out_off, uint8_t *out_all,
+                                                     uint64_t out_cap, LzMatch *__restrict__ mlist_all, uint32_t *__restrict__ tfirst_all,
+                                                     uint32_t *__restrict__ redo) {
+    __shared__ InfSegLdsW<W> hh;  // (its own LDS object, so that every access stays an LDS instruction)
+    InfSegLds &h = hh.t;
+    const uint32_t lane = tid & 63u, wave = tid >> 6;
+    constexpr uint32_t NT = 64u * W;
+    DBlock *blk = blk_all + b;
+    const uint32_t isize = blk->isize;
+    if (tid == 0) blk->nmatch = 0;
+    if (isize == 0) return;  // src/par/decompress.rs:163-171: nothing to decode
+    const uint64_t ooff = out_off[b];
+    if (ooff + isize > out_cap) {
+        if (tid == 0) blk->status = kInfInsufficientSpace;
+        return;
+    }
+    uint8_t *out = out_all + ooff;
+    const uint8_t *pay = in_all + blk->in_off + hdr_len;
+    const uint32_t pay_len = blk->size - hdr_len - 8;
+    LzMatch *ml = mlist_all + (ooff / 3u + b);
+    uint32_t *tf = tfirst_all + ((ooff >> 15) + 2ull * b);
+    const bool multi = isize > kLzTile;  // more than one k_lzcopy tile: the first record of every tile is noted
+    if (multi && tid == 0) tf[0] = 0;
+    const long long t_begin = DBG ? clock64() : 0;
+    uint32_t dbg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+
+    const uint32_t pmis = (uint32_t)((uintptr_t)pay & 3u);
+    const uint32_t *pay32 = (const uint32_t *)(pay - pmis);
+    const uint32_t pay_words = (pmis + pay_len + 8 + 3) >> 2;  // the 8 footer bytes are readable too
+    const uint32_t last_w = pay_words - 1;
+    const uint32_t bit0 = 8u * pmis, bit_end = bit0 + 8u * pay_len;
+    SegWin win;
+    win.pay32 = pay32;
+    win.last_w = last_w;
+    win.rl = hh.ring + tid * kSegRingStride;
+    win.w0 = 0;
+
+    uint32_t bp = bit0, o = 0, mtot = 0;
+    bool final_block = false, bad = false;
+    uint32_t bad_line = 0;  // (diagnostics: where the member was given up)
+#define SEG_BAD() do { bad = true; bad_line = __LINE__; } while (0)
+    while (!final_block && !bad) {
+        bp = uniform(bp);
+        o = uniform(o);
+        mtot = uniform(mtot);
+        const long long t_hdr = DBG ? clock64() : 0;
+        if (W > 1) __syncthreads();  // (the other waves are done with the tables and with hres)
+        if (wave == 0) seg_header(h, (uint16_t *)hh.ring, hh.hres, pay32, last_w, bit_end, bp, lane);
+        if (W > 1) __syncthreads();
+        bad = uniform(hh.hres[0]) != 0;
+        if (bad) bad_line = __LINE__;
+        final_block = uniform(hh.hres[1]) != 0;
+        const uint32_t btype = uniform(hh.hres[2]);
+        bp = uniform(hh.hres[3]);
+        if (bad) break;
+        if (btype == 0) {
+            // stored: raw bytes straight from the payload to their place (final bytes, like literals)
+            const uint32_t len = uniform(hh.hres[4]);
+            const uint32_t src = (bp - bit0) >> 3;
+            if (src + len > pay_len || o + len > isize) {
+                SEG_BAD();
+                break;
+            }
+            const uint8_t *sp = pay + src;
+            uint8_t *dp = out + o;
+            uint32_t head = (uint32_t)((4u - ((uintptr_t)dp & 3u)) & 3u);
+            if (head > len) head = len;
+            if (tid < head) dp[tid] = sp[tid];
+            const uint32_t nw = (len - head) >> 2;
+            const uint32_t smis = (uint32_t)((uintptr_t)(sp + head) & 3u);
+            const uint32_t *s32 = (const uint32_t *)(sp + head - smis);
+            for (uint32_t k = tid; k < nw; k += NT) {
+                const uint32_t lo = s32[k], hi = smis ? s32[k + 1] : 0u;  // (hi: inside the member, the footer follows)
+                *(uint32_t *)(dp + head + 4 * k) = __builtin_amdgcn_alignbyte(hi, lo, smis);
+            }
+            const uint32_t donew = head + 4 * nw;
+            if (tid < 3 && donew + tid < len) dp[donew + tid] = sp[donew + tid];
+            if (multi && tid == 0)
+                for (uint32_t k = (o >> 15) + 1; k <= ((o + len) >> 15); k++) tf[k] = mtot;
+            o += len;
+            bp += 8u * len;
+            continue;
         }
         if (DBG) dbg[1] += (uint32_t)(clock64() - t_hdr);
 
-        // ---- the block's symbols, one span of 64 segments after the other until its end-of-block code
+        // ---- the block's symbols, one span of 64 W segments after the other until its end-of-block code
         bool eob = false;
         while (!eob && !bad) {
             bp = uniform(bp);
             o = uniform(o);
             mtot = uniform(mtot);
             if (bp >= bit_end) {  // no end-of-block code before the payload's end
-                bad = true;
+                SEG_BAD();
                 break;
             }
             if (DBG) dbg[5]++;
             const uint32_t rem = bit_end - bp;
-            uint32_t S = (((rem + 63u) >> 6) + 31u) & ~31u;
+            uint32_t S = (((rem + NT - 1u) / NT) + 31u) & ~31u;
             S = S < kSegMinBits ? kSegMinBits : S > kSegMaxBits ? kSegMaxBits : S;
-            const uint32_t my_start = bp + lane * S;
+            const uint32_t my_start = bp + tid * S;
             win.w0 = my_start >> 5;
             const uint32_t rel0 = 32u * win.w0;           // absolute position of relative bit 0
             const uint32_t r_start = my_start - rel0;      // 0..31
@@ -521,14 +570,20 @@ __device__ __attribute__((noinline)) void seg_member(const uint32_t b, const uin
             uint32_t entry = my_start, ex = exit1, nn = n1, mm = m1, fl = fl1;
             uint32_t iters = 0;
             for (;;) {
+                // (every lane with data follows its predecessor's exit, also behind a lane that stopped: a speculative path
+                // that ran into an end-of-block code or an unused codeword in front of its meeting point is put right like any
+                // other, and does not hold up the lanes behind it for an iteration of its own)
+                if (W > 1) {  // the wave's last exit, for the wave behind it
+                    __syncthreads();
+                    if (lane == 63) hh.x_ex[wave] = ex;
+                    __syncthreads();
+                }
                 uint32_t new_entry = (uint32_t)__shfl_up((int)ex, 1);
-                if (lane == 0) new_entry = bp;
-                const uint64_t stopped = __ballot(fl != 0);
-                const bool dead = (stopped & lane_below) != 0;
-                const bool need = !dead && new_entry != entry;
-                if (__ballot(need) == 0) break;
+                if (lane == 0) new_entry = wave == 0 ? bp : hh.x_ex[wave > 0 ? wave - 1 : 0];
+                const bool need = has_data && new_entry != entry && new_entry >= my_start;
+                if (W > 1 ? __syncthreads_or(need ? 1 : 0) == 0 : __ballot(need) == 0) break;
                 if (++iters > kSegMaxFix) {
-                    bad = true;
+                    SEG_BAD();
                     break;
                 }
                 // both replays run in the lane's relative coordinates, window by window like pass 1
@@ -603,21 +658,63 @@ __device__ __attribute__((noinline)) void seg_member(const uint32_t b, const uin
             if (bad) break;
             // ---- what the span holds: live lanes up to the first one that stopped
             const uint64_t stopped = __ballot(fl != 0);
-            const uint32_t first_stop = stopped ? (uint32_t)__ffsll((long long)stopped) - 1u : 64u;
-            const bool live = lane <= first_stop;
-            if (first_stop < 64u) {
-                if (rdlane(fl, first_stop) != 1u) {  // an invalid symbol on the true path
-                    bad = true;
+            const uint32_t wstop = stopped ? (uint32_t)__ffsll((long long)stopped) - 1u : 64u;  // this wave's first stop
+            uint32_t stop_wave = wave, first_stop = wstop;  // the span's: (wave, lane)
+            uint32_t stop_fl = wstop < 64u ? rdlane(fl, wstop) : 0u, stop_ex = rdlane(ex, wstop < 64u ? wstop : 63u);
+            if (W > 1) {
+                __syncthreads();
+                if (lane == 0) {
+                    hh.x_first[wave] = wstop;
+                    hh.x_fl[wave] = stop_fl;
+                    hh.x_ex[wave] = stop_ex;  // (the stop lane's exit, or the wave's last)
+                }
+                __syncthreads();
+                stop_wave = (uint32_t)W;
+                first_stop = 64u;
+                for (uint32_t w2 = 0; w2 < (uint32_t)W; w2++)
+                    if (stop_wave == (uint32_t)W && hh.x_first[w2] < 64u) {
+                        stop_wave = w2;
+                        first_stop = hh.x_first[w2];
+                    }
+                const uint32_t from = stop_wave < (uint32_t)W ? stop_wave : (uint32_t)W - 1u;
+                stop_fl = hh.x_fl[from];
+                stop_ex = hh.x_ex[from];
+            } else if (wstop == 64u) {
+                stop_wave = 1u;  // (= W: no stop in the span)
+            }
+            const bool live = wave < stop_wave || (wave == stop_wave && lane <= first_stop);
+            if (stop_wave < (uint32_t)W) {
+                if (stop_fl != 1u) {  // an invalid symbol on the true path
+                    SEG_BAD();
                     break;
                 }
                 eob = true;
             }
             const uint32_t my_n = live ? nn : 0u, my_m = live ? mm : 0u;
-            const uint32_t in_n = wave_incl_add(my_n), in_m = wave_incl_add(my_m);
-            const uint32_t tot_n = rdlane(in_n, 63), tot_m = rdlane(in_m, 63);
-            const uint32_t new_bp = rdlane(ex, first_stop < 64u ? first_stop : 63u);
+            uint32_t in_n = wave_incl_add(my_n), in_m = wave_incl_add(my_m);
+            uint32_t tot_n = rdlane(in_n, 63), tot_m = rdlane(in_m, 63);
+            if (W > 1) {  // the waves' totals -> every wave's base
+                if (lane == 0) {
+                    hh.x_n[wave] = tot_n;
+                    hh.x_m[wave] = tot_m;
+                }
+                __syncthreads();
+                uint32_t base_n = 0, base_m = 0;
+                tot_n = tot_m = 0;
+                for (uint32_t w2 = 0; w2 < (uint32_t)W; w2++) {
+                    if (w2 < wave) {
+                        base_n += hh.x_n[w2];
+                        base_m += hh.x_m[w2];
+                    }
+                    tot_n += hh.x_n[w2];
+                    tot_m += hh.x_m[w2];
+                }
+                in_n += base_n;
+                in_m += base_m;
+            }
+            const uint32_t new_bp = stop_ex;
             if (o + tot_n > isize || new_bp > bit_end + (eob ? 0u : 64u)) {
-                bad = true;
+                SEG_BAD();
                 break;
             }
             // ---- pass 3: the segment again from its true entry, now writing
@@ -669,8 +766,8 @@ __device__ __attribute__((noinline)) void seg_member(const uint32_t b, const uin
                 }
             }
             if (DBG) dbg[4] += (uint32_t)(clock64() - t_p3);
-            if (__ballot(bad_dist)) {
-                bad = true;
+            if (W > 1 ? __syncthreads_or(bad_dist ? 1 : 0) != 0 : __ballot(bad_dist) != 0) {
+                SEG_BAD();
                 break;
             }
             o += tot_n;
@@ -678,39 +775,46 @@ __device__ __attribute__((noinline)) void seg_member(const uint32_t b, const uin
             bp = new_bp;
         }
     }
-    if (!bad && (o != isize || bp > bit_end)) bad = true;
+    if (!bad && (o != isize || bp > bit_end)) SEG_BAD();
     if (bad) {
-        seg_redo(blk, redo, b, lane);
-    } else if (lane == 0) {
+#ifdef GZPX_EMU
+        if (tid == 0 && getenv("GZPX_TRACE_SEG")) fprintf(stderr, "seg redo: member %u line %u bp %u/%u o %u/%u\n", b, bad_line, bp, bit_end, o, isize);
+#endif
+        seg_redo(blk, redo, b, tid);
+    } else if (tid == 0) {
         blk->status = kInfOk;
         blk->produced = o;
         blk->nmatch = mtot;
         if (multi) tf[(isize >> 15) + 1] = mtot;
     }
-    if (DBG && lane == 0) {
+    if (DBG && tid == 0) {
         dbg[0] = (uint32_t)(clock64() - t_begin);
         for (uint32_t k = 0; k < 8; k++) blk->cyc[k] = dbg[k];
     }
 }
 
-// One wave per member, the members claimed from a ticket counter (redo[1 + nb]): the launch holds as many waves as the
-// chip keeps resident, and a wave that finishes a member takes the next one -- 8,835 members on 4,096 wave slots are
-// 2.16 member times, not three.
-template <bool DBG>
-__global__ __launch_bounds__(64, GZPX_SEG_WAVES) void k_inflate_seg(uint32_t hdr_len, const uint8_t *__restrict__ in_all,
-                                                                   DBlock *__restrict__ blk_all,
-                                                                   const uint64_t *__restrict__ out_off, uint8_t *out_all,
-                                                                   uint64_t out_cap, LzMatch *__restrict__ mlist_all,
-                                                                   uint32_t *__restrict__ tfirst_all,
-                                                                   uint32_t *__restrict__ redo, uint32_t nb) {
-    const uint32_t lane = threadIdx.x;
+#undef SEG_BAD
+
+// The members are claimed from a ticket counter (redo[1 + nb]): the launch holds as many workgroups as the chip keeps
+// resident, and one that finishes a member takes the next -- 8,835 members on 4,096 wave slots are 2.16 member times, not three.
+template <bool DBG, int W>
+__global__ __launch_bounds__(64 * W, GZPX_SEG_WAVES) void k_inflate_seg(uint32_t hdr_len, const uint8_t *__restrict__ in_all,
+                                                                       DBlock *__restrict__ blk_all,
+                                                                       const uint64_t *__restrict__ out_off, uint8_t *out_all,
+                                                                       uint64_t out_cap, LzMatch *__restrict__ mlist_all,
+                                                                       uint32_t *__restrict__ tfirst_all,
+                                                                       uint32_t *__restrict__ redo, uint32_t nb) {
+    __shared__ uint32_t s_ticket;
+    const uint32_t tid = threadIdx.x;
     for (;;) {
-        uint32_t b = 0;
-        if (lane == 0) b = atomicAdd(&redo[1 + nb], 1u);
-        b = uniform(b);
+        if (W > 1) __syncthreads();  // (everybody has read the last ticket)
+        if (tid == 0) s_ticket = atomicAdd(&redo[1 + nb], 1u);
+        if (W > 1) __syncthreads();
+        else wave_sync();
+        const uint32_t b = uniform(s_ticket);
         if (b >= nb) break;
         wave_sync();
-        seg_member<DBG>(b, lane, hdr_len, in_all, blk_all, out_off, out_all, out_cap, mlist_all, tfirst_all, redo);
+        seg_member<DBG, W>(b, tid, hdr_len, in_all, blk_all, out_off, out_all, out_cap, mlist_all, tfirst_all, redo);
     }
 }
 

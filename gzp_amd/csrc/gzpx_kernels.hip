@@ -5771,33 +5771,39 @@ void launch_inflate(uint32_t hdr_len, const uint8_t *d_in, const uint64_t *d_off
     if (seg) {
         // decode (literals + match records), LZ copy, then k_inflate over whatever the two left on the redo list
         LzMatch *ml = (LzMatch *)sc.mlist;
-        const uint32_t seg_slots = (uint32_t)(sc.n_cu > 0 ? sc.n_cu : 256) * 4u * GZPX_SEG_WAVES;  // resident waves of k_inflate_seg
-        const uint32_t seg_grid = nb < seg_slots ? nb : seg_slots;
+        const bool big = sc.big_members != 0;  // Mgzip-sized members: kSegBigW waves each
+        const uint32_t seg_wgs = (uint32_t)(sc.n_cu > 0 ? sc.n_cu : 256) * 4u * GZPX_SEG_WAVES / (big ? (uint32_t)kSegBigW : 1u);  // resident workgroups
+        const uint32_t seg_grid = nb < seg_wgs ? nb : seg_wgs;
+#define GZPX_LAUNCH_SEG(DBG_)                                                                                              \
+    do {                                                                                                                   \
+        if (big)                                                                                                           \
+            hipLaunchKernelGGL((k_inflate_seg<DBG_, kSegBigW>), dim3(seg_grid), dim3(64 * kSegBigW), 0, stream, hdr_len,   \
+                               d_in, blk, (const uint64_t *)d_out_off, d_out, out_cap, ml, sc.tfirst, sc.redo, nb);        \
+        else                                                                                                               \
+            hipLaunchKernelGGL((k_inflate_seg<DBG_, 1>), dim3(seg_grid), dim3(64), 0, stream, hdr_len, d_in, blk,          \
+                               (const uint64_t *)d_out_off, d_out, out_cap, ml, sc.tfirst, sc.redo, nb);                   \
+        if (ev_mid) (void)hipEventRecord(ev_mid, stream);                                                                  \
+    } while (0)
         if (debug == 1) {
-            hipLaunchKernelGGL((k_inflate_seg<true>), dim3(seg_grid), dim3(64), 0, stream, hdr_len, d_in, blk,
-                               (const uint64_t *)d_out_off, d_out, out_cap, ml, sc.tfirst, sc.redo, nb);
-            if (ev_mid) (void)hipEventRecord(ev_mid, stream);
+            GZPX_LAUNCH_SEG(true);
             hipLaunchKernelGGL((k_lzcopy<false>), dim3(nb), dim3(kLcThreads), 0, stream, blk, (const uint64_t *)d_out_off,
                                d_out, (const LzMatch *)ml, (const uint32_t *)sc.tfirst, sc.redo);
             hipLaunchKernelGGL((k_inflate<true, true>), dim3(nb), dim3(64), 0, stream, hdr_len, d_in, blk,
                                (const uint64_t *)d_out_off, d_out, out_cap, (const uint32_t *)sc.redo);
         } else if (debug == 2) {  // k_lzcopy's clocks instead of k_inflate_seg's
-            hipLaunchKernelGGL((k_inflate_seg<false>), dim3(seg_grid), dim3(64), 0, stream, hdr_len, d_in, blk,
-                               (const uint64_t *)d_out_off, d_out, out_cap, ml, sc.tfirst, sc.redo, nb);
+            GZPX_LAUNCH_SEG(false);
             hipLaunchKernelGGL((k_lzcopy<true>), dim3(nb), dim3(kLcThreads), 0, stream, blk, (const uint64_t *)d_out_off,
                                d_out, (const LzMatch *)ml, (const uint32_t *)sc.tfirst, sc.redo);
             hipLaunchKernelGGL((k_inflate<false, true>), dim3(nb), dim3(64), 0, stream, hdr_len, d_in, blk,
                                (const uint64_t *)d_out_off, d_out, out_cap, (const uint32_t *)sc.redo);
         } else {
-            hipLaunchKernelGGL((k_inflate_seg<false>), dim3(seg_grid), dim3(64), 0, stream, hdr_len, d_in, blk,
-                               (const uint64_t *)d_out_off, d_out, out_cap, ml, sc.tfirst, sc.redo, nb);
-            if (ev_mid) (void)hipEventRecord(ev_mid, stream);
+            GZPX_LAUNCH_SEG(false);
             hipLaunchKernelGGL((k_lzcopy<false>), dim3(nb), dim3(kLcThreads), 0, stream, blk, (const uint64_t *)d_out_off,
                                d_out, (const LzMatch *)ml, (const uint32_t *)sc.tfirst, sc.redo);
-
             hipLaunchKernelGGL((k_inflate<false, true>), dim3(nb), dim3(64), 0, stream, hdr_len, d_in, blk,
                                (const uint64_t *)d_out_off, d_out, out_cap, (const uint32_t *)sc.redo);
         }
+#undef GZPX_LAUNCH_SEG
     } else if (debug) {
         hipLaunchKernelGGL((k_inflate<true, true>), dim3(nb), dim3(64), 0, stream, hdr_len, d_in, blk,
                            (const uint64_t *)d_out_off, d_out, out_cap, (const uint32_t *)nullptr);
