@@ -196,7 +196,7 @@ def available_cores():
     return n, note
 
 
-def cpu_baseline(slab, wall_s=8.0):
+def cpu_baseline(slab, wall_s=3.0):
     """gzp's CPU path on this box's host cores, the way ParCompress runs it -- one worker per usable
     hardware thread, each owning a contiguous run of the slab's blocks -- natively timed (pthreads,
     oracle/cpu_bench.c) for `wall_s` seconds.  The work per block is libdeflate_deflate_compress
@@ -224,7 +224,7 @@ def cpu_baseline(slab, wall_s=8.0):
     }
 
 
-def cpu_baseline_parcompress(slab, want_sha=None, wall_s=8.0):
+def cpu_baseline_parcompress(slab, want_sha=None, wall_s=3.0):
     """The CPU baseline BASELINE.md 3 / SURVEY 8(d) promise: gzp's ParCompress<Bgzf> itself -- a caller thread that
     write_all()s the slab in 64 KiB chunks (benches/bench.rs:36-45,121) and cuts blocks, num_threads workers behind
     queues bounded at 2 N, one in-order writer thread into an in-memory sink (src/par/compress.rs:248-469, restated
@@ -254,7 +254,7 @@ def cpu_baseline_parcompress(slab, want_sha=None, wall_s=8.0):
     }
 
 
-def cpu_baseline_inflate(comp, offs, sizes, wall_s=8.0):
+def cpu_baseline_inflate(comp, offs, sizes, wall_s=3.0):
     """CPU side of the ParDecompress row: the image's libdeflate binary (the library gzp binds through
     libdeflater: libdeflate_deflate_decompress + libdeflate_crc32 per block, src/bgzf.rs:103-121 /
     src/par/decompress.rs:162-186), one native worker per hardware thread over its contiguous share
@@ -429,7 +429,7 @@ def run_inflate(args, env, emit=True, d_stream=None, comp_host=None, slab=None, 
         if seg_route:
             res["roofline"]["k_lzcopy_ms"] = round(copy_ms, 3)
         if not args.no_cpu_baseline and env.world == 1:
-            res["cpu_baseline"] = cpu_baseline_inflate(comp_host, offs, sizes, wall_s=8.0 if emit else 4.0)
+            res["cpu_baseline"] = cpu_baseline_inflate(comp_host, offs, sizes, wall_s=3.0 if emit else 2.0)  # (a rate measurement, not a soak)
         if emit:
             print(json.dumps(res))
     d.close()
@@ -514,7 +514,7 @@ def mgzip3_leg(env, n=4 << 30):
     env.sync()
     inflate_leg = {"MiBps": round(n / 2**20 / ((time.perf_counter() - t1) / 3), 1), "k_inflate_ms": round(kms, 3),
                    "members": int(offs.size),
-                   "roofline": {"bound": "hbm", "kernel": "k_inflate", "achieved": round((n + out_len) / (kms * 1e-3) / 1e9, 2),
+                   "roofline": {"bound": "hbm", "kernel": "k_inflate_seg + k_lzcopy (every inflate kernel of the step)", "achieved": round((n + out_len) / (kms * 1e-3) / 1e9, 2),
                                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round((n + out_len) / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)}}
     d.close()
     ctx.close()
@@ -1280,6 +1280,20 @@ def main():
                     res["mgzip3"] = mgzip3_leg(env)
                 except Exception as e:
                     res["mgzip3"] = {"error": repr(e)}
+        if world == 1:
+            # how much of this run the GPU was at work: the timed steps of every leg x their step time (kernels and launch
+            # gaps; data generation, digests and the CPU legs are the rest of the run)
+            act = (args.steps + args.warmup + other_steps) * ms_per_step * 1e-3
+            inf = res.get("inflate", {})
+            if "ms_per_step" in inf:
+                act += (max(2, min(args.steps, 5)) + 2) * inf["ms_per_step"] * 1e-3
+            for leg in res.get("levels", {}).values():
+                if isinstance(leg, dict) and "ms_per_step" in leg:
+                    act += (leg.get("steps", 1) + 1) * leg["ms_per_step"] * 1e-3
+            mg = res.get("mgzip3", {})
+            if "ms_per_step" in mg:
+                act += (mg.get("steps", 1) + 1) * mg["ms_per_step"] * 1e-3 + 4 * mg.get("inflate_of_output", {}).get("k_inflate_ms", 0.0) * 1e-3
+            res["gpu_active_s"] = round(act, 3)
         if not args.no_cpu_baseline and world == 1:  # the CPU leg is timed at N = 1 only
             res["cpu_baseline"] = cpu_baseline(slab)
             try:  # ... and gzp's own orchestration around the same library (queues, 64 KiB writes, in-order writer)
