@@ -859,7 +859,10 @@ class PeerWatchdog:
     measured RCCL figures with it."""
 
     def __init__(self, seconds, rank, res):
-        self.seconds, self.rank, self.res = seconds, rank, res
+        # (the line as it stands when the peer leg begins: the timer thread prints this snapshot, never the live dict the
+        # main thread may be adding the peer figures to)
+        self.seconds, self.rank = seconds, rank
+        self.res = json.loads(json.dumps(res)) if res is not None else None
         self.lock, self.done = threading.Lock(), False
         self.timer = threading.Timer(seconds, self._fire)
         self.timer.daemon = True
@@ -874,6 +877,7 @@ class PeerWatchdog:
             self.res.setdefault("writeouts", {})["peer_error"] = (
                 "the peer-window write-out did not finish within %.0f s (watchdog; GZPX_BENCH_PEER_TIMEOUT): the line "
                 "carries the other write-outs only" % self.seconds)
+            self.res["writeouts"]["peer_leg"] = "timeout"  # (the exit code stays 0: the measured line is complete)
             print(json.dumps(self.res), flush=True)
         else:
             time.sleep(2.0)  # (rank 0 writes first)
@@ -1335,6 +1339,7 @@ def main():
         if peer_err is not None:
             if rank == 0:
                 res["writeouts"]["peer_error"] = peer_err
+                res["writeouts"]["peer_leg"] = "failed"
                 print(json.dumps(res), flush=True)
             os._exit(0)  # (a rank that failed alone leaves the others inside a collective: nobody waits for a clean close)
     if rank == 0:

@@ -494,7 +494,7 @@ class MultiContext:
         self.lib.check(self.lib.L.gzpx_multi_shard(self.h, in_len, g, ctypes.byref(off), ctypes.byref(n)))
         return off.value, n.value
 
-    def compress_slab_device(self, d_in_ptrs, in_len, d_out_ptr, out_cap, mode=SLAB_LAST, root=0, sync=True):
+    def compress_slab_device(self, d_in_ptrs, in_len, d_out_ptr, out_cap, mode=SLAB_LAST, root=0, sync=True, wait_events=None):
         """Every range already on its own device (d_in_ptrs[g]); the shards are gathered device to device
         into d_out_ptr on devices[root].  Returns (out_len, block_sizes).
 
@@ -502,7 +502,17 @@ class MultiContext:
         on entry -- the call takes no stream of the caller's to wait behind (it submits with GZPX_STREAM_NONE; since
         round 4 nothing is ordered behind the legacy default stream either).  `sync=True` (the default) makes that true
         for PyTorch callers, whose producers run asynchronously on torch's current stream: every device of the context
-        is synchronised first.  Pass sync=False only when the inputs were produced synchronously."""
+        is synchronised first.  Pass sync=False only when the inputs were produced synchronously.
+
+        `wait_events` (round 6): the producers' own events (objects with .synchronize(): torch.cuda.Event, or anything
+        else a runtime hands out) -- waited for INSTEAD of whole devices, so that what the caller has queued for slab
+        k + 1 keeps running while slab k is compressed.  The full-device wait assumes that this context's device numbers
+        are torch's ordinals (true when both see the same HIP_VISIBLE_DEVICES) and does nothing for producers of a
+        runtime that is not torch: those callers pass their events, or synchronise themselves and say sync=False."""
+        if wait_events is not None:
+            for ev in wait_events:
+                ev.synchronize()
+            sync = False
         if sync:
             import sys
             torch = sys.modules.get("torch")  # (only callers that use torch have asynchronous producers to wait for)

@@ -10,7 +10,7 @@
 namespace gzpx {
 
 constexpr unsigned kTile = 65536;         // positions handled per LDS tile (k_parse) / stage window
-constexpr unsigned kMaxBlockSize = 1u << 24;  // largest buffer_size the kernels accept (16 MiB)
+constexpr unsigned kMaxBlockSize = 1u << 26;  // largest buffer_size the kernels accept (64 MiB; round 6: tested at 32 MiB)
 constexpr unsigned kSeqPerSub = 8192;      // FAST_SEQ_STORE_LENGTH
 constexpr unsigned kSoftMaxSub = 65535;    // FAST_SOFT_MAX_BLOCK_LENGTH
 constexpr unsigned kMinBlockLen = 5000;    // MIN_BLOCK_LENGTH

@@ -2600,7 +2600,7 @@ __global__ __launch_bounds__(kMpThreads, GZPX_PHC_WAVES) void k_parse_hc(
     Config cfg, const uint8_t *__restrict__ slab, BlockMeta *__restrict__ meta_all,
     SubMeta *__restrict__ sub_all, HcState *__restrict__ hc_all, const uint8_t *__restrict__ len8_all,
     const uint32_t *__restrict__ mbits_all, const uint16_t *__restrict__ val_all,
-    uint32_t *__restrict__ tok_all, uint32_t *__restrict__ pending, uint32_t *__restrict__ stale) {
+    uint32_t *__restrict__ tok_all, uint32_t *__restrict__ pending, uint32_t *__restrict__ stale, uint32_t may_list_stale) {
     __shared__ uint32_t len8_w[kHpTile / 4];
     __shared__ unsigned long long tok_bits[kHpGroups];  // 1 = a token starts here (tile-relative)
     __shared__ unsigned long long mb[kHpGroups];        // 1 = k_match_hc's match here is long enough for min_len
@@ -3057,6 +3057,10 @@ __global__ __launch_bounds__(kMpThreads, GZPX_PHC_WAVES) void k_parse_hc(
                     // here on: the dense k_match_hc goes over the block from bp before the next round parses it
                     // (`stale`: their list for k_match_hc_stale -- count, then block indices; Scratch.redo, idle at these levels)
                     if (st->sparse == kHcArraysPath) {
+                        // (k_match_hc_stale runs once, behind the FIRST round: a round can only end at `done` or here, so no
+                        // block is still kHcArraysPath after it.  Should that ever stop being true, a block listed later would
+                        // be parsed over first-node matches -- a valid stream that is not libdeflate's: stop loudly instead.)
+                        if (!may_list_stale) __builtin_trap();
                         st->sparse = kHcArraysStale;
                         stale[1u + atomicAdd(&stale[0], 1u)] = b;
                     }
@@ -5680,10 +5684,10 @@ void launch_hc(const Config &cfg, const uint8_t *slab, uint32_t nb, const Scratc
                            (const uint16_t *)s.cand, (const uint16_t *)s.d4, s.len8, s.which, s.alt,
                            (uint8_t *)nullptr, (uint16_t *)nullptr);
     };
-    auto parse_round = [&]() {
+    auto parse_round = [&](uint32_t may_list_stale) {
         hipLaunchKernelGGL(k_parse_hc<false>, dim3(nb), dim3(kMpThreads), 0, stream, cfg, slab, s.meta, s.sub, s.hc,
                            (const uint8_t *)s.len8, (const uint32_t *)s.which, (const uint16_t *)s.alt, s.tok,
-                           s.pending, s.redo);
+                           s.pending, s.redo, may_list_stale);
     };
     // Round 5: the full search only where the greedy parse starts a token (k_match_hc_sparse).  Config.debug bit 4: the
     // dense kernel for every block, as in rounds 2-4 (A/B runs and the tests that compare the two routes).
@@ -5701,17 +5705,17 @@ void launch_hc(const Config &cfg, const uint8_t *slab, uint32_t nb, const Scratc
     // two single rounds (the second finds nearly every block done), then the looping form for the rest.  A block whose
     // first round ended at a sub-block with another min_len has arrays that are no use from there on if they came from
     // the sparse kernel (kHcArraysStale): the dense kernel goes over it before its second round.
-    parse_round();
+    parse_round(1u);
     if (sparse) {  // (the list of stale blocks is Scratch.redo: zeroed by the batch's first k_candidates launch, filled by the round above)
         const uint32_t wgs = cfg.n_cu ? cfg.n_cu : 256u;
         hipLaunchKernelGGL(k_match_hc_stale, dim3(wgs), dim3(1024), 0, stream, cfg, slab, (const BlockMeta *)s.meta,
                            s.hc, (const uint16_t *)s.cand, (const uint16_t *)s.d4, s.len8, s.which, s.alt,
                            (const uint32_t *)s.redo);
     }
-    parse_round();
+    parse_round(0u);
     hipLaunchKernelGGL(k_parse_hc<true>, dim3(nb), dim3(kMpThreads), 0, stream, cfg, slab, s.meta, s.sub, s.hc,
                        (const uint8_t *)s.len8, (const uint32_t *)s.which, (const uint16_t *)s.alt, s.tok,
-                       s.pending, s.redo);
+                       s.pending, s.redo, 0u);
 }
 
 void launch_lazy(const Config &cfg, const uint8_t *slab, uint32_t nb, const Scratch &s, hipStream_t stream) {

@@ -158,6 +158,7 @@ class PeerWindow:
         self.world = dist.get_world_size(group)
         self.buf = None
         self.capacity, self.depth, self._step = int(capacity), max(1, int(depth)), 0
+        self._unwaited = 0  # handles handed out and not yet wait()ed: the reuse contract allows depth - 1 (at least one)
         # Set-up is collective and must fail on EVERY rank or on none: the writer broadcasts its handle or its error, every
         # rank says whether it could map the buffer, and all of them raise together if one could not (a box whose devices
         # cannot map each other's memory then simply runs without this write-out).
@@ -199,6 +200,14 @@ class PeerWindow:
         off, total = sum(sz[:self.rank]), sum(sz)
         if total > self.capacity:
             raise ValueError("PeerWindow: the stream (%d bytes) does not fit the window (%d)" % (total, self.capacity))
+        # The reuse contract, enforced: the barrier inside wait(k) is what tells the peers that the writer is done with the
+        # view of step k - depth + 1; a caller that starts step k + depth - 1 before waiting for step k would let peers copy
+        # into a buffer the writer still reads (silent corruption of the written stream).  Every rank runs the same
+        # sequence of calls, so every rank raises here together.
+        if self._unwaited >= max(1, self.depth - 1):
+            raise RuntimeError("PeerWindow: gather_start() with %d step(s) not yet wait()ed (depth %d allows %d): "
+                               "wait() for the oldest handle first" % (self._unwaited, self.depth, max(1, self.depth - 1)))
+        self._unwaited += 1
         base = (self._step % self.depth) * self.capacity  # this step's buffer of the window (see the reuse contract)
         self._step += 1
         ev = None
@@ -214,6 +223,7 @@ class PeerWindow:
 class _PeerHandle:
     def __init__(self, win, ev, total, base=0):
         self._w, self._ev, self._total, self._base = win, ev, total, base
+        self._waited = False
 
     def wait(self):
         """Completes the step on every rank; on the writer returns the stream -- a VIEW of this step's buffer of the
@@ -222,4 +232,7 @@ class _PeerHandle:
         if self._ev is not None:
             self._ev.synchronize()  # my shard has landed
         dist.barrier(group=self._w.group)  # ... and so has everybody's: the writer may read the window
+        if not self._waited:
+            self._waited = True
+            self._w._unwaited -= 1
         return self._w.buf[self._base:self._base + self._total] if self._w.rank == self._w.dst else None

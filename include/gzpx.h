@@ -43,7 +43,7 @@ extern "C" {
 #define GZPX_ERR_BLOCK_SIZE_EXCEEDED 5 /* GzpError::BlockSizeExceeded(c, 65536), src/bgzf.rs:218-223  */
 #define GZPX_ERR_DEVICE 6              /* HIP runtime error (the Io-like class)                       */
 #define GZPX_ERR_NO_DEVICE 7           /* no MI355X / HIP device: there is NO CPU fallback            */
-#define GZPX_ERR_UNSUPPORTED 8         /* valid in the reference, not built yet (blocks > 16 MiB) */
+#define GZPX_ERR_UNSUPPORTED 8         /* valid in the reference, not built yet (blocks > 64 MiB) */
 #define GZPX_ERR_NUM_THREADS 9         /* GzpError::NumThreads(0), src/par/compress.rs:84-90          */
 #define GZPX_ERR_IO 10                 /* GzpError::Io: the wrapped writer failed                     */
 #define GZPX_ERR_CHANNEL 11            /* GzpError::ChannelSend/Receive: pipeline already closed      */

@@ -170,3 +170,19 @@ def test_heterogeneous_blocks_vs_oracle_near_optimal(hip_lib, oracle, level):
             got = c.compress_slab(a, True)
         assert got == oracle.compress_stream(a, ofmt, level, oracle.COMPAT_1_10, bs), (level, fmt, bs)
         assert gzip.decompress(got) == a.tobytes()
+
+
+@pytest.mark.parametrize("level", [1, 3])
+def test_mgzip_blocks_of_32_mib(hip_lib, oracle, level):
+    """src/mgzip.rs:187-218 puts no limit on a block's size (until round 6 this library stopped at 16 MiB): 32 MiB
+    Mgzip blocks, level 1 and gzp's default level, against the oracle's stream; inflated again by both routes."""
+    bs = 32 << 20
+    a = np.concatenate([synth.make("text", 20 << 20, 3), synth.make("mixed", 30 << 20, 4), synth.make("fastq", (20 << 20) + 12345, 5)])
+    want = oracle.compress_stream(a, oracle.FMT_MGZIP, level, oracle.COMPAT_1_24, bs)
+    with _native.Context(format=_native.FORMAT_MGZIP, level=level, buffer_size=bs, lib=hip_lib) as c:
+        got = c.compress_slab(a, True)
+    assert bytes(got) == bytes(want)
+    for route in (_native.INFLATE_SEG, _native.INFLATE_WAVE):
+        with _native.DContext(format=_native.FORMAT_MGZIP, lib=hip_lib) as d:
+            d.set_route(route)
+            assert d.decompress(got) == a.tobytes()
