@@ -48,7 +48,8 @@ EXPORTS = [
     "gzpx_ctx_set_profiling", "gzpx_ctx_last_stage_ms", "gzpx_stage_name", "gzpx_ctx_stage_kernel", "gzpx_debug_tokens",
     "gzpx_debug_set_flags", "gzpx_debug_redo_count", "gzpx_strerror", "gzpx_device_name", "gzpx_version",
     "gzpx_compress_slab_submit", "gzpx_compress_slab_submit_device", "gzpx_compress_slab_wait",
-    "gzpx_compress_slab_event", "gzpx_crc32_checked", "gzpx_last_status",
+    "gzpx_compress_slab_event", "gzpx_crc32_checked", "gzpx_last_status", "gzpx_crc32_combine", "gzpx_adler32",
+    "gzpx_adler32_checked", "gzpx_adler32_combine",
     "gzpx_par_create", "gzpx_par_write", "gzpx_par_write_chunked", "gzpx_par_flush", "gzpx_par_finish", "gzpx_par_destroy",
     "gzpx_par_last_error", "gzpx_par_create_pinned", "gzpx_par_reserve", "gzpx_par_commit", "gzpx_par_index", "gzpx_gzi_size",
     "gzpx_gzi_write", "gzpx_dctx_create", "gzpx_dctx_destroy", "gzpx_scan_blocks",
@@ -226,6 +227,14 @@ class GzpxLib:
         L.gzpx_dctx_last_inflate_ms.argtypes = [vp, ctypes.POINTER(ctypes.c_float)]
         L.gzpx_debug_inflate.restype = i32
         L.gzpx_debug_inflate.argtypes = [vp, i32, ctypes.POINTER(ctypes.c_uint64)]
+        L.gzpx_crc32_combine.restype = ctypes.c_uint32
+        L.gzpx_crc32_combine.argtypes = [ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint64]
+        L.gzpx_adler32_combine.restype = ctypes.c_uint32
+        L.gzpx_adler32_combine.argtypes = [ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint64]
+        L.gzpx_adler32.restype = ctypes.c_uint32
+        L.gzpx_adler32.argtypes = [ctypes.c_uint32, vp, ctypes.c_size_t]
+        L.gzpx_adler32_checked.restype = i32
+        L.gzpx_adler32_checked.argtypes = [ctypes.c_uint32, vp, ctypes.c_size_t, ctypes.POINTER(ctypes.c_uint32)]
         L.gzpx_dctx_last_inflate_stage_ms.restype = i32
         L.gzpx_dctx_last_inflate_stage_ms.argtypes = [vp, ctypes.POINTER(ctypes.c_float)]
         L.gzpx_dctx_set_route.restype = i32
@@ -602,6 +611,27 @@ def crc32(data, crc=0, lib=None):
     out = ctypes.c_uint32(0)
     lib.check(lib.L.gzpx_crc32_checked(crc, a.ctypes.data, a.size, ctypes.byref(out)))
     return int(out.value)
+
+
+def crc32_combine(crc1, crc2, len2, lib=None):
+    """Crc32::combine (src/check.rs:160-163): the CRC-32 of A || B from crc(A), crc(B), len(B)."""
+    lib = lib or load()
+    return int(lib.L.gzpx_crc32_combine(crc1, crc2, len2))
+
+
+def adler32(data, adler=1, lib=None):
+    """Adler32::update (src/check.rs:112-119) on the device."""
+    lib = lib or load()
+    a = _u8(data)
+    out = ctypes.c_uint32(0)
+    lib.check(lib.L.gzpx_adler32_checked(adler, a.ctypes.data, a.size, ctypes.byref(out)))
+    return int(out.value)
+
+
+def adler32_combine(adler1, adler2, len2, lib=None):
+    """Adler32::combine (src/check.rs:121-127)."""
+    lib = lib or load()
+    return int(lib.L.gzpx_adler32_combine(adler1, adler2, len2))
 
 
 class DContext:

@@ -7,7 +7,7 @@ CSRC = os.path.join(_HERE, "csrc")
 LIB_DIR = os.path.join(_HERE, "lib")
 LIB = os.path.join(LIB_DIR, "libgzpx.so")
 INCLUDE = os.path.abspath(os.path.join(_HERE, "..", "include"))
-SOURCES = ["gzpx_kernels.hip", "gzpx_nearopt.hip", "gzpx_synth.hip", "gzpx_api.cpp", "gzpx_par.cpp"]
+SOURCES = ["gzpx_kernels.hip", "gzpx_nearopt.hip", "gzpx_synth.hip", "gzpx_check.hip", "gzpx_api.cpp", "gzpx_par.cpp"]
 
 
 def _hipcc():

@@ -1331,6 +1331,74 @@ uint32_t gzpx_crc32(uint32_t crc, const void *buf, size_t n) {
 
 int gzpx_last_status(void) { return t_last_status; }
 
+// ---- Crc32::combine, Adler32::update / combine (src/check.rs:85-164): see gzpx_check.hip
+uint32_t gzpx_crc32_combine(uint32_t crc1, uint32_t crc2, uint64_t len2) { return crc32_combine(crc1, crc2, len2); }
+
+uint32_t gzpx_adler32_combine(uint32_t adler1, uint32_t adler2, uint64_t len2) {
+    // zlib's adler32_combine (zlib 1.2.11 / zlib-ng 2.x: the same arithmetic), restated from its published algorithm
+    const uint32_t base = 65521u;
+    const uint32_t rem = (uint32_t)(len2 % base);
+    uint32_t sum1 = adler1 & 0xFFFFu;
+    uint32_t sum2 = (uint32_t)(((uint64_t)rem * sum1) % base);
+    sum1 += (adler2 & 0xFFFFu) + base - 1;
+    sum2 += ((adler1 >> 16) & 0xFFFFu) + ((adler2 >> 16) & 0xFFFFu) + base - rem;
+    if (sum1 >= base) sum1 -= base;
+    if (sum1 >= base) sum1 -= base;
+    if (sum2 >= (base << 1)) sum2 -= (base << 1);
+    if (sum2 >= base) sum2 -= base;
+    return sum1 | (sum2 << 16);
+}
+
+int gzpx_adler32_checked(uint32_t adler, const void *buf, size_t n, uint32_t *out) {
+    static std::mutex mu;
+    static uint8_t *d_in = nullptr;
+    static uint32_t *d_out3 = nullptr, *h_out3 = nullptr;
+    static hipStream_t stream = nullptr;
+    constexpr size_t kChunk = (size_t)64 << 20, kTiles = kChunk / 65536;
+    if (!out || (!buf && n)) return GZPX_ERR_INVALID_ARG;
+    *out = adler;
+    if (n == 0) return GZPX_OK;
+    std::lock_guard<std::mutex> lock(mu);
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return GZPX_ERR_NO_DEVICE;
+    if (hipSetDevice(0) != hipSuccess) return GZPX_ERR_DEVICE;
+    if (!stream) {
+        HIP_TRY(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+        HIP_TRY(hipMalloc((void **)&d_in, kChunk));
+        HIP_TRY(hipMalloc((void **)&d_out3, kTiles * 12));
+        HIP_TRY(hipHostMalloc((void **)&h_out3, kTiles * 12, hipHostMallocDefault));
+    }
+    const uint32_t base = 65521u;
+    uint32_t a = adler & 0xFFFFu, b = (adler >> 16) & 0xFFFFu;
+    const uint8_t *p = (const uint8_t *)buf;
+    while (n) {
+        const size_t take = n < kChunk ? n : kChunk;
+        const size_t tiles = (take + 65535) / 65536;
+        HIP_TRY(hipMemcpyAsync(d_in, p, take, hipMemcpyHostToDevice, stream));
+        launch_adler32(d_in, take, d_out3, stream);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(h_out3, d_out3, tiles * 12, hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+        for (size_t t = 0; t < tiles; t++) {  // a' = a + s1, b' = b + len a + s2
+            const uint32_t s1 = h_out3[3 * t], s2 = h_out3[3 * t + 1], len = h_out3[3 * t + 2];
+            b = (uint32_t)((b + (uint64_t)(len % base) * a + s2) % base);
+            a = (a + s1) % base;
+        }
+        p += take;
+        n -= take;
+    }
+    *out = a | (b << 16);
+    return GZPX_OK;
+}
+
+uint32_t gzpx_adler32(uint32_t adler, const void *buf, size_t n) {
+    // zlib's adler32 signature has no error channel: a device failure leaves `adler` unchanged and is reported through
+    // gzpx_last_status() (thread-local), as with gzpx_crc32
+    uint32_t out = adler;
+    t_last_status = gzpx_adler32_checked(adler, buf, n, &out);
+    return t_last_status == GZPX_OK ? out : adler;
+}
+
 // ---------------------------------------------------------------- ParDecompress side
 namespace {
 

@@ -183,4 +183,7 @@ void launch_inflate(uint32_t hdr_len, const uint8_t *d_in, const uint64_t *d_off
                     uint32_t *d_crc_found, const CrcConsts &cc, int debug, hipEvent_t ev_begin,
                     hipEvent_t ev_end, hipStream_t stream, const InflateScratch &sc, int route, hipEvent_t ev_mid = nullptr);
 
+// gzpx_check.hip: (s1, s2, n) of every 64 KiB tile of d_in[0..n) -> d_out3[3 * tile + ..]
+void launch_adler32(const uint8_t *d_in, uint64_t n, uint32_t *d_out3, hipStream_t stream);
+
 }  // namespace gzpx

@@ -32,7 +32,11 @@ constexpr uint32_t kSegRingDw = 2u * kSegWinDw;  // the ring: two windows
 constexpr uint32_t kSegRingStride = kSegRingDw + 1u;  // dwords per lane: + a copy of slot 0 behind the last slot (odd: no bank conflicts)
 constexpr uint32_t kSegLRoot = 10u, kSegORoot = 8u, kSegPRoot = 7u;  // root bits of the litlen / offset / precode tables
 constexpr uint32_t kSegLSub = 320u, kSegOSub = 160u;  // second-level entries (ENOUGH(288,10,15) - 1024 = 310, (32,8,15): 146)
-constexpr uint32_t kLzTile = 32768u;     // k_lzcopy works on 32 KiB of output at a time
+#ifndef GZPX_LZ_TILE_SHIFT
+#define GZPX_LZ_TILE_SHIFT 14
+#endif
+constexpr uint32_t kLzTileShift = GZPX_LZ_TILE_SHIFT;
+constexpr uint32_t kLzTile = 1u << kLzTileShift;  // k_lzcopy works on this much output at a time (16 KiB: six workgroups per CU; measured 1.84 ms at 32 KiB / four, 1.56 at 16 / six, 1.61 at 8 / eight)
 
 struct __attribute__((aligned(8))) LzMatch {
     uint32_t pos;       // first output byte, relative to the member's output
@@ -443,7 +447,7 @@ __device__ __attribute__((noinline)) void seg_member(const uint32_t b, const uin
     const uint8_t *pay = in_all + blk->in_off + hdr_len;
     const uint32_t pay_len = blk->size - hdr_len - 8;
     LzMatch *ml = mlist_all + (ooff / 3u + b);
-    uint32_t *tf = tfirst_all + ((ooff >> 15) + 2ull * b);
+    uint32_t *tf = tfirst_all + ((ooff >> kLzTileShift) + 2ull * b);
     const bool multi = isize > kLzTile;  // more than one k_lzcopy tile: the first record of every tile is noted
     if (multi && tid == 0) tf[0] = 0;
     const long long t_begin = DBG ? clock64() : 0;
@@ -501,7 +505,7 @@ __device__ __attribute__((noinline)) void seg_member(const uint32_t b, const uin
             const uint32_t donew = head + 4 * nw;
             if (tid < 3 && donew + tid < len) dp[donew + tid] = sp[donew + tid];
             if (multi && tid == 0)
-                for (uint32_t k = (o >> 15) + 1; k <= ((o + len) >> 15); k++) tf[k] = mtot;
+                for (uint32_t k = (o >> kLzTileShift) + 1; k <= ((o + len) >> kLzTileShift); k++) tf[k] = mtot;
             o += len;
             bp += 8u * len;
             continue;
@@ -751,7 +755,7 @@ __device__ __attribute__((noinline)) void seg_member(const uint32_t b, const uin
                         }
                         if (go) {
                             const uint32_t np = pos + outlen;
-                            if (multi && ((pos ^ np) >> 15)) tf[np >> 15] = mi;  // the next record is the tile's first
+                            if (multi && ((pos ^ np) >> kLzTileShift)) tf[np >> kLzTileShift] = mi;  // the next record is the tile's first
                             pos = np;
                             rp += used;
                             f3 = kind >= 2u ? kind - 1u : 0u;
@@ -785,7 +789,7 @@ __device__ __attribute__((noinline)) void seg_member(const uint32_t b, const uin
         blk->status = kInfOk;
         blk->produced = o;
         blk->nmatch = mtot;
-        if (multi) tf[(isize >> 15) + 1] = mtot;
+        if (multi) tf[(isize >> kLzTileShift) + 1] = mtot;
     }
     if (DBG && tid == 0) {
         dbg[0] = (uint32_t)(clock64() - t_begin);
@@ -939,8 +943,11 @@ __device__ __forceinline__ void lc_prepare(LcWork &w, const LzMatch &m, bool val
 // DBlock.cyc of a debug launch of k_lzcopy (wave 0's clocks): [0] whole member, [1] tile staged in, [2] chunk set-up
 // (records, bitmap cleared, sources in front of the tile fetched, barrier), [3] polling loop, [4] tile written out,
 // counts [5] polling iterations of all waves, [6] of them without progress, [7] matches
+#ifndef GZPX_LC_WAVES
+#define GZPX_LC_WAVES 6
+#endif
 template <bool DBG>
-__global__ __launch_bounds__(kLcThreads, 4) void k_lzcopy(DBlock *__restrict__ blk_all, const uint64_t *__restrict__ out_off,
+__global__ __launch_bounds__(kLcThreads, GZPX_LC_WAVES) void k_lzcopy(DBlock *__restrict__ blk_all, const uint64_t *__restrict__ out_off,
                                                          uint8_t *out_all, const LzMatch *__restrict__ mlist_all,
                                                          const uint32_t *__restrict__ tfirst_all, uint32_t *__restrict__ redo) {
     __shared__ LcLds l;
@@ -953,7 +960,7 @@ __global__ __launch_bounds__(kLcThreads, 4) void k_lzcopy(DBlock *__restrict__ b
     const uint64_t ooff = out_off[b];
     uint8_t *out = out_all + ooff;
     const LzMatch *ml = mlist_all + (ooff / 3u + b);
-    const uint32_t *tf = tfirst_all + ((ooff >> 15) + 2ull * b);
+    const uint32_t *tf = tfirst_all + ((ooff >> kLzTileShift) + 2ull * b);
     const bool multi = isize > kLzTile;
     const uint32_t phase = (uint32_t)((uintptr_t)out & 15u);
     const uint32_t gmis = (uint32_t)((uintptr_t)out & 3u);

@@ -5821,6 +5821,6 @@ void launch_inflate(uint32_t hdr_len, const uint8_t *d_in, const uint64_t *d_off
 }
 
 size_t inflate_mlist_bytes(uint64_t out_cap, uint64_t nb) { return (size_t)((out_cap / 3u + nb + 2u) * sizeof(LzMatch)); }
-size_t inflate_tfirst_bytes(uint64_t out_cap, uint64_t nb) { return (size_t)(((out_cap >> 15) + 2u * nb + 4u) * 4u); }
+size_t inflate_tfirst_bytes(uint64_t out_cap, uint64_t nb) { return (size_t)(((out_cap >> kLzTileShift) + 2u * nb + 4u) * 4u); }
 
 }  // namespace gzpx

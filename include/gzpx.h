@@ -203,6 +203,18 @@ uint32_t gzpx_crc32(uint32_t crc, const void *buf, size_t n);
 int gzpx_crc32_checked(uint32_t crc, const void *buf, size_t n, uint32_t *out);
 int gzpx_last_status(void);
 
+/* The checks of gzp's Gzip / Zlib formats (src/check.rs:85-164) as helpers; the encoders of those formats are not
+ * built (zlib-ng's output cannot be pinned in this image), so nothing inside the library calls these.
+ *   gzpx_crc32_combine    Crc32::combine (flate2::Crc::combine, src/check.rs:160-163): the CRC-32 of A || B from crc(A),
+ *                         crc(B) and |B|.  Arithmetic only.  (Crc32::update is gzpx_crc32 above.)
+ *   gzpx_adler32          Adler32::update (libz_ng_sys::adler32, src/check.rs:112-119): start with 1.  On the device;
+ *                         errors as gzpx_crc32 (gzpx_last_status), gzpx_adler32_checked returns them.
+ *   gzpx_adler32_combine  Adler32::combine (adler32_combine, src/check.rs:121-127).  Arithmetic only. */
+uint32_t gzpx_crc32_combine(uint32_t crc1, uint32_t crc2, uint64_t len2);
+uint32_t gzpx_adler32(uint32_t adler, const void *buf, size_t n);
+int gzpx_adler32_checked(uint32_t adler, const void *buf, size_t n, uint32_t *out);
+uint32_t gzpx_adler32_combine(uint32_t adler1, uint32_t adler2, uint64_t len2);
+
 /* ---- ParCompress<Bgzf/Mgzip> twin: Write + ZWriter::finish over device lanes (C++ class
  * gzp::ParCompress in gzp_amd/csrc/gzpx_par.hpp; src/par/compress.rs:33-469) ---- */
 typedef struct gzpx_par gzpx_par;

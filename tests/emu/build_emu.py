@@ -8,7 +8,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.abspath(os.path.join(HERE, "..", ".."))
 CSRC = os.path.join(ROOT, "gzp_amd", "csrc")
 OUT = os.path.join(HERE, "libgzpx_emu.so")
-SOURCES = [os.path.join(CSRC, "gzpx_kernels.hip"), os.path.join(CSRC, "gzpx_nearopt.hip"), os.path.join(CSRC, "gzpx_synth.hip"),
+SOURCES = [os.path.join(CSRC, "gzpx_kernels.hip"), os.path.join(CSRC, "gzpx_nearopt.hip"), os.path.join(CSRC, "gzpx_synth.hip"), os.path.join(CSRC, "gzpx_check.hip"),
            os.path.join(CSRC, "gzpx_api.cpp"),
            os.path.join(CSRC, "gzpx_par.cpp"), os.path.join(HERE, "emu_runtime.cpp")]
 

@@ -8,7 +8,7 @@ import sys
 ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
 tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
 rows = []
-for src in ("gzpx_kernels.hip", "gzpx_nearopt.hip", "gzpx_synth.hip"):
+for src in ("gzpx_kernels.hip", "gzpx_nearopt.hip", "gzpx_synth.hip", "gzpx_check.hip"):
     p = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-c", "-I", os.path.join(ROOT, "include"),
                         os.path.join(ROOT, "gzp_amd", "csrc", src), "-o", "/dev/null", "-Rpass-analysis=kernel-resource-usage"],
                        capture_output=True, text=True)
