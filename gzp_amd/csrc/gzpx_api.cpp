@@ -1417,6 +1417,8 @@ struct DSlot {
     uint64_t *h_offsets = nullptr;  // pinned copies of the caller's arrays (the caller's may be pageable
     uint32_t *h_sizes = nullptr;    //  and must not be referenced after submit returns)
     uint64_t *h_total = nullptr;  // pinned
+    uint32_t *h_summary = nullptr;  // pinned: k_dsummary's record (the first failing member, its checksums)
+    bool have_blk = false;          // h_blk holds this launch's records (debug launches only)
     uint8_t *d_in = nullptr, *d_out = nullptr;
     size_t d_in_cap = 0, d_out_cap = 0;
     InflateScratch sc;  // match records / tile table of k_inflate_seg + k_lzcopy; sc.redo lives with the block tables
@@ -1456,6 +1458,8 @@ int dslot_reserve(DSlot &c, size_t nb) {
         HIP_TRY(hipEventCreate(&c.ev_t1));
         HIP_TRY(hipEventCreate(&c.ev_tm));
         HIP_TRY(hipHostMalloc((void **)&c.h_total, 64, hipHostMallocDefault));
+        HIP_TRY(hipHostMalloc((void **)&c.h_summary, 64, hipHostMallocDefault));
+        HIP_TRY(hipMalloc((void **)&c.sc.summary, 64));
     }
     if (nb <= c.cap_blocks) return GZPX_OK;
     dslot_free_tables(c);
@@ -1597,8 +1601,11 @@ int dsubmit_enqueue(gzpx_dctx *c, const uint8_t *host_in, const uint8_t *d_in, s
         launch_inflate(hdr_len, d_in, sl.d_offsets, sl.d_sizes, (uint32_t)nb, sl.d_blk, sl.d_out_off, d_out, out_cap,
                        sl.d_crc, c->cc, c->debug, sl.ev_t0, sl.ev_t1, stream, sl.sc, c->route, sl.ev_tm);
         HIP_TRY(hipGetLastError());
-        HIP_TRY(hipMemcpyAsync(sl.h_blk, sl.d_blk, nb * sizeof(DBlockHost), hipMemcpyDeviceToHost, stream));
-        HIP_TRY(hipMemcpyAsync(sl.h_crc, sl.d_crc, nb * 4, hipMemcpyDeviceToHost, stream));
+        // what the host needs of the members' records is k_dsummary's 48 bytes; the records themselves only for the
+        // debug counters
+        HIP_TRY(hipMemcpyAsync(sl.h_summary, sl.sc.summary, 48, hipMemcpyDeviceToHost, stream));
+        sl.have_blk = c->debug != 0;
+        if (c->debug) HIP_TRY(hipMemcpyAsync(sl.h_blk, sl.d_blk, nb * sizeof(DBlockHost), hipMemcpyDeviceToHost, stream));
         HIP_TRY(hipMemcpyAsync(sl.h_total, sl.d_out_off + nb, 8, hipMemcpyDeviceToHost, stream));
         HIP_TRY(hipEventRecord(sl.ev_kernels, stream));
         if (host_out) {
@@ -1642,21 +1649,18 @@ int dwait_ticket(gzpx_dctx *c, uint64_t ticket, size_t *out_len, gzpx_check_info
         if (hipSetDevice(c->device) != hipSuccess || hipEventSynchronize(sl.ev_done) != hipSuccess) {
             rc = GZPX_ERR_DEVICE;
         } else {
-            for (size_t b = 0; b < sl.nb; b++) {  // first failing block, in stream order (src/par/decompress.rs:162-186)
-                const DBlockHost &d = sl.h_blk[b];
-                int err = GZPX_OK;
-                if (d.status == 1) err = GZPX_ERR_BAD_DATA;
-                else if (d.status == 2) err = GZPX_ERR_INSUFFICIENT_SPACE;
-                else if (d.status != 0 && !short_ok) err = GZPX_ERR_BAD_DATA;  // 3: fewer bytes than ISIZE
-                else if (sl.h_crc[b] != d.crc) err = GZPX_ERR_INVALID_CHECK;
-                if (err != GZPX_OK) {
-                    if (info) {
-                        info->block = b;
-                        info->found = sl.h_crc[b];
-                        info->expected = d.crc;
-                    }
-                    rc = err;
-                    break;
+            // the first failing block in stream order (src/par/decompress.rs:162-186), found on the device (k_dsummary)
+            const uint32_t *q = sl.h_summary + (short_ok ? 4 : 0);
+            if (q[0] != 0xFFFFFFFFu) {
+                const uint32_t st = q[1];
+                rc = st == 1 ? GZPX_ERR_BAD_DATA
+                     : st == 2 ? GZPX_ERR_INSUFFICIENT_SPACE
+                     : (st != 0 && !short_ok) ? GZPX_ERR_BAD_DATA  // 3: fewer bytes than ISIZE
+                                              : GZPX_ERR_INVALID_CHECK;
+                if (info) {
+                    info->block = q[0];
+                    info->found = q[2];
+                    info->expected = q[3];
                 }
             }
             if (rc == GZPX_OK) produced = (size_t)*sl.h_total;
@@ -1717,6 +1721,8 @@ void gzpx_dctx_destroy(gzpx_dctx *c) {
     for (DSlot &sl : c->slots) {
         dslot_free_tables(sl);
         if (sl.h_total) (void)hipHostFree(sl.h_total);
+        if (sl.h_summary) (void)hipHostFree(sl.h_summary);
+        if (sl.sc.summary) (void)hipFree(sl.sc.summary);
         if (sl.d_in) (void)hipFree(sl.d_in);
         if (sl.d_out) (void)hipFree(sl.d_out);
         if (sl.sc.mlist) (void)hipFree(sl.sc.mlist);
@@ -1865,7 +1871,7 @@ int gzpx_deflate_decompress(gzpx_decompressor *d, const void *in, size_t n, void
     if (rc != GZPX_OK) return rc;
     {
         std::lock_guard<std::mutex> lk(c->mu);  // (this handle is single-threaded like libdeflate's: the
-        got = sl.h_blk[0].produced;             //  slot has not been reused since the wait)
+        got = sl.h_summary[8];                  //  slot has not been reused since the wait)
     }
     if (got > cap) return GZPX_ERR_INSUFFICIENT_SPACE;  // cap == 0 and the stream has output
     if (got) memcpy(out, tmp.data(), got);
@@ -2003,7 +2009,7 @@ int gzpx_debug_inflate(gzpx_dctx *ctx, int enable, uint64_t sums[8]) {
     ctx->debug = enable < 0 ? 0 : enable > 2 ? 1 : enable;
     if (sums) {
         for (int k = 0; k < 8; k++) sums[k] = 0;
-        if (ctx->last_slot >= 0)
+        if (ctx->last_slot >= 0 && ctx->slots[ctx->last_slot].have_blk)
             for (size_t b = 0; b < ctx->last_nb; b++)
                 for (int k = 0; k < 8; k++) sums[k] += ctx->slots[ctx->last_slot].h_blk[b].cyc[k];
     }

@@ -5569,6 +5569,34 @@ __global__ __launch_bounds__(kCrcThreads, 8) void k_dcrc32(const uint8_t *__rest
     if (threadIdx.x == 0) crc_found[b] = total;
 }
 
+// What the host wants to know of a launch: the first failing member in stream order (src/par/decompress.rs:162-186),
+// once under the framed rule (a member that inflates to fewer bytes than its footer says is BadData) and once under
+// the libdeflate-shaped call's (fewer bytes are accepted), with its status and the two checksums -- 48 bytes instead
+// of a record per member.  DSummary: [0] first failing member, strict (0xFFFFFFFF: none), [1] its status, [2] CRC
+// found, [3] CRC expected, [4..7] the same under the lenient rule, [8] bytes member 0 produced.
+__global__ __launch_bounds__(256) void k_dsummary(uint32_t nb, const DBlock *__restrict__ blk, const uint32_t *__restrict__ crc_found,
+                                                  uint32_t *__restrict__ sum) {
+    __shared__ uint32_t first[2];
+    const uint32_t tid = threadIdx.x;
+    if (tid < 2) first[tid] = 0xFFFFFFFFu;
+    __syncthreads();
+    for (uint32_t b = tid; b < nb; b += 256) {
+        const uint32_t st = blk[b].status;
+        const bool crc_bad = crc_found[b] != blk[b].crc;
+        if (st != 0 || crc_bad) atomicMin(&first[0], b);
+        if (st == 1 || st == 2 || crc_bad) atomicMin(&first[1], b);
+    }
+    __syncthreads();
+    if (tid < 2) {
+        const uint32_t b = first[tid];
+        sum[4 * tid + 0] = b;
+        sum[4 * tid + 1] = b != 0xFFFFFFFFu ? blk[b].status : 0u;
+        sum[4 * tid + 2] = b != 0xFFFFFFFFu ? crc_found[b] : 0u;
+        sum[4 * tid + 3] = b != 0xFFFFFFFFu ? blk[b].crc : 0u;
+    }
+    if (tid == 0) sum[8] = nb ? blk[0].produced : 0u;
+}
+
 // ------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------
@@ -5818,6 +5846,8 @@ void launch_inflate(uint32_t hdr_len, const uint8_t *d_in, const uint64_t *d_off
     if (ev_end) (void)hipEventRecord(ev_end, stream);
     hipLaunchKernelGGL(k_dcrc32, dim3(nb), dim3(kCrcThreads), 0, stream, (const uint8_t *)d_out,
                        (const uint64_t *)d_out_off, (const DBlock *)blk, d_crc_found, cc);
+    if (sc.summary)
+        hipLaunchKernelGGL(k_dsummary, dim3(1), dim3(256), 0, stream, nb, (const DBlock *)blk, (const uint32_t *)d_crc_found, sc.summary);
 }
 
 size_t inflate_mlist_bytes(uint64_t out_cap, uint64_t nb) { return (size_t)((out_cap / 3u + nb + 2u) * sizeof(LzMatch)); }

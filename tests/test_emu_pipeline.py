@@ -144,8 +144,8 @@ def test_builder_validation(emu_lib):
     with pytest.raises(_native.GzpxError) as ei:
         _native.Context(level=13, lib=emu_lib)
     assert ei.value.code == _native.ERR_COMPRESSION_LEVEL
-    with pytest.raises(_native.GzpxError) as ei:  # valid in gzp, not built (blocks above 16 MiB): never a CPU fallback
-        _native.Context(format=_native.FORMAT_MGZIP, buffer_size=(16 << 20) + 1, lib=emu_lib)
+    with pytest.raises(_native.GzpxError) as ei:  # valid in gzp, not built (blocks above 64 MiB): never a CPU fallback
+        _native.Context(format=_native.FORMAT_MGZIP, buffer_size=(64 << 20) + 1, lib=emu_lib)
     assert ei.value.code == _native.ERR_UNSUPPORTED
     _native.Context(level=12, lib=emu_lib, max_slab_bytes=65280).close()  # CompressionLvl accepts 0..12 (src/deflate.rs:596-599)
 

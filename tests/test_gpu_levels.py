@@ -122,7 +122,7 @@ def test_builder_best_level(hip_lib, oracle):
 
 @pytest.mark.parametrize("level", [1, 3, 6])
 def test_largest_block_16mib(hip_lib, oracle, level):
-    """buffer_size = 16 MiB (the largest the kernels accept): one full block and a ragged second one,
+    """buffer_size = 16 MiB: one full block and a ragged second one,
     heterogeneous content so that sub-blocks split and min_len changes along the block."""
     bs = 1 << 24
     a = hetero(bs + 1_234_567, 77 + level)

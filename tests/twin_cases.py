@@ -319,8 +319,8 @@ def builder_errors(lib):
     w12.write_all(a12)
     w12.finish()
     assert gzip.decompress(sink12.getvalue()) == a12.tobytes()
-    with pytest.raises(par.GzpError) as e:  # valid in gzp, not built (blocks above 16 MiB): never a CPU fallback
-        par.ParCompressBuilder(par.Mgzip, lib=lib).buffer_size((16 << 20) + 1).from_writer(io.BytesIO())
+    with pytest.raises(par.GzpError) as e:  # valid in gzp, not built (blocks above 64 MiB): never a CPU fallback
+        par.ParCompressBuilder(par.Mgzip, lib=lib).buffer_size((64 << 20) + 1).from_writer(io.BytesIO())
     assert e.value.code == _native.ERR_UNSUPPORTED
     with pytest.raises(par.GzpError) as e:
         par.ParDecompressBuilder(par.Bgzf, lib=lib).num_threads(0)
