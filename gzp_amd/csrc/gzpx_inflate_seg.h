@@ -1130,34 +1130,43 @@ __global__ __launch_bounds__(kLcThreads, GZPX_LC_WAVES) void k_lzcopy(DBlock *__
                     LcWork w;
                     w.pos = w.dist = w.k0 = w.k1 = 0;
                     w.kind = kLcNone;
-                    bool ready = false;
-                    if (have && !is_short) {
+                    bool mine = have && !is_short, open_range = false;
+                    uint32_t need_a = 0, need_e = 0;
+                    if (mine) {
                         lc_prepare(w, cm, true, ts, te, gmis);
                         const uint32_t s0 = w.pos - w.dist + w.k0, s1 = w.pos - w.dist + w.k1, d0 = w.pos + w.k0;
                         const uint32_t pa = s0 > ts ? s0 : ts, pe = s1 < d0 ? s1 : d0;  // the part inside the tile that it does not write itself
-                        uint32_t need_a = pa + xo;
+                        need_a = pa + xo;
+                        need_e = pe + xo;
                         if (need_a < chunk_lo) need_a = chunk_lo;  // everything in front of the chunk is final
-                        ready = pa >= pe || need_a >= pe + xo || lc_all_set(l.bm, need_a, pe + xo);
+                        open_range = pa < pe && need_a < need_e;
                     }
-                    uint64_t longs = __ballot(ready);
-                    progress = progress || longs != 0;
-                    while (longs) {
-                        const uint32_t jl = (uint32_t)__ffsll((long long)longs) - 1u;
-                        longs &= longs - 1ull;
-                        const uint32_t jp = rdlane(w.pos, jl), jdist = rdlane(w.dist, jl), jk = rdlane(w.k0, jl), jk1 = rdlane(w.k1, jl);
-                        for (uint32_t i = jk + lane; i < jk1; i += 64) {
-                            const uint32_t r = i < jdist ? i : i % jdist;
-                            const uint32_t sp = jp - jdist + r;
-                            LC_CHK(sp < ts || sp + xo < kLcBytes, "slow sp=%u ts=%u jp=%u i=%u dist=%u\n", sp, ts, jp, i, jdist);
-                            LC_CHK(jp + i + xo < kLcBytes, "slowd jp=%u i=%u ts=%u\n", jp, i, ts);
-                            const uint32_t v = sp < ts ? (uint32_t)out[sp] : (uint32_t)tile8[sp + xo];
-                            tile8[jp + i + xo] = (uint8_t)v;
+                    // (again and again while something became ready: a run of long matches that each copy from the one
+                    // before -- the 254 matches of a block of zeros -- goes link by link here, not one polling iteration each)
+                    for (;;) {
+                        const bool ready = mine && (!open_range || lc_all_set(l.bm, need_a, need_e));
+                        uint64_t longs = __ballot(ready);
+                        if (longs == 0) break;
+                        progress = true;
+                        while (longs) {
+                            const uint32_t jl = (uint32_t)__ffsll((long long)longs) - 1u;
+                            longs &= longs - 1ull;
+                            const uint32_t jp = rdlane(w.pos, jl), jdist = rdlane(w.dist, jl), jk = rdlane(w.k0, jl), jk1 = rdlane(w.k1, jl);
+                            for (uint32_t i = jk + lane; i < jk1; i += 64) {
+                                const uint32_t r = i < jdist ? i : i % jdist;
+                                const uint32_t sp = jp - jdist + r;
+                                LC_CHK(sp < ts || sp + xo < kLcBytes, "slow sp=%u ts=%u jp=%u i=%u dist=%u\n", sp, ts, jp, i, jdist);
+                                LC_CHK(jp + i + xo < kLcBytes, "slowd jp=%u i=%u ts=%u\n", jp, i, ts);
+                                const uint32_t v = sp < ts ? (uint32_t)out[sp] : (uint32_t)tile8[sp + xo];
+                                tile8[jp + i + xo] = (uint8_t)v;
+                            }
                         }
-                    }
-                    wave_sync();  // (the wave's byte stores above are other lanes' stores for the owning lane)
-                    if (ready) {
-                        lc_mark<true>(l.bm, w.pos + w.k0 + xo, w.pos + w.k1 + xo);
-                        have = false;
+                        wave_sync();  // (the wave's byte stores above are other lanes' stores for the owning lane)
+                        if (ready) {
+                            lc_mark<true>(l.bm, w.pos + w.k0 + xo, w.pos + w.k1 + xo);
+                            have = false;
+                            mine = false;
+                        }
                     }
                 }
                 if (DBG) dbg[5]++;
