@@ -841,7 +841,13 @@ struct LcLds {
     uint32_t bm[kLcBytes / 32 + 2];
     uint32_t chunk_lo;
     uint32_t gave_up;
+    // the member's CRC-32, taken from the finished tiles while they are in LDS (k_dcrc32 then skips the member)
+    uint32_t crc_tab[4][256];       // slice-by-4 tables
+    uint32_t crc_pw[kLcThreads];    // x^(8 * 64 * (255 - t)): what thread t's 64-byte piece of a tile is shifted by
+    uint32_t crc_part[kLcThreads / 64];
+    uint32_t crc_total;
 };
+constexpr uint32_t kLcCrcDone = 0x80000000u;  // DBlock.nmatch, top bit: crc_found[] holds the member's CRC already
 
 // MEM = (MEM & ~mask) | data on an LDS dword, atomically: lanes that write different bytes of one dword in the same
 // instruction (neighbouring matches) do not lose each other's bytes
@@ -949,7 +955,8 @@ __device__ __forceinline__ void lc_prepare(LcWork &w, const LzMatch &m, bool val
 template <bool DBG>
 __global__ __launch_bounds__(kLcThreads, GZPX_LC_WAVES) void k_lzcopy(DBlock *__restrict__ blk_all, const uint64_t *__restrict__ out_off,
                                                          uint8_t *out_all, const LzMatch *__restrict__ mlist_all,
-                                                         const uint32_t *__restrict__ tfirst_all, uint32_t *__restrict__ redo) {
+                                                         const uint32_t *__restrict__ tfirst_all, uint32_t *__restrict__ redo,
+                                                         uint32_t *__restrict__ crc_found, CrcConsts cc) {
     __shared__ LcLds l;
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
     const uint32_t b = blockIdx.x;
@@ -967,7 +974,28 @@ __global__ __launch_bounds__(kLcThreads, GZPX_LC_WAVES) void k_lzcopy(DBlock *__
     const uint32_t *out32 = (const uint32_t *)(out - gmis);  // the member's output as aligned dwords: byte p is byte p + gmis of it
     uint8_t *tile8 = (uint8_t *)l.tile;
     for (uint32_t i = tid; i < kLcBytes / 32 + 2; i += kLcThreads) l.bm[i] = 0xFFFFFFFFu;
-    if (tid == 0) l.gave_up = 0;
+    if (tid == 0) {
+        l.gave_up = 0;
+        l.crc_total = 0;
+    }
+    {  // CRC tables (one entry of each per thread) and the thread's shift: the product of the x^(512 * 2^k) of its bits
+        uint32_t c = tid;
+        for (int k = 0; k < 8; k++) c = (c >> 1) ^ (0xEDB88320u & (0u - (c & 1u)));
+        l.crc_tab[0][tid] = c;
+        uint32_t pw = 0x80000000u;  // x^0
+        const uint32_t q = kLcThreads - 1u - tid;
+        for (uint32_t k = 0; k < 8; k++)
+            if ((q >> k) & 1u) pw = gf2_multmodp(cc.pow64[k], pw);
+        l.crc_pw[tid] = pw;
+        __syncthreads();
+        const uint32_t t0 = l.crc_tab[0][tid];
+        const uint32_t t1 = (t0 >> 8) ^ l.crc_tab[0][t0 & 0xFFu];
+        const uint32_t t2 = (t1 >> 8) ^ l.crc_tab[0][t1 & 0xFFu];
+        const uint32_t t3 = (t2 >> 8) ^ l.crc_tab[0][t2 & 0xFFu];
+        l.crc_tab[1][tid] = t1;
+        l.crc_tab[2][tid] = t2;
+        l.crc_tab[3][tid] = t3;
+    }
     uint32_t spins = 0;
     bool give_up = false;
     const long long t_begin = DBG ? clock64() : 0;
@@ -1183,6 +1211,47 @@ __global__ __launch_bounds__(kLcThreads, GZPX_LC_WAVES) void k_lzcopy(DBlock *__
         }
         __syncthreads();
         const long long t_out = DBG ? clock64() : 0;
+        // ---- the tile's CRC-32 while it is here: thread t takes the 64-byte piece that ends 64 (255 - t) bytes in front
+        // of the tile's end (only the first pieces of a short tile are empty), shifts its CRC to the tile's end, the
+        // pieces are XORed, and thread 0 appends the tile to the member's running CRC
+        if (!give_up) {
+            const uint32_t tl = te - ts, a0 = ts + xo;
+            const int32_t e_i = (int32_t)tl - 64 * (int32_t)(kLcThreads - 1u - tid);
+            uint32_t piece = 0;
+            if (e_i > 0) {
+                uint32_t pos = a0 + (e_i > 64 ? (uint32_t)(e_i - 64) : 0u);
+                const uint32_t end = a0 + (uint32_t)e_i;
+                uint32_t c = 0xFFFFFFFFu;
+                while (pos < end && (pos & 3u)) {
+                    c = (c >> 8) ^ l.crc_tab[0][(c ^ tile8[pos]) & 0xFFu];
+                    pos++;
+                }
+                while (pos + 4 <= end) {
+                    c ^= l.tile[pos >> 2];
+                    c = l.crc_tab[3][c & 0xFFu] ^ l.crc_tab[2][(c >> 8) & 0xFFu] ^ l.crc_tab[1][(c >> 16) & 0xFFu] ^ l.crc_tab[0][c >> 24];
+                    pos += 4;
+                }
+                while (pos < end) {
+                    c = (c >> 8) ^ l.crc_tab[0][(c ^ tile8[pos]) & 0xFFu];
+                    pos++;
+                }
+                piece = gf2_multmodp(l.crc_pw[tid], ~c);
+            }
+            for (int m = 32; m >= 1; m >>= 1) piece ^= __shfl_xor(piece, m);
+            if (lane == 0) l.crc_part[tid >> 6] = piece;
+            __syncthreads();
+            if (tid == 0) {
+                uint32_t tile_crc = 0;
+                for (uint32_t w2 = 0; w2 < kLcThreads / 64; w2++) tile_crc ^= l.crc_part[w2];
+                uint32_t tot = l.crc_total;
+                if (t > 0) {  // crc(A || B) = crc(A) x^(8 |B|) + crc(B): 64-byte steps from the table, the rest byte by byte
+                    const uint32_t q = tl >> 6;
+                    tot = gf2_multmodp(q >= kLcThreads ? cc.pow64[8] : l.crc_pw[kLcThreads - 1u - q], tot);
+                    for (uint32_t r = 0; r < (tl & 63u); r++) tot = (tot >> 8) ^ l.crc_tab[0][tot & 0xFFu];
+                }
+                l.crc_total = tot ^ tile_crc;
+            }
+        }
         // ---- the finished tile back to HBM; what the next tile reads of it comes from there
         if (!give_up) {
             const uint32_t a0 = ts + xo, a1 = te + xo;
@@ -1208,7 +1277,12 @@ __global__ __launch_bounds__(kLcThreads, GZPX_LC_WAVES) void k_lzcopy(DBlock *__
             dbg[4] += (uint32_t)(clock64() - t_out);
         }
     }
-    if (give_up) seg_redo(blk, redo, b, tid);
+    if (give_up) {
+        seg_redo(blk, redo, b, tid);
+    } else if (tid == 0) {  // (thread 0 wrote crc_total last: its own program order)
+        crc_found[b] = l.crc_total;
+        blk->nmatch = nmatch | kLcCrcDone;
+    }
     if (DBG) {
         if (tid == 0) {
             blk->cyc[0] = (uint32_t)(clock64() - t_begin);

@@ -5565,6 +5565,7 @@ __global__ __launch_bounds__(kCrcThreads, 8) void k_dcrc32(const uint8_t *__rest
                                                 uint32_t *__restrict__ crc_found, CrcConsts cc) {
     __shared__ CrcLds l;
     const uint32_t b = blockIdx.x;
+    if (blk_all[b].nmatch & 0x80000000u) return;  // (kLcCrcDone: k_lzcopy took the member's CRC from its tiles in LDS)
     const uint32_t total = crc32_workgroup<kCrcThreads>(l, out_all + out_off[b], blk_all[b].isize, cc, threadIdx.x);
     if (threadIdx.x == 0) crc_found[b] = total;
 }
@@ -5819,19 +5820,19 @@ void launch_inflate(uint32_t hdr_len, const uint8_t *d_in, const uint64_t *d_off
         if (debug == 1) {
             GZPX_LAUNCH_SEG(true);
             hipLaunchKernelGGL((k_lzcopy<false>), dim3(nb), dim3(kLcThreads), 0, stream, blk, (const uint64_t *)d_out_off,
-                               d_out, (const LzMatch *)ml, (const uint32_t *)sc.tfirst, sc.redo);
+                               d_out, (const LzMatch *)ml, (const uint32_t *)sc.tfirst, sc.redo, d_crc_found, cc);
             hipLaunchKernelGGL((k_inflate<true, true>), dim3(nb), dim3(64), 0, stream, hdr_len, d_in, blk,
                                (const uint64_t *)d_out_off, d_out, out_cap, (const uint32_t *)sc.redo);
         } else if (debug == 2) {  // k_lzcopy's clocks instead of k_inflate_seg's
             GZPX_LAUNCH_SEG(false);
             hipLaunchKernelGGL((k_lzcopy<true>), dim3(nb), dim3(kLcThreads), 0, stream, blk, (const uint64_t *)d_out_off,
-                               d_out, (const LzMatch *)ml, (const uint32_t *)sc.tfirst, sc.redo);
+                               d_out, (const LzMatch *)ml, (const uint32_t *)sc.tfirst, sc.redo, d_crc_found, cc);
             hipLaunchKernelGGL((k_inflate<false, true>), dim3(nb), dim3(64), 0, stream, hdr_len, d_in, blk,
                                (const uint64_t *)d_out_off, d_out, out_cap, (const uint32_t *)sc.redo);
         } else {
             GZPX_LAUNCH_SEG(false);
             hipLaunchKernelGGL((k_lzcopy<false>), dim3(nb), dim3(kLcThreads), 0, stream, blk, (const uint64_t *)d_out_off,
-                               d_out, (const LzMatch *)ml, (const uint32_t *)sc.tfirst, sc.redo);
+                               d_out, (const LzMatch *)ml, (const uint32_t *)sc.tfirst, sc.redo, d_crc_found, cc);
             hipLaunchKernelGGL((k_inflate<false, true>), dim3(nb), dim3(64), 0, stream, hdr_len, d_in, blk,
                                (const uint64_t *)d_out_off, d_out, out_cap, (const uint32_t *)sc.redo);
         }
