@@ -248,12 +248,15 @@ __device__ __forceinline__ void seg_sym(const InfSegLds &h, const SegWin &s, uin
     }
     const uint32_t dcl = oe & 15u, dxb = (oe >> 8) & 15u;
     const uint32_t dist = (oe >> 16) + ((b2 >> dcl) & ((1u << dxb) - 1u));
-    const bool is_len = type == 1u;
-    const bool bad = cl == 0 || type == 3u || (is_len && (dcl == 0 || (oe & 16u)));
+    // (flags as integers and selects only: with && / || the compiler builds exec-mask branches around these few lines)
+    const uint32_t is_len = type == 1u ? 1u : 0u;
+    const uint32_t lbad = (cl == 0 ? 1u : 0u) | (type == 3u ? 1u : 0u);
+    const uint32_t obad = (dcl == 0 ? 1u : 0u) | ((oe >> 4) & 1u);
+    const uint32_t bad = lbad | (is_len & obad);
     kind = bad ? 3u : type;
-    used = bad ? 0u : is_len ? u1 + dcl + dxb : cl;
+    used = bad ? 0u : u1 + (is_len ? dcl + dxb : 0u);  // (u1 = cl for a literal or the end-of-block code: no extra bits)
     val = is_len ? (lv << 16) | dist : lv;
-    outlen = bad || type == 2u ? 0u : is_len ? lv : 1u;
+    outlen = (bad | (type == 2u ? 1u : 0u)) ? 0u : is_len ? lv : 1u;
 }
 
 __device__ __forceinline__ void seg_redo(DBlock *blk, uint32_t *redo, uint32_t b, uint32_t lane) {
