@@ -469,8 +469,7 @@ __device__ __attribute__((noinline)) void seg_member(const uint32_t b, const uin
 
     uint32_t bp = bit0, o = 0, mtot = 0;
     bool final_block = false, bad = false;
-    uint32_t bad_line = 0;  // (diagnostics: where the member was given up)
-#define SEG_BAD() do { bad = true; bad_line = __LINE__; } while (0)
+#define SEG_BAD() do { bad = true; } while (0)  // (the member goes to k_inflate)
     while (!final_block && !bad) {
         bp = uniform(bp);
         o = uniform(o);
@@ -480,7 +479,6 @@ __device__ __attribute__((noinline)) void seg_member(const uint32_t b, const uin
         if (wave == 0) seg_header(h, (uint16_t *)hh.ring, hh.hres, pay32, last_w, bit_end, bp, lane);
         if (W > 1) __syncthreads();
         bad = uniform(hh.hres[0]) != 0;
-        if (bad) bad_line = __LINE__;
         final_block = uniform(hh.hres[1]) != 0;
         const uint32_t btype = uniform(hh.hres[2]);
         bp = uniform(hh.hres[3]);
@@ -784,9 +782,6 @@ __device__ __attribute__((noinline)) void seg_member(const uint32_t b, const uin
     }
     if (!bad && (o != isize || bp > bit_end)) SEG_BAD();
     if (bad) {
-#ifdef GZPX_EMU
-        if (tid == 0 && getenv("GZPX_TRACE_SEG")) fprintf(stderr, "seg redo: member %u line %u bp %u/%u o %u/%u\n", b, bad_line, bp, bit_end, o, isize);
-#endif
         seg_redo(blk, redo, b, tid);
     } else if (tid == 0) {
         blk->status = kInfOk;
@@ -863,11 +858,6 @@ __device__ __forceinline__ void lds_mskor(uint32_t *p, uint32_t mask, uint32_t d
 #endif
 }
 
-#ifdef GZPX_EMU
-#define LC_CHK(c, ...) do { if (!(c)) { fprintf(stderr, __VA_ARGS__); abort(); } } while (0)
-#else
-#define LC_CHK(c, ...) ((void)0)
-#endif
 // bits [a, e) of the bitmap: all ones?
 __device__ __forceinline__ bool lc_all_set(const uint32_t *bm, uint32_t a, uint32_t e) {
     bool ok = true;
@@ -884,7 +874,6 @@ template <bool SET>
 __device__ __forceinline__ void lc_mark(uint32_t *bm, uint32_t a, uint32_t e) {
     while (a < e) {
         const uint32_t w = a >> 5, lo = a & 31u;
-        LC_CHK(w < kLcBytes / 32 + 2, "mark a=%u e=%u\n", a, e);
         const uint32_t n = (e - a) < (32u - lo) ? (e - a) : (32u - lo);
         const uint32_t mask = (n == 32u ? 0xFFFFFFFFu : ((1u << n) - 1u)) << lo;
         if (SET) atomicOr(&bm[w], mask);
@@ -905,7 +894,6 @@ __device__ __forceinline__ void lc_put16(uint32_t *tile, uint32_t w0, uint32_t w
                    v4 = __builtin_amdgcn_alignbyte(w5, w4, r);
     const uint32_t m20 = ((1u << n) - 1u) << (D & 3u);  // one bit per byte of the five destination dwords
     const uint32_t d = D >> 2;
-    LC_CHK(d + 4 < kLcBytes / 4, "put16 D=%u n=%u\n", D, n);
     const uint32_t m0 = lc_bytes(m20), m1 = lc_bytes(m20 >> 4), m2 = lc_bytes(m20 >> 8);
     lds_mskor(&tile[d + 0], m0, v0 & m0);
     lds_mskor(&tile[d + 1], m1, v1 & m1);
@@ -1012,9 +1000,6 @@ __global__ __launch_bounds__(kLcThreads, GZPX_LC_WAVES) void k_lzcopy(DBlock *__
         // ---- the tile's matches: list entries [m0, m1), and the one before if it reaches into the tile
         uint32_t m0 = multi ? tf[t] : 0u;
         const uint32_t m1 = (multi && t + 1 < ntiles) ? tf[t + 1] : nmatch;
-#ifdef GZPX_EMU
-        if (tid == 0 && getenv("GZPX_TRACE_LZ")) fprintf(stderr, "lz b=%u isize=%u nmatch=%u t=%u m0=%u m1=%u\n", b, isize, nmatch, t, m0, m1);
-#endif
         if (t > 0 && m0 > 0) {
             const LzMatch pm = ml[m0 - 1];
             if (pm.pos + (pm.len_dist >> 16) > ts) m0--;
@@ -1142,7 +1127,6 @@ __global__ __launch_bounds__(kLcThreads, GZPX_LC_WAVES) void k_lzcopy(DBlock *__
                 {
                     const bool mine = have && is_short;
                     const uint32_t bw = mine ? f_bw : 0u, u = mine ? f_u : 0u;
-                    LC_CHK(bw + 1 < kLcBytes / 32 + 2 && u + 5 < kLcBytes / 4, "poll bw=%u u=%u pos=%u ld=%x ts=%u\n", bw, u, cm.pos, cm.len_dist, ts);
                     const uint32_t b_lo = l.bm[bw], b_hi = l.bm[bw + 1];
                     const bool go = mine && (b_lo & f_want_lo) == f_want_lo && (b_hi & f_want_hi) == f_want_hi;
                     if (go) {
@@ -1186,8 +1170,6 @@ __global__ __launch_bounds__(kLcThreads, GZPX_LC_WAVES) void k_lzcopy(DBlock *__
                             for (uint32_t i = jk + lane; i < jk1; i += 64) {
                                 const uint32_t r = i < jdist ? i : i % jdist;
                                 const uint32_t sp = jp - jdist + r;
-                                LC_CHK(sp < ts || sp + xo < kLcBytes, "slow sp=%u ts=%u jp=%u i=%u dist=%u\n", sp, ts, jp, i, jdist);
-                                LC_CHK(jp + i + xo < kLcBytes, "slowd jp=%u i=%u ts=%u\n", jp, i, ts);
                                 const uint32_t v = sp < ts ? (uint32_t)out[sp] : (uint32_t)tile8[sp + xo];
                                 tile8[jp + i + xo] = (uint8_t)v;
                             }

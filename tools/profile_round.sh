@@ -4,7 +4,7 @@
 # kernel-trace stats of the bench workloads (compress = headline, inflate, bgzf3 / mgzip3 for the hc
 # kernels, the text slab at levels 6 and 9 for the lazy parsers) and the two PMC passes (FETCH_SIZE / WRITE_SIZE, each in its own run, never combined with
 # other trace domains).  Summaries: tools/summarize_profiles.py.
-tag=${1:-r02}
+tag=${1:-r06}
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out
 cd /tmp && export TMPDIR=/tmp
@@ -13,6 +13,7 @@ rocprofv3 --kernel-trace --stats -d $O/prof_$tag -o $tag --output-format csv -- 
 rocprofv3 --kernel-trace --stats -d $O/prof_${tag}_inflate -o ${tag}_inflate --output-format csv -- $B --workload inflate > $O/prof_${tag}_inflate.log 2>&1
 rocprofv3 --kernel-trace --stats -d $O/prof_${tag}_bgzf3 -o ${tag}_bgzf3 --output-format csv -- $B --workload bgzf3 > $O/prof_${tag}_bgzf3.log 2>&1
 rocprofv3 --kernel-trace --stats -d $O/prof_${tag}_mgzip3 -o ${tag}_mgzip3 --output-format csv -- $B --workload mgzip3 --steps 2 > $O/prof_${tag}_mgzip3.log 2>&1
+GZPX_INFLATE_ROUTE=wave rocprofv3 --kernel-trace --stats -d $O/prof_${tag}_inflate_wave -o ${tag}_inflate_wave --output-format csv -- $B --workload inflate > $O/prof_${tag}_inflate_wave.log 2>&1
 for L in 6 9 ${PROFILE_L12:+12}; do
   rocprofv3 --kernel-trace --stats -d $O/prof_${tag}_bgzf$L -o ${tag}_bgzf$L --output-format csv -- $B --workload bgzf3 --level $L --steps 2 > $O/prof_${tag}_bgzf$L.log 2>&1
 done
