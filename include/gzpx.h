@@ -366,10 +366,13 @@ int gzpx_dctx_last_inflate_stage_ms(gzpx_dctx *ctx, float ms[2]);
 int gzpx_dctx_set_route(gzpx_dctx *ctx, int route);
 /* How many members of the last launch the decode / copy pair handed to k_inflate (diagnostics). */
 int gzpx_dctx_last_redo_count(gzpx_dctx *ctx, uint32_t *count);
-/* inflate: switch the instrumented kernels on/off; sums[] = per-member counters of the last launch summed over
- * its members.  GZPX_INFLATE_SEG: [0] cycles of k_inflate_seg, [1] headers + tables, [2] pass 1, [3] pass 2,
- * [4] pass 3, [5] spans + k_lzcopy rounds, [6] pass-2 iterations, [7] bytes.  GZPX_INFLATE_WAVE: [0] cycles,
- * [1] headers + tables, [2] round set-up, [3] stores + copies, [4] rounds, [5] literals, [6] matches, [7] flushes */
+/* inflate: switch the instrumented kernels on (1, or 2 on the GZPX_INFLATE_SEG route for k_lzcopy's clocks instead
+ * of k_inflate_seg's) / off (0); sums[] = per-member counters of the last instrumented launch summed over its members.
+ * enable = 1, GZPX_INFLATE_SEG: [0] cycles of k_inflate_seg, [1] headers + tables, [2] pass 1, [3] pass 2, [4] pass 3,
+ * [5] spans, [6] pass-2 iterations, [7] symbol steps of passes 1 and 3.  enable = 2: [0] cycles of k_lzcopy, [1] tile
+ * staged in, [2] chunk set-up, [3] polling, [4] CRC + tile written out, [5] polling iterations, [6] of them without
+ * progress, [7] matches.  GZPX_INFLATE_WAVE: [0] cycles, [1] headers + tables, [2] round set-up, [3] stores + copies,
+ * [4] rounds, [5] literals, [6] matches, [7] flushes */
 int gzpx_debug_inflate(gzpx_dctx *ctx, int enable, uint64_t sums[8]);
 
 const char *gzpx_strerror(int code);
