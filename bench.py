@@ -428,12 +428,60 @@ def run_inflate(args, env, emit=True, d_stream=None, comp_host=None, slab=None, 
         }
         if seg_route:
             res["roofline"]["k_lzcopy_ms"] = round(copy_ms, 3)
+        if env.world == 1 and not env.emulate:
+            try:  # what a caller of the Read API sees: host stream in, host bytes out (PCIe both ways; never `value`)
+                res["e2e"] = inflate_e2e(env, comp_host, slab)
+            except Exception as e:
+                res["e2e"] = {"error": repr(e)}
         if not args.no_cpu_baseline and env.world == 1:
             res["cpu_baseline"] = cpu_baseline_inflate(comp_host, offs, sizes, wall_s=3.0 if emit else 2.0)  # (a rate measurement, not a soak)
         if emit:
             print(json.dumps(res))
     d.close()
     return res
+
+
+def inflate_e2e(env, comp_host, slab):
+    """The ParDecompress twin (gzp::ParDecompress, src/par/decompress.rs:112-352) host to host over the bench stream: a
+    reader thread that cuts slabs of whole blocks, a device thread with three slabs in flight, the caller draining in
+    stream order -- through BufRead's fill_buf / consume (the slab's page-locked bytes, no copy) and through
+    `Read::read` into a caller's buffer (one memcpy per byte).  Best of two passes each; every pass CRC-checked by
+    the kernels, the bytes of the readinto pass compared with the input."""
+    import io
+    import zlib
+    from gzp_amd import par
+    blob = comp_host.tobytes()
+    n = slab.size
+    out = {}
+    buf = bytearray(64 << 20)
+    for mode in ("fill_buf", "readinto"):
+        best, ok = None, True
+        for rep in range(2):
+            r = par.ParDecompressBuilder(par.Bgzf, lib=env.lib).device(env.device_index).from_reader(io.BytesIO(blob))
+            t0 = time.perf_counter()
+            total, crc = 0, 0
+            check = mode == "readinto" and rep == 0  # (the first readinto pass carries the comparison, the second the rate)
+            while True:
+                if mode == "fill_buf":
+                    k = len(r.fill_buf())
+                    r.consume(k)
+                else:
+                    k = r.readinto(buf)
+                    if k and check:
+                        crc = zlib.crc32(memoryview(buf)[:k], crc)
+                if not k:
+                    break
+                total += k
+            dt = time.perf_counter() - t0
+            r.close()
+            ok = ok and total == n and (not check or crc == zlib.crc32(slab))
+            if not check:
+                best = dt if best is None else min(best, dt)
+        out["read_%s_MiBps" % mode] = round(n / 2**20 / best, 1)
+        out["read_%s_ok" % mode] = bool(ok)
+    out["what"] = ("ParDecompress twin, host stream -> host bytes, default slabs (16 MiB compressed), three in flight; "
+                   "fill_buf = the slab's page-locked bytes without a copy, readinto = one memcpy into the caller's buffer")
+    return out
 
 
 def verify(slab, out_bytes, block_sizes, tail=True):
@@ -1268,6 +1316,8 @@ def main():
                                   steps=max(2, min(args.steps, 5)))
                 res["inflate"] = {k: inf[k] for k in ("metric", "value", "unit", "ms_per_step", "roofline")}
                 res["inflate"]["verified_round_trip"] = inf["config"]["verified_round_trip"]
+                if "e2e" in inf:
+                    res["inflate"]["e2e"] = inf["e2e"]
                 if "cpu_baseline" in inf:
                     res["inflate"]["cpu_baseline"] = inf["cpu_baseline"]
             except Exception as e:

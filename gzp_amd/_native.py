@@ -55,7 +55,7 @@ EXPORTS = [
     "gzpx_gzi_write", "gzpx_dctx_create", "gzpx_dctx_destroy", "gzpx_scan_blocks",
     "gzpx_decompress_blocks", "gzpx_decompress_blocks_device", "gzpx_decompress_blocks_submit",
     "gzpx_decompress_blocks_wait", "gzpx_alloc_decompressor", "gzpx_deflate_decompress",
-    "gzpx_free_decompressor", "gzpx_pard_create", "gzpx_pard_read", "gzpx_pard_destroy",
+    "gzpx_free_decompressor", "gzpx_pard_create", "gzpx_pard_read", "gzpx_pard_fill_buf", "gzpx_pard_consume", "gzpx_pard_destroy",
     "gzpx_pard_last_error", "gzpx_host_alloc", "gzpx_host_free", "gzpx_dctx_last_inflate_ms",
     "gzpx_debug_inflate", "gzpx_dctx_last_inflate_stage_ms", "gzpx_dctx_set_route", "gzpx_dctx_last_redo_count", "gzpx_synth_fastq_device", "gzpx_synth_ascii_device",
     "gzpx_ctx_active_compat", "gzpx_build_id", "gzpx_multi_create", "gzpx_multi_destroy", "gzpx_multi_devices", "gzpx_multi_compress_slab",
@@ -261,6 +261,10 @@ class GzpxLib:
         L.gzpx_pard_create.argtypes = [i32, i32, sz, READ_FN, vp, ctypes.POINTER(vp)]
         L.gzpx_pard_read.restype = i32
         L.gzpx_pard_read.argtypes = [vp, vp, sz, psz]
+        L.gzpx_pard_fill_buf.restype = i32
+        L.gzpx_pard_fill_buf.argtypes = [vp, ctypes.POINTER(vp), psz]
+        L.gzpx_pard_consume.restype = i32
+        L.gzpx_pard_consume.argtypes = [vp, sz]
         L.gzpx_pard_destroy.restype = None
         L.gzpx_pard_destroy.argtypes = [vp]
         L.gzpx_pard_last_error.restype = ctypes.c_char_p

@@ -670,7 +670,8 @@ void ParDecompress::device_main() {
     }
 }
 
-size_t ParDecompress::read(uint8_t *buf, size_t n) {
+const uint8_t *ParDecompress::fill_buf(size_t *len) {
+    *len = 0;
     if (sticky_) std::rethrow_exception(sticky_);
     while (!cur_ || out_pos_ == cur_->out.len) {
         if (cur_) {
@@ -678,11 +679,11 @@ size_t ParDecompress::read(uint8_t *buf, size_t n) {
             free_.push_back(std::move(cur_));
             cur_ = nullptr;
         }
-        if (done_) return 0;
+        if (done_) return nullptr;
         SlabPtr s = pop(out_q_, cv_out_, true);
         if (!s || s->end) {
             done_ = true;
-            return 0;
+            return nullptr;
         }
         if (s->error) {
             sticky_ = s->error;
@@ -693,9 +694,21 @@ size_t ParDecompress::read(uint8_t *buf, size_t n) {
         cur_ = std::move(s);  // (a slab of empty blocks only -- e.g. the EOF marker -- is skipped by the loop)
         out_pos_ = 0;
     }
-    const size_t take = cur_->out.len - out_pos_ < n ? cur_->out.len - out_pos_ : n;
-    memcpy(buf, cur_->out.p + out_pos_, take);
-    out_pos_ += take;
+    *len = cur_->out.len - out_pos_;
+    return cur_->out.p + out_pos_;
+}
+
+void ParDecompress::consume(size_t n) {
+    if (cur_) out_pos_ += n < cur_->out.len - out_pos_ ? n : cur_->out.len - out_pos_;
+}
+
+size_t ParDecompress::read(uint8_t *buf, size_t n) {
+    size_t have = 0;
+    const uint8_t *p = fill_buf(&have);
+    if (!p || !have) return 0;
+    const size_t take = have < n ? have : n;
+    memcpy(buf, p, take);
+    consume(take);
     return take;
 }
 
@@ -907,6 +920,18 @@ int gzpx_pard_read(gzpx_pard *p, uint8_t *buf, size_t n, size_t *got) {
     if (!p || (!buf && n) || !got) return GZPX_ERR_INVALID_ARG;
     *got = 0;
     return guarded_d(p, [&] { *got = p->pd->read(buf, n); });
+}
+
+int gzpx_pard_fill_buf(gzpx_pard *p, const uint8_t **ptr, size_t *len) {
+    if (!p || !ptr || !len) return GZPX_ERR_INVALID_ARG;
+    *ptr = nullptr;
+    *len = 0;
+    return guarded_d(p, [&] { *ptr = p->pd->fill_buf(len); });
+}
+
+int gzpx_pard_consume(gzpx_pard *p, size_t n) {
+    if (!p) return GZPX_ERR_INVALID_ARG;
+    return guarded_d(p, [&] { p->pd->consume(n); });
 }
 
 void gzpx_pard_destroy(gzpx_pard *p) { delete p; }

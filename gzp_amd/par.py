@@ -279,26 +279,66 @@ class ParDecompress:
                                                      ctypes.byref(h)))
         self._h = h
 
+    def _fail(self, rc):
+        msg = self._lib.L.gzpx_pard_last_error(self._h).decode() or self._lib.strerror(rc)
+        err = _native.GzpxError(rc, msg)
+        if self._io_error is not None:
+            raise err from self._io_error
+        raise err
+
+    def readinto(self, b):
+        """io.RawIOBase.readinto: up to len(b) inflated bytes straight into the caller's buffer (no allocation, one copy
+        out of the slab); 0 at the end of the stream."""
+        mv = memoryview(b).cast("B")
+        if len(mv) == 0:
+            return 0
+        got = ctypes.c_size_t(0)
+        dst = (ctypes.c_uint8 * len(mv)).from_buffer(mv)
+        rc = self._lib.L.gzpx_pard_read(self._h, dst, len(mv), ctypes.byref(got))
+        if rc != _native.OK:
+            self._fail(rc)
+        return got.value
+
+    def fill_buf(self):
+        """std::io::BufRead::fill_buf: a memoryview of the inflated bytes where they lie (the current slab's page-locked
+        buffer) -- no copy; empty at the end of the stream.  Valid until the fill_buf / read after the consume() of all
+        of it."""
+        ptr, n = ctypes.c_void_p(), ctypes.c_size_t(0)
+        rc = self._lib.L.gzpx_pard_fill_buf(self._h, ctypes.byref(ptr), ctypes.byref(n))
+        if rc != _native.OK:
+            self._fail(rc)
+        if not n.value:
+            return memoryview(b"")
+        return memoryview((ctypes.c_uint8 * n.value).from_address(ptr.value)).cast("B")
+
+    def consume(self, n):
+        rc = self._lib.L.gzpx_pard_consume(self._h, n)
+        if rc != _native.OK:
+            self._fail(rc)
+
     def read(self, n=-1):
-        chunks = []
-        want = n
-        buf = np.empty(1 << 20 if n < 0 else max(n, 1), dtype=np.uint8)
-        while want != 0:
-            got = ctypes.c_size_t(0)
-            ask = buf.size if want < 0 else min(buf.size, want)
-            rc = self._lib.L.gzpx_pard_read(self._h, buf.ctypes.data, ask, ctypes.byref(got))
-            if rc != _native.OK:
-                msg = self._lib.L.gzpx_pard_last_error(self._h).decode() or self._lib.strerror(rc)
-                err = _native.GzpxError(rc, msg)
-                if self._io_error is not None:
-                    raise err from self._io_error
-                raise err
-            if got.value == 0:
+        """`Read::read` / read_to_end (n < 0).  One allocation for the result and one copy out of the slabs (until
+        round 6: a scratch array per call, a bytes object per piece and a join -- 2 GiB/s of page faults)."""
+        if n == 0:
+            return b""
+        if n > 0:
+            out = bytearray(n)
+            got, mv = 0, memoryview(out)
+            while got < n:
+                k = self.readinto(mv[got:])
+                if k == 0:
+                    break
+                got += k
+            del mv
+            return bytes(out[:got]) if got < n else bytes(out)  # (readinto / fill_buf are the ways without this copy)
+        parts = []
+        while True:
+            v = self.fill_buf()
+            if len(v) == 0:
                 break
-            chunks.append(buf[:got.value].tobytes())
-            if want > 0:
-                want -= got.value
-        return b"".join(chunks)
+            parts.append(bytes(v))
+            self.consume(len(v))
+        return b"".join(parts)
 
     def finish(self):
         return self._reader

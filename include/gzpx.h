@@ -311,6 +311,12 @@ typedef long (*gzpx_read_fn)(void *user, uint8_t *buf, size_t cap); /* bytes rea
 int gzpx_pard_create(int format, int device, size_t batch_bytes, gzpx_read_fn read_fn, void *user,
                      gzpx_pard **out);
 int gzpx_pard_read(gzpx_pard *p, uint8_t *buf, size_t n, size_t *got);
+/* std::io::BufRead's fill_buf / consume for the same stream: *ptr = the inflated bytes where they lie (the current slab's
+ * page-locked buffer, valid until the next fill_buf / read that follows a consume of all of them), *len = how many
+ * (0 at the end of the stream).  gzp's ParDecompress is `Read` only (src/par/decompress.rs:241-352); a binding that
+ * wants no copy between the slab and its own buffer implements BufRead over these two. */
+int gzpx_pard_fill_buf(gzpx_pard *p, const uint8_t **ptr, size_t *len);
+int gzpx_pard_consume(gzpx_pard *p, size_t n);
 void gzpx_pard_destroy(gzpx_pard *p);
 const char *gzpx_pard_last_error(const gzpx_pard *p);
 

@@ -356,6 +356,35 @@ def par_decompress_overlapped(lib, oracle, scale=1):
     assert out == a.tobytes()
     assert r.read(10) == b""
     r.close()
+    # round 6: the same stream through readinto (the caller's buffer) and through BufRead's fill_buf / consume (the
+    # slab's own bytes, consumed in odd pieces), mixed with read
+    r = par.ParDecompressBuilder(par.Bgzf, lib=lib).batch_bytes(3 * 30000).from_reader(Dribble(comp))
+    buf = bytearray(50001)
+    out = bytearray()
+    k = 0
+    while True:
+        k += 1
+        if k % 3 == 0:
+            n = r.readinto(buf)
+            if n == 0:
+                break
+            out += buf[:n]
+        elif k % 3 == 1:
+            v = r.fill_buf()
+            if len(v) == 0:
+                break
+            take = min(len(v), 1 + (k * 104729) % 40000)
+            out += bytes(v[:take])
+            del v
+            r.consume(take)
+        else:
+            piece = r.read(777)
+            if not piece:
+                break
+            out += piece
+    assert bytes(out) == a.tobytes()
+    assert len(r.fill_buf()) == 0 and r.readinto(buf) == 0
+    r.close()
     # a footer CRC broken in a late block: everything before that slab is delivered, then InvalidCheck
     with _native.DContext(lib=lib) as d:
         offs, sizes, _ = d.scan_blocks(comp)
