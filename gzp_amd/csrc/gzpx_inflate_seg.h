@@ -29,7 +29,7 @@ constexpr uint32_t kSegMaxBits = 8192u;
 constexpr uint32_t kSegMaxFix = 8u;      // pass-2 iterations before the member is handed to k_inflate
 constexpr uint32_t kSegWinDw = 4u;       // dwords per refill window (128 bits of every lane's stream)
 constexpr uint32_t kSegRingDw = 2u * kSegWinDw;  // the ring: two windows
-constexpr uint32_t kSegRingStride = kSegRingDw + 1u;  // dwords per lane: + a copy of slot 0 behind the last slot (odd: no bank conflicts)
+constexpr uint32_t kSegRingStride = kSegRingDw + 2u;  // dwords per lane: + copies of slots 0 and 1 behind the last slot (a step reads three consecutive dwords)
 constexpr uint32_t kSegLRoot = 10u, kSegORoot = 8u, kSegPRoot = 7u;  // root bits of the litlen / offset / precode tables
 constexpr uint32_t kSegLSub = 320u, kSegOSub = 160u;  // second-level entries (ENOUGH(288,10,15) - 1024 = 310, (32,8,15): 146)
 #ifndef GZPX_LZ_TILE_SHIFT
@@ -44,19 +44,26 @@ struct __attribute__((aligned(8))) LzMatch {
 };
 
 // Table entries (32 bit).  bits 0-3: codeword length; 0 = a pointer (bits 12-15: index bits of the second level,
-// bits 16-31: its first entry) or, all zero, an unused codeword.
-//   litlen:  bits 4-5 type (0 literal, 1 length, 2 end of block, 3 invalid symbol), bits 8-10 extra bits (0 unless a
-//            length), bits 16-24 the literal byte or the base length;
-//   offset:  bit 4 invalid symbol, bits 8-11 extra bits, bits 16-31 base distance;
+// bits 16-24: its first entry) -- an unused codeword of the root is the all-zero pointer to second-level entry 0, which
+// holds the "invalid" entry like every second-level slot no codeword fills.
+//   litlen:  bit 4 a length, bit 5 end of block, bit 6 a literal (none of the three: an invalid codeword); bits 8-10 extra
+//            bits (0 unless a length), bits 16-24 the literal byte or the base length, bits 25-29 codeword length + extra bits;
+//   offset:  bit 4 invalid, bits 8-11 extra bits, bits 16-30 base distance;
 //   precode: bits 16-20 the symbol.
+// An invalid codeword is ONE BIT LONG and produces nothing (kSegBadL / kSegBadO): a path that meets one steps over it.
+// Only speculative paths do in a valid stream, and they are better off walking on until they meet the true path than
+// stopping (pass 2 would have to replay their whole segment); on the true path pass 3 sees the missing type bits / bit 4
+// and hands the member to k_inflate.  Every pass applies the same rule, so their bit positions and counts agree.
 enum SegKind { kSegLitlen = 0, kSegOffset = 1, kSegPrecode = 2 };
+constexpr uint32_t kSegLen = 1u << 4, kSegEob = 1u << 5, kSegLit = 1u << 6;
+constexpr uint32_t kSegBadL = 1u | (1u << 25), kSegBadO = 1u | (1u << 4);
 template <int KIND>
 __device__ __forceinline__ uint32_t seg_entry(uint32_t sym, uint32_t cl) {
     if (KIND == kSegPrecode) return cl | (sym << 16);
     if (KIND == kSegLitlen) {
-        if (sym < 256) return cl | (sym << 16);
-        if (sym == 256) return cl | (2u << 4);
-        if (sym > 285) return cl | (3u << 4);
+        if (sym < 256) return cl | kSegLit | (sym << 16) | (cl << 25);
+        if (sym == 256) return cl | kSegEob | (cl << 25);
+        if (sym > 285) return kSegBadL;
         const uint32_t slot = sym - 257;
         uint32_t base, xb = 0;
         if (slot < 8) {
@@ -67,9 +74,9 @@ __device__ __forceinline__ uint32_t seg_entry(uint32_t sym, uint32_t cl) {
             xb = (slot - 4) >> 2;
             base = 3 + ((4 + (slot & 3)) << xb);
         }
-        return cl | (1u << 4) | (xb << 8) | (base << 16);
+        return cl | kSegLen | (xb << 8) | (base << 16) | ((cl + xb) << 25);
     }
-    if (sym > 29) return cl | (1u << 4);
+    if (sym > 29) return kSegBadO;
     uint32_t base, xb = 0;
     if (sym < 4) {
         base = 1 + sym;
@@ -101,7 +108,7 @@ struct InfSegLdsW {
 };
 
 // Build the two-level decode table of one code from lens[0 .. nsyms) (nsyms <= 320): `root` index bits in
-// main[], longer codewords behind pointer entries in sub[] (sub[0] stays 0: where unused codewords land).  All 64
+// main[], longer codewords behind pointer entries in sub[] (sub[0] stays "invalid": where unused codewords land).  All 64
 // lanes call it.  Returns false for an over-subscribed code or a second level that does not fit.
 template <int KIND>
 __device__ __attribute__((noinline)) bool seg_build(InfSegLds &h, uint16_t *cwtab, const uint8_t *lens, uint32_t nsyms, uint32_t root,
@@ -129,7 +136,7 @@ __device__ __attribute__((noinline)) bool seg_build(InfSegLds &h, uint16_t *cwta
     if (kraft > (1u << 15)) return false;
     for (uint32_t i = lane; i < (1u << root); i += 64) main[i] = 0;
     if (sub)
-        for (uint32_t i = lane; i < sub_cap; i += 64) sub[i] = 0;
+        for (uint32_t i = lane; i < sub_cap; i += 64) sub[i] = KIND == kSegLitlen ? kSegBadL : kSegBadO;
     if (lane == 0) h.alloc = 1;
     wave_sync();
     // codewords by rank among the symbols of the same length; short ones fill main[], long ones leave their
@@ -193,7 +200,7 @@ __device__ __attribute__((noinline)) bool seg_build(InfSegLds &h, uint16_t *cwta
 struct SegWin {
     const uint32_t *pay32;
     uint32_t last_w;  // last readable dword of the member
-    uint32_t *rl;     // the lane's 17 ring dwords
+    uint32_t *rl;     // the lane's ring dwords (kSegRingStride of them)
     uint32_t w0;      // payload dword at relative bit 0
 };
 __device__ __forceinline__ dword4 seg_load16(const SegWin &s, uint32_t w) {
@@ -215,30 +222,40 @@ __device__ __forceinline__ void seg_win_put(const SegWin &s, uint32_t k, const d
     d[1] = a.y;
     d[2] = a.z;
     d[3] = a.w;
-    if ((k & 1u) == 0) s.rl[kSegRingDw] = a.x;
+    if ((k & 1u) == 0) {
+        s.rl[kSegRingDw] = a.x;
+        s.rl[kSegRingDw + 1u] = a.y;
+    }
 }
 __device__ __forceinline__ void seg_win_load(const SegWin &s, uint32_t k, dword4 &a) { a = seg_load16(s, s.w0 + kSegWinDw * k); }
-// 32 bits from relative bit position rp (inside the two resident windows)
-__device__ __forceinline__ uint32_t seg_bits(const SegWin &s, uint32_t rp) {
+// One symbol at relative position rp, straight-line.  y.e = its litlen entry (kSegLit: y.lv the byte; kSegLen: y.lv the
+// length, y.dist the distance, y.obad != 0 an invalid offset codeword; kSegEob; none of the three: an invalid codeword),
+// y.used = its bits, y.outlen = the bytes it produces.
+//   PAIR: a literal takes the literal BEHIND it along in the same step (y.pair, y.val2 the second byte, y.u1 where it
+//   starts) when that one's codeword sits in the root table and starts in front of `r_end`, the segment's end.  The bits
+//   behind the first symbol are fetched for the offset code anyway, so the second literal costs one more table read; and a
+//   wave's step count is that of its lane with the most symbols, which is the one in a run of literals (a match is
+//   20-odd bits a step, a literal 6-9).  The rule depends on the position only, not on where a path started, so a
+//   segment's exit -- the first symbol that starts at or behind r_end -- is what single steps give.
+struct SegSym {
+    uint32_t e, lv, dist, obad, used, outlen, u1, pair, val2;
+};
+template <bool PAIR>
+__device__ __forceinline__ void seg_sym(const InfSegLds &h, const SegWin &s, uint32_t rp, uint32_t r_end, SegSym &y) {
+    // 96 bits from rp's dword on: the litlen symbol (<= 20 bits) and what follows it (<= 28) start inside the first 51
     const uint32_t *d = s.rl + ((rp >> 5) & (kSegRingDw - 1u));
-    return __builtin_amdgcn_alignbit(d[1], d[0], rp & 31u);
-}
-
-// One symbol at relative position rp, straight-line.  kind: 0 literal (val = the byte), 1 match (val = length << 16 |
-// distance), 2 end of block, 3 invalid; `used` = its bits (0 for an invalid one), `outlen` = bytes it produces.
-__device__ __forceinline__ void seg_sym(const InfSegLds &h, const SegWin &s, uint32_t rp, uint32_t &kind, uint32_t &val,
-                                        uint32_t &used, uint32_t &outlen) {
-    const uint32_t b = seg_bits(s, rp);
+    const uint32_t d0 = d[0], d1 = d[1], d2 = d[2];
+    const uint32_t b = __builtin_amdgcn_alignbit(d1, d0, rp & 31u);
     uint32_t e = h.lfast[b & ((1u << kSegLRoot) - 1u)];
     {
         const uint32_t sb = (e >> 12) & 15u;
-        const uint32_t e2 = h.lsub[(e >> 16) + ((b >> kSegLRoot) & ((1u << sb) - 1u))];  // (a plain entry: sb = 0, index <= 258)
+        const uint32_t e2 = h.lsub[((e >> 16) & 511u) + ((b >> kSegLRoot) & ((1u << sb) - 1u))];  // (a plain entry: sb = 0, index <= 258)
         e = (e & 15u) ? e : e2;
     }
-    const uint32_t cl = e & 15u, type = (e >> 4) & 3u, xb = (e >> 8) & 7u;
-    const uint32_t lv = (e >> 16) + ((b >> cl) & ((1u << xb) - 1u));  // the byte, or the length
-    const uint32_t u1 = cl + xb;  // <= 20
-    const uint32_t b2 = seg_bits(s, rp + u1);
+    const uint32_t cl = e & 15u, xb = (e >> 8) & 7u, u1 = e >> 25;  // (u1 = cl + xb, <= 20)
+    y.lv = ((e >> 16) & 511u) + ((b >> cl) & ((1u << xb) - 1u));
+    const uint32_t sh = (rp & 31u) + u1;  // (<= 51; alignbit takes the low five bits)
+    const uint32_t b2 = __builtin_amdgcn_alignbit(sh >= 32u ? d2 : d1, sh >= 32u ? d1 : d0, sh);
     uint32_t oe = h.ofast[b2 & ((1u << kSegORoot) - 1u)];
     {
         const uint32_t sb = (oe >> 12) & 15u;
@@ -247,16 +264,24 @@ __device__ __forceinline__ void seg_sym(const InfSegLds &h, const SegWin &s, uin
         oe = (oe & 15u) ? oe : oe2;
     }
     const uint32_t dcl = oe & 15u, dxb = (oe >> 8) & 15u;
-    const uint32_t dist = (oe >> 16) + ((b2 >> dcl) & ((1u << dxb) - 1u));
-    // (flags as integers and selects only: with && / || the compiler builds exec-mask branches around these few lines)
-    const uint32_t is_len = type == 1u ? 1u : 0u;
-    const uint32_t lbad = (cl == 0 ? 1u : 0u) | (type == 3u ? 1u : 0u);
-    const uint32_t obad = (dcl == 0 ? 1u : 0u) | ((oe >> 4) & 1u);
-    const uint32_t bad = lbad | (is_len & obad);
-    kind = bad ? 3u : type;
-    used = bad ? 0u : u1 + (is_len ? dcl + dxb : 0u);  // (u1 = cl for a literal or the end-of-block code: no extra bits)
-    val = is_len ? (lv << 16) | dist : lv;
-    outlen = (bad | (type == 2u ? 1u : 0u)) ? 0u : is_len ? lv : 1u;
+    y.dist = (oe >> 16) + ((b2 >> dcl) & ((1u << dxb) - 1u));
+    const uint32_t is_len = (e >> 4) & 1u;
+    y.e = e;
+    y.obad = oe & (is_len << 4);
+    y.u1 = u1;
+    y.used = u1 + (is_len ? dcl + dxb : 0u);
+    y.outlen = is_len ? y.lv : (e >> 6) & 1u;
+    y.pair = 0;
+    y.val2 = 0;
+    if (PAIR) {
+        const uint32_t en = h.lfast[b2 & ((1u << kSegLRoot) - 1u)];  // the symbol behind this one, if this one is a literal
+        // (bit 6 in both: this one is a literal, and the entry behind it is a literal's own -- a pointer has no type bits)
+        const uint32_t pair = ((e & en) >> 6) & (rp + u1 < r_end ? 1u : 0u);
+        y.used += pair ? (en & 15u) : 0u;
+        y.outlen += pair;
+        y.pair = pair;
+        y.val2 = (en >> 16) & 511u;
+    }
 }
 
 __device__ __forceinline__ void seg_redo(DBlock *blk, uint32_t *redo, uint32_t b, uint32_t lane) {
@@ -270,6 +295,10 @@ __device__ __forceinline__ void seg_redo(DBlock *blk, uint32_t *redo, uint32_t b
 #ifndef GZPX_SEG_WAVES
 #define GZPX_SEG_WAVES 4
 #endif
+#ifndef GZPX_SEG_SMALLW
+#define GZPX_SEG_SMALLW 1
+#endif
+constexpr int kSegSmallW = GZPX_SEG_SMALLW;    // waves per member for BGZF-sized members
 constexpr int kSegBigW = 8;                    // waves per member in the launch form for large members (Mgzip)
 constexpr uint32_t kSegBigBytes = 131072u;     // compressed bytes per member (average of the slab) from which it is used
 
@@ -551,13 +580,14 @@ __device__ __attribute__((noinline)) void seg_member(const uint32_t b, const uin
                     const uint32_t wend = 32u * kSegWinDw * (k + 1);
                     const uint32_t lim = r_end < wend ? r_end : wend;
                     while (__ballot(fl1 == 0 && rp < lim)) {
-                        uint32_t kind, val, used, outlen;
-                        seg_sym(h, win, rp, kind, val, used, outlen);
-                        const bool go = fl1 == 0 && rp < lim;
-                        rp += go ? used : 0u;
-                        n1 += go ? outlen : 0u;
-                        m1 += (go && kind == 1u) ? 1u : 0u;
-                        fl1 = (go && kind >= 2u) ? kind - 1u : fl1;
+                        if (fl1 == 0 && rp < lim) {  // (one exec mask around the step instead of a select per result)
+                            SegSym y;
+                            seg_sym<true>(h, win, rp, r_end, y);
+                            rp += y.used;
+                            n1 += y.outlen;
+                            m1 += (y.e >> 4) & 1u;
+                            fl1 = (y.e >> 5) & 1u;  // the end-of-block code stops the path
+                        }
                         if (DBG) dbg[7]++;
                     }
                     if (k + 2 < nwin + 1) {
@@ -615,23 +645,30 @@ __device__ __attribute__((noinline)) void seg_member(const uint32_t b, const uin
                             done = true;
                         }
                         const bool step_a = b_fin || a < bq;
-                        const uint32_t p = step_a ? a : bq;
+                        const uint32_t p = step_a ? a : bq, other = step_a ? bq : a;
                         const bool go = !done && p < wend;
                         if (__ballot(go) == 0) break;
-                        uint32_t kind, val, used, outlen;
-                        seg_sym(h, win, go ? p : r_start, kind, val, used, outlen);
-                        const uint32_t f = kind >= 2u ? kind - 1u : 0u;
-                        if (go && step_a) {
-                            a += used;
-                            na += outlen;
-                            ma += kind == 1u ? 1u : 0u;
-                            fa = f;
-                        }
-                        if (go && !step_a) {
-                            bq += used;
-                            nb2 += outlen;
-                            mb += kind == 1u ? 1u : 0u;
-                            fb = f;
+                        if (go) {
+                            SegSym y;
+                            seg_sym<true>(h, win, p, r_end, y);
+                            // a pair whose second literal starts where the other path stands: the paths have met there,
+                            // this one takes the first literal only and lands on it (they could leap over each other for
+                            // ever otherwise; a meeting point in the middle of the OTHER path's last step shows one step
+                            // later, as the end of that path's next step or the middle of this one's)
+                            const bool half = y.pair && p + y.u1 == other;
+                            const uint32_t used = half ? y.u1 : y.used, outlen = half ? 1u : y.outlen;
+                            const uint32_t isl = (y.e >> 4) & 1u, f = (y.e >> 5) & 1u;
+                            if (step_a) {
+                                a += used;
+                                na += outlen;
+                                ma += isl;
+                                fa = f;
+                            } else {
+                                bq += used;
+                                nb2 += outlen;
+                                mb += isl;
+                                fb = f;
+                            }
                         }
                     }
                     if (__ballot(!done) == 0) break;
@@ -742,24 +779,27 @@ __device__ __attribute__((noinline)) void seg_member(const uint32_t b, const uin
                     const uint32_t wend = 32u * kSegWinDw * (k + 1);
                     const uint32_t lim = r_end < wend ? r_end : wend;
                     while (__ballot(f3 == 0 && rp < lim)) {
-                        uint32_t kind, val, used, outlen;
-                        seg_sym(h, win, rp, kind, val, used, outlen);
-                        const bool go = f3 == 0 && rp < lim;
-                        if (go && kind == 0u) out[pos] = (uint8_t)val;
-                        if (go && kind == 1u) {
-                            if ((val & 0xFFFFu) > pos) bad_dist = true;
-                            LzMatch rec;
-                            rec.pos = pos;
-                            rec.len_dist = val;
-                            ml[mi] = rec;
-                            mi++;
-                        }
-                        if (go) {
-                            const uint32_t np = pos + outlen;
+                        if (f3 == 0 && rp < lim) {
+                            SegSym y;
+                            seg_sym<true>(h, win, rp, r_end, y);
+                            if (y.e & kSegLit) {
+                                out[pos] = (uint8_t)y.lv;
+                                if (y.pair) out[pos + 1] = (uint8_t)y.val2;
+                            } else if (y.e & kSegLen) {
+                                if (y.dist > pos || y.obad) bad_dist = true;
+                                LzMatch rec;
+                                rec.pos = pos;
+                                rec.len_dist = (y.lv << 16) | y.dist;
+                                ml[mi] = rec;
+                                mi++;
+                            } else if (!(y.e & kSegEob)) {
+                                bad_dist = true;  // an invalid codeword on the true path
+                            }
+                            const uint32_t np = pos + y.outlen;
                             if (multi && ((pos ^ np) >> kLzTileShift)) tf[np >> kLzTileShift] = mi;  // the next record is the tile's first
                             pos = np;
-                            rp += used;
-                            f3 = kind >= 2u ? kind - 1u : 0u;
+                            rp += y.used;
+                            f3 = (y.e >> 5) & 1u;
                         }
                         if (DBG) dbg[7]++;
                     }

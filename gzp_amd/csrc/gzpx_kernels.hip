@@ -5805,7 +5805,7 @@ void launch_inflate(uint32_t hdr_len, const uint8_t *d_in, const uint64_t *d_off
         // decode (literals + match records), LZ copy, then k_inflate over whatever the two left on the redo list
         LzMatch *ml = (LzMatch *)sc.mlist;
         const bool big = sc.big_members != 0;  // Mgzip-sized members: kSegBigW waves each
-        const uint32_t seg_wgs = (uint32_t)(sc.n_cu > 0 ? sc.n_cu : 256) * 4u * GZPX_SEG_WAVES / (big ? (uint32_t)kSegBigW : 1u);  // resident workgroups
+        const uint32_t seg_wgs = (uint32_t)(sc.n_cu > 0 ? sc.n_cu : 256) * 4u * GZPX_SEG_WAVES / (big ? (uint32_t)kSegBigW : (uint32_t)kSegSmallW);  // resident workgroups
         const uint32_t seg_grid = nb < seg_wgs ? nb : seg_wgs;
 #define GZPX_LAUNCH_SEG(DBG_)                                                                                              \
     do {                                                                                                                   \
@@ -5813,7 +5813,7 @@ void launch_inflate(uint32_t hdr_len, const uint8_t *d_in, const uint64_t *d_off
             hipLaunchKernelGGL((k_inflate_seg<DBG_, kSegBigW>), dim3(seg_grid), dim3(64 * kSegBigW), 0, stream, hdr_len,   \
                                d_in, blk, (const uint64_t *)d_out_off, d_out, out_cap, ml, sc.tfirst, sc.redo, nb);        \
         else                                                                                                               \
-            hipLaunchKernelGGL((k_inflate_seg<DBG_, 1>), dim3(seg_grid), dim3(64), 0, stream, hdr_len, d_in, blk,          \
+            hipLaunchKernelGGL((k_inflate_seg<DBG_, kSegSmallW>), dim3(seg_grid), dim3(64 * kSegSmallW), 0, stream, hdr_len, d_in, blk, \
                                (const uint64_t *)d_out_off, d_out, out_cap, ml, sc.tfirst, sc.redo, nb);                   \
         if (ev_mid) (void)hipEventRecord(ev_mid, stream);                                                                  \
     } while (0)
