@@ -565,7 +565,15 @@ __device__ __attribute__((noinline)) void seg_member(const uint32_t b, const uin
             const bool has_data = my_start < bit_end;
             // ---- pass 1: from the speculative start (lane 0: the true one) to the segment's end
             const long long t_p1 = DBG ? clock64() : 0;
-            uint32_t rp = r_start, n1 = 0, m1 = 0, fl1 = has_data ? 0u : 2u;  // fl: 0 runs / ran through, 1 end of block, 2 invalid / no data
+            uint32_t rp = r_start, n1 = 0, m1 = 0;
+            const uint32_t fl1 = has_data ? 0u : 2u;  // fl: 0 runs / ran through, 1 end of block, 2 no data
+            // A speculative path does not stop at an end-of-block code either: in front of the point where it meets the true
+            // path the code is as likely garbage as not (15 bits that happen to match, once or twice per span of ASCII
+            // noise), and a path that stopped there left pass 2 its whole segment to replay alone, with the wave -- the
+            // workgroup, for W > 1 -- waiting.  It notes its FIRST one (exit | matches in front << 16, bytes in front) and
+            // the exit of its LAST one and walks on; which one counts, if any, is decided where the true path joins it
+            // (pass 2).  (Selects, not a branch: the rare branch cost the loop thirty register copies per step.)
+            uint32_t e1p = 0, e1n = 0, eLx = 0;
             {
                 dword4 a0, a1;
                 seg_win_load(win, 0, a0);
@@ -584,9 +592,12 @@ __device__ __attribute__((noinline)) void seg_member(const uint32_t b, const uin
                             SegSym y;
                             seg_sym<true>(h, win, rp, r_end, y);
                             rp += y.used;
+                            const bool is_eob = (y.e & kSegEob) != 0, first = is_eob && e1p == 0;
+                            e1p = first ? rp | (m1 << 16) : e1p;  // (rp < 2^14, m1 < 2^16)
+                            e1n = first ? n1 : e1n;
+                            eLx = is_eob ? rp : eLx;
                             n1 += y.outlen;
                             m1 += (y.e >> 4) & 1u;
-                            fl1 = (y.e >> 5) & 1u;  // the end-of-block code stops the path
                         }
                         if (DBG) dbg[7]++;
                     }
@@ -602,7 +613,9 @@ __device__ __attribute__((noinline)) void seg_member(const uint32_t b, const uin
             // ---- pass 2: the true entries.  Lane i enters where lane i - 1 leaves; it replays from there beside
             // its speculative path until the two meet (then the rest of pass 1 holds) or its segment ends.
             const long long t_p2 = DBG ? clock64() : 0;
-            uint32_t entry = my_start, ex = exit1, nn = n1, mm = m1, fl = fl1;
+            // (until pass 2 says otherwise a path's first end-of-block code counts: it does on the true path, lane 0's)
+            const uint32_t e1x = e1p & 0xFFFFu, e1m = e1p >> 16;
+            uint32_t entry = my_start, ex = e1p ? rel0 + e1x : exit1, nn = e1p ? e1n : n1, mm = e1p ? e1m : m1, fl = e1p ? 1u : fl1;
             uint32_t iters = 0;
             for (;;) {
                 // (every lane with data follows its predecessor's exit, also behind a lane that stopped: a speculative path
@@ -641,8 +654,16 @@ __device__ __attribute__((noinline)) void seg_member(const uint32_t b, const uin
                         const bool b_fin = fb != 0 || bq >= r_end;
                         if (!done && a_fin) done = true;
                         if (!done && !b_fin && a == bq) {
-                            synced = true;
-                            done = true;
+                            // the paths have met, and from here on the speculative one IS the true one: its first
+                            // end-of-block code ends the block if it lies behind this point; if its last one lies in
+                            // front, there is none and pass 1's exit holds.  (In between -- a garbage code in front and
+                            // another one behind, of which pass 1 kept no counts -- the replay goes on alone.)
+                            if ((e1p != 0 && e1x > a) || eLx <= a) {
+                                synced = true;
+                                done = true;
+                            } else {
+                                fb = 2u;
+                            }
                         }
                         const bool step_a = b_fin || a < bq;
                         const uint32_t p = step_a ? a : bq, other = step_a ? bq : a;
@@ -662,12 +683,11 @@ __device__ __attribute__((noinline)) void seg_member(const uint32_t b, const uin
                                 a += used;
                                 na += outlen;
                                 ma += isl;
-                                fa = f;
+                                fa = f;  // (this one stops at an end-of-block code: from a true entry it is the block's)
                             } else {
                                 bq += used;
                                 nb2 += outlen;
                                 mb += isl;
-                                fb = f;
                             }
                         }
                     }
@@ -680,10 +700,17 @@ __device__ __attribute__((noinline)) void seg_member(const uint32_t b, const uin
                 }
                 if (need) {
                     if (synced) {
-                        ex = exit1;
-                        nn = n1 - nb2 + na;
-                        mm = m1 - mb + ma;
-                        fl = fl1;
+                        if (e1p != 0 && e1x > a) {
+                            ex = rel0 + e1x;
+                            nn = e1n - nb2 + na;
+                            mm = e1m - mb + ma;
+                            fl = 1u;
+                        } else {
+                            ex = exit1;
+                            nn = n1 - nb2 + na;
+                            mm = m1 - mb + ma;
+                            fl = fl1;
+                        }
                     } else {
                         ex = rel0 + a;
                         nn = na;
