@@ -376,27 +376,22 @@ __device__ __attribute__((noinline)) void seg_header(InfSegLds &h, uint16_t *cwt
             const uint32_t total = nlit + ndist;
             uint32_t prev = 0;
             uint8_t *tmp = (uint8_t *)h.lfast;  // 320 bytes of scratch in front of the staged header
-            while (i < total) {
-                if (bp - 32u * hbase > 96u * 32u - 64u) {  // (a header never needs this much: garbage)
+            // The code lengths are a serial chain of precode symbols, but WHAT a symbol is depends only on where it
+            // starts: every lane decodes the one that would start at bit bp + lane (two LDS round trips for all 64),
+            // and the chain through them is scalar work on lane values -- a dozen symbols per round instead of one
+            // symbol per pair of round trips (a fifth of a BGZF member's decode time went into these headers).
+            while (i < total && !bad) {
+                if (bp + 64u - 32u * hbase > 96u * 32u - 64u) {  // (a header never needs this much: garbage)
                     bad = true;
                     break;
                 }
-                const uint32_t bb = uniform(hbits(bp));
-                const uint32_t e = uniform(h.ofast[bb & 127u]);
+                const uint32_t bb = hbits(bp + lane);
+                const uint32_t e = h.ofast[bb & 127u];
                 const uint32_t cl = e & 15u, sym = e >> 16;
-                if (cl == 0) {
-                    bad = true;
-                    break;
-                }
                 uint32_t rep = 1, val = sym, used = cl;
                 if (sym == 16) {
-                    if (i == 0) {
-                        bad = true;
-                        break;
-                    }
                     rep = 3 + ((bb >> cl) & 3u);
                     used += 2;
-                    val = prev;
                 } else if (sym == 17) {
                     rep = 3 + ((bb >> cl) & 7u);
                     used += 3;
@@ -406,16 +401,36 @@ __device__ __attribute__((noinline)) void seg_header(InfSegLds &h, uint16_t *cwt
                     used += 7;
                     val = 0;
                 }
-                bp += used;
-                if (i + rep > total) {
-                    bad = true;
-                    break;
+                // used (<= 14) | rep (<= 138) << 8 | val (<= 16: 16 = the length before) << 16; 0 = an unused codeword
+                const uint32_t pack = cl ? used | (rep << 8) | (val << 16) : 0u;
+                uint32_t cur = 0;
+                while (cur < 64u && i < total) {
+                    const uint32_t pk = rdlane(pack, cur);
+                    if (pk == 0) {
+                        bad = true;
+                        break;
+                    }
+                    const uint32_t r = (pk >> 8) & 255u;
+                    uint32_t v = pk >> 16;
+                    if (v == 16) {
+                        if (i == 0) {
+                            bad = true;
+                            break;
+                        }
+                        v = prev;
+                    }
+                    if (i + r > total) {
+                        bad = true;
+                        break;
+                    }
+                    if (lane < r) tmp[i + lane] = (uint8_t)v;
+                    if (lane + 64 < r) tmp[i + lane + 64] = (uint8_t)v;
+                    if (lane + 128 < r) tmp[i + lane + 128] = (uint8_t)v;
+                    prev = v;
+                    i += r;
+                    cur += pk & 255u;
                 }
-                if (lane < rep) tmp[i + lane] = (uint8_t)val;
-                if (lane + 64 < rep) tmp[i + lane + 64] = (uint8_t)val;
-                if (lane + 128 < rep) tmp[i + lane + 128] = (uint8_t)val;
-                prev = val;
-                i += rep;
+                bp += cur;
             }
             if (bad) break;
             wave_sync();
