@@ -428,7 +428,7 @@ def run_inflate(args, env, emit=True, d_stream=None, comp_host=None, slab=None, 
         }
         if seg_route:
             res["roofline"]["k_lzcopy_ms"] = round(copy_ms, 3)
-        if env.world == 1 and not env.emulate:
+        if env.world == 1 and not env.emulate and not args.no_extras:  # (--no-extras: the profiling runs want the step's launches only)
             try:  # what a caller of the Read API sees: host stream in, host bytes out (PCIe both ways; never `value`)
                 res["e2e"] = inflate_e2e(env, comp_host, slab)
             except Exception as e:

@@ -58,6 +58,42 @@ def test_reference_test_inputs_roundtrip(dctx, emu_lib, golden):
         assert dctx.decompress(comp) == data
 
 
+def flushed_member(chunk, level, every, strategy=zlib.Z_DEFAULT_STRATEGY):
+    """A BGZF member whose DEFLATE stream is flushed every `every` bytes: hundreds of blocks, an end-of-block code each."""
+    co = zlib.compressobj(level, zlib.DEFLATED, -15, 9, strategy)
+    parts = []
+    for i in range(0, len(chunk), every):
+        parts.append(co.compress(chunk[i:i + every]))
+        parts.append(co.flush(zlib.Z_FULL_FLUSH if (i // every) % 3 == 0 else zlib.Z_SYNC_FLUSH))
+    parts.append(co.flush())
+    payload = b"".join(parts)
+    hdr = struct.pack("<BBBBIBBHBBHH", 31, 139, 8, 4, 0, 0, 255, 6, ord("B"), ord("C"), 2, len(payload) + 25)
+    return hdr + payload + struct.pack("<II", zlib.crc32(chunk), len(chunk))
+
+
+def test_speculative_paths_walk_on_behind_garbage_codes(emu_lib, oracle):
+    """k_inflate_seg's speculative paths step over invalid codewords and walk on behind end-of-block codes (round 6): the
+    streams where they meet such garbage most -- printable noise, whose codes are all 6-7 bits long, so that a path stays
+    out of step for long and the 15-bit end-of-block code turns up by chance; Huffman-only members; members of hundreds of
+    tiny blocks -- come out right, and the noise (libdeflate's streams of it) without a member handed back to k_inflate."""
+    noise = synth.make("ascii", (1 << 20) + 200000, 5)
+    with _native.DContext(lib=emu_lib) as d:
+        comp = oracle.compress_stream(noise, oracle.FMT_BGZF, 3, oracle.COMPAT_1_24, 65280)
+        assert d.decompress(comp) == noise.tobytes() and d.last_redo_count() == 0
+    with _native.DContext(format=_native.FORMAT_MGZIP, lib=emu_lib) as d:
+        comp = oracle.compress_stream(noise, oracle.FMT_MGZIP, 3, oracle.COMPAT_1_24, 1 << 20)
+        assert d.decompress(comp) == noise.tobytes() and d.last_redo_count() == 0
+    with _native.DContext(lib=emu_lib) as d:
+        for cls, seed in (("ascii", 1), ("text", 2)):
+            a = synth.make(cls, 120000, seed).tobytes()
+            for strategy in (zlib.Z_HUFFMAN_ONLY, zlib.Z_FIXED, zlib.Z_DEFAULT_STRATEGY):
+                s = b"".join(bgzf_member(a[i:i + 60000], 6, strategy) for i in range(0, len(a), 60000))
+                assert d.decompress(s) == a, (cls, strategy)
+            for every in (37, 4000):
+                s = b"".join(flushed_member(a[i:i + 40000], 6, every) for i in range(0, 80000, 40000))
+                assert d.decompress(s) == a[:80000], (cls, every)
+
+
 def test_mgzip_large_blocks(emu_lib, oracle):
     a = synth.make("text", (1 << 20) + 999, 3)
     comp = oracle.compress_stream(a, oracle.FMT_MGZIP, 3, oracle.COMPAT_1_24, 1 << 20)

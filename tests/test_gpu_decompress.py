@@ -62,6 +62,44 @@ def test_decode_copy_pair_takes_ordinary_members_itself(hip_lib):
         assert (e2.value.code, e2.value.block) == (e.value.code, e.value.block)
 
 
+def flushed_member(chunk, level, every, strategy=zlib.Z_DEFAULT_STRATEGY):
+    """A BGZF member whose DEFLATE stream is flushed every `every` bytes: hundreds of blocks, an end-of-block code each."""
+    co = zlib.compressobj(level, zlib.DEFLATED, -15, 9, strategy)
+    parts = []
+    for i in range(0, len(chunk), every):
+        parts.append(co.compress(chunk[i:i + every]))
+        parts.append(co.flush(zlib.Z_FULL_FLUSH if (i // every) % 3 == 0 else zlib.Z_SYNC_FLUSH))
+    parts.append(co.flush())
+    payload = b"".join(parts)
+    hdr = struct.pack("<BBBBIBBHBBHH", 31, 139, 8, 4, 0, 0, 255, 6, ord("B"), ord("C"), 2, len(payload) + 25)
+    return hdr + payload + struct.pack("<II", zlib.crc32(chunk), len(chunk))
+
+
+def test_speculative_paths_walk_on_behind_garbage_codes(hip_lib):
+    """k_inflate_seg's speculative paths step over invalid codewords and walk on behind end-of-block codes (round 6): the
+    streams where they meet such garbage most -- printable noise, whose codes are all 6-7 bits long, so that a path stays
+    out of step for long and the 15-bit end-of-block code turns up by chance; Huffman-only members; members of hundreds of
+    tiny blocks -- come out right, and the noise of our own compressor without a member handed back to k_inflate."""
+    noise = synth.make("ascii", 24 << 20, 5)
+    with _native.DContext(lib=hip_lib) as d:
+        with _native.Context(level=3, lib=hip_lib) as c:
+            comp = c.compress_slab(noise, True)
+        assert d.decompress(comp) == noise.tobytes() and d.last_redo_count() == 0
+    with _native.DContext(format=_native.FORMAT_MGZIP, lib=hip_lib) as d:
+        with _native.Context(format=_native.FORMAT_MGZIP, level=3, buffer_size=1 << 20, lib=hip_lib) as c:
+            comp = c.compress_slab(noise, True)
+        assert d.decompress(comp) == noise.tobytes() and d.last_redo_count() == 0
+    with _native.DContext(lib=hip_lib) as d:
+        for cls, seed in (("ascii", 1), ("text", 2), ("random", 3), ("dna", 4)):
+            a = synth.make(cls, 480000, seed).tobytes()
+            for strategy in (zlib.Z_HUFFMAN_ONLY, zlib.Z_FIXED, zlib.Z_DEFAULT_STRATEGY):
+                s = b"".join(bgzf_member(a[i:i + 60000], 6, strategy) for i in range(0, len(a), 60000))
+                assert d.decompress(s) == a, (cls, strategy)
+            for every in (37, 300, 4000):
+                s = b"".join(flushed_member(a[i:i + 40000], 6, every) for i in range(0, 240000, 40000))
+                assert d.decompress(s) == a[:240000], (cls, every)
+
+
 def test_config5_shape_256mib(dctx, hip_lib):
     # configs[5]: inflate the output of configs[2] (256 MiB here), verify per-block CRC on device
     a = synth.text_slab(256 << 20, seed=5)
