@@ -358,8 +358,13 @@ int enqueue_batch(gzpx_ctx *ctx, const uint8_t *d_in, size_t in_len, uint32_t nb
         HIP_TRY(hipEventRecord(ctx->ev_crc, ctx->s_side));
         return GZPX_OK;
     };
-    // (Config.debug bits 8-9, experiments: 1 = fork behind all match / parse kernels, 2 = behind the first of them)
-    const uint32_t fork_sel = (c.debug >> 8) & 3u, fork_at = fork_sel == 0 ? 1u : fork_sel == 1 ? 0u : 2u;
+    // Levels 2-12 fork BEHIND their match / parse kernels, beside k_hist / k_huffman (round 6, tools/gpu_r6_fork_ab.sh: the
+    // one-workgroup-per-CU matchers lose more to the CRC's waves than the small kernels do -- configs[2] 61.2-62.0 ->
+    // 60.7 ms, text at levels 2-9 0.04 ms each).
+    // (Config.debug bits 8-9, experiments: 1 = fork behind all match / parse kernels, 2 = behind the first of them,
+    // 3 = beside them whatever the level)
+    const uint32_t fork_sel = (c.debug >> 8) & 3u;
+    const uint32_t fork_at = fork_sel == 0 ? (c.level <= 1 ? 1u : 0u) : fork_sel == 1 ? 0u : fork_sel == 2 ? 2u : 1u;
     // (the slab is cut into blocks -- BlockMeta -- by the first k_candidates launch; level 0: k_init_meta)
     int t = pp.begin(c.level == 0 ? 0 : 1, stream);
     launch_candidates(c, d_in, in_len, nb, is_last, s, stream);
