@@ -100,6 +100,17 @@ def test_speculative_paths_walk_on_behind_garbage_codes(hip_lib):
                 assert d.decompress(s) == a[:240000], (cls, every)
 
 
+def test_bgzip_like_streams_stay_on_the_pair(hip_lib):
+    """What bgzip / htslib write -- zlib's default strategy, 65,280-byte members -- is inflated by the decode / copy pair
+    alone: no member handed back to k_inflate (the exotic strategies of the fuzzer are where hand-backs come from)."""
+    with _native.DContext(lib=hip_lib) as d:
+        for cls in ("text", "fastq", "dna", "ascii", "mixed"):
+            a = synth.make(cls, 4 << 20, 9).tobytes()
+            for level in (1, 6, 9):
+                s = b"".join(bgzf_member(a[i:i + 65280], level) for i in range(0, len(a), 65280))
+                assert d.decompress(s) == a and d.last_redo_count() == 0, (cls, level)
+
+
 def test_config5_shape_256mib(dctx, hip_lib):
     # configs[5]: inflate the output of configs[2] (256 MiB here), verify per-block CRC on device
     a = synth.text_slab(256 << 20, seed=5)
