@@ -564,13 +564,16 @@ __device__ __attribute__((noinline)) void seg_member(const uint32_t b, const uin
         // work.  So a block's spans are HALF as long as the block before it (two spans for a block like the last one,
         // at most a quarter of the second wasted), a block that outlives its span goes on with spans of the same length,
         // and a member's first block starts with the whole member (one wave per member: BGZF members hold one to three
-        // blocks, and half / a quarter measured 4 % slower / the same) or a sixteenth of it (Mgzip).  Measured, 512 MiB
+        // blocks, and a half measured 4 % slower, also with short spans for what outlives it) or a sixteenth of it (Mgzip).  Measured, 512 MiB
         // in 1 MiB members, decode ms: text level 1 8.05 -> 3.22, level 3 2.98 -> 1.92, FASTQ 10.9 -> 4.39, printable
         // noise 4.55 -> 3.80 (tools/gpu_r6_ab_mgzip_inflate.py; a whole / 5/4 / 3/4 / a quarter of the block before and
         // a half ... a thirty-second of the member all within 8 % of this).
         bool eob = false;
         const uint32_t blk_bp0 = bp;
         uint32_t span_bits = prev_blk_bits ? prev_blk_bits / 2u : (bit_end - bp) / (W > 1 ? 16u : 1u);
+        // (a FINAL block ends where the member ends: what is left IS its length -- without this the rule above cost BGZF
+        // members of DNA / FASTQ, whose last block is not half of the one before it, 8 %)
+        if (final_block) span_bits = bit_end - bp;
         while (!eob && !bad) {
             bp = uniform(bp);
             o = uniform(o);
