@@ -1465,6 +1465,7 @@ int dslot_reserve(DSlot &c, size_t nb) {
         HIP_TRY(hipHostMalloc((void **)&c.h_total, 64, hipHostMallocDefault));
         HIP_TRY(hipHostMalloc((void **)&c.h_summary, 64, hipHostMallocDefault));
         HIP_TRY(hipMalloc((void **)&c.sc.summary, 64));
+        HIP_TRY(hipMemset(c.sc.summary, 0, 64));  // (word 15: k_inflate_seg's first-block hint, kept from launch to launch)
     }
     if (nb <= c.cap_blocks) return GZPX_OK;
     dslot_free_tables(c);

@@ -172,7 +172,7 @@ struct InflateScratch {
     void *mlist = nullptr;       // inflate_mlist_bytes(out_cap, nb)
     uint32_t *tfirst = nullptr;  // inflate_tfirst_bytes(out_cap, nb)
     uint32_t *redo = nullptr;    // [1 + nb] the list, [1 + nb] behind it k_inflate_seg's ticket counter
-    uint32_t *summary = nullptr; // [12] k_dsummary: the first failing member and its checksums (both routes)
+    uint32_t *summary = nullptr; // [12] k_dsummary: the first failing member and its checksums (both routes); [15] k_inflate_seg's first-block hint
     int n_cu = 0;                // compute units of the device (the size of the persistent launch)
     int big_members = 0;         // the slab's members average >= 128 KiB compressed: several waves work on each
 };

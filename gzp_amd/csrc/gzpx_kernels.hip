@@ -5807,14 +5807,15 @@ void launch_inflate(uint32_t hdr_len, const uint8_t *d_in, const uint64_t *d_off
         const bool big = sc.big_members != 0;  // Mgzip-sized members: kSegBigW waves each
         const uint32_t seg_wgs = (uint32_t)(sc.n_cu > 0 ? sc.n_cu : 256) * 4u * GZPX_SEG_WAVES / (big ? (uint32_t)kSegBigW : (uint32_t)kSegSmallW);  // resident workgroups
         const uint32_t seg_grid = nb < seg_wgs ? nb : seg_wgs;
+        uint32_t *seg_hint = sc.summary ? sc.summary + 15 : nullptr;  // (where a member's first block ended, per mille: the next members' guess)
 #define GZPX_LAUNCH_SEG(DBG_)                                                                                              \
     do {                                                                                                                   \
         if (big)                                                                                                           \
             hipLaunchKernelGGL((k_inflate_seg<DBG_, kSegBigW>), dim3(seg_grid), dim3(64 * kSegBigW), 0, stream, hdr_len,   \
-                               d_in, blk, (const uint64_t *)d_out_off, d_out, out_cap, ml, sc.tfirst, sc.redo, nb);        \
+                               d_in, blk, (const uint64_t *)d_out_off, d_out, out_cap, ml, sc.tfirst, sc.redo, nb, seg_hint); \
         else                                                                                                               \
             hipLaunchKernelGGL((k_inflate_seg<DBG_, kSegSmallW>), dim3(seg_grid), dim3(64 * kSegSmallW), 0, stream, hdr_len, d_in, blk, \
-                               (const uint64_t *)d_out_off, d_out, out_cap, ml, sc.tfirst, sc.redo, nb);                   \
+                               (const uint64_t *)d_out_off, d_out, out_cap, ml, sc.tfirst, sc.redo, nb, seg_hint);         \
         if (ev_mid) (void)hipEventRecord(ev_mid, stream);                                                                  \
     } while (0)
         if (debug == 1) {
