@@ -94,6 +94,20 @@ def test_speculative_paths_walk_on_behind_garbage_codes(emu_lib, oracle):
                 assert d.decompress(s) == a[:80000], (cls, every)
 
 
+def test_first_block_hint_may_be_stale(emu_lib, oracle):
+    """k_inflate_seg guesses where a BGZF member's first block ends from the members it decoded before (a word of the
+    context): streams of different kinds through ONE context, back and forth -- the hint of one is the wrong guess for
+    the next -- come out right, with no member handed back."""
+    streams = []
+    for cls, seed in (("dna", 1), ("text", 2), ("fastq", 3), ("zeros", 5)):
+        a = synth.make(cls, 3 * 65280 + 123, seed)
+        streams.append((a.tobytes(), oracle.compress_stream(a, oracle.FMT_BGZF, 1, oracle.COMPAT_1_24, 65280)))
+    with _native.DContext(lib=emu_lib) as d:
+        for _ in range(2):
+            for raw, comp in streams:
+                assert d.decompress(comp) == raw and d.last_redo_count() == 0
+
+
 def test_mgzip_large_blocks(emu_lib, oracle):
     a = synth.make("text", (1 << 20) + 999, 3)
     comp = oracle.compress_stream(a, oracle.FMT_MGZIP, 3, oracle.COMPAT_1_24, 1 << 20)

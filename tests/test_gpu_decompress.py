@@ -111,6 +111,21 @@ def test_bgzip_like_streams_stay_on_the_pair(hip_lib):
                 assert d.decompress(s) == a and d.last_redo_count() == 0, (cls, level)
 
 
+def test_first_block_hint_may_be_stale(hip_lib):
+    """k_inflate_seg guesses where a BGZF member's first block ends from the members it decoded before (a word of the
+    context): streams of different kinds through ONE context, back and forth -- the hint of one is the wrong guess for
+    the next -- come out right, with no member handed back."""
+    streams = []
+    for cls, seed in (("dna", 1), ("text", 2), ("fastq", 3), ("ascii", 4), ("zeros", 5), ("text", 6)):
+        a = synth.make(cls, 40 * 65280 + 123, seed)
+        with _native.Context(level=1, lib=hip_lib) as c:
+            streams.append((a.tobytes(), c.compress_slab(a, True)))
+    with _native.DContext(lib=hip_lib) as d:
+        for _ in range(2):
+            for raw, comp in streams:
+                assert d.decompress(comp) == raw and d.last_redo_count() == 0
+
+
 def test_config5_shape_256mib(dctx, hip_lib):
     # configs[5]: inflate the output of configs[2] (256 MiB here), verify per-block CRC on device
     a = synth.text_slab(256 << 20, seed=5)
